@@ -1,0 +1,74 @@
+"""ctypes binding of libcdnet_hip.so (the C ABI of include/cdnet_hip.h).
+
+There is NO fallback: if the library is missing or a symbol is absent the import of the compute path fails
+loudly.  PyTorch is used by the callers only for device memory and streams; nothing torch-typed crosses the ABI.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcdnet_hip.so')
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/cdnet_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    'cdnet_abi_version': (_i, []),
+    'cdnet_last_error': (C.c_char_p, []),
+    'cdnet_build_info': (C.c_char_p, []),
+    'cdnet_ddm_codes': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'cdnet_ddm_normalize': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'cdnet_probmaps': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'cdnet_tta_boost_argmax': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_cc_workspace_bytes': (_sz, [_i, _i, _i]),
+    'cdnet_cc_chain': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class CdnetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise if it is not built (python -m cdnet_amd.csrc.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CdnetHipError('libcdnet_hip.so is not built: run `python -m cdnet_amd.csrc.build` '
+                            '(or __graft_entry__.build()). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cdnet_abi_version() != 1:
+        raise CdnetHipError('ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = load().cdnet_last_error().decode(errors='replace')
+        raise CdnetHipError('%s failed (code %d): %s' % (what, status, msg))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def stream_ptr():
+    """The current PyTorch HIP stream as a void* for the ABI."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'ABI needs contiguous device tensors'
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,726 @@
+// Integer / byte post-processing kernels of the CDNet inference path for gfx950 (wave64).
+//   DDM codes + normalise      <- data_prepare/getDirectionDiffMap.py:44-108
+//   get_probmaps epilogue      <- test_dam.py:982-1015
+//   TTA mean / boost / argmax  <- test_dam.py:445-450, 479-491, 529-539
+//   CC chain                   <- test_dam.py:546-563
+// All of this is HBM/latency-bound byte and index work: coalesced row-segment accesses, wave-level ballots for
+// the row runs, union-find with agent-scope atomics for the label propagation.  Results are bit-exact against
+// the CPU oracle (tests/test_gpu_postproc.py).
+#include "common.h"
+
+using namespace cdnet;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// view transforms (test_dam.py:313-441): bit0 hflip, bit1 vflip (both in the view frame), bit2 rot90 ccw first.
+// image pixel (y,x) of an HxW image -> offset inside the stored view plane.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int view_offset(int xf, int y, int x, int H, int W) {
+    int hv, wv, yv, xv;
+    if (xf & 4) { hv = W; wv = H; yv = W - 1 - x; xv = y; }
+    else        { hv = H; wv = W; yv = y;         xv = x; }
+    if (xf & 1) xv = wv - 1 - xv;
+    if (xf & 2) yv = hv - 1 - yv;
+    return yv * wv + xv;
+}
+
+struct DdmLut { int8_t v[17 * 17]; };
+struct ViewXf { int v[16]; };
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DDM
+// ------------------------------------------------------------------------------------------------------
+__global__ void init_minmax_kernel(int32_t *minmax, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { minmax[2 * i] = 0x7fffffff; minmax[2 * i + 1] = -0x7fffffff; }
+}
+
+// block (64,4): 256 px x 4 rows, 4 consecutive pixels per thread
+__global__ __launch_bounds__(256) void ddm_codes_kernel(const uint8_t *__restrict__ dcm, int H, int W, int classes,
+                                                        DdmLut lut, int nbr, int extra_zero,
+                                                        uint8_t *__restrict__ code, int32_t *minmax) {
+    __shared__ int8_t s_lut[17 * 17];
+    __shared__ int s_red[8];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < classes * classes; i += 256) s_lut[i] = lut.v[i];
+    __syncthreads();
+
+    const int n = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const uint8_t *src = dcm + n * plane;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    int lmin = 0x7fffffff, lmax = -0x7fffffff;
+    if (y < H && x0 < W) {
+        uint8_t t[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int yy = y + r - 1;
+            bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                int xx = x0 + c - 1;
+                t[r][c] = (rowok && xx >= 0 && xx < W) ? src[(size_t)yy * W + xx] : (uint8_t)0;
+            }
+        }
+        uint8_t out[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = t[1][j + 1];
+            int v = 0;
+            if (c != 0) {
+                int m = extra_zero ? 0 : 2;
+                const int8_t *row = s_lut + c * classes;
+                if (nbr == 8) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            if (r == 1 && d == 1) continue;
+                            int q = row[t[r][j + d]];
+                            m = q < m ? q : m;
+                        }
+                } else {
+                    int q;
+                    q = row[t[0][j + 1]]; m = q < m ? q : m;
+                    q = row[t[2][j + 1]]; m = q < m ? q : m;
+                    q = row[t[1][j]];     m = q < m ? q : m;
+                    q = row[t[1][j + 2]]; m = q < m ? q : m;
+                }
+                v = 1 - m;
+            }
+            out[j] = (uint8_t)v;
+            if (x0 + j < W) { lmin = v < lmin ? v : lmin; lmax = v > lmax ? v : lmax; }
+        }
+        uint8_t *dst = code + n * plane + (size_t)y * W + x0;
+        if ((W & 3) == 0) {
+            *reinterpret_cast<uchar4 *>(dst) = make_uchar4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x0 + j < W) dst[j] = out[j];
+        }
+    }
+    lmin = wave_min(lmin);
+    lmax = wave_max(lmax);
+    if (threadIdx.x == 0) { s_red[threadIdx.y] = lmin; s_red[4 + threadIdx.y] = lmax; }
+    __syncthreads();
+    if (tid == 0) {
+        int a = s_red[0], b = s_red[4];
+        for (int i = 1; i < 4; ++i) { a = s_red[i] < a ? s_red[i] : a; b = s_red[4 + i] > b ? s_red[4 + i] : b; }
+        if (a != 0x7fffffff) { atomicMin(&minmax[2 * n], a); atomicMax(&minmax[2 * n + 1], b); }
+    }
+}
+
+__global__ __launch_bounds__(256) void ddm_normalize_kernel(const uint8_t *__restrict__ code,
+                                                            const int32_t *__restrict__ minmax, int plane,
+                                                            float *__restrict__ out) {
+    const int n = blockIdx.y;
+    const float mn = (float)minmax[2 * n], den = (float)(minmax[2 * n + 1] - minmax[2 * n]);
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x)
+        out[base + i] = ((float)code[base + i] - mn) / den;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// get_probmaps epilogue
+// ------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void probmaps_kernel(const float *__restrict__ ml, const float *__restrict__ dl,
+                                                       int plane, float *__restrict__ prob,
+                                                       uint8_t *__restrict__ dcm) {
+    const int n = blockIdx.y;
+    const float *m = ml + (size_t)n * 3 * plane;
+    const float *d = dl + (size_t)n * C * plane;
+    float *p = prob + (size_t)n * 3 * plane;
+    uint8_t *o = dcm + (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        float a0 = m[i], a1 = m[plane + i], a2 = m[2 * plane + i];
+        float mx = fmaxf(a0, fmaxf(a1, a2));
+        float e0 = expf(a0 - mx), e1 = expf(a1 - mx), e2 = expf(a2 - mx);
+        float s = (e0 + e1) + e2;
+        float p0 = e0 / s;
+        p[i] = p0; p[plane + i] = e1 / s; p[2 * plane + i] = e2 / s;
+        float q[C];
+        float dm = d[i];
+        q[0] = dm;
+#pragma unroll
+        for (int c = 1; c < C; ++c) { q[c] = d[(size_t)c * plane + i]; dm = fmaxf(dm, q[c]); }
+        float ds = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { q[c] = expf(q[c] - dm); ds += q[c]; }
+        int best = 0;
+        float bv = (q[0] / ds) * p0;
+#pragma unroll
+        for (int c = 1; c < C; ++c) { float v = q[c] / ds; if (v > bv) { bv = v; best = c; } }
+        o[i] = (uint8_t)best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TTA mean + boost + argmax
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2key(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// block (64,4); one pixel per thread
+__global__ __launch_bounds__(256) void tta_mean_kernel(const float *__restrict__ probs, const float *__restrict__ points,
+                                                       int V, ViewXf xf, int H, int W, float *__restrict__ prob_mean,
+                                                       float *__restrict__ point_mean, unsigned *pmax_key) {
+    __shared__ float s_red[4];
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int plane = H * W;
+    float pm = -INFINITY;
+    if (x < W && y < H) {
+        const float *pr = probs + (size_t)img * V * 3 * plane;
+        const float *pt = points + (size_t)img * V * plane;
+        int o = view_offset(xf.v[0], y, x, H, W);
+        float s0 = pr[o], s1 = pr[plane + o], s2 = pr[2 * plane + o], sp = pt[o];
+        for (int v = 1; v < V; ++v) {
+            o = view_offset(xf.v[v], y, x, H, W);
+            const float *q = pr + (size_t)v * 3 * plane;
+            s0 = s0 + q[o]; s1 = s1 + q[plane + o]; s2 = s2 + q[2 * plane + o];
+            sp = sp + pt[(size_t)v * plane + o];
+        }
+        const float fv = (float)V;
+        const int p = y * W + x;
+        if (prob_mean) {
+            float *dst = prob_mean + (size_t)img * 3 * plane;
+            dst[p] = s0 / fv; dst[plane + p] = s1 / fv; dst[2 * plane + p] = s2 / fv;
+        }
+        pm = sp / fv;
+        point_mean[(size_t)img * plane + p] = pm;
+    }
+    pm = wave_maxf(pm);
+    if (threadIdx.x == 0) s_red[threadIdx.y] = pm;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        if (m != -INFINITY) atomicMax(&pmax_key[img], f2key(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void boost_argmax_kernel(const float *__restrict__ probs, const float *__restrict__ prob_mean,
+                                                           const float *__restrict__ point_mean,
+                                                           const uint8_t *__restrict__ codes, const int32_t *__restrict__ minmax,
+                                                           int V, ViewXf xf, int H, int W, const unsigned *__restrict__ pmax_key,
+                                                           uint8_t *__restrict__ ddm16, uint8_t *__restrict__ pred) {
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int plane = H * W, p = y * W + x;
+    const float pmax = key2f(pmax_key[img]);
+    const float *pt = point_mean + (size_t)img * plane;
+    // inside3 = dilation((point/max > 0.2), disk(1))   (test_dam.py:530-531)
+    bool in3 = pt[p] / pmax > 0.2f;
+    if (y > 0) in3 |= pt[p - W] / pmax > 0.2f;
+    if (y < H - 1) in3 |= pt[p + W] / pmax > 0.2f;
+    if (x > 0) in3 |= pt[p - 1] / pmax > 0.2f;
+    if (x < W - 1) in3 |= pt[p + 1] / pmax > 0.2f;
+    // mean over views of the per-view normalised DDM (float32 values, float64 mean)   (:479-491)
+    double s = 0.0;
+    const uint8_t *cd = codes + (size_t)img * V * plane;
+    const int32_t *mm = minmax + (size_t)img * V * 2;
+    for (int v = 0; v < V; ++v) {
+        int o = view_offset(xf.v[v], y, x, H, W);
+        float mn = (float)mm[2 * v], den = (float)(mm[2 * v + 1] - mm[2 * v]);
+        float val = ((float)cd[(size_t)v * plane + o] - mn) / den;
+        s += (double)val;
+    }
+    const double ddm = s / (double)V;
+    if (ddm16) {
+        double t = ddm * 16.0;
+        ddm16[(size_t)img * plane + p] = (t >= 0.0 && t <= 254.0 && t == (double)(int)t) ? (uint8_t)(int)t : (uint8_t)255;
+    }
+    // boost (:532-536) in float64, stored back to the float32 probability map, then argmax (:537)
+    const double eb = 2.0 * (ddm - ddm * (double)(in3 ? 1 : 0));
+    float p0, p1, p2;
+    if (prob_mean) {
+        const float *pm = prob_mean + (size_t)img * 3 * plane;
+        p0 = pm[p]; p1 = pm[plane + p]; p2 = pm[2 * plane + p];
+    } else {
+        const float *pr = probs + (size_t)img * V * 3 * plane;
+        int o = view_offset(xf.v[0], y, x, H, W);
+        p0 = pr[o]; p1 = pr[plane + o]; p2 = pr[2 * plane + o];
+        for (int v = 1; v < V; ++v) {
+            o = view_offset(xf.v[v], y, x, H, W);
+            const float *q = pr + (size_t)v * 3 * plane;
+            p0 = p0 + q[o]; p1 = p1 + q[plane + o]; p2 = p2 + q[2 * plane + o];
+        }
+        const float fv = (float)V;
+        p0 = p0 / fv; p1 = p1 / fv; p2 = p2 / fv;
+    }
+    p2 = (float)(((double)p2 + 0.5 * eb) * (1.0 + eb));
+    int a = 0;
+    float m = p0;
+    if (p1 > m || (p1 != p1 && m == m)) { a = 1; m = p1; }
+    if (p2 > m || (p2 != p2 && m == m)) { a = 2; m = p2; }
+    pred[(size_t)img * plane + p] = (uint8_t)a;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Connected components: union-find over pixel indices, roots = smallest (raster-first) index of a component.
+// One wave = 64 consecutive pixels of one row: the row runs come from a ballot, so only run heads talk to
+// the forest.  Block (64,4); grid (ceil(W/64), ceil(H/4), N).  L: int32 per pixel, -1 = not in the mask.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ld_relaxed(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int uf_find(const int *L, int a) {
+    int p = ld_relaxed(L + a);
+    while (p != a) { a = p; p = ld_relaxed(L + a); }
+    return a;
+}
+
+__device__ __forceinline__ void uf_union(int *L, int a, int b) {
+    bool done;
+    do {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a < b) { int old = atomicMin(L + b, a); done = (old == b); b = old; }
+        else if (b < a) { int old = atomicMin(L + a, b); done = (old == a); a = old; }
+        else done = true;
+    } while (!done);
+}
+
+// index of the first lane of the run of set bits that contains `lane`
+__device__ __forceinline__ int run_start(unsigned long long m, int lane) {
+    unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);
+    return zeros_below ? 64 - __clzll(zeros_below) : 0;
+}
+// number of set bits in the run starting at `lane` (lane is a run head)
+__device__ __forceinline__ int run_length(unsigned long long m, int lane) {
+    unsigned long long z = ~(m >> lane);          // first zero above
+    return z ? __ffsll((long long)z) - 1 : 64 - lane;
+}
+
+// MODE 0: mask = (src != fgval)  [background of pred_inside, for fill-holes]; MODE 1: mask = (src != 0)
+template <int MODE>
+__device__ __forceinline__ bool in_mask(uint8_t v, int fgval) { return MODE == 0 ? (v != fgval) : (v != 0); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void cc_init_kernel(const uint8_t *__restrict__ src, int fgval, int H, int W,
+                                                      int *__restrict__ L) {
+    const int n = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const size_t base = (size_t)n * H * W;
+    const bool valid = x < W && y < H;
+    const bool fg = valid && in_mask<MODE>(src[base + (size_t)y * W + x], fgval);
+    const unsigned long long b = __ballot(fg);
+    if (valid) L[base + (size_t)y * W + x] = fg ? (y * W + blockIdx.x * 64 + run_start(b, threadIdx.x)) : -1;
+}
+
+// CONN: 4 or 8.  Unions between a row run and the runs of the row above, plus the stitch to the left segment.
+template <int MODE, int CONN>
+__global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t *__restrict__ src, int fgval, int H, int W,
+                                                       int *L) {
+    const int n = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, x = x0 + lane, y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= H) return;                                   // whole wave exits together (y is wave-uniform)
+    const size_t base = (size_t)n * H * W;
+    const uint8_t *m = src + base;
+    int *Ln = L + base;
+    const bool valid = x < W;
+    const bool fg = valid && in_mask<MODE>(m[(size_t)y * W + x], fgval);
+    const bool up = valid && y > 0 && in_mask<MODE>(m[(size_t)(y - 1) * W + x], fgval);
+    // edge pixels outside this 64-segment
+    bool left_edge = false, upleft_edge = false, upright_edge = false;
+    if (lane == 0 && x0 > 0) {
+        left_edge = in_mask<MODE>(m[(size_t)y * W + x0 - 1], fgval);
+        if (y > 0) upleft_edge = in_mask<MODE>(m[(size_t)(y - 1) * W + x0 - 1], fgval);
+    }
+    if (lane == 63 && x0 + 64 < W && y > 0) upright_edge = in_mask<MODE>(m[(size_t)(y - 1) * W + x0 + 64], fgval);
+    const unsigned long long bf = __ballot(fg), bu = __ballot(up);
+    if (!fg) return;
+    const bool left = lane > 0 ? ((bf >> (lane - 1)) & 1ull) : left_edge;
+    const bool a = lane > 0 ? ((bu >> (lane - 1)) & 1ull) : upleft_edge;      // NW
+    const bool b = (bu >> lane) & 1ull;                                        // N
+    const bool c = lane < 63 ? ((bu >> (lane + 1)) & 1ull) : upright_edge;    // NE
+    const int p = y * W + x;
+    if (lane == 0 && left_edge) uf_union(Ln, p, p - 1);
+    if (CONN == 4) {
+        if (b && !(left && a)) uf_union(Ln, p, p - W);
+    } else {
+        if (b) { if (!left) uf_union(Ln, p, p - W); }
+        else {
+            if (a && !left) uf_union(Ln, p, p - W - 1);
+            if (c) uf_union(Ln, p, p - W + 1);
+        }
+    }
+}
+
+// L[p] <- root(p).  AREA: additionally area[root] += run length (one atomic per row run).
+template <bool AREA>
+__global__ __launch_bounds__(256) void cc_flatten_kernel(int H, int W, int *L, int *area) {
+    const int n = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + threadIdx.y;
+    const size_t base = (size_t)n * H * W;
+    int *Ln = L + base;
+    const bool valid = x < W && y < H;
+    int r = -1;
+    if (valid) {
+        int l = Ln[(size_t)y * W + x];
+        if (l >= 0) { r = uf_find(Ln, l); }
+    }
+    const unsigned long long bf = __ballot(r >= 0);
+    if (r >= 0) {
+        Ln[(size_t)y * W + x] = r;
+        if (AREA) {
+            bool head = lane == 0 || !((bf >> (lane - 1)) & 1ull);
+            if (head) atomicAdd(area + base + r, run_length(bf, lane));
+        }
+    }
+}
+
+// fill-holes: mark the roots of background components that touch the image border (L[root] = ~root < 0 ... -1 is
+// "not background", so use -2-root).
+__global__ __launch_bounds__(256) void fill_mark_border_kernel(int H, int W, int *L) {
+    const int n = blockIdx.y;
+    int *Ln = L + (size_t)n * H * W;
+    const int per = 2 * W + 2 * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+        int y, x;
+        if (i < W) { y = 0; x = i; }
+        else if (i < 2 * W) { y = H - 1; x = i - W; }
+        else if (i < 2 * W + H) { y = i - 2 * W; x = 0; }
+        else { y = i - 2 * W - H; x = W - 1; }
+        int l = ld_relaxed(Ln + (size_t)y * W + x);
+        if (l >= 0) {                     // background pixel whose root is not marked yet (as far as we saw)
+            int rl = ld_relaxed(Ln + l);  // l is a root after flatten: rl == l, or already marked
+            if (rl >= 0) __hip_atomic_store(Ln + l, -2 - l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// out = foreground OR background component not connected to the border
+__global__ __launch_bounds__(256) void fill_output_kernel(const uint8_t *__restrict__ src, int fgval, int plane,
+                                                          const int *__restrict__ L, uint8_t *__restrict__ out) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        int l = L[base + i];
+        uint8_t o;
+        if (src[base + i] == fgval) o = 1;
+        else {
+            bool outer;
+            if (l == -1) outer = false;                       // cannot happen for background, keep defined
+            else if (l < -1) outer = true;                    // a marked root itself
+            else outer = L[base + l] < -1;
+            o = outer ? 0 : 1;
+        }
+        out[base + i] = o;
+    }
+}
+
+// remove-small + diagonal merge: components (4-conn) with area < min_area are dropped; the survivors get the
+// extra NW/NE unions that turn the 4-connected forest into the 8-connected one (skimage.measure.label).
+__global__ __launch_bounds__(256) void cc_diag_merge_kernel(const uint8_t *__restrict__ A, int H, int W, int min_area,
+                                                            const int *__restrict__ area, int *L,
+                                                            uint8_t *__restrict__ small) {   // small: required
+    const int n = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t base = (size_t)n * H * W;
+    const uint8_t *m = A + base;
+    int *Ln = L + base;
+    const int p = y * W + x;
+    const int l = ld_relaxed(Ln + p);            // flattened label (root of the 4-connected component) or -1
+    // `area` is non-zero exactly at the roots of the 4-connected forest (cc_flatten<AREA>).  Entries of non-root
+    // pixels are never touched by uf_union, so for them l is still that root; a root pixel's own entry may already
+    // have been lowered by a concurrent diagonal union, hence the area[p] test instead of (l == p).
+    bool keep = false;
+    if (l >= 0) {
+        const int r0 = area[base + p] > 0 ? p : l;
+        keep = area[base + r0] >= min_area;
+    }
+    small[base + p] = keep ? 1 : 0;
+    if (!keep) return;
+    if (y == 0) return;
+    const bool N = m[p - W] != 0;
+    if (N) return;                               // NW / NE already 4-connected to p through N
+    const bool Wp = x > 0 && m[p - 1] != 0;
+    const bool Ep = x < W - 1 && m[p + 1] != 0;
+    if (x > 0 && !Wp && m[p - W - 1] != 0) {
+        int q = p - W - 1;
+        int rq = area[base + q] > 0 ? q : ld_relaxed(Ln + q);
+        if (area[base + rq] >= min_area) uf_union(Ln, p, q);
+    }
+    if (x < W - 1 && !Ep && m[p - W + 1] != 0) {
+        int q = p - W + 1;
+        int rq = area[base + q] > 0 ? q : ld_relaxed(Ln + q);
+        if (area[base + rq] >= min_area) uf_union(Ln, p, q);
+    }
+}
+
+// second flatten: survivors point at the root of their 8-connected component, everything else is -1
+__global__ __launch_bounds__(256) void cc_flatten_kept_kernel(const uint8_t *__restrict__ keep, int plane, int *L) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    int *Ln = L + base;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        if (keep[base + i]) Ln[i] = uf_find(Ln, i);
+        else Ln[i] = -1;
+    }
+}
+
+// raster-order numbering of the roots: chunk = 1024 consecutive pixels, 4 per thread
+constexpr int CHUNK = 1024;
+
+__device__ __forceinline__ int block_excl_scan(int v, int *total, int *s_w) {
+    // 256 threads, returns exclusive prefix of v over the block in thread order
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < w) woff += s_w[i]; tot += s_w[i]; }
+    *total = tot;
+    return woff + inc - v;
+}
+
+__global__ __launch_bounds__(256) void cc_count_roots_kernel(const int *__restrict__ L, int plane, int nchunk,
+                                                             int *__restrict__ chunk_cnt) {
+    __shared__ int s_w[4];
+    const int n = blockIdx.y, c = blockIdx.x;
+    const int *Ln = L + (size_t)n * plane;
+    int cnt = 0;
+    const int p0 = c * CHUNK + threadIdx.x * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { int p = p0 + j; if (p < plane && Ln[p] == p) ++cnt; }
+    int tot;
+    block_excl_scan(cnt, &tot, s_w);
+    if (threadIdx.x == 0) chunk_cnt[(size_t)n * nchunk + c] = tot;
+}
+
+// one block per image: exclusive scan of the chunk counts (in place) + instance count
+__global__ __launch_bounds__(256) void cc_scan_chunks_kernel(int nchunk, int *chunk_cnt, int *__restrict__ counts) {
+    __shared__ int s_w[4];
+    __shared__ int s_carry;
+    const int n = blockIdx.x;
+    int *c = chunk_cnt + (size_t)n * nchunk;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nchunk; b0 += 256) {
+        int i = b0 + threadIdx.x;
+        int v = i < nchunk ? c[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot, s_w);
+        int carry = s_carry;
+        if (i < nchunk) c[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && counts) counts[n] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void cc_rank_roots_kernel(const int *__restrict__ L, int plane, int nchunk,
+                                                            const int *__restrict__ chunk_off, int *__restrict__ rank) {
+    __shared__ int s_w[4];
+    const int n = blockIdx.y, c = blockIdx.x;
+    const int *Ln = L + (size_t)n * plane;
+    int *rk = rank + (size_t)n * plane;
+    bool f[4];
+    int cnt = 0;
+    const int p0 = c * CHUNK + threadIdx.x * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { int p = p0 + j; f[j] = p < plane && Ln[p] == p; cnt += f[j] ? 1 : 0; }
+    int tot;
+    int ex = block_excl_scan(cnt, &tot, s_w) + chunk_off[(size_t)n * nchunk + c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (f[j]) { ++ex; rk[p0 + j] = ex; }
+}
+
+__global__ __launch_bounds__(256) void cc_relabel_kernel(const int *__restrict__ L, const int *__restrict__ rank,
+                                                         int plane, int32_t *__restrict__ label) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        int l = L[base + i];
+        label[base + i] = l >= 0 ? rank[base + l] : 0;
+    }
+}
+
+// grey dilation by disk(r): max label over {dy^2+dx^2 <= r^2} (skimage.morphology.dilation, test_dam.py:563)
+__global__ __launch_bounds__(256) void dilate_disk_kernel(const int32_t *__restrict__ label, int H, int W, int r,
+                                                          int32_t *__restrict__ out) {
+    const int n = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int32_t *src = label + (size_t)n * H * W;
+    int32_t v = src[(size_t)y * W + x];
+    for (int dy = -r; dy <= r; ++dy) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -r; dx <= r; ++dx) {
+            if (dy * dy + dx * dx > r * r) continue;
+            int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            int32_t q = src[(size_t)yy * W + xx];
+            v = q > v ? q : v;
+        }
+    }
+    out[(size_t)n * H * W + (size_t)y * W + x] = v;
+}
+
+inline dim3 grid_rows(int N, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4), N); }
+inline int grid_lin(int plane) { int g = cdiv(plane, 256); return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" int cdnet_ddm_codes(const uint8_t *dcm, int N, int H, int W, int classes, const int8_t *lut_host, int nbr,
+                               int extra_zero, uint8_t *code, int32_t *minmax, void *stream) {
+    CDNET_REQUIRE(dcm && code && minmax && lut_host, "cdnet_ddm_codes: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0, "cdnet_ddm_codes: bad size N=%d H=%d W=%d", N, H, W);
+    CDNET_REQUIRE(classes >= 2 && classes <= 17, "cdnet_ddm_codes: classes=%d not in [2,17]", classes);
+    CDNET_REQUIRE(nbr == 4 || nbr == 8, "cdnet_ddm_codes: nbr must be 4 or 8");
+    hipStream_t st = (hipStream_t)stream;
+    DdmLut lut;
+    for (int i = 0; i < 17 * 17; ++i) lut.v[i] = i < classes * classes ? lut_host[i] : 0;
+    init_minmax_kernel<<<cdiv(N, 256), 256, 0, st>>>(minmax, N);
+    dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
+    ddm_codes_kernel<<<grid, dim3(64, 4), 0, st>>>(dcm, H, W, classes, lut, nbr, extra_zero, code, minmax);
+    return check_launch("cdnet_ddm_codes");
+}
+
+extern "C" int cdnet_ddm_normalize(const uint8_t *code, const int32_t *minmax, int N, int H, int W, float *out,
+                                   void *stream) {
+    CDNET_REQUIRE(code && minmax && out, "cdnet_ddm_normalize: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0, "cdnet_ddm_normalize: bad size");
+    ddm_normalize_kernel<<<dim3(grid_lin(H * W), N), 256, 0, (hipStream_t)stream>>>(code, minmax, H * W, out);
+    return check_launch("cdnet_ddm_normalize");
+}
+
+extern "C" int cdnet_probmaps(const float *mask_logits, const float *dir_logits, int N, int C, int H, int W,
+                              float *prob, uint8_t *dcm, void *stream) {
+    CDNET_REQUIRE(mask_logits && dir_logits && prob && dcm, "cdnet_probmaps: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0, "cdnet_probmaps: bad size");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(grid_lin(H * W), N);
+    if (C == 9) probmaps_kernel<9><<<grid, 256, 0, st>>>(mask_logits, dir_logits, H * W, prob, dcm);
+    else if (C == 5) probmaps_kernel<5><<<grid, 256, 0, st>>>(mask_logits, dir_logits, H * W, prob, dcm);
+    else if (C == 17) probmaps_kernel<17><<<grid, 256, 0, st>>>(mask_logits, dir_logits, H * W, prob, dcm);
+    else CDNET_REQUIRE(false, "cdnet_probmaps: direction classes %d not in {5,9,17}", C);
+    return check_launch("cdnet_probmaps");
+}
+
+extern "C" int cdnet_tta_boost_argmax(const float *probs, const float *points, const uint8_t *codes,
+                                      const int32_t *minmax, int I, int V, const int *view_xform_host, int H, int W,
+                                      float *prob_mean, float *point_mean, uint8_t *ddm16, uint8_t *pred,
+                                      float *pmax_ws, void *stream) {
+    CDNET_REQUIRE(probs && points && codes && minmax && point_mean && pred && pmax_ws && view_xform_host,
+                  "cdnet_tta_boost_argmax: null pointer");
+    CDNET_REQUIRE(I > 0 && H > 0 && W > 0 && V >= 1 && V <= 16, "cdnet_tta_boost_argmax: bad size I=%d V=%d", I, V);
+    hipStream_t st = (hipStream_t)stream;
+    ViewXf xf;
+    for (int v = 0; v < 16; ++v) {
+        xf.v[v] = v < V ? view_xform_host[v] : 0;
+        CDNET_REQUIRE(xf.v[v] >= 0 && xf.v[v] < 8, "cdnet_tta_boost_argmax: view_xform[%d]=%d", v, xf.v[v]);
+    }
+    if (hipMemsetAsync(pmax_ws, 0, sizeof(float) * I, st) != hipSuccess) return check_launch("memset pmax");
+    dim3 grid = grid_rows(I, H, W);
+    tta_mean_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, points, V, xf, H, W, prob_mean, point_mean,
+                                                  reinterpret_cast<unsigned *>(pmax_ws));
+    boost_argmax_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, prob_mean, point_mean, codes, minmax, V, xf, H, W,
+                                                      reinterpret_cast<const unsigned *>(pmax_ws), ddm16, pred);
+    return check_launch("cdnet_tta_boost_argmax");
+}
+
+// workspace layout (per call): L i32[N*P] | aux i32[N*P] | A u8[N*P] | B u8[N*P] | chunk i32[N*nchunk]
+static size_t cc_ws_layout(int N, int H, int W, size_t *oL, size_t *oAux, size_t *oA, size_t *oB, size_t *oC) {
+    size_t P = (size_t)N * H * W, off = 0;
+    *oL = off; off = align_up(off + P * 4, 256);
+    *oAux = off; off = align_up(off + P * 4, 256);
+    *oA = off; off = align_up(off + P, 256);
+    *oB = off; off = align_up(off + P, 256);
+    *oC = off; off = align_up(off + (size_t)N * cdiv(H * W, CHUNK) * 4, 256);
+    return off;
+}
+
+extern "C" size_t cdnet_cc_workspace_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    size_t a, b, c, d, e;
+    return cc_ws_layout(N, H, W, &a, &b, &c, &d, &e);
+}
+
+extern "C" int cdnet_cc_chain(const uint8_t *pred, int fg_value, int N, int H, int W, int min_area, int radius,
+                              void *workspace, size_t workspace_bytes, uint8_t *fill, uint8_t *small, int32_t *label,
+                              int32_t *final_, int32_t *counts, void *stream) {
+    CDNET_REQUIRE(pred && final_ && workspace, "cdnet_cc_chain: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0, "cdnet_cc_chain: bad size N=%d H=%d W=%d", N, H, W);
+    CDNET_REQUIRE((size_t)H * W < (1u << 30), "cdnet_cc_chain: image too large for 32-bit pixel indices");
+    CDNET_REQUIRE(radius >= 0 && radius <= 8, "cdnet_cc_chain: radius %d not in [0,8]", radius);
+    size_t oL, oAux, oA, oB, oC;
+    size_t need = cc_ws_layout(N, H, W, &oL, &oAux, &oA, &oB, &oC);
+    if (workspace_bytes < need) {
+        set_error("cdnet_cc_chain: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CDNET_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int *L = (int *)(ws + oL), *aux = (int *)(ws + oAux), *chunk = (int *)(ws + oC);
+    uint8_t *A = fill ? fill : (uint8_t *)(ws + oA);
+    uint8_t *B = small ? small : (uint8_t *)(ws + oB);
+    const int plane = H * W, nchunk = cdiv(plane, CHUNK);
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    const dim3 gl(grid_lin(plane), N);
+
+    // 1. fill holes: 4-connected components of the background; those touching the border stay background
+    cc_init_kernel<0><<<gr, br, 0, st>>>(pred, fg_value, H, W, L);
+    cc_merge_kernel<0, 4><<<gr, br, 0, st>>>(pred, fg_value, H, W, L);
+    cc_flatten_kernel<false><<<gr, br, 0, st>>>(H, W, L, nullptr);
+    fill_mark_border_kernel<<<dim3(cdiv(2 * (H + W), 256), N), 256, 0, st>>>(H, W, L);
+    fill_output_kernel<<<gl, 256, 0, st>>>(pred, fg_value, plane, L, A);
+    // 2. remove small objects: 4-connected components of A with their areas
+    if (hipMemsetAsync(aux, 0, (size_t)N * plane * 4, st) != hipSuccess) return check_launch("memset area");
+    cc_init_kernel<1><<<gr, br, 0, st>>>(A, 0, H, W, L);
+    cc_merge_kernel<1, 4><<<gr, br, 0, st>>>(A, 0, H, W, L);
+    cc_flatten_kernel<true><<<gr, br, 0, st>>>(H, W, L, aux);
+    // 3. drop small components, add the diagonal unions (8-connectivity) among the survivors, number in raster order
+    cc_diag_merge_kernel<<<gr, br, 0, st>>>(A, H, W, min_area, aux, L, B);
+    cc_flatten_kept_kernel<<<gl, 256, 0, st>>>(B, plane, L);
+    cc_count_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L, plane, nchunk, chunk);
+    cc_scan_chunks_kernel<<<N, 256, 0, st>>>(nchunk, chunk, counts);
+    cc_rank_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L, plane, nchunk, chunk, aux);
+    // 4. labels and the disk dilation
+    int32_t *lab = label ? label : (int32_t *)L;      // in-place relabel is safe: rank lives in aux
+    if (label) cc_relabel_kernel<<<gl, 256, 0, st>>>(L, aux, plane, lab);
+    else {
+        // L is overwritten element-wise with rank[L[i]]; reads of L[i] and writes of lab[i] touch the same element only
+        cc_relabel_kernel<<<gl, 256, 0, st>>>(L, aux, plane, lab);
+    }
+    dilate_disk_kernel<<<gr, br, 0, st>>>(lab, H, W, radius, final_);
+    return check_launch("cdnet_cc_chain");
+}
