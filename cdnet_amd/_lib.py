@@ -36,6 +36,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7, the same
+    # as /opt/rocm's).  Importing torch FIRST makes the dynamic loader satisfy our NEEDED libamdhip64.so.7 with
+    # the copy torch already mapped, so torch's streams / allocations and our launches share one runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CdnetHipError('libcdnet_hip.so is not built: run `python -m cdnet_amd.csrc.build` '
                             '(or __graft_entry__.build()). There is no CPU fallback.')
