@@ -22,6 +22,9 @@ SIGNATURES = {
     'cdnet_tta_boost_argmax': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_cc_workspace_bytes': (_sz, [_i, _i, _i]),
     'cdnet_cc_chain': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_conv_packed_weight_elems': (_sz, [_i] * 6),
+    'cdnet_pack_conv_weights': (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    'cdnet_conv_forward': (_i, [_vp, _vp]),
 }
 
 _lib = None

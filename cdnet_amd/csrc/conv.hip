@@ -1,0 +1,428 @@
+// Implicit-GEMM convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16), NHWC bf16 activations,
+// fp32 accumulation.  One kernel family serves
+//   3x3 pad 1 convolution   (models/dam/model_unet_rev1.py: VGG16-BN encoder :40-41, UpsampleBlock.conv2 :112-114,
+//                            ResidualUnit :146-170; models/unet.py encoder/decoder :8-50)
+//   1x1 convolution         (ResidualUnit.conv_1x1 :158)
+//   ConvTranspose2d k4 s2 p1 as four 2x2 sub-pixel convolutions (UpsampleBlock.up :100-101)
+//   ConvTranspose2d k2 s2   as four 1x1 sub-pixel convolutions  (models/unet.py decoder.up :30)
+// and, with transposed/flipped weight packs, their backward-data passes.
+//
+// Tiling: one workgroup (4 waves) = TH x TW output pixels x BN output channels.  The (TH+2)x(TW+2) input halo of a
+// CK-channel chunk is staged through LDS once and reused by all taps; the chunk's weights are staged in the exact
+// MFMA B-fragment order (a linear copy of the host-side pack).  While staging, the producer layer's BatchNorm+ReLU
+// (per-channel scale/shift), an optional residual add, a 2x2 max-pool and the decoder's zero-pad + concat are
+// applied on the fly, so none of those ever makes its own pass over HBM.  The epilogue either applies a folded
+// eval-mode BN (+ReLU) or emits the raw convolution output together with per-tile channel sums / sums of squares
+// (training-mode BN statistics, reduced deterministically by bn_finalize).
+#include "common.h"
+#include "conv_args.h"
+
+using namespace cdnet;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+union V16 {
+    uint4 u;
+    unsigned short h[8];
+    bf16x8 v;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing: fp32 master weights -> bf16 MFMA B-fragment order
+//   packed[cout_tile][chunk][tap][kc][half][col BN][8]   value = w(cout = tile*BN+col, cin = chunk*CK+kc*16+half*8+j, tap)
+// mode 0: Conv2d weight [Cout][Cin][KH][KW], forward       tap = kh*KW+kw
+// mode 1: Conv2d weight, backward-data: roles of cin/cout swap, taps flip: "cout" := original cin,
+//         "cin" := original cout, tap (kh,kw) := original (KH-1-kh, KW-1-kw)
+// mode 2: ConvTranspose2d weight [Cin][Cout][4][4] forward, sub-pixel parity (a,b) in `parity`:
+//         tap t=(ty,tx) in 2x2: rows {a==0: kh 1 (dy 0), kh 3 (dy -1); a==1: kh 0 (dy +1), kh 2 (dy 0)}
+// mode 3: ConvTranspose2d weight [Cin][Cout][2][2] forward, parity (a,b): single tap (kh=a, kw=b)
+// Channels beyond the real Cin/Cout (padding to CK / BN multiples) are zero.
+// ------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout, int Cin,
+                                    int KH, int KW, int CK, int BN, int nchunk, int ntile, int TAPS, int mode,
+                                    int parity) {
+    const size_t total = (size_t)ntile * nchunk * TAPS * (CK / 16) * 2 * BN * 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        int j = r % 8; r /= 8;
+        int col = r % BN; r /= BN;
+        int half = r % 2; r /= 2;
+        int kc = r % (CK / 16); r /= (CK / 16);
+        int tap = r % TAPS; r /= TAPS;
+        int chunk = r % nchunk; r /= nchunk;
+        int tile = (int)r;
+        int co = tile * BN + col;
+        int ci = chunk * CK + kc * 16 + half * 8 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            if (mode == 0) {
+                v = w[(((size_t)co * Cin + ci) * KH + tap / KW) * KW + tap % KW];
+            } else if (mode == 1) {
+                int kh = KH - 1 - tap / KW, kw = KW - 1 - tap % KW;
+                // here Cout/Cin are the ROLES in the backward GEMM: co indexes original cin, ci original cout
+                v = w[(((size_t)ci * Cout + co) * KH + kh) * KW + kw];
+            } else if (mode == 2) {
+                int a = parity >> 1, b = parity & 1, ty = tap >> 1, tx = tap & 1;
+                int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
+                int kw = b == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+                v = w[(((size_t)ci * Cout + co) * 4 + kh) * 4 + kw];
+            } else {
+                int a = parity >> 1, b = parity & 1;
+                v = w[(((size_t)ci * Cout + co) * 2 + a) * 2 + b];
+            }
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// input staging
+// ------------------------------------------------------------------------------------------------------
+struct ChanXf {           // per-thread channel transform for its 8 channels of the current chunk
+    float sc[8], sh[8];
+    bool on;
+};
+
+__device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, bool relu) {
+    V16 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = bf2f(raw.h[j]);
+        if (t.on) v = fmaf(v, t.sc[j], t.sh[j]);
+        if (res) v += bf2f(res->h[j]);
+        if (relu) v = fmaxf(v, 0.f);
+        o.h[j] = f2bf(v);
+    }
+    return o;
+}
+
+__device__ __forceinline__ V16 max8(V16 a, V16 b) {
+    V16 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = bf2f(a.h[j]) >= bf2f(b.h[j]) ? a.h[j] : b.h[j];
+    return o;
+}
+
+template <int TH, int TW, int CK>
+__device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
+                                            unsigned char *lds_a, int tid) {
+    constexpr int VPP = CK / 8;                  // 16-byte vectors per pixel
+    constexpr int PSTR = CK * 2 + 16;            // padded pixel stride in LDS (bank-conflict free b128 reads)
+    constexpr int HW_ = TW + 2, NPIX = (TH + 2) * (TW + 2);
+    const int slot = tid % VPP;                  // constant per thread because 256 % VPP == 0
+    ChanXf t;
+    t.on = s.scale != nullptr;
+    if (t.on) {
+        const float4 *ps = reinterpret_cast<const float4 *>(s.scale + cc0 + slot * 8);
+        const float4 *ph = reinterpret_cast<const float4 *>(s.shift + cc0 + slot * 8);
+        float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
+        t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
+        t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
+    }
+    const bool relu = s.relu != 0;
+    const bool plain = !t.on && !relu && s.res == nullptr;
+    // logical source extent (after the optional 2x2 pool)
+    const int Hl = s.pool ? s.Hs / 2 : s.Hs, Wl = s.pool ? s.Ws / 2 : s.Ws;
+    const size_t img = (size_t)n * s.Hs * s.Ws;
+    for (int v = tid; v < NPIX * VPP; v += 256) {
+        const int pix = v / VPP;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        V16 val;
+        val.u = make_uint4(0, 0, 0, 0);
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        if (y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
+            if (!s.pool) {
+                const size_t e = (img + (size_t)ys * s.Ws + xs) * s.C + cc0 + slot * 8;
+                V16 raw;
+                raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
+                if (plain) val = raw;
+                else if (s.res) { V16 r; r.u = *reinterpret_cast<const uint4 *>(s.res + e); val = xform8(raw, &r, t, relu); }
+                else val = xform8(raw, nullptr, t, relu);
+            } else {
+                // maxpool 2x2 stride 2 of the transformed source (torchvision VGG 'M' layers / unet.py :19)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t e = (img + (size_t)(2 * ys + (q >> 1)) * s.Ws + (2 * xs + (q & 1))) * s.C + cc0 + slot * 8;
+                    V16 raw;
+                    raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
+                    V16 tv = plain ? raw : xform8(raw, nullptr, t, relu);
+                    val = q == 0 ? tv : max8(val, tv);
+                }
+            }
+        }
+        *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------------
+template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
+    constexpr int PSTR = CK * 2 + 16;
+    constexpr int HW_ = TW + 2;
+    constexpr int KC = CK / 16;
+    constexpr int MT = TH * TW / 32, NT = BN / 32;
+    constexpr int MPW = MT / WM, NPW = NT / WN;
+    constexpr int A_BYTES = (TH + 2) * (TW + 2) * PSTR;
+    constexpr int B_BYTES = TAPS * CK * BN * 2;
+    constexpr int OSTR = BN * 2 + 8;             // out staging row stride (bytes)
+    static_assert(MT % WM == 0 && NT % WN == 0 && WM * WN == 4, "wave tiling");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_a = smem;
+    unsigned char *lds_b = smem + A_BYTES;
+    __shared__ float s_stats[4][2][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int tiles_x = (A.W + TW - 1) / TW;
+    const int ty_ = blockIdx.x / tiles_x, tx_ = blockIdx.x - ty_ * tiles_x;
+    const int y0 = ty_ * TH, x0 = tx_ * TW;
+    const int cout_tile = blockIdx.y;
+    const int n = blockIdx.z / A.npar, par = blockIdx.z - n * A.npar;
+
+    // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
+    int toff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        int r, c;
+        if (TAPS == 9) { r = t / 3; c = t % 3; }
+        else if (TAPS == 4) {
+            const int a = par >> 1, b = par & 1, ty = t >> 1, tx = t & 1;
+            r = a == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+            c = b == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+        } else { r = 1; c = 1; }
+        toff[t] = (r * HW_ + c) * PSTR;
+    }
+
+    // per-lane A base for each of this wave's M tiles
+    int abase[MPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int m = (wm * MPW + mi) * 32 + l31;
+        const int py = m / TW, px = m % TW;
+        abase[mi] = (py * HW_ + px) * PSTR + half * 16;
+    }
+    const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
+
+    f32x16 acc[MPW][NPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nchunk_total = A.nchunk;
+    const unsigned short *wbase = A.w + ((size_t)(par * gridDim.y + cout_tile) * nchunk_total) * (B_BYTES / 2);
+
+    int chunk = 0;
+    for (int si = 0; si < A.nsrc; ++si) {
+        const ConvSrc &s = A.src[si];
+        for (int cc0 = 0; cc0 < s.C; cc0 += CK, ++chunk) {
+            __syncthreads();
+            stage_input<TH, TW, CK>(s, cc0, n, y0, x0, A.H, A.W, lds_a, tid);
+            {   // weights of this chunk: linear copy
+                const uint4 *src = reinterpret_cast<const uint4 *>(wbase + (size_t)chunk * (B_BYTES / 2));
+                uint4 *dst = reinterpret_cast<uint4 *>(lds_b);
+                for (int v = tid; v < B_BYTES / 16; v += 256) dst[v] = src[v];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    bf16x8 af[MPW], bfr[NPW];
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+                        af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + abase[mi] + toff[t] + kc * 32);
+#pragma unroll
+                    for (int ni = 0; ni < NPW; ++ni)
+                        bfr[ni] = *reinterpret_cast<const bf16x8 *>(lds_b + bbase + ((t * KC + kc) * 2) * BN * 16 + ni * 512);
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NPW; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- epilogue ----------------
+    const int cout0 = cout_tile * BN;
+    unsigned char *s_out = smem;
+    const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
+    float ssum[NPW], ssq[NPW];
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) {
+        const int col = (wn * NPW + ni) * 32 + l31;
+        const int co = cout0 + col;
+        const bool cok = co < A.Cout;
+        const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
+        const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
+        const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[mi][ni][r];
+                if (A.stats) {
+                    bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
+                    if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
+                }
+                v += bias;
+                v = fmaf(v, osc, osh);
+                if (A.orelu) v = fmaxf(v, 0.f);
+                *reinterpret_cast<unsigned short *>(s_out + m * OSTR + col * 2) = f2bf(v);
+            }
+        }
+    }
+    if (A.stats) {
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) {
+            ssum[ni] += __shfl_xor(ssum[ni], 32);
+            ssq[ni] += __shfl_xor(ssq[ni], 32);
+            if (half == 0) {
+                s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
+                s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
+            }
+        }
+    }
+    __syncthreads();
+    if (A.stats && tid < 2 * BN) {
+        const int which = tid / BN, col = tid % BN;
+        const int wn_of = col / (NPW * 32);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
+        const int co = cout0 + col;
+        if (co < A.Cout) {
+            const size_t tile_lin = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+            A.stats[(tile_lin * 2 + which) * A.Cout + co] = v;
+        }
+    }
+    // coalesced store of the tile: 16-byte vectors, BN/8 per pixel
+    {
+        constexpr int VO = BN / 8;
+        const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
+        const int pa = par >> 1, pb = par & 1;
+        for (int v = tid; v < TH * TW * VO; v += 256) {
+            const int m = v / VO, q = v % VO;
+            const int y = y0 + m / TW, x = x0 + m % TW;
+            const int co = cout0 + q * 8;
+            if (y < A.H && x < A.W && co < A.Cout) {
+                const int oy = y * A.ostride + pa, ox = x * A.ostride + pb;
+                const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
+                unsigned short *dst = A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co;
+                if (co + 8 <= A.Cout) *reinterpret_cast<uint4 *>(dst) = val;
+                else {
+                    const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
+                    for (int j = 0; j < 8 && co + j < A.Cout; ++j) dst[j] = hv[j];
+                }
+            }
+        }
+    }
+}
+
+template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
+int launch_conv(const ConvArgs &A, hipStream_t st) {
+    constexpr int PSTR = CK * 2 + 16;
+    constexpr int stage_bytes = (TH + 2) * (TW + 2) * PSTR + TAPS * CK * BN * 2;
+    constexpr int out_bytes = TH * TW * (BN * 2 + 8);          // the out tile reuses the staging buffers
+    constexpr int smem = stage_bytes > out_bytes ? stage_bytes : out_bytes;
+    auto kern = conv_fwd_kernel<TH, TW, CK, BN, WM, WN, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(conv)");
+        attr_done = true;
+    }
+    dim3 grid(cdiv(A.W, TW) * cdiv(A.H, TH), cdiv(A.Cout, BN), A.N * A.npar);
+    kern<<<grid, 256, smem, st>>>(A);
+    return check_launch("conv_fwd_kernel");
+}
+
+template <int TAPS>
+int dispatch_conv(const ConvArgs &A, hipStream_t st) {
+    // configuration key: (tile, CK, BN); chosen by the host (cdnet_amd/engine.py) per layer
+    const int key = A.tile * 10000 + A.CK * 100 + (A.BN == 128 ? 99 : A.BN);
+    switch (key) {
+        case 16 * 10000 + 16 * 100 + 32: return launch_conv<16, 16, 16, 32, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 16 * 100 + 64: return launch_conv<16, 16, 16, 64, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 32 * 100 + 32: return launch_conv<16, 16, 32, 32, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 32 * 100 + 64: return launch_conv<16, 16, 32, 64, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 32 * 100 + 99: return launch_conv<16, 16, 32, 128, 2, 2, TAPS>(A, st);
+        case 16 * 10000 + 64 * 100 + 64: return launch_conv<16, 16, 64, 64, 4, 1, TAPS>(A, st);
+        case 8 * 10000 + 32 * 100 + 64: return launch_conv<8, 8, 32, 64, 2, 2, TAPS>(A, st);
+        case 8 * 10000 + 32 * 100 + 99: return launch_conv<8, 8, 32, 128, 2, 2, TAPS>(A, st);
+        case 8 * 10000 + 64 * 100 + 64: return launch_conv<8, 8, 64, 64, 2, 2, TAPS>(A, st);
+        default:
+            set_error("cdnet_conv: unsupported configuration tile=%d CK=%d BN=%d", A.tile, A.CK, A.BN);
+            return CDNET_E_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cdnet_conv_packed_weight_elems(int Cout, int Cin_padded_chunks, int taps, int CK, int BN, int npar) {
+    return (size_t)npar * cdiv(Cout, BN) * Cin_padded_chunks * taps * CK * BN;
+}
+
+extern "C" int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN,
+                                       int mode, void *stream) {
+    CDNET_REQUIRE(w && packed, "cdnet_pack_conv_weights: null pointer");
+    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0, "cdnet_pack_conv_weights: Cin=%d CK=%d BN=%d", Cin, CK, BN);
+    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : KH * KW);
+    const int npar = (mode == 2 || mode == 3) ? 4 : 1;
+    const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
+    const size_t per = (size_t)ntile * nchunk * taps * CK * BN;
+    for (int p = 0; p < npar; ++p) {
+        int blocks = (int)((per + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        pack_weights_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, (unsigned short *)packed + p * per, Cout, Cin, KH,
+                                                                   KW, CK, BN, nchunk, ntile, taps, mode, p);
+    }
+    return check_launch("cdnet_pack_conv_weights");
+}
+
+extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
+    CDNET_REQUIRE(args, "cdnet_conv_forward: null args");
+    const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
+    CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && A.out, "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
+    CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0, "cdnet_conv_forward: bad size");
+    int nchunk = 0;
+    for (int i = 0; i < A.nsrc; ++i) {
+        CDNET_REQUIRE(A.src[i].x && A.src[i].C % A.CK == 0, "cdnet_conv_forward: source %d channels %d not a multiple of CK=%d",
+                      i, A.src[i].C, A.CK);
+        CDNET_REQUIRE(!(A.src[i].pool && A.src[i].res), "cdnet_conv_forward: pool+residual source unsupported");
+        nchunk += A.src[i].C / A.CK;
+    }
+    CDNET_REQUIRE(nchunk == A.nchunk, "cdnet_conv_forward: nchunk %d != %d", A.nchunk, nchunk);
+    CDNET_REQUIRE((A.taps == 9 && A.npar == 1 && A.ostride == 1) || (A.taps == 1 && A.npar == 1 && A.ostride == 1) ||
+                  (A.taps == 4 && A.npar == 4 && A.ostride == 2) || (A.taps == 1 && A.npar == 4 && A.ostride == 2),
+                  "cdnet_conv_forward: taps=%d npar=%d ostride=%d", A.taps, A.npar, A.ostride);
+    CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (A.taps == 9) return dispatch_conv<9>(A, st);
+    if (A.taps == 4) return dispatch_conv<4>(A, st);
+    return dispatch_conv<1>(A, st);
+}

@@ -1,0 +1,30 @@
+// Kernel-side aliases of the public argument structs (include/cdnet_hip.h).
+#pragma once
+#include "../../include/cdnet_hip.h"
+
+struct ConvSrc {
+    const unsigned short *x;
+    const unsigned short *res;
+    const float *scale;
+    const float *shift;
+    int C, Hs, Ws, pool, relu, off_y, off_x;
+};
+
+struct ConvArgs {
+    ConvSrc src[2];
+    int nsrc;
+    const unsigned short *w;
+    const float *bias;
+    const float *oscale;
+    const float *oshift;
+    int orelu;
+    unsigned short *out;
+    int Cout, out_cstride, out_coff;
+    float *stats;
+    int N, H, W;
+    int taps, npar, ostride, nchunk;
+    int tile, CK, BN;
+};
+
+static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");
+static_assert(sizeof(ConvArgs) == sizeof(cdnet_conv_args), "ConvArgs layout");

@@ -1,0 +1,143 @@
+"""Host-side plumbing for the convolution stack: ctypes mirrors of the ABI structs, weight packing, per-layer
+kernel configuration and thin call wrappers.  No compute happens here - every function ends in a C-ABI call
+into libcdnet_hip.so (torch tensors only provide device memory and the current stream).
+"""
+import ctypes as C
+import torch
+
+from . import _lib
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('res', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('C', C.c_int), ('Hs', C.c_int), ('Ws', C.c_int), ('pool', C.c_int), ('relu', C.c_int),
+                ('off_y', C.c_int), ('off_x', C.c_int)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('src', ConvSrc * 2), ('nsrc', C.c_int), ('w', C.c_void_p), ('bias', C.c_void_p),
+                ('oscale', C.c_void_p), ('oshift', C.c_void_p), ('orelu', C.c_int), ('out', C.c_void_p),
+                ('Cout', C.c_int), ('out_cstride', C.c_int), ('out_coff', C.c_int), ('stats', C.c_void_p),
+                ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
+                ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int)]
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+class Src:
+    """One convolution source: an NHWC bf16 tensor [N,Hs,Ws,C] plus the producer's lazily-applied transform."""
+
+    def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0)):
+        assert x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+        self.x, self.scale, self.shift, self.relu, self.pool, self.res, self.off = x, scale, shift, relu, pool, res, off
+
+    @property
+    def C(self):
+        return self.x.shape[3]
+
+    def logical_hw(self):
+        h, w = self.x.shape[1], self.x.shape[2]
+        return (h // 2, w // 2) if self.pool else (h, w)
+
+
+_SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 128), (16, 64, 64),
+              (8, 32, 64), (8, 32, 128), (8, 64, 64)}
+
+
+def choose_cfg(src_channels, Cout, H, W, override=None):
+    """(tile, CK, BN) for a layer.  CK must divide every source's channel count."""
+    if override is not None:
+        assert tuple(override) in _SUPPORTED, override
+        return tuple(override)
+    small = min(H, W) <= 8
+    ck = 64
+    while any(c % ck for c in src_channels):
+        ck //= 2
+    assert ck >= 16, 'source channels must be multiples of 16: %s' % (src_channels,)
+    if small:
+        assert ck >= 32
+        if Cout >= 128:
+            return (8, 32, 128)
+        return (8, ck, 64)
+    if ck == 64:
+        ck = 32                       # 2 workgroups per CU (LDS) beat one fat one
+    bn = 64 if Cout > 32 else 32
+    if ck == 16 and bn > 64:
+        bn = 64
+    return (16, ck, bn)
+
+
+def packed_elems(Cout, nchunk, taps, CK, BN, npar):
+    return _lib.load().cdnet_conv_packed_weight_elems(Cout, nchunk, taps, CK, BN, npar)
+
+
+def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
+    """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
+    Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
+    _, CK, BN = cfg
+    assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
+    if mode == 0:
+        Cout, Cin, KH, KW = w.shape
+    elif mode == 1:
+        Cin, Cout, KH, KW = w.shape          # roles swap: GEMM-Cout = original in_channels
+    else:
+        Cin, Cout, KH, KW = w.shape
+    Cin_p = Cin if Cin_pad is None else Cin_pad
+    if Cin_p != Cin:
+        # zero-extend the reduction channels (only the RGB stem needs this)
+        if mode == 0:
+            wp = torch.zeros((Cout, Cin_p, KH, KW), dtype=torch.float32, device=w.device)
+            wp[:, :Cin] = w
+        else:
+            raise NotImplementedError
+        w, Cin = wp.contiguous(), Cin_p
+    taps = 4 if mode == 2 else (1 if mode == 3 else KH * KW)
+    npar = 4 if mode in (2, 3) else 1
+    n = packed_elems(Cout, Cin // CK, taps, CK, BN, npar)
+    if out is None:
+        out = torch.empty((n,), dtype=torch.int16, device=w.device)
+    assert out.numel() == n
+    _lib.call('cdnet_pack_conv_weights', _lib.ptr(w), _lib.ptr(out), Cout, Cin, KH, KW, CK, BN, mode, _lib.stream_ptr())
+    return out
+
+
+def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
+                 orelu=False, out=None, stats=None, H=None, W=None):
+    """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
+    tile, CK, BN = cfg
+    s0 = srcs[0]
+    N = s0.x.shape[0]
+    if H is None:
+        H, W = s0.logical_hw()
+        H, W = H + 0, W + 0
+    ostride = 2 if transposed else 1
+    npar = 4 if transposed else 1
+    a = ConvArgs()
+    nchunk = 0
+    for i, s in enumerate(srcs):
+        assert s.C % CK == 0, (s.C, CK)
+        a.src[i].x = _dp(s.x)
+        a.src[i].res = _dp(s.res)
+        a.src[i].scale = _dp(s.scale)
+        a.src[i].shift = _dp(s.shift)
+        a.src[i].C, a.src[i].Hs, a.src[i].Ws = s.C, s.x.shape[1], s.x.shape[2]
+        a.src[i].pool, a.src[i].relu = int(s.pool), int(s.relu)
+        a.src[i].off_y, a.src[i].off_x = s.off
+        nchunk += s.C // CK
+    a.nsrc = len(srcs)
+    if out is None:
+        out = torch.empty((N, H * ostride, W * ostride, Cout), dtype=torch.bfloat16, device=s0.x.device)
+    ntiles = ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
+    if stats is True:
+        stats = torch.empty((N * npar * ntiles, 2, Cout), dtype=torch.float32, device=s0.x.device)
+    a.w, a.bias, a.oscale, a.oshift = _dp(wpacked), _dp(bias), _dp(oscale), _dp(oshift)
+    a.orelu = int(orelu)
+    a.out, a.Cout, a.out_cstride, a.out_coff = out.data_ptr(), Cout, out.shape[3], 0
+    a.stats = _dp(stats)
+    a.N, a.H, a.W = N, H, W
+    a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
+    a.tile, a.CK, a.BN = tile, CK, BN
+    _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
+    return out, stats

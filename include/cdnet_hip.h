@@ -96,6 +96,58 @@ int cdnet_cc_chain(const uint8_t *pred, int fg_value, int N, int H, int W, int m
                    uint8_t *fill, uint8_t *small, int32_t *label, int32_t *final_, int32_t *counts,
                    void *stream);
 
+
+/* ------------------------------------------------------------------------------------------------------
+ * Convolution stack (MFMA implicit GEMM, NHWC bf16, fp32 accumulate).   Replaces the cuDNN/MIOpen calls behind
+ * nn.Conv2d / nn.ConvTranspose2d / nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d / F.pad / torch.cat in
+ * models/dam/model_unet_rev1.py:86-170,244-287 and models/unet.py:8-50,90-106 (see DESIGN.md for the fusion map).
+ *
+ * A convolution reads up to two sources (virtual channel concat, torch.cat order).  Each source may carry the
+ * PRODUCER's per-channel affine (BatchNorm as scale/shift), a residual tensor added before the ReLU, a ReLU, a 2x2
+ * max-pool and an F.pad offset - all applied while the input tile is staged, never as separate passes.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct cdnet_conv_src {
+    const uint16_t *x;      /* bf16 NHWC [N][Hs][Ws][C] */
+    const uint16_t *res;    /* optional bf16 tensor of the same shape added before the ReLU (ResidualUnit) */
+    const float *scale;     /* optional per-channel affine of the producer (BN): v*scale[c]+shift[c] */
+    const float *shift;
+    int C;                  /* channels of this source (multiple of CK) */
+    int Hs, Ws;             /* stored spatial size */
+    int pool;               /* 1: logical input = maxpool2x2(transformed source), size Hs/2 x Ws/2 */
+    int relu;
+    int off_y, off_x;       /* F.pad: logical (y,x) reads source (y-off_y, x-off_x); outside -> 0 */
+} cdnet_conv_src;
+
+typedef struct cdnet_conv_args {
+    cdnet_conv_src src[2];
+    int nsrc;
+    const uint16_t *w;      /* packed bf16 weights (cdnet_pack_conv_weights) */
+    const float *bias;      /* [Cout] or NULL: added in the epilogue (before oscale/oshift) */
+    const float *oscale;    /* epilogue affine (eval-mode BN fold) or NULL */
+    const float *oshift;
+    int orelu;
+    uint16_t *out;          /* bf16 NHWC [N][H*ostride][W*ostride][out_cstride], channels [out_coff, out_coff+Cout) */
+    int Cout, out_cstride, out_coff;
+    float *stats;           /* NULL or f32 [N*npar*tiles][2][Cout]: per-tile channel sum / sum of squares of the
+                               fp32 accumulators (training-mode BatchNorm statistics, bias excluded) */
+    int N, H, W;            /* logical input size (= output size / ostride) */
+    int taps;               /* 9: 3x3 pad 1; 1: 1x1; 4: sub-pixel 2x2 of ConvTranspose2d(k4,s2,p1) */
+    int npar;               /* 1, or 4 sub-pixel parities (ConvTranspose2d stride 2) */
+    int ostride;            /* 1, or 2 for the transposed convolutions */
+    int nchunk;             /* total Cin chunks over both sources */
+    int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
+} cdnet_conv_args;
+
+/* packed element count for a weight tensor; nchunk = Cin/CK over all sources */
+size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, int BN, int npar);
+/* fp32 master weights -> packed bf16.  mode 0: Conv2d [Cout][Cin][KH][KW] forward; mode 1: Conv2d backward-data
+ * (Cout/Cin are the ROLES in the backward GEMM: Cout := original in_channels, Cin := original out_channels);
+ * mode 2: ConvTranspose2d [Cin][Cout][4][4] k4 s2 p1 forward (4 parities); mode 3: ConvTranspose2d [Cin][Cout][2][2]
+ * k2 s2 forward (4 parities). */
+int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode,
+                            void *stream);
+int cdnet_conv_forward(const cdnet_conv_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

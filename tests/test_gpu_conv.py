@@ -1,0 +1,163 @@
+"""GPU numerics of the MFMA convolution kernels against a plain PyTorch fp32 (CPU) reference of the same op.
+Inputs and weights are bf16-representable, accumulation is fp32, the output is rounded to bf16:
+tolerance |got - want| <= 2^-7 * |want| + 2e-3 (one bf16 ulp + accumulation-order slack)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    import torch
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _close(got, want, what=''):
+    import torch
+    err = (got - want).abs()
+    tol = want.abs() * 2 ** -7 + 2e-3
+    bad = err > tol
+    assert not bool(bad.any()), '%s: %d bad, max err %g at want %g' % (
+        what, int(bad.sum()), float(err.max()), float(want.flatten()[err.flatten().argmax()]))
+
+
+def _nhwc(x):     # NCHW fp32 cpu -> NHWC bf16 cuda
+    import torch
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def _nchw(y):     # NHWC bf16 cuda -> NCHW fp32 cpu
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+CASES_3x3 = [
+    # N, Cin, Cout, H, W, cfg
+    (2, 32, 64, 32, 32, (16, 32, 64)),
+    (1, 64, 64, 48, 40, (16, 32, 64)),        # ragged vs the 16x16 tile
+    (2, 16, 64, 33, 17, (16, 16, 64)),
+    (1, 64, 32, 32, 32, (16, 32, 32)),
+    (1, 16, 16, 32, 48, (16, 16, 32)),        # Cout 16 padded to a 32-wide tile
+    (1, 128, 128, 16, 16, (16, 32, 128)),
+    (2, 64, 64, 16, 32, (16, 64, 64)),
+    (2, 128, 256, 8, 8, (8, 32, 128)),
+    (1, 64, 64, 8, 16, (8, 64, 64)),
+    (1, 128, 64, 12, 20, (8, 32, 64)),
+    (1, 64, 128, 8, 8, (8, 32, 128)),
+]
+
+
+@pytest.mark.parametrize('case', CASES_3x3)
+def test_conv3x3_plain(case):
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, cfg = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = _bf(torch.randn((N, Cin, H, W), generator=g))
+    w = _bf(torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (9 * Cin)) ** 0.5)
+    b = torch.randn((Cout,), generator=g)
+    want = F.conv2d(x, w, b, padding=1)
+    wp = engine.pack_weights(w.cuda(), cfg, 0)
+    out, stats = engine.conv_forward([engine.Src(_nhwc(x))], wp, Cout, cfg, bias=b.cuda(), stats=True)
+    _close(_nchw(out), want, 'conv3x3')
+    # per-tile statistics of the bias-free fp32 accumulators
+    raw = F.conv2d(x, w, None, padding=1)
+    s = stats.sum(0).cpu()
+    np.testing.assert_allclose(s[0].numpy(), raw.sum((0, 2, 3)).numpy(), rtol=2e-4, atol=2e-2)
+    np.testing.assert_allclose(s[1].numpy(), (raw * raw).sum((0, 2, 3)).numpy(), rtol=2e-4, atol=2e-2)
+
+
+def test_conv3x3_fused_bn_relu_pool_concat_pad_epilogue():
+    """every staging transform at once: source A = maxpool2x2(relu(bn(a))) ; source B = relu(bn(b) + res) with an
+    F.pad offset; epilogue = folded eval BN + ReLU."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(5)
+    N, Ca, Cb, Cout, H, W = 2, 32, 64, 64, 20, 28
+    a = _bf(torch.randn((N, Ca, 2 * H, 2 * W), generator=g))
+    b = _bf(torch.randn((N, Cb, H - 1, W - 3), generator=g))          # smaller: padded by (0,1) rows, (1,2) cols
+    res = _bf(torch.randn((N, Cb, H - 1, W - 3), generator=g))
+    sa, ha = torch.rand((Ca,), generator=g) + 0.5, torch.randn((Ca,), generator=g) * 0.3
+    sa[::3] *= -1                                                      # negative gamma: pool must follow the affine
+    sb, hb = torch.rand((Cb,), generator=g) + 0.5, torch.randn((Cb,), generator=g) * 0.3
+    w = _bf(torch.randn((Cout, Ca + Cb, 3, 3), generator=g) * (2.0 / (9 * (Ca + Cb))) ** 0.5)
+    osc, osh = torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.2
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    ta = _bf(F.max_pool2d(_bf(F.relu(a * sa.view(1, -1, 1, 1) + ha.view(1, -1, 1, 1))), 2))
+    tb = _bf(F.relu(b * sb.view(1, -1, 1, 1) + hb.view(1, -1, 1, 1) + res))
+    tb = F.pad(tb, (1, 2, 0, 1))
+    want = F.relu((F.conv2d(torch.cat([ta, tb], 1), w, bias, padding=1)) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
+    cfg = (16, 32, 64)
+    wp = engine.pack_weights(w.cuda(), cfg, 0)
+    srcs = [engine.Src(_nhwc(a), sa.cuda(), ha.cuda(), relu=True, pool=True),
+            engine.Src(_nhwc(b), sb.cuda(), hb.cuda(), relu=True, res=_nhwc(res), off=(0, 1))]
+    out, _ = engine.conv_forward(srcs, wp, Cout, cfg, bias=bias.cuda(), oscale=osc.cuda(), oshift=osh.cuda(),
+                                 orelu=True, H=H, W=W)
+    _close(_nchw(out), want, 'fused')
+
+
+@pytest.mark.parametrize('case', [(2, 32, 64, 24, 24, (16, 32, 64)), (1, 16, 64, 40, 24, (16, 16, 64)),
+                                  (2, 64, 128, 8, 8, (8, 32, 128))])
+def test_conv1x1(case):
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, cfg = case
+    g = torch.Generator().manual_seed(11)
+    x = _bf(torch.randn((N, Cin, H, W), generator=g))
+    w = _bf(torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5)
+    b = torch.randn((Cout,), generator=g)
+    want = F.conv2d(x, w, b)
+    wp = engine.pack_weights(w.cuda(), cfg, 0)
+    out, _ = engine.conv_forward([engine.Src(_nhwc(x))], wp, Cout, cfg, taps=1, bias=b.cuda())
+    _close(_nchw(out), want, 'conv1x1')
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, 8, 8, (8, 64, 64)), (1, 32, 16, 24, 40, (16, 32, 32)),
+                                  (2, 128, 64, 16, 16, (16, 32, 64)), (1, 512, 256, 8, 8, (8, 32, 128))])
+def test_conv_transpose_k4s2p1(case):
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, cfg = case
+    g = torch.Generator().manual_seed(13)
+    x = _bf(torch.randn((N, Cin, H, W), generator=g))
+    w = _bf(torch.randn((Cin, Cout, 4, 4), generator=g) * (2.0 / (4 * Cin)) ** 0.5)
+    want = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    wp = engine.pack_weights(w.cuda(), cfg, 2)
+    out, stats = engine.conv_forward([engine.Src(_nhwc(x))], wp, Cout, cfg, taps=4, transposed=True, stats=True)
+    assert tuple(out.shape) == (N, 2 * H, 2 * W, Cout)
+    _close(_nchw(out), want, 'convT4')
+    np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), want.sum((0, 2, 3)).numpy(), rtol=2e-4, atol=3e-2)
+
+
+def test_conv_transpose_k2s2():
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(17)
+    N, Cin, Cout, H, W, cfg = 2, 64, 32, 12, 20, (16, 32, 32)
+    x = _bf(torch.randn((N, Cin, H, W), generator=g))
+    w = _bf(torch.randn((Cin, Cout, 2, 2), generator=g) * (2.0 / Cin) ** 0.5)
+    b = torch.randn((Cout,), generator=g)
+    want = F.conv_transpose2d(x, w, b, stride=2)
+    wp = engine.pack_weights(w.cuda(), cfg, 3)
+    out, _ = engine.conv_forward([engine.Src(_nhwc(x))], wp, Cout, cfg, taps=1, transposed=True, bias=b.cuda())
+    _close(_nchw(out), want, 'convT2')
+
+
+def test_conv_backward_data_pack():
+    """backward-data of a 3x3 conv = forward conv with the flipped/transposed pack (mode 1)"""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(19)
+    N, Cin, Cout, H, W = 2, 32, 64, 24, 16
+    w = _bf(torch.randn((Cout, Cin, 3, 3), generator=g) * 0.1)
+    dy = _bf(torch.randn((N, Cout, H, W), generator=g))
+    want = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, padding=1)
+    cfg = (16, 32, 32)
+    wp = engine.pack_weights(w.cuda(), cfg, 1)
+    out, _ = engine.conv_forward([engine.Src(_nhwc(dy))], wp, Cin, cfg)
+    _close(_nchw(out), want, 'bwd-data')
