@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcdnet_hip.so')
 
-_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/cdnet_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -25,6 +25,11 @@ SIGNATURES = {
     'cdnet_conv_packed_weight_elems': (_sz, [_i] * 6),
     'cdnet_pack_conv_weights': (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     'cdnet_conv_forward': (_i, [_vp, _vp]),
+    'cdnet_input_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_bn_fold_eval': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    'cdnet_bn_finalize_train': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_dam_head_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'cdnet_final_conv1x1': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

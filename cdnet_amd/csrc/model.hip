@@ -1,0 +1,263 @@
+// Streaming (HBM-bound) kernels of the model path that are not convolutions:
+//   input pack (ToTensor'd NCHW f32 -> NHWC bf16, channels zero-padded to 16)
+//   BatchNorm bookkeeping: eval fold (model_unet_rev1.py BN layers in eval()), training finalize from the
+//     per-tile statistics the convolution epilogue emits (nn.BatchNorm2d training semantics: biased variance for
+//     normalisation, unbiased for running_var, momentum 0.1, eps 1e-5)
+//   DAM head: point_conv, directionAtt, direction_conv, maskAtt, mask_conv fused per pixel
+//     (models/dam/model_unet_rev1.py:8-17, 227-231, 258-263)
+#include "common.h"
+
+using namespace cdnet;
+
+namespace {
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+// x f32 [N][C][H][W] -> out bf16 [N][H][W][16]  (C <= 16)
+__global__ __launch_bounds__(256) void input_pack_kernel(const float *__restrict__ x, int N, int C, int plane,
+                                                         unsigned short *__restrict__ out) {
+    const size_t total = (size_t)N * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, p = i - n * plane;
+        unsigned short v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = c < C ? f2bf(x[(n * C + c) * plane + p]) : (unsigned short)0;
+        uint4 *dst = reinterpret_cast<uint4 *>(out + i * 16);
+        dst[0] = *reinterpret_cast<const uint4 *>(v);
+        dst[1] = *reinterpret_cast<const uint4 *>(v + 8);
+    }
+}
+
+// eval-mode fold: scale = g / sqrt(rv + eps); shift = b + (bias - rm) * scale
+__global__ void bn_fold_eval_kernel(const float *g, const float *b, const float *rm, const float *rv, const float *bias,
+                                    float eps, int C, float *scale, float *shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = g[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = b[c] + ((bias ? bias[c] : 0.f) - rm[c]) * s;
+}
+
+// training finalize: stats f32 [T][2][C] (sum, sumsq of the bias-free conv output over `count` elements per channel)
+// -> scale = g*invstd, shift = b - mean*scale (bias cancels), mean/invstd saved for backward,
+//    running_mean = (1-m)*rm + m*(mean + bias), running_var = (1-m)*rv + m*var*count/(count-1)
+__global__ __launch_bounds__(256) void bn_finalize_train_kernel(const float *__restrict__ stats, int T, int C, float count,
+                                                                const float *g, const float *b, const float *bias,
+                                                                float eps, float momentum, float *rm, float *rv,
+                                                                float *scale, float *shift, float *mean_out,
+                                                                float *invstd_out) {
+    // one wave per channel: deterministic tree over the tiles
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int t = lane; t < T; t += 64) {
+        s += (double)stats[((size_t)t * 2) * C + c];
+        q += (double)stats[((size_t)t * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane == 0) {
+        double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0) var = 0;
+        float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        float sc = g[c] * invstd;
+        scale[c] = sc;
+        shift[c] = b[c] - (float)mean * sc;
+        if (mean_out) mean_out[c] = (float)mean;
+        if (invstd_out) invstd_out[c] = invstd;
+        if (rm) {
+            float mb = (float)mean + (bias ? bias[c] : 0.f);
+            rm[c] = (1.f - momentum) * rm[c] + momentum * mb;
+            float unb = (float)(var * (count / (count > 1.f ? count - 1.f : 1.f)));
+            rv[c] = (1.f - momentum) * rv[c] + momentum * unb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DAM head.  Each feature F_k = relu(raw*scale + shift + res) is recomputed from its stored pieces
+// (scale==NULL: the tensor already holds the activated feature).
+// ------------------------------------------------------------------------------------------------------
+struct HeadFeat {
+    const unsigned short *raw;
+    const unsigned short *res;
+    const float *scale;
+    const float *shift;
+    int relu;
+};
+
+struct HeadW {            // 64-channel 1x1 heads, fp32
+    float wp[64], wd[9][64], wm[3][64];
+    float bp, bd[9], bm[3];
+    float a1;             // directionAtt.Conv1x1 (1->1, no bias)
+    float a2[9];          // maskAtt.Conv1x1 (9->1, no bias)
+};
+
+__device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const float *s_sc, const float *s_sh, float *v) {
+    const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64);
+    const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64) : nullptr;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint4 r = pr[q];
+        const unsigned short *h = reinterpret_cast<const unsigned short *>(&r);
+        uint4 rr = make_uint4(0, 0, 0, 0);
+        if (ps) rr = ps[q];
+        const unsigned short *hr = reinterpret_cast<const unsigned short *>(&rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = bf2f(h[j]);
+            if (f.scale || ps || f.relu) {
+                if (f.scale) x = fmaf(x, s_sc[q * 8 + j], s_sh[q * 8 + j]);
+                if (ps) x += bf2f(hr[j]);
+                if (f.relu) x = fmaxf(x, 0.f);
+                x = bf2f(f2bf(x));       // the convolutions consume the feature rounded to bf16; keep the head consistent
+            }
+            v[q * 8 + j] = x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
+                                                           int N, int plane, float *__restrict__ mask,
+                                                           float *__restrict__ point, float *__restrict__ dirn) {
+    __shared__ HeadW w;
+    __shared__ float s_sc[3][64], s_sh[3][64];
+    {
+        const float *src = reinterpret_cast<const float *>(hw);
+        float *dst = reinterpret_cast<float *>(&w);
+        for (int i = threadIdx.x; i < (int)(sizeof(HeadW) / 4); i += 256) dst[i] = src[i];
+        if (threadIdx.x < 64) {
+            const HeadFeat *fs[3] = {&f1, &f2, &f3};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s_sc[k][threadIdx.x] = fs[k]->scale ? fs[k]->scale[threadIdx.x] : 1.f;
+                s_sh[k][threadIdx.x] = fs[k]->scale ? fs[k]->shift[threadIdx.x] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, p = i - n * plane;
+        float v[64];
+        // point = point_conv(F3)
+        load_feat64(f3, i, s_sc[2], s_sh[2], v);
+        float pt = w.bp;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) pt = fmaf(w.wp[c], v[c], pt);
+        point[n * plane + p] = pt;
+        // direction = direction_conv(F2 * (1 + sigmoid(a1 * point)))
+        const float g1 = 1.f + 1.f / (1.f + expf(-(w.a1 * pt)));
+        load_feat64(f2, i, s_sc[1], s_sh[1], v);
+        float d[9];
+        float q2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(w.wd[k][c], v[c], s);
+            d[k] = fmaf(g1, s, w.bd[k]);
+            dirn[(n * 9 + k) * plane + p] = d[k];
+            q2 = fmaf(w.a2[k], d[k], q2);
+        }
+        // mask = mask_conv(F1 * (1 + sigmoid(maskAtt(direction))))
+        const float g2 = 1.f + 1.f / (1.f + expf(-q2));
+        load_feat64(f1, i, s_sc[0], s_sh[0], v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(w.wm[k][c], v[c], s);
+            mask[(n * 3 + k) * plane + p] = fmaf(g2, s, w.bm[k]);
+        }
+    }
+}
+
+// final 1x1 classifier of the plain UNet (models/unet.py:75,104): logits f32 NCHW from a 64-channel feature
+__global__ __launch_bounds__(256) void final_conv1x1_kernel(HeadFeat f, const float *__restrict__ w, const float *__restrict__ b,
+                                                            int K, int N, int plane, float *__restrict__ out) {
+    __shared__ float s_w[16 * 64], s_b[16], s_sc[64], s_sh[64];
+    for (int i = threadIdx.x; i < K * 64; i += 256) s_w[i] = w[i];
+    if (threadIdx.x < K) s_b[threadIdx.x] = b[threadIdx.x];
+    if (threadIdx.x < 64) {
+        s_sc[threadIdx.x] = f.scale ? f.scale[threadIdx.x] : 1.f;
+        s_sh[threadIdx.x] = f.scale ? f.shift[threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, p = i - n * plane;
+        float v[64];
+        load_feat64(f, i, s_sc, s_sh, v);
+        for (int k = 0; k < K; ++k) {
+            float s = s_b[k];
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(s_w[k * 64 + c], v[c], s);
+            out[(n * K + k) * plane + p] = s;
+        }
+    }
+}
+
+inline int lin_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int cdnet_input_pack(const float *x, int N, int C, int H, int W, void *out, void *stream) {
+    CDNET_REQUIRE(x && out, "cdnet_input_pack: null pointer");
+    CDNET_REQUIRE(N > 0 && C > 0 && C <= 16 && H > 0 && W > 0, "cdnet_input_pack: bad size (C=%d must be <= 16)", C);
+    input_pack_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(x, N, C, H * W, (unsigned short *)out);
+    return check_launch("cdnet_input_pack");
+}
+
+extern "C" int cdnet_bn_fold_eval(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                                  const float *conv_bias, float eps, int C, float *scale, float *shift, void *stream) {
+    CDNET_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "cdnet_bn_fold_eval: bad args");
+    bn_fold_eval_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, conv_bias, eps, C,
+                                                                      scale, shift);
+    return check_launch("cdnet_bn_fold_eval");
+}
+
+extern "C" int cdnet_bn_finalize_train(const float *stats, int T, int C, float count, const float *gamma, const float *beta,
+                                       const float *conv_bias, float eps, float momentum, float *running_mean,
+                                       float *running_var, float *scale, float *shift, float *save_mean,
+                                       float *save_invstd, void *stream) {
+    CDNET_REQUIRE(stats && gamma && beta && scale && shift && T > 0 && C > 0 && count > 0, "cdnet_bn_finalize_train: bad args");
+    bn_finalize_train_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, T, C, count, gamma, beta, conv_bias, eps, momentum,
+                                                                         running_mean, running_var, scale, shift, save_mean,
+                                                                         save_invstd);
+    return check_launch("cdnet_bn_finalize_train");
+}
+
+static HeadFeat mk_feat(const cdnet_head_feat &f) {
+    HeadFeat h;
+    h.raw = f.raw; h.res = f.res; h.scale = f.scale; h.shift = f.shift; h.relu = f.relu;
+    return h;
+}
+
+extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_head_feat *f2, const cdnet_head_feat *f3,
+                                      const float *head_weights, int N, int H, int W, float *mask, float *point,
+                                      float *direction, void *stream) {
+    CDNET_REQUIRE(f1 && f2 && f3 && head_weights && mask && point && direction, "cdnet_dam_head_forward: null pointer");
+    CDNET_REQUIRE(f1->raw && f2->raw && f3->raw && N > 0 && H > 0 && W > 0, "cdnet_dam_head_forward: bad args");
+    static_assert(sizeof(HeadW) == CDNET_HEAD_WEIGHT_FLOATS * 4, "head weight block layout");
+    dam_head_fwd_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(
+        mk_feat(*f1), mk_feat(*f2), mk_feat(*f3), reinterpret_cast<const HeadW *>(head_weights), N, H * W, mask, point, direction);
+    return check_launch("cdnet_dam_head_forward");
+}
+
+extern "C" int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, const float *b, int K, int N, int H, int W,
+                                   float *out, void *stream) {
+    CDNET_REQUIRE(f && f->raw && w && b && out, "cdnet_final_conv1x1: null pointer");
+    CDNET_REQUIRE(K >= 1 && K <= 16 && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1: K=%d must be in [1,16]", K);
+    final_conv1x1_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(mk_feat(*f), w, b, K, N, H * W, out);
+    return check_launch("cdnet_final_conv1x1");
+}

@@ -148,6 +148,47 @@ int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int
                             void *stream);
 int cdnet_conv_forward(const cdnet_conv_args *args, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Model-path streaming kernels (not convolutions).
+ * cdnet_input_pack: f32 NCHW [N][C<=16][H][W] (the ToTensor output, my_transforms_direction.py:945) -> bf16 NHWC
+ *   [N][H][W][16] with zero-padded channels.
+ * cdnet_bn_fold_eval: nn.BatchNorm2d in eval(): scale = g/sqrt(rv+eps), shift = b + (conv_bias - rm)*scale.
+ * cdnet_bn_finalize_train: nn.BatchNorm2d in train(): reduces the per-tile statistics emitted by cdnet_conv_forward
+ *   (stats f32 [T][2][C], `count` = N*H*W elements per channel) into scale/shift for the consumers, saves
+ *   mean/invstd for backward and updates running_mean/var (momentum, unbiased variance); all reductions are
+ *   deterministic (fixed tree, fp64).
+ * ---------------------------------------------------------------------------------------------------- */
+int cdnet_input_pack(const float *x, int N, int C, int H, int W, void *out_bf16_nhwc16, void *stream);
+int cdnet_bn_fold_eval(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                       const float *conv_bias, float eps, int C, float *scale, float *shift, void *stream);
+int cdnet_bn_finalize_train(const float *stats, int T, int C, float count, const float *gamma, const float *beta,
+                            const float *conv_bias, float eps, float momentum, float *running_mean,
+                            float *running_var, float *scale, float *shift, float *save_mean, float *save_invstd,
+                            void *stream);
+
+/* A 64-channel head feature F = [relu](raw*scale + shift + res), recomputed on the fly from its stored pieces. */
+typedef struct cdnet_head_feat {
+    const uint16_t *raw;    /* bf16 NHWC [N][H][W][64] */
+    const uint16_t *res;    /* optional bf16 residual, same shape */
+    const float *scale;     /* optional per-channel affine */
+    const float *shift;
+    int relu;
+    int pad_;
+} cdnet_head_feat;
+
+/* Direction-aware-mask head: replaces models/dam/model_unet_rev1.py:258-263 (point_conv, directionAtt,
+ * direction_conv, maskAtt, mask_conv; revAttention :8-17).  head_weights: device f32 block of
+ * CDNET_HEAD_WEIGHT_FLOATS = { point_conv.w[64], direction_conv.w[9][64], mask_conv.w[3][64], point_conv.b,
+ * direction_conv.b[9], mask_conv.b[3], directionAtt.w, maskAtt.w[9] }.
+ * Outputs f32 NCHW: mask [N][3][H][W], point [N][1][H][W], direction [N][9][H][W] (the tuple Unet.forward returns). */
+#define CDNET_HEAD_WEIGHT_FLOATS 855
+int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_head_feat *f2, const cdnet_head_feat *f3,
+                           const float *head_weights, int N, int H, int W, float *mask, float *point,
+                           float *direction, void *stream);
+/* plain UNet classifier (models/unet.py:75,104 final_conv 64->K): f32 NCHW logits from a 64-channel feature */
+int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, const float *b, int K, int N, int H, int W,
+                        float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

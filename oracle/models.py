@@ -1,0 +1,172 @@
+"""ORACLE (test infrastructure): plain PyTorch fp32 CPU restatements of the reference networks, with the
+reference's state_dict key names.  Pinned to tests/golden/{unet_fwd,dam_fwd,train_iter}.npz (outputs of the
+reference itself with closed-form weights) by tests/test_oracle_models.py.
+
+Follows (paths relative to /root/reference):
+  UNet                     models/unet.py:8-106
+  Unet (UNet2RevA1_vgg16)  models/dam/model_unet_rev1.py:8-17 (revAttention), :86-143 (UpsampleBlock),
+                           :150-170 (ResidualUnit), :180-266 (Unet); backbone = torchvision vgg16_bn.features
+                           (configuration D with BatchNorm), skips after children '5','12','22','32','42',
+                           output after '43' (:66-67)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------------
+class _Enc(nn.Module):                                   # models/unet.py:8-24
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.down_conv = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                                       nn.Conv2d(cout, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+        self.pool = nn.MaxPool2d(kernel_size=2, ceil_mode=True)
+
+    def forward(self, x):
+        x = self.down_conv(x)
+        return x, self.pool(x)
+
+
+class _Dec(nn.Module):                                   # models/unet.py:27-50
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2)
+        self.up_conv = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                                     nn.Conv2d(cout, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x_copy, x):
+        x = self.up(x)
+        dy, dx = x_copy.size(2) - x.size(2), x_copy.size(3) - x.size(3)
+        x = F.pad(x, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+        return self.up_conv(torch.cat([x_copy, x], dim=1))        # NB order [skip, up] (:48)
+
+
+class UNet(nn.Module):                                   # models/unet.py:53-106
+    def __init__(self, num_classes, in_channels=3):
+        super().__init__()
+        self.down1, self.down2 = _Enc(in_channels, 64), _Enc(64, 128)
+        self.down3, self.down4 = _Enc(128, 256), _Enc(256, 512)
+        self.middle_conv = nn.Sequential(nn.Conv2d(512, 1024, 3, padding=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
+                                         nn.Conv2d(1024, 1024, 3, padding=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True))
+        self.up1, self.up2, self.up3, self.up4 = _Dec(1024, 512), _Dec(512, 256), _Dec(256, 128), _Dec(128, 64)
+        self.up = nn.ConvTranspose2d(128, 128, kernel_size=2, stride=2)          # unused parameters (:72-73)
+        self.beforefinal2_conv = nn.Conv2d(128, num_classes, kernel_size=1)
+        self.final_conv = nn.Conv2d(64, num_classes, kernel_size=1)
+
+    def forward(self, x):
+        x1, x = self.down1(x)
+        x2, x = self.down2(x)
+        x3, x = self.down3(x)
+        x4, x = self.down4(x)
+        x = self.middle_conv(x)
+        x = self.up1(x4, x)
+        x = self.up2(x3, x)
+        x = self.up3(x2, x)
+        x = self.up4(x1, x)
+        return self.final_conv(x)
+
+
+# ------------------------------------------------------------------------------------------------------
+VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+def vgg16_bn_features():
+    layers, c = [], 3
+    for v in VGG16_CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+            c = v
+    return nn.Sequential(*layers)
+
+
+class revAttention(nn.Module):                           # model_unet_rev1.py:8-17
+    def __init__(self, cin):
+        super().__init__()
+        self.Conv1x1 = nn.Conv2d(cin, 1, kernel_size=1, bias=False)
+
+    def forward(self, U, V):
+        return U * (1 + torch.sigmoid(self.Conv1x1(V)))
+
+
+class UpsampleBlock(nn.Module):                          # model_unet_rev1.py:86-143, parametric branch
+    def __init__(self, ch_in, ch_out, skip_in):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(ch_in, ch_out, kernel_size=(4, 4), stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(ch_out)
+        self.conv2 = nn.Conv2d(ch_out + skip_in, ch_out, kernel_size=3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(ch_out)
+
+    def forward(self, x, skip):
+        x = F.relu(self.bn1(self.up(x)))
+        dy, dx = skip.size(2) - x.size(2), skip.size(3) - x.size(3)
+        x = F.pad(x, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+        x = torch.cat([x, skip], dim=1)                   # NB order [up, skip] (:133)
+        return F.relu(self.bn2(self.conv2(x)))
+
+
+class ResidualUnit(nn.Module):                           # model_unet_rev1.py:150-170
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.conv_1x1 = nn.Conv2d(cin, cout, kernel_size=1)
+
+    def forward(self, x):
+        r = self.conv_1x1(x)
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return F.relu(out + r)
+
+
+class Unet(nn.Module):                                   # model_unet_rev1.py:180-266 with backbone_name='vgg16_bn'
+    SKIPS = ('5', '12', '22', '32', '42')
+    BB_OUT = '43'
+
+    def __init__(self, classes=3, decoder_filters=(256, 128, 64, 32, 16)):
+        super().__init__()
+        self.backbone = vgg16_bn_features()
+        skip_ch = [64, 128, 256, 512, 512]
+        fin = [512] + list(decoder_filters[:-1])
+        self.upsample_blocks = nn.ModuleList(
+            [UpsampleBlock(a, b, skip_ch[len(skip_ch) - i - 1]) for i, (a, b) in enumerate(zip(fin, decoder_filters))])
+        self.final_conv = nn.Conv2d(decoder_filters[-1], classes, kernel_size=(1, 1))        # unused (:213)
+        self.child0 = nn.Conv2d(1, 64, kernel_size=3, padding=1)                             # unused (:220)
+        self.child_conv1 = nn.Conv2d(1, 64, kernel_size=7, stride=2, padding=3, bias=False)  # unused (:221)
+        self.mask_feature = ResidualUnit(decoder_filters[-1], 64)
+        self.direction_feature = ResidualUnit(64, 64)
+        self.point_feature = ResidualUnit(64, 64)
+        self.point_conv = nn.Conv2d(64, 1, kernel_size=1)
+        self.directionAtt = revAttention(1)
+        self.direction_conv = nn.Conv2d(64, 9, kernel_size=1)
+        self.maskAtt = revAttention(9)
+        self.mask_conv = nn.Conv2d(64, 3, kernel_size=1)
+
+    def forward(self, x):
+        feats = {}
+        for name, child in self.backbone.named_children():
+            x = child(x)
+            if name in self.SKIPS:
+                feats[name] = x
+            if name == self.BB_OUT:
+                break
+        for skip_name, blk in zip(self.SKIPS[::-1], self.upsample_blocks):
+            x = blk(x, feats[skip_name])
+        f1 = self.mask_feature(x)
+        f2 = self.direction_feature(f1)
+        f3 = self.point_feature(f2)
+        point = self.point_conv(f3)
+        direction = self.direction_conv(self.directionAtt(f2, point))
+        mask = self.mask_conv(self.maskAtt(f1, direction))
+        return mask, point, direction
+
+
+def det_fill(model):
+    from cdnet_amd import synth
+    bn = {n for n, m in model.named_modules() if isinstance(m, nn.BatchNorm2d)}
+    with torch.no_grad():
+        synth.det_fill_state_dict(model.state_dict(), bn)
+    return model

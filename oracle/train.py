@@ -1,0 +1,98 @@
+"""ORACLE (test infrastructure): the reference's DAM training iteration restated in plain PyTorch fp32 (CPU),
+vectorised.  Pinned by tests/test_oracle_models.py against tests/golden/{losses,train_iter}.npz.
+
+Follows train_util_dam.py:54-311 (paths relative to /root/reference):
+  targets        :73-142  (label // 127, one-hot of the 3-class label, direction one-hot masked by SAMPLE 0's
+                           foreground - reference quirk :139, kept)
+  losses         :167-276 with loss.py:131-147 (DiceLoss), :150-176 (MulticlassDiceLoss), :181-199
+                 (Weight_DiceLoss), :202-260 (WeightMulticlassDiceLoss)
+  optimiser      utils.py:915-918: Adam(lr, betas=(0.9, 0.99), weight_decay) - L2 added to the gradient
+"""
+import torch
+import torch.nn.functional as F
+
+
+def dice_loss(p, t):                                   # loss.py:135-147
+    N = t.size(0)
+    pf, tf = p.reshape(N, -1), t.reshape(N, -1)
+    inter = (pf * tf).sum(1)
+    loss = 2 * (inter + 1) / (pf.sum(1) + tf.sum(1) + 1)
+    return 1 - loss.sum() / N
+
+
+def wdice_loss(p, t, w):                               # loss.py:185-199
+    N = t.size(0)
+    pf, tf, wf = p.reshape(N, -1), t.reshape(N, -1), w.reshape(N, -1)
+    inter = (pf * tf * wf).sum(1)
+    d = 2 * (inter + 1) / ((pf * wf).sum(1) + (tf * wf).sum(1) + 1)
+    return 1 - d.sum() / N
+
+
+def multiclass_dice(prob, onehot):                     # loss.py:160-176
+    return sum(dice_loss(prob[:, i], onehot[:, i]) for i in range(onehot.shape[1]))
+
+
+def weight_multiclass_dice(prob, onehot, w):           # loss.py:216-260
+    C = onehot.shape[1]
+    total = 0
+    for i in range(C):
+        if i == 0:
+            d = wdice_loss(prob[:, 0], onehot[:, 0], w) * 2
+        else:
+            prev = C - 1 if i == 1 else i - 1
+            nxt = 1 if i == C - 1 else i + 1
+            d = wdice_loss(prob[:, i], onehot[:, i], w)
+            d = d - (1 - wdice_loss(prob[:, i], onehot[:, prev], w)) - (1 - wdice_loss(prob[:, i], onehot[:, nxt], w))
+        total = total + d
+    return total / C
+
+
+def direction_onehot(direction, label, classes=9, quirk_sample0=True):
+    """train_util_dam.py:123-142.  direction int [B,H,W], label int [B,H,W] in {0,1,2}."""
+    B = direction.shape[0]
+    oh = torch.zeros((B, classes) + tuple(direction.shape[1:]), dtype=torch.float32)
+    for j in range(B):
+        uniq = torch.unique(direction[j])
+        if len(uniq) > 1:
+            m = (label[0] if quirk_sample0 else label[j]) != 0
+            for k in uniq.tolist():
+                oh[j, k] = ((direction[j] == k) & m).float()
+        else:
+            oh[j, 0] = (direction[j] == uniq[0]).float()
+    return oh
+
+
+def dam_losses(mask_logits, point_out, dir_logits, label, direction, point_target, weight_png, quirk_sample0=True):
+    """Returns dict of the five terms and the total (train_util_dam.py:167-276, default options)."""
+    w = weight_png.float().div(20)
+    if w.dim() == 4:
+        w = w.squeeze(1)
+    label = label.long()
+    direction = direction.long()
+    ce = (F.nll_loss(F.log_softmax(mask_logits, 1), label, reduction='none') * w).mean()
+    onehot3 = F.one_hot(label, 3).permute(0, 3, 1, 2).float()
+    dice = multiclass_dice(F.softmax(mask_logits, 1), onehot3)
+    dce = (F.nll_loss(F.log_softmax(dir_logits, 1), direction, reduction='none') * w).mean()
+    oh9 = direction_onehot(direction, label, dir_logits.shape[1], quirk_sample0)
+    wdice = weight_multiclass_dice(F.softmax(dir_logits, 1), oh9, w)
+    pt = point_target.float()
+    if pt.dim() == 3:
+        pt = pt.unsqueeze(1)
+    mse = F.mse_loss(point_out, pt)
+    total = ce + dice + dce + wdice + mse
+    return dict(ce=ce, dice=dice, dce=dce, wdice=wdice, mse=mse, total=total)
+
+
+def make_adam(model, lr=1e-3, weight_decay=1e-4):
+    return torch.optim.Adam(model.parameters(), lr=lr, betas=(0.9, 0.99), weight_decay=weight_decay)
+
+
+def train_iteration(model, optimizer, x, label, direction, point_target, weight_png):
+    """One reference iteration; returns the loss dict (floats)."""
+    model.train()
+    mask, point, dirn = model(x)
+    L = dam_losses(mask, point, dirn, label, direction, point_target, weight_png)
+    optimizer.zero_grad()
+    L['total'].backward()
+    optimizer.step()
+    return {k: float(v) for k, v in L.items()}
