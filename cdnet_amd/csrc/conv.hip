@@ -26,6 +26,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 namespace {
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+// storage formats: 0 = bf16 (activated tensors, gradients: MFMA operands), 1 = fp16 (raw pre-BatchNorm outputs and
+// residual branches: the consumer's affine must see more than bf16's 8 significant bits when |mean| >> std)
+__device__ __forceinline__ float ld16(unsigned short u, bool f16) { return f16 ? h2f(u) : bf2f(u); }
 __device__ __forceinline__ unsigned short f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
@@ -93,13 +98,13 @@ struct ChanXf {           // per-thread channel transform for its 8 channels of 
     bool on;
 };
 
-__device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, bool relu) {
+__device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, bool relu, bool f16) {
     V16 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float v = bf2f(raw.h[j]);
+        float v = ld16(raw.h[j], f16);
         if (t.on) v = fmaf(v, t.sc[j], t.sh[j]);
-        if (res) v += bf2f(res->h[j]);
+        if (res) v += ld16(res->h[j], f16);
         if (relu) v = fmaxf(v, 0.f);
         o.h[j] = f2bf(v);
     }
@@ -130,9 +135,11 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
         t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
     }
     const bool relu = s.relu != 0;
-    const bool plain = !t.on && !relu && s.res == nullptr;
+    const bool f16 = s.f16 != 0;
+    const bool plain = !t.on && !relu && s.res == nullptr && !f16;
     // logical source extent (after the optional 2x2 pool)
-    const int Hl = s.pool ? s.Hs / 2 : s.Hs, Wl = s.pool ? s.Ws / 2 : s.Ws;
+    // pool: 1 = floor mode (torchvision VGG 'M'), 2 = ceil mode (models/unet.py:19, partial windows at the edge)
+    const int Hl = s.pool ? (s.Hs + (s.pool == 2)) / 2 : s.Hs, Wl = s.pool ? (s.Ws + (s.pool == 2)) / 2 : s.Ws;
     const size_t img = (size_t)n * s.Hs * s.Ws;
     for (int v = tid; v < NPIX * VPP; v += 256) {
         const int pix = v / VPP;
@@ -147,16 +154,18 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
                 V16 raw;
                 raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
                 if (plain) val = raw;
-                else if (s.res) { V16 r; r.u = *reinterpret_cast<const uint4 *>(s.res + e); val = xform8(raw, &r, t, relu); }
-                else val = xform8(raw, nullptr, t, relu);
+                else if (s.res) { V16 r; r.u = *reinterpret_cast<const uint4 *>(s.res + e); val = xform8(raw, &r, t, relu, f16); }
+                else val = xform8(raw, nullptr, t, relu, f16);
             } else {
                 // maxpool 2x2 stride 2 of the transformed source (torchvision VGG 'M' layers / unet.py :19)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const size_t e = (img + (size_t)(2 * ys + (q >> 1)) * s.Ws + (2 * xs + (q & 1))) * s.C + cc0 + slot * 8;
+                    const int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
+                    if (q != 0 && (yy >= s.Hs || xx >= s.Ws)) continue;          // ceil-mode partial window
+                    const size_t e = (img + (size_t)yy * s.Ws + xx) * s.C + cc0 + slot * 8;
                     V16 raw;
                     raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
-                    V16 tv = plain ? raw : xform8(raw, nullptr, t, relu);
+                    V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
                     val = q == 0 ? tv : max8(val, tv);
                 }
             }
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
                 v += bias;
                 v = fmaf(v, osc, osh);
                 if (A.orelu) v = fmaxf(v, 0.f);
-                *reinterpret_cast<unsigned short *>(s_out + m * OSTR + col * 2) = f2bf(v);
+                *reinterpret_cast<unsigned short *>(s_out + m * OSTR + col * 2) = A.out_f16 ? f2h(v) : f2bf(v);
             }
         }
     }

@@ -8,6 +8,7 @@ struct ConvSrc {
     const float *scale;
     const float *shift;
     int C, Hs, Ws, pool, relu, off_y, off_x;
+    int f16, pad_;
 };
 
 struct ConvArgs {
@@ -24,6 +25,7 @@ struct ConvArgs {
     int N, H, W;
     int taps, npar, ostride, nchunk;
     int tile, CK, BN;
+    int out_f16;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");

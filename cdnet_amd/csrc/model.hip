@@ -16,6 +16,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
 }
+__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
 
 // x f32 [N][C][H][W] -> out bf16 [N][H][W][16]  (C <= 16)
 __global__ __launch_bounds__(256) void input_pack_kernel(const float *__restrict__ x, int N, int C, int plane,
@@ -90,6 +91,7 @@ struct HeadFeat {
     const float *scale;
     const float *shift;
     int relu;
+    int f16;
 };
 
 struct HeadW {            // 64-channel 1x1 heads, fp32
@@ -111,10 +113,10 @@ __device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const
         const unsigned short *hr = reinterpret_cast<const unsigned short *>(&rr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float x = bf2f(h[j]);
+            float x = f.f16 ? h2f(h[j]) : bf2f(h[j]);
             if (f.scale || ps || f.relu) {
                 if (f.scale) x = fmaf(x, s_sc[q * 8 + j], s_sh[q * 8 + j]);
-                if (ps) x += bf2f(hr[j]);
+                if (ps) x += f.f16 ? h2f(hr[j]) : bf2f(hr[j]);
                 if (f.relu) x = fmaxf(x, 0.f);
                 x = bf2f(f2bf(x));       // the convolutions consume the feature rounded to bf16; keep the head consistent
             }
@@ -239,7 +241,7 @@ extern "C" int cdnet_bn_finalize_train(const float *stats, int T, int C, float c
 
 static HeadFeat mk_feat(const cdnet_head_feat &f) {
     HeadFeat h;
-    h.raw = f.raw; h.res = f.res; h.scale = f.scale; h.shift = f.shift; h.relu = f.relu;
+    h.raw = f.raw; h.res = f.res; h.scale = f.scale; h.shift = f.shift; h.relu = f.relu; h.f16 = f.f16;
     return h;
 }
 

@@ -11,7 +11,7 @@ from . import _lib
 class ConvSrc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('res', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
                 ('C', C.c_int), ('Hs', C.c_int), ('Ws', C.c_int), ('pool', C.c_int), ('relu', C.c_int),
-                ('off_y', C.c_int), ('off_x', C.c_int)]
+                ('off_y', C.c_int), ('off_x', C.c_int), ('f16', C.c_int), ('pad_', C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -19,7 +19,8 @@ class ConvArgs(C.Structure):
                 ('oscale', C.c_void_p), ('oshift', C.c_void_p), ('orelu', C.c_int), ('out', C.c_void_p),
                 ('Cout', C.c_int), ('out_cstride', C.c_int), ('out_coff', C.c_int), ('stats', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
-                ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int)]
+                ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
+                ('out_f16', C.c_int)]
 
 
 def _dp(t):
@@ -30,8 +31,13 @@ class Src:
     """One convolution source: an NHWC bf16 tensor [N,Hs,Ws,C] plus the producer's lazily-applied transform."""
 
     def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0)):
-        assert x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+        assert x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.is_contiguous()
+        assert res is None or res.dtype == x.dtype
         self.x, self.scale, self.shift, self.relu, self.pool, self.res, self.off = x, scale, shift, relu, pool, res, off
+
+    @property
+    def f16(self):
+        return self.x.dtype == torch.float16
 
     @property
     def C(self):
@@ -39,7 +45,10 @@ class Src:
 
     def logical_hw(self):
         h, w = self.x.shape[1], self.x.shape[2]
-        return (h // 2, w // 2) if self.pool else (h, w)
+        if self.pool:                      # 1/True: floor mode, 2: ceil mode
+            c = 1 if int(self.pool) == 2 else 0
+            return ((h + c) // 2, (w + c) // 2)
+        return (h, w)
 
 
 _SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 128), (16, 64, 64),
@@ -104,7 +113,7 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
     tile, CK, BN = cfg
     s0 = srcs[0]
@@ -125,10 +134,11 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
         a.src[i].C, a.src[i].Hs, a.src[i].Ws = s.C, s.x.shape[1], s.x.shape[2]
         a.src[i].pool, a.src[i].relu = int(s.pool), int(s.relu)
         a.src[i].off_y, a.src[i].off_x = s.off
+        a.src[i].f16 = int(s.f16)
         nchunk += s.C // CK
     a.nsrc = len(srcs)
     if out is None:
-        out = torch.empty((N, H * ostride, W * ostride, Cout), dtype=torch.bfloat16, device=s0.x.device)
+        out = torch.empty((N, H * ostride, W * ostride, Cout), dtype=out_dtype, device=s0.x.device)
     ntiles = ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
     if stats is True:
         stats = torch.empty((N * npar * ntiles, 2, Cout), dtype=torch.float32, device=s0.x.device)
@@ -139,5 +149,6 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.N, a.H, a.W = N, H, W
     a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
     a.tile, a.CK, a.BN = tile, CK, BN
+    a.out_f16 = int(out.dtype == torch.float16)
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

@@ -1,0 +1,215 @@
+"""`Unet` - the default CDNet model `UNet2RevA1_vgg16` (VGG16-BN encoder, transposed-conv decoder, direction-aware
+mask head), host-side mirror of the reference's models/dam/model_unet_rev1.py:180-320.
+
+Same constructor arguments, same `forward(x) -> (mask, point, direction)` (float32 NCHW), same state_dict key
+names (backbone.N.*, upsample_blocks.i.{up,bn1,conv2,bn2}.*, {mask,direction,point}_feature.*, point_conv,
+directionAtt.Conv1x1, direction_conv, maskAtt.Conv1x1, mask_conv and the reference's never-used final_conv /
+child0 / child_conv1) - so checkpoints interchange.  The torch.nn modules below are PARAMETER CONTAINERS ONLY:
+forward() never calls them; every convolution / BatchNorm / ReLU / pool / concat / head op runs in the HIP
+kernels of libcdnet_hip.so through cdnet_amd.runtime (NHWC bf16 activations, fp32 accumulation).  There is no
+CPU or eager fallback: forward() on a non-CUDA tensor raises.
+"""
+import torch
+import torch.nn as nn
+
+from ... import _lib, runtime
+from ...runtime import ConvLayer, Src, pooled, pad_offsets
+
+VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+def vgg16_bn_features():
+    """torchvision.models.vgg16_bn().features layout (children '0'..'43'), as parameter containers."""
+    layers, c = [], 3
+    for v in VGG16_CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+            c = v
+    return nn.Sequential(*layers)
+
+
+class revAttention(nn.Module):                # model_unet_rev1.py:8-17 (weights only; fused into the head kernel)
+    def __init__(self, in_channels):
+        super().__init__()
+        self.Conv1x1 = nn.Conv2d(in_channels, 1, kernel_size=1, bias=False)
+
+
+def get_backbone(name, pretrained=True):
+    """model_unet_rev1.py:22-83 for the one backbone the CDNet path uses.  There is no network access for the
+    ImageNet weights: load them through load_state_dict (keys backbone.N.*)."""
+    if name != 'vgg16_bn':
+        raise NotImplementedError('{} backbone model is not implemented so far.'.format(name))
+    return vgg16_bn_features(), ['5', '12', '22', '32', '42'], '43'
+
+
+class UpsampleBlock(nn.Module):               # model_unet_rev1.py:86-143, parametric branch
+    def __init__(self, ch_in, ch_out=None, skip_in=0, use_bn=True, parametric=True):
+        super().__init__()
+        assert parametric and use_bn, 'only the parametric (transposed-conv) + BatchNorm decoder is on the CDNet path'
+        self.up = nn.ConvTranspose2d(ch_in, ch_out, kernel_size=(4, 4), stride=2, padding=1, output_padding=0, bias=False)
+        self.bn1 = nn.BatchNorm2d(ch_out)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(ch_out + skip_in, ch_out, kernel_size=(3, 3), stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(ch_out)
+
+
+class ResidualUnit(nn.Module):                # model_unet_rev1.py:150-170
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv_1x1 = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+
+class _RU:
+    """runtime view of a ResidualUnit: three ConvLayers"""
+
+    def __init__(self, name, m):
+        self.c1 = ConvLayer(name + '.conv1', 'conv3', m.conv1.weight, None, m.bn1)
+        self.c2 = ConvLayer(name + '.conv2', 'conv3', m.conv2.weight, None, m.bn2)
+        self.cr = ConvLayer(name + '.conv_1x1', 'conv1', m.conv_1x1.weight, m.conv_1x1.bias, None)
+
+    def layers(self):
+        return [self.c1, self.c2, self.cr]
+
+    def forward(self, x, training):
+        # the pre-activation pair (bn2 output, residual) is kept in fp16: it is only ever read through the consumer's
+        # add+ReLU transform, never as an MFMA operand
+        r = self.cr.forward([x], training, out_dtype=torch.float16)               # residual = conv_1x1(x)   (:162)
+        h = self.c1.forward([x], training, relu=True)                             # relu1(bn1(conv1(x)))     (:163-165)
+        y = self.c2.forward([h], training, relu=False, out_dtype=torch.float16)   # bn2(conv2(.))            (:166-167)
+        return Src(y.x, y.scale, y.shift, relu=True, res=r.x)    # relu2(out + residual)             (:168-169)
+
+
+class Unet(nn.Module):
+
+    def __init__(self, backbone_name='vgg16_bn', pretrained=True, encoder_freeze=False, classes=21,
+                 decoder_filters=(256, 128, 64, 32, 16), parametric_upsampling=True, shortcut_features='default',
+                 decoder_use_batchnorm=True):
+        super().__init__()
+        self.backbone_name = backbone_name
+        self.backbone, self.shortcut_features, self.bb_out_name = get_backbone(backbone_name, pretrained=pretrained)
+        shortcut_chs, bb_out_chs = [64, 128, 256, 512, 512], 512       # infer_skip_channels (:289-305) for vgg16_bn
+        decoder_filters = decoder_filters[:len(self.shortcut_features)]
+        decoder_filters_in = [bb_out_chs] + list(decoder_filters[:-1])
+        num_blocks = len(self.shortcut_features)
+        self.upsample_blocks = nn.ModuleList()
+        for i, (fin, fout) in enumerate(zip(decoder_filters_in, decoder_filters)):
+            self.upsample_blocks.append(UpsampleBlock(fin, fout, skip_in=shortcut_chs[num_blocks - i - 1],
+                                                      parametric=parametric_upsampling, use_bn=decoder_use_batchnorm))
+        self.final_conv = nn.Conv2d(decoder_filters[-1], classes, kernel_size=(1, 1))          # never used (:213)
+        self.replaced_conv1 = False
+        self.child0 = nn.Conv2d(1, 64, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1))       # never used (:220)
+        self.child_conv1 = nn.Conv2d(1, 64, kernel_size=(7, 7), stride=(2, 2), padding=(3, 3), bias=False)
+        self.mask_feature = ResidualUnit(decoder_filters[-1], 64)
+        self.direction_feature = ResidualUnit(64, 64)
+        self.point_feature = ResidualUnit(64, 64)
+        self.point_conv = nn.Conv2d(64, 1, kernel_size=1)
+        self.directionAtt = revAttention(1)
+        self.direction_conv = nn.Conv2d(64, 9, kernel_size=1)
+        self.maskAtt = revAttention(9)
+        self.mask_conv = nn.Conv2d(64, 3, kernel_size=1)
+        if encoder_freeze:
+            self.freeze_encoder()
+        self._rt = None
+        self._head_w = None
+        self._head_ver = None
+
+    def freeze_encoder(self):
+        for p in self.backbone.parameters():
+            p.requires_grad = False
+
+    # parameters that never take part in forward for 3-channel input: no gradient, excluded from DDP
+    UNUSED_PREFIXES = ('final_conv.', 'child0.', 'child_conv1.')
+
+    # ---------------------------------------------------------------------------------------------------
+    def _build_runtime(self):
+        enc, i = [], 0
+        mods = list(self.backbone.children())
+        while i < len(mods):
+            if isinstance(mods[i], nn.Conv2d):
+                enc.append(('conv', ConvLayer('backbone.%d' % i, 'conv3', mods[i].weight, mods[i].bias, mods[i + 1]), str(i + 2)))
+                i += 3
+            else:
+                enc.append(('pool', None, str(i)))
+                i += 1
+        dec = []
+        for k, b in enumerate(self.upsample_blocks):
+            dec.append((ConvLayer('upsample_blocks.%d.up' % k, 'convT4', b.up.weight, None, b.bn1),
+                        ConvLayer('upsample_blocks.%d.conv2' % k, 'conv3', b.conv2.weight, None, b.bn2)))
+        self._rt = dict(enc=enc, dec=dec, ru=[_RU('mask_feature', self.mask_feature),
+                                               _RU('direction_feature', self.direction_feature),
+                                               _RU('point_feature', self.point_feature)])
+
+    def conv_layers(self):
+        if self._rt is None:
+            self._build_runtime()
+        out = [l for kind, l, _ in self._rt['enc'] if kind == 'conv']
+        for up, c2 in self._rt['dec']:
+            out += [up, c2]
+        for ru in self._rt['ru']:
+            out += ru.layers()
+        return out
+
+    def head_weight_block(self):
+        """f32 device block in the CDNET_HEAD_WEIGHT_FLOATS layout (include/cdnet_hip.h)"""
+        ps = [self.point_conv.weight, self.direction_conv.weight, self.mask_conv.weight, self.point_conv.bias,
+              self.direction_conv.bias, self.mask_conv.bias, self.directionAtt.Conv1x1.weight, self.maskAtt.Conv1x1.weight]
+        ver = tuple(p._version for p in ps)
+        if self._head_w is None or self._head_ver != ver:
+            with torch.no_grad():
+                self._head_w = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+            assert self._head_w.numel() == 855
+            self._head_ver = ver
+        return self._head_w
+
+    def forward_features(self, x, training):
+        """runs the encoder/decoder/residual units; returns the three head features as Src"""
+        if self._rt is None:
+            self._build_runtime()
+        if not x.is_cuda:
+            raise RuntimeError('cdnet_amd.models.dam.model_unet_rev1.Unet runs on the MI355X only (no CPU fallback)')
+        assert x.shape[1] == 3, 'the CDNet path feeds 3-channel tiles (child0/child_conv1 branches are never taken)'
+        t = Src(runtime.input_pack(x.float()))
+        feats = {}
+        for kind, layer, out_name in self._rt['enc']:              # forward_backbone (:268-287)
+            if kind == 'conv':
+                t = layer.forward([t], training)
+            else:
+                t = pooled(t)
+            if out_name in self.shortcut_features:
+                feats[out_name] = t
+            if out_name == self.bb_out_name:
+                break
+        for skip_name, (up, conv2) in zip(self.shortcut_features[::-1], self._rt['dec']):   # :250-252
+            skip = feats[skip_name]
+            u = up.forward([t], training)                           # relu(bn1(up(x)))   (:119-123)
+            sh, sw = skip.logical_hw()
+            uh, uw = u.logical_hw()
+            u.off = pad_offsets((uh, uw), (sh, sw))                # F.pad (:126-131)
+            t = conv2.forward([u, skip], training, H=sh, W=sw)      # cat([x, skip]) -> conv2 -> bn2 -> relu (:133-141)
+        f1 = self._rt['ru'][0].forward(t, training)
+        f2 = self._rt['ru'][1].forward(f1, training)
+        f3 = self._rt['ru'][2].forward(f2, training)
+        return f1, f2, f3
+
+    def forward(self, *input):
+        x = input[0]
+        f1, f2, f3 = self.forward_features(x, self.training)
+        N, H, W, _ = f1.x.shape
+        dev = x.device
+        mask = torch.empty((N, 3, H, W), dtype=torch.float32, device=dev)
+        point = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+        direction = torch.empty((N, 9, H, W), dtype=torch.float32, device=dev)
+        hf = [runtime.head_feat(f) for f in (f1, f2, f3)]
+        import ctypes as C
+        _lib.call('cdnet_dam_head_forward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(self.head_weight_block()),
+                  N, H, W, _lib.ptr(mask), _lib.ptr(point), _lib.ptr(direction), _lib.stream_ptr())
+        self._last_feats = (f1, f2, f3)
+        return mask, point, direction

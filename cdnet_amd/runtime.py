@@ -1,0 +1,155 @@
+"""Execution runtime of the convolutional networks on the HIP kernels.
+
+A network (cdnet_amd/models/...) owns its parameters as fp32 torch tensors with the reference's state_dict names;
+this module turns them into packed bf16 MFMA weights and drives the C-ABI calls.  Nothing here computes on torch
+tensors: torch is the allocator / stream provider.
+
+Activation convention: NHWC bf16.  A tensor handed from layer to layer is an `engine.Src`: the stored tensor plus
+the producer's not-yet-applied per-channel affine / residual / ReLU / 2x2 max-pool, which the consumer's staging
+code applies on the fly.  In eval mode convolutions fold BatchNorm into their epilogue and store activated values;
+in train mode they store the raw convolution output and emit BN statistics, and consumers apply
+relu(raw*scale+shift).
+"""
+import ctypes as C
+import torch
+
+from . import _lib, engine
+from .engine import Src
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class HeadFeat(C.Structure):
+    _fields_ = [('raw', C.c_void_p), ('res', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('relu', C.c_int), ('f16', C.c_int)]
+
+
+def head_feat(s):
+    assert not s.pool and s.off == (0, 0) and s.C == 64
+    f = HeadFeat()
+    f.raw, f.res = s.x.data_ptr(), (None if s.res is None else s.res.data_ptr())
+    f.scale = None if s.scale is None else s.scale.data_ptr()
+    f.shift = None if s.shift is None else s.shift.data_ptr()
+    f.relu = int(s.relu)
+    f.f16 = int(s.f16)
+    return f
+
+
+class ConvLayer:
+    """One convolution (optionally followed by BatchNorm) of a network."""
+
+    def __init__(self, name, kind, weight, bias=None, bn=None, cfg_override=None):
+        assert kind in ('conv3', 'conv1', 'convT4', 'convT2')
+        self.name, self.kind, self.weight, self.bias, self.bn = name, kind, weight, bias, bn
+        self.cfg_override = cfg_override
+        if kind in ('conv3', 'conv1'):
+            self.Cout, self.Cin = weight.shape[0], weight.shape[1]
+        else:
+            self.Cin, self.Cout = weight.shape[0], weight.shape[1]
+        self.taps = {'conv3': 9, 'conv1': 1, 'convT4': 4, 'convT2': 1}[kind]
+        self.transposed = kind in ('convT4', 'convT2')
+        self.pack_mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3}[kind]
+        self.cfg = None
+        self.wp = None
+        self.wp_version = None
+        self.fold = None                       # eval-mode (scale, shift)
+        self.fold_version = None
+        dev = weight.device
+        if bn is not None:
+            self.scale = torch.empty((self.Cout,), dtype=torch.float32, device=dev)
+            self.shift = torch.empty((self.Cout,), dtype=torch.float32, device=dev)
+            self.save_mean = torch.empty((self.Cout,), dtype=torch.float32, device=dev)
+            self.save_invstd = torch.empty((self.Cout,), dtype=torch.float32, device=dev)
+        self.stats = None
+        self.saved = None                      # (srcs, raw, H, W) of the last training forward
+
+    # -- weights ------------------------------------------------------------------------------------
+    def _version(self):
+        v = self.weight._version
+        if self.bias is not None:
+            v = (v, self.bias._version)
+        return v
+
+    def prepare(self, src_channels, H, W):
+        cin_total = sum(src_channels)
+        if self.cfg is None:
+            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override)
+        ver = self.weight._version
+        if self.wp is None or self.wp_version != ver:
+            pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16
+            self.wp = engine.pack_weights(self.weight.detach(), self.cfg, self.pack_mode, Cin_pad=pad, out=self.wp)
+            self.wp_version = ver
+
+    def eval_fold(self):
+        bn = self.bn
+        ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               None if self.bias is None else self.bias._version)
+        if self.fold is None or self.fold_version != ver:
+            if self.fold is None:
+                self.fold = (torch.empty_like(self.scale), torch.empty_like(self.shift))
+            _lib.call('cdnet_bn_fold_eval', _lib.ptr(bn.weight.detach()), _lib.ptr(bn.bias.detach()),
+                      _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                      None if self.bias is None else _lib.ptr(self.bias.detach()), BN_EPS, self.Cout,
+                      _lib.ptr(self.fold[0]), _lib.ptr(self.fold[1]), _lib.stream_ptr())
+            self.fold_version = ver
+        return self.fold
+
+    # -- forward ------------------------------------------------------------------------------------
+    def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=torch.bfloat16):
+        """Returns the output as a Src (lazy transform attached in train mode).  Raw (pre-BatchNorm) outputs of the
+        training path are stored as fp16: the consumer's affine needs more than bf16's 8 significant bits."""
+        if H is None:
+            H, W = srcs[0].logical_hw()
+        self.prepare([s.C for s in srcs], H, W)
+        bias = None if self.bias is None else self.bias.detach()
+        if self.bn is None:
+            out, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, bias=bias, H=H, W=W,
+                                         out_dtype=out_dtype)
+            if training:
+                self.saved = (srcs, out, H, W)
+            return Src(out)
+        if not training:
+            sc, sh = self.eval_fold()
+            out, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, oscale=sc,
+                                         oshift=sh, orelu=relu, H=H, W=W, out_dtype=out_dtype)
+            return Src(out)
+        tile = self.cfg[0]
+        N = srcs[0].x.shape[0]
+        npar = 4 if self.transposed else 1
+        T = N * npar * ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
+        if self.stats is None or self.stats.shape[0] != T:
+            self.stats = torch.empty((T, 2, self.Cout), dtype=torch.float32, device=self.weight.device)
+        raw, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, stats=self.stats,
+                                     H=H, W=W, out_dtype=torch.float16)
+        count = float(N * H * W * npar)
+        bn = self.bn
+        _lib.call('cdnet_bn_finalize_train', _lib.ptr(self.stats), T, self.Cout, count, _lib.ptr(bn.weight.detach()),
+                  _lib.ptr(bn.bias.detach()), None if bias is None else _lib.ptr(bias), BN_EPS, BN_MOMENTUM,
+                  _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(self.scale), _lib.ptr(self.shift),
+                  _lib.ptr(self.save_mean), _lib.ptr(self.save_invstd), _lib.stream_ptr())
+        self.saved = (srcs, raw, H, W)
+        return Src(raw, self.scale, self.shift, relu=relu)
+
+
+def input_pack(x):
+    """f32 NCHW [N,C<=16,H,W] cuda -> bf16 NHWC [N,H,W,16]"""
+    assert x.dtype == torch.float32 and x.is_cuda and x.dim() == 4
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, H, W, 16), dtype=torch.bfloat16, device=x.device)
+    _lib.call('cdnet_input_pack', _lib.ptr(x), N, Cc, H, W, _lib.ptr(out), _lib.stream_ptr())
+    return out
+
+
+def pooled(s, ceil_mode=False):
+    """The 2x2 max-pooled view of a Src (nn.MaxPool2d(2,2[,ceil_mode]) applied after the Src's own transform)."""
+    assert not s.pool and s.res is None
+    return Src(s.x, s.scale, s.shift, relu=s.relu, pool=2 if ceil_mode else 1)
+
+
+def pad_offsets(small_hw, big_hw):
+    """F.pad(x, (dx//2, dx-dx//2, dy//2, dy-dy//2)) of model_unet_rev1.py:128-131 / unet.py:42-46 as (off_y, off_x)"""
+    dy, dx = big_hw[0] - small_hw[0], big_hw[1] - small_hw[1]
+    assert dy >= 0 and dx >= 0
+    return (dy // 2, dx // 2)

@@ -107,7 +107,7 @@ int cdnet_cc_chain(const uint8_t *pred, int fg_value, int N, int H, int W, int m
  * max-pool and an F.pad offset - all applied while the input tile is staged, never as separate passes.
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct cdnet_conv_src {
-    const uint16_t *x;      /* bf16 NHWC [N][Hs][Ws][C] */
+    const uint16_t *x;      /* 16-bit NHWC [N][Hs][Ws][C] (bf16, or fp16 when f16 = 1) */
     const uint16_t *res;    /* optional bf16 tensor of the same shape added before the ReLU (ResidualUnit) */
     const float *scale;     /* optional per-channel affine of the producer (BN): v*scale[c]+shift[c] */
     const float *shift;
@@ -116,6 +116,8 @@ typedef struct cdnet_conv_src {
     int pool;               /* 1: logical input = maxpool2x2(transformed source), size Hs/2 x Ws/2 */
     int relu;
     int off_y, off_x;       /* F.pad: logical (y,x) reads source (y-off_y, x-off_x); outside -> 0 */
+    int f16;                /* storage of x / res: 0 = bf16, 1 = fp16 (raw pre-BatchNorm outputs, residual branches) */
+    int pad_;
 } cdnet_conv_src;
 
 typedef struct cdnet_conv_args {
@@ -136,6 +138,7 @@ typedef struct cdnet_conv_args {
     int ostride;            /* 1, or 2 for the transposed convolutions */
     int nchunk;             /* total Cin chunks over both sources */
     int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
+    int out_f16;            /* 1: store the output as fp16 instead of bf16 */
 } cdnet_conv_args;
 
 /* packed element count for a weight tensor; nchunk = Cin/CK over all sources */
@@ -168,12 +171,12 @@ int cdnet_bn_finalize_train(const float *stats, int T, int C, float count, const
 
 /* A 64-channel head feature F = [relu](raw*scale + shift + res), recomputed on the fly from its stored pieces. */
 typedef struct cdnet_head_feat {
-    const uint16_t *raw;    /* bf16 NHWC [N][H][W][64] */
-    const uint16_t *res;    /* optional bf16 residual, same shape */
+    const uint16_t *raw;    /* 16-bit NHWC [N][H][W][64] */
+    const uint16_t *res;    /* optional residual, same shape and format */
     const float *scale;     /* optional per-channel affine */
     const float *shift;
     int relu;
-    int pad_;
+    int f16;                /* 0: raw/res are bf16, 1: fp16 */
 } cdnet_head_feat;
 
 /* Direction-aware-mask head: replaces models/dam/model_unet_rev1.py:258-263 (point_conv, directionAtt,
