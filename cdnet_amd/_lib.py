@@ -30,6 +30,15 @@ SIGNATURES = {
     'cdnet_bn_finalize_train': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_dam_head_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_final_conv1x1': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_conv_wgrad_slab_floats': (_sz, [_i] * 6),
+    'cdnet_conv_backward_weight': (_i, [_vp, _i, _i, _i, _vp] + [_i] * 9 + [_vp, _vp, _i, _vp]),
+    'cdnet_bn_backward_workspace_floats': (_sz, [_i]),
+    'cdnet_bn_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    'cdnet_dam_head_backward_workspace_floats': (_sz, []),
+    'cdnet_dam_head_backward': (_i, [_vp] * 7 + [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'cdnet_dam_loss_workspace_floats': (_sz, [_i, _i]),
+    'cdnet_dam_loss': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 
 _lib = None

@@ -81,9 +81,21 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, unsigned short 
                 int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
                 int kw = b == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
                 v = w[(((size_t)ci * Cout + co) * 4 + kh) * 4 + kw];
-            } else {
+            } else if (mode == 3) {
                 int a = parity >> 1, b = parity & 1;
                 v = w[(((size_t)ci * Cout + co) * 2 + a) * 2 + b];
+            } else {
+                // modes 4/5: backward-data of a stride-2 transposed convolution as a convolution over the space-to-depth
+                // view of the output gradient.  GEMM "cin" ci = a*(2*Ct) + b*Ct + c (row parity a = source, column parity
+                // b, channel c of the transposed conv's Ct out_channels); GEMM "cout" co = its in_channel.
+                const int Ct = Cin / 4;
+                const int a = ci / (2 * Ct), b = (ci / Ct) & 1, c = ci % Ct;
+                if (mode == 4) {
+                    const int kh = 2 * (tap / 3) + a - 1, kw = 2 * (tap % 3) + b - 1;      // 3x3 taps (ky, kx)
+                    if (kh >= 0 && kh < 4 && kw >= 0 && kw < 4) v = w[(((size_t)co * Ct + c) * 4 + kh) * 4 + kw];
+                } else {
+                    v = w[(((size_t)co * Ct + c) * 2 + a) * 2 + b];
+                }
             }
         }
         out[i] = f2bf(v);
@@ -140,7 +152,8 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
     // logical source extent (after the optional 2x2 pool)
     // pool: 1 = floor mode (torchvision VGG 'M'), 2 = ceil mode (models/unet.py:19, partial windows at the edge)
     const int Hl = s.pool ? (s.Hs + (s.pool == 2)) / 2 : s.Hs, Wl = s.pool ? (s.Ws + (s.pool == 2)) / 2 : s.Ws;
-    const size_t img = (size_t)n * s.Hs * s.Ws;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;      // elements per row
+    const size_t img = (size_t)n * s.Hs * rs;
     for (int v = tid; v < NPIX * VPP; v += 256) {
         const int pix = v / VPP;
         const int hy = pix / HW_, hx = pix - hy * HW_;
@@ -150,7 +163,7 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
         const int ys = y - s.off_y, xs = x - s.off_x;
         if (y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
             if (!s.pool) {
-                const size_t e = (img + (size_t)ys * s.Ws + xs) * s.C + cc0 + slot * 8;
+                const size_t e = img + (size_t)ys * rs + (size_t)xs * s.C + cc0 + slot * 8;
                 V16 raw;
                 raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
                 if (plain) val = raw;
@@ -162,7 +175,7 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
                 for (int q = 0; q < 4; ++q) {
                     const int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
                     if (q != 0 && (yy >= s.Hs || xx >= s.Ws)) continue;          // ceil-mode partial window
-                    const size_t e = (img + (size_t)yy * s.Ws + xx) * s.C + cc0 + slot * 8;
+                    const size_t e = img + (size_t)yy * rs + (size_t)xx * s.C + cc0 + slot * 8;
                     V16 raw;
                     raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
                     V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
@@ -342,11 +355,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
                 const int oy = y * A.ostride + pa, ox = x * A.ostride + pb;
                 const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
                 unsigned short *dst = A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co;
-                if (co + 8 <= A.Cout) *reinterpret_cast<uint4 *>(dst) = val;
-                else {
-                    const unsigned short *hv = reinterpret_cast<const unsigned short *>(&val);
-                    for (int j = 0; j < 8 && co + j < A.Cout; ++j) dst[j] = hv[j];
-                }
+                *reinterpret_cast<uint4 *>(dst) = val;               // Cout % 8 == 0 (checked by the ABI entry)
             }
         }
     }
@@ -400,7 +409,7 @@ extern "C" int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, i
                                        int mode, void *stream) {
     CDNET_REQUIRE(w && packed, "cdnet_pack_conv_weights: null pointer");
     CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0, "cdnet_pack_conv_weights: Cin=%d CK=%d BN=%d", Cin, CK, BN);
-    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : KH * KW);
+    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : (mode == 4 ? 9 : (mode == 5 ? 1 : KH * KW)));
     const int npar = (mode == 2 || mode == 3) ? 4 : 1;
     const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
     const size_t per = (size_t)ntile * nchunk * taps * CK * BN;
@@ -417,7 +426,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     CDNET_REQUIRE(args, "cdnet_conv_forward: null args");
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && A.out, "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
-    CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0, "cdnet_conv_forward: bad size");
+    CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0 && A.Cout % 8 == 0, "cdnet_conv_forward: bad size (Cout must be a multiple of 8)");
     int nchunk = 0;
     for (int i = 0; i < A.nsrc; ++i) {
         CDNET_REQUIRE(A.src[i].x && A.src[i].C % A.CK == 0, "cdnet_conv_forward: source %d channels %d not a multiple of CK=%d",

@@ -8,7 +8,7 @@ struct ConvSrc {
     const float *scale;
     const float *shift;
     int C, Hs, Ws, pool, relu, off_y, off_x;
-    int f16, pad_;
+    int f16, row_stride;
 };
 
 struct ConvArgs {

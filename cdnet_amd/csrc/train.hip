@@ -1,0 +1,820 @@
+// Training-only streaming kernels (HBM-bound): BatchNorm/ReLU/max-pool backward, the DAM head backward, the five-term
+// CDNet loss with its gradient, and the fused Adam step.  Everything reduces through per-block partials that are
+// summed in a fixed order, so a training step is bit-reproducible.
+//
+// Replaces, in the reference's train_util_dam.py:
+//   loss terms :167-276 with loss.py:131-260 (dice / weighted cyclic dice), nn.NLLLoss(reduction='none') x weight map,
+//   nn.MSELoss; loss.backward() :307 (non-convolution parts); optimizer.step() :308 with utils.py:915-918 (Adam).
+#include "common.h"
+
+using namespace cdnet;
+
+namespace {
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ float ld16(unsigned short u, bool f16) { return f16 ? h2f(u) : bf2f(u); }
+
+union V16 {
+    uint4 u;
+    unsigned short h[8];
+};
+
+inline int lin_grid(size_t total, int cap = 2048) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+// out[k] = sum_b partial[b][k]  (fixed order)
+__global__ void reduce_partials_kernel(const float *__restrict__ partial, int nb, int K, float *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * K + k];
+    out[k] = s;
+}
+
+// ======================================================================================================
+// BatchNorm + ReLU (+ residual) (+ consumers' max-pool / F.pad) backward
+// ======================================================================================================
+struct GradIn {
+    const unsigned short *g;     // bf16 NHWC [N][Hg][Wg][C]: gradient w.r.t. this tensor as seen by one consumer
+    int Hg, Wg;
+    int oy, ox;                  // consumer read (y - oy, x - ox) of this tensor  => gradient sits at (y + oy, x + ox)
+    int pooled;                  // consumer read maxpool2x2 of this tensor (1 floor / 2 ceil): route to the argmax
+    int coff, cstride;           // channel slice of a wider gradient tensor
+};
+
+struct BnBwdArgs {
+    const unsigned short *raw;   // stored forward output [N][H][W][C]
+    const unsigned short *res;   // optional residual added before the ReLU
+    int f16;                     // storage format of raw/res
+    const float *scale, *shift;  // forward affine (NULL: identity)
+    int relu;
+    const float *mean, *invstd;  // saved batch statistics
+    GradIn gin[3];
+    int ngin;
+    int N, H, W, C;
+    float *partial;              // reduce: [nblocks][2][C]
+    const float *k1, *k2, *k3;   // apply: draw = k1*(dz - k2 - xhat*k3)
+    unsigned short *draw;        // bf16 [N][H][W][C]
+    unsigned short *dz_out;      // optional bf16 copy of dz (gradient of the residual branch)
+};
+
+// activated value (rounded to bf16 like the forward staging does) of 8 channels at one pixel
+__device__ __forceinline__ void act8(const BnBwdArgs &A, size_t e, const float *sc, const float *sh, float *a, float *rawf) {
+    V16 r, rr;
+    r.u = *reinterpret_cast<const uint4 *>(A.raw + e);
+    rr.u = make_uint4(0, 0, 0, 0);
+    if (A.res) rr.u = *reinterpret_cast<const uint4 *>(A.res + e);
+    const bool f16 = A.f16 != 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = ld16(r.h[j], f16);
+        if (rawf) rawf[j] = x;
+        float v = A.scale ? fmaf(x, sc[j], sh[j]) : x;
+        if (A.res) v += ld16(rr.h[j], f16);
+        if (A.relu) v = fmaxf(v, 0.f);
+        a[j] = bf2f(f2bf(v));
+    }
+}
+
+// dz for 8 channels of pixel (n,y,x); also returns xhat
+template <bool WANT_XHAT>
+__device__ __forceinline__ void dz8(const BnBwdArgs &A, int n, int y, int x, int c0, const float *sc, const float *sh,
+                                    const float *mu, const float *is, float *dz, float *xhat) {
+    const size_t e = (((size_t)n * A.H + y) * A.W + x) * A.C + c0;
+    float a[8], rawf[8];
+    act8(A, e, sc, sh, a, rawf);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    for (int k = 0; k < A.ngin; ++k) {
+        const GradIn &gi = A.gin[k];
+        if (!gi.pooled) {
+            const int yy = y + gi.oy, xx = x + gi.ox;
+            if (yy >= 0 && yy < gi.Hg && xx >= 0 && xx < gi.Wg) {
+                V16 v;
+                v.u = *reinterpret_cast<const uint4 *>(gi.g + (((size_t)n * gi.Hg + yy) * gi.Wg + xx) * gi.cstride + gi.coff + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] += bf2f(v.h[j]);
+            }
+        } else {
+            const int py = y >> 1, px = x >> 1;
+            if (py < gi.Hg && px < gi.Wg) {
+                // is (y,x) the first maximum of its 2x2 window?  (nn.MaxPool2d backward)
+                bool sel[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sel[j] = true;
+                const int q0 = (y & 1) * 2 + (x & 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q == q0) continue;
+                    const int yy = (y & ~1) + (q >> 1), xx = (x & ~1) + (q & 1);
+                    if (yy >= A.H || xx >= A.W) continue;
+                    float b[8];
+                    act8(A, (((size_t)n * A.H + yy) * A.W + xx) * A.C + c0, sc, sh, b, nullptr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sel[j] = sel[j] && (q < q0 ? a[j] > b[j] : a[j] >= b[j]);
+                }
+                V16 v;
+                v.u = *reinterpret_cast<const uint4 *>(gi.g + (((size_t)n * gi.Hg + py) * gi.Wg + px) * gi.cstride + gi.coff + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] += sel[j] ? bf2f(v.h[j]) : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dz[j] = (A.relu && !(a[j] > 0.f)) ? 0.f : g[j];
+        if (WANT_XHAT) xhat[j] = A.mean ? (rawf[j] - mu[j]) * is[j] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void load8(const float *p, int c0, float *o, float dflt) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = p ? p[c0 + j] : dflt;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
+    __shared__ float s_red[256][17];
+    const int VPP = A.C / 8;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 8;
+    float sc[8], sh[8], mu[8], is[8];
+    load8(A.scale, c0, sc, 1.f); load8(A.shift, c0, sh, 0.f); load8(A.mean, c0, mu, 0.f); load8(A.invstd, c0, is, 1.f);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const size_t npix = (size_t)A.N * A.H * A.W;
+    const size_t ppb = 256 / VPP;                                   // pixels per block per iteration
+    for (size_t p = (size_t)blockIdx.x * ppb + tid / VPP; p < npix; p += (size_t)gridDim.x * ppb) {
+        const int n = (int)(p / ((size_t)A.H * A.W));
+        const int r = (int)(p - (size_t)n * A.H * A.W);
+        float dz[8], xh[8];
+        dz8<true>(A, n, r / A.W, r % A.W, c0, sc, sh, mu, is, dz, xh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += dz[j]; s2[j] = fmaf(dz[j], xh[j], s2[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_red[tid][j] = s1[j]; s_red[tid][8 + j] = s2[j]; }
+    __syncthreads();
+    // threads with the same slot: tid, tid+VPP, ...  -> fixed-order sum by the first VPP threads
+    if (tid < VPP) {
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = 0.f;
+        for (int k = tid; k < 256; k += VPP)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t[j] += s_red[k][j];
+        float *o = A.partial + (size_t)blockIdx.x * 2 * A.C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[c0 + j] = t[j]; o[A.C + c0 + j] = t[8 + j]; }
+    }
+}
+
+// sums [nb][2][C] -> dgamma, dbeta and the apply coefficients
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int C, float M, const float *gamma,
+                                       const float *invstd, float *dgamma, float *dbeta, float *k1, float *k2, float *k3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nb; ++b) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    k1[c] = gamma[c] * invstd[c];
+    k2[c] = (float)(s1 / M);
+    k3[c] = (float)(s2 / M);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs A) {
+    const int VPP = A.C / 8;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 8;
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8], k3[8];
+    load8(A.scale, c0, sc, 1.f); load8(A.shift, c0, sh, 0.f); load8(A.mean, c0, mu, 0.f); load8(A.invstd, c0, is, 1.f);
+    load8(A.k1, c0, k1, 1.f); load8(A.k2, c0, k2, 0.f); load8(A.k3, c0, k3, 0.f);
+    const size_t npix = (size_t)A.N * A.H * A.W;
+    const size_t ppb = 256 / VPP;
+    for (size_t p = (size_t)blockIdx.x * ppb + tid / VPP; p < npix; p += (size_t)gridDim.x * ppb) {
+        const int n = (int)(p / ((size_t)A.H * A.W));
+        const int r = (int)(p - (size_t)n * A.H * A.W);
+        float dz[8], xh[8];
+        dz8<true>(A, n, r / A.W, r % A.W, c0, sc, sh, mu, is, dz, xh);
+        V16 o, z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o.h[j] = f2bf(k1[j] * (dz[j] - k2[j] - xh[j] * k3[j]));
+            z.h[j] = f2bf(dz[j]);
+        }
+        if (A.draw) *reinterpret_cast<uint4 *>(A.draw + p * A.C + c0) = o.u;
+        if (A.dz_out) *reinterpret_cast<uint4 *>(A.dz_out + p * A.C + c0) = z.u;
+    }
+}
+
+// ======================================================================================================
+// DAM head backward
+// ======================================================================================================
+struct HeadFeat {
+    const unsigned short *raw;
+    const unsigned short *res;
+    const float *scale;
+    const float *shift;
+    int relu;
+    int f16;
+};
+
+struct HeadW {
+    float wp[64], wd[9][64], wm[3][64];
+    float bp, bd[9], bm[3];
+    float a1;
+    float a2[9];
+};
+constexpr int HEADW_FLOATS = sizeof(HeadW) / 4;      // 855; the gradient block has the same layout
+
+__device__ __forceinline__ float feat1(const HeadFeat &f, size_t pix, int c, const float *s_sc, const float *s_sh) {
+    float x = f.f16 ? h2f(f.raw[pix * 64 + c]) : bf2f(f.raw[pix * 64 + c]);
+    if (f.scale || f.res || f.relu) {
+        if (f.scale) x = fmaf(x, s_sc[c], s_sh[c]);
+        if (f.res) x += f.f16 ? h2f(f.res[pix * 64 + c]) : bf2f(f.res[pix * 64 + c]);
+        if (f.relu) x = fmaxf(x, 0.f);
+        x = bf2f(f2bf(x));
+    }
+    return x;
+}
+
+__device__ __forceinline__ void feat64(const HeadFeat &f, size_t pix, const float *s_sc, const float *s_sh, float *v) {
+    const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64);
+    const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64) : nullptr;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        V16 r, rr;
+        r.u = pr[q];
+        rr.u = make_uint4(0, 0, 0, 0);
+        if (ps) rr.u = ps[q];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = f.f16 ? h2f(r.h[j]) : bf2f(r.h[j]);
+            if (f.scale || ps || f.relu) {
+                if (f.scale) x = fmaf(x, s_sc[q * 8 + j], s_sh[q * 8 + j]);
+                if (ps) x += f.f16 ? h2f(rr.h[j]) : bf2f(rr.h[j]);
+                if (f.relu) x = fmaxf(x, 0.f);
+                x = bf2f(f2bf(x));
+            }
+            v[q * 8 + j] = x;
+        }
+    }
+}
+
+__device__ __forceinline__ void store64_bf16(unsigned short *dst, const float *v) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        V16 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = f2bf(v[q * 8 + j]);
+        reinterpret_cast<uint4 *>(dst)[q] = o.u;
+    }
+}
+
+// one block = 256 consecutive pixels per iteration.  Phase 1: thread = pixel (feature gradients, the 13 per-pixel
+// coefficients, the 23 scalar gradients).  Phase 2: thread = (channel, quarter of the pixels) for the weight gradients.
+__global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
+                                                           const float *__restrict__ dmask, const float *__restrict__ dpoint,
+                                                           const float *__restrict__ ddir, int N, int plane,
+                                                           unsigned short *__restrict__ df1, unsigned short *__restrict__ df2,
+                                                           unsigned short *__restrict__ df3, float *__restrict__ partial) {
+    __shared__ HeadW w;
+    __shared__ float s_sc[3][64], s_sh[3][64];
+    __shared__ float s_coef[256][14];
+    __shared__ float s_red[256][24];
+    const int tid = threadIdx.x;
+    {
+        const float *src = reinterpret_cast<const float *>(hw);
+        float *dst = reinterpret_cast<float *>(&w);
+        for (int i = tid; i < HEADW_FLOATS; i += 256) dst[i] = src[i];
+        if (tid < 64) {
+            const HeadFeat *fs[3] = {&f1, &f2, &f3};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s_sc[k][tid] = fs[k]->scale ? fs[k]->scale[tid] : 1.f;
+                s_sh[k][tid] = fs[k]->scale ? fs[k]->shift[tid] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * plane;
+    // scalar gradient accumulators: dbm[3], dbd[9], dbp, da1, da2[9]  (23)
+    float sg[23];
+#pragma unroll
+    for (int j = 0; j < 23; ++j) sg[j] = 0.f;
+    // weight gradient accumulators for channel c = tid & 63 over this thread's quarter of each pixel block
+    float gwm[3], gwd[9], gwp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gwm[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) gwd[j] = 0.f;
+    const int c = tid & 63, part = tid >> 6;
+
+    for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {
+        const size_t i = base + tid;
+        float coef[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) coef[j] = 0.f;
+        if (i < total) {
+            const size_t n = i / plane, p = i - n * plane;
+            float v[64];
+            feat64(f3, i, s_sc[2], s_sh[2], v);
+            float pt = w.bp;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) pt = fmaf(w.wp[k], v[k], pt);
+            const float sg1 = 1.f / (1.f + expf(-(w.a1 * pt)));
+            const float g1 = 1.f + sg1;
+            feat64(f2, i, s_sc[1], s_sh[1], v);
+            float u[9], d[9], q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float s = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 64; ++cc) s = fmaf(w.wd[k][cc], v[cc], s);
+                u[k] = s;
+                d[k] = fmaf(g1, s, w.bd[k]);
+                q2 = fmaf(w.a2[k], d[k], q2);
+            }
+            const float sg2 = 1.f / (1.f + expf(-q2));
+            const float g2 = 1.f + sg2;
+            feat64(f1, i, s_sc[0], s_sh[0], v);
+            float dm[3], dg2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float s = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 64; ++cc) s = fmaf(w.wm[k][cc], v[cc], s);
+                const float go = dmask[(n * 3 + k) * plane + p];
+                dg2 = fmaf(go, s, dg2);
+                dm[k] = go * g2;
+                sg[k] += go;                       // d mask_conv.bias
+            }
+            // dF1 = sum_k dm_k * wm_k
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc) v[cc] = dm[0] * w.wm[0][cc] + dm[1] * w.wm[1][cc] + dm[2] * w.wm[2][cc];
+            store64_bf16(df1 + i * 64, v);
+            const float dq2 = dg2 * sg2 * (1.f - sg2);
+            float du[9], dg1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float dd = ddir[(n * 9 + k) * plane + p] + dq2 * w.a2[k];
+                sg[3 + k] += dd;                   // d direction_conv.bias
+                sg[14 + k] = fmaf(dq2, d[k], sg[14 + k]);   // d maskAtt.Conv1x1.weight
+                dg1 = fmaf(dd, u[k], dg1);
+                du[k] = dd * g1;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s = fmaf(du[k], w.wd[k][cc], s);
+                v[cc] = s;
+            }
+            store64_bf16(df2 + i * 64, v);
+            const float dsg1 = dg1 * sg1 * (1.f - sg1);
+            const float dpt = dpoint[n * plane + p] + dsg1 * w.a1;
+            sg[12] += dpt;                         // d point_conv.bias
+            sg[13] = fmaf(dsg1, pt, sg[13]);       // d directionAtt.Conv1x1.weight
+#pragma unroll
+            for (int cc = 0; cc < 64; ++cc) v[cc] = dpt * w.wp[cc];
+            store64_bf16(df3 + i * 64, v);
+            coef[0] = dm[0]; coef[1] = dm[1]; coef[2] = dm[2];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) coef[3 + k] = du[k];
+            coef[12] = dpt;
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) s_coef[tid][j] = coef[j];
+        __syncthreads();
+        // phase 2: weight gradients for channel c over pixels part*64 .. part*64+63 of this block
+        for (int k = 0; k < 64; ++k) {
+            const int px = part * 64 + k;
+            const size_t ip = base + px;
+            if (ip >= total) break;
+            const float x1 = feat1(f1, ip, c, s_sc[0], s_sh[0]);
+            const float x2 = feat1(f2, ip, c, s_sc[1], s_sh[1]);
+            const float x3 = feat1(f3, ip, c, s_sc[2], s_sh[2]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gwm[j] = fmaf(s_coef[px][j], x1, gwm[j]);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) gwd[j] = fmaf(s_coef[px][3 + j], x2, gwd[j]);
+            gwp = fmaf(s_coef[px][12], x3, gwp);
+        }
+        __syncthreads();
+    }
+    // block reduction -> partial[block][855]  (layout of HeadW)
+    float *o = partial + (size_t)blockIdx.x * HEADW_FLOATS;
+    // weights: sum the 4 parts per channel
+    __shared__ float s_w[4][13][64];
+    s_w[part][0][c] = gwp;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s_w[part][1 + j][c] = gwd[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s_w[part][10 + j][c] = gwm[j];
+#pragma unroll
+    for (int j = 0; j < 23; ++j) s_red[tid][j] = sg[j];
+    __syncthreads();
+    for (int idx = tid; idx < 13 * 64; idx += 256) {
+        const int row = idx / 64, cc = idx % 64;
+        o[idx] = (s_w[0][row][cc] + s_w[1][row][cc]) + (s_w[2][row][cc] + s_w[3][row][cc]);   // wp | wd[9] | wm[3] contiguous
+    }
+    if (tid < 23) {
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s += s_red[k][tid];
+        // HeadW tail: bp, bd[9], bm[3], a1, a2[9]
+        int dst;
+        if (tid < 3) dst = 832 + 10 + tid;            // bm
+        else if (tid < 12) dst = 832 + 1 + (tid - 3); // bd
+        else if (tid == 12) dst = 832;                // bp
+        else if (tid == 13) dst = 832 + 13;           // a1
+        else dst = 832 + 14 + (tid - 14);             // a2
+        o[dst] = s;
+    }
+}
+
+// ======================================================================================================
+// Loss (train_util_dam.py:167-276) - two passes over the logits
+// ======================================================================================================
+// per-sample sums (K_SUMS floats):
+//   0..2  I_c   sum p_c [label==c]      3..5  P_c   sum p_c          6..8  T_c   sum [label==c]
+//   9..17 Pw_i  sum w q_i               18..26 Tw_j sum w t_j
+//   27..35 S[j][j]  36..44 S[next(j)][j]  45..53 S[prev(j)][j]   (S[i][j] = sum w q_i t_j, j = target class)
+//   54 ce  55 dce  56 mse
+constexpr int K_SUMS = 57;
+__device__ __forceinline__ int dnext(int i) { return i == 8 ? 1 : i + 1; }      // cyclic over 1..8 (loss.py:231-258)
+__device__ __forceinline__ int dprev(int i) { return i == 1 ? 8 : i - 1; }
+
+struct LossIn {
+    const float *mask, *point, *dirn;        // f32 NCHW logits [B][3][P], [B][1][P], [B][9][P]
+    const unsigned char *label, *dirlab;     // u8 [B][P]
+    const unsigned short *point_t;           // f16 [B][P]
+    const unsigned char *weight;             // u8 [B][P]  (png weight map; /20 on the fly)
+    const int *single;                       // [B]: 1 if the sample's direction map is constant (train_util_dam.py:133,141)
+    int B, P;
+    int quirk0;                              // mask the direction one-hot with SAMPLE 0's foreground (:139)
+};
+
+__global__ void loss_single_kernel(const unsigned char *dirlab, int P, int *single) {
+    __shared__ int s_min[256], s_max[256];
+    const unsigned char *d = dirlab + (size_t)blockIdx.x * P;
+    int mn = 255, mx = 0;
+    for (int i = threadIdx.x; i < P; i += 256) { int v = d[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    s_min[threadIdx.x] = mn; s_max[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
+        single[blockIdx.x] = (mn == mx) ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ void softmax3(const float *l, float *p, float *logp) {
+    const float m = fmaxf(l[0], fmaxf(l[1], l[2]));
+    float e[3], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { e[c] = expf(l[c] - m); s += e[c]; }
+    const float ls = logf(s);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p[c] = e[c] / s; logp[c] = l[c] - m - ls; }
+}
+__device__ __forceinline__ void softmax9(const float *l, float *p, float *logp) {
+    float m = l[0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) m = fmaxf(m, l[c]);
+    float e[9], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { e[c] = expf(l[c] - m); s += e[c]; }
+    const float ls = logf(s);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { p[c] = e[c] / s; logp[c] = l[c] - m - ls; }
+}
+
+// target class of the weighted dice for pixel i of sample b: -1 = all nine one-hot channels are zero
+__device__ __forceinline__ int dice_target(const LossIn &L, int b, int i) {
+    if (L.single[b]) return 0;
+    const int t = L.dirlab[(size_t)b * L.P + i];
+    if (L.quirk0) return L.label[i] != 0 ? t : -1;               // sample 0's label
+    return L.label[(size_t)b * L.P + i] != 0 ? t : -1;
+}
+
+// grid (chunks, B); private accumulators live in LDS ([k][tid]) because several are indexed by the target class
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossIn L, float *__restrict__ partial) {
+    __shared__ float acc[K_SUMS][256];
+    const int tid = threadIdx.x, b = blockIdx.y;
+#pragma unroll
+    for (int k = 0; k < K_SUMS; ++k) acc[k][tid] = 0.f;
+    const size_t ob = (size_t)b * L.P;
+    for (int i = blockIdx.x * 256 + tid; i < L.P; i += gridDim.x * 256) {
+        float l3[3], p3[3], lp3[3], l9[9], p9[9], lp9[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l3[c] = L.mask[((size_t)b * 3 + c) * L.P + i];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) l9[c] = L.dirn[((size_t)b * 9 + c) * L.P + i];
+        softmax3(l3, p3, lp3);
+        softmax9(l9, p9, lp9);
+        const float w = (float)L.weight[ob + i] / 20.f;
+        const int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        acc[lab][tid] += p3[lab];
+        acc[6 + lab][tid] += 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[3 + c][tid] += p3[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[9 + c][tid] = fmaf(w, p9[c], acc[9 + c][tid]);
+        const int t = dice_target(L, b, i);
+        if (t >= 0) {
+            acc[18 + t][tid] += w;
+            acc[27 + t][tid] = fmaf(w, p9[t], acc[27 + t][tid]);
+            if (t >= 1) {
+                acc[36 + t][tid] = fmaf(w, p9[dnext(t)], acc[36 + t][tid]);
+                acc[45 + t][tid] = fmaf(w, p9[dprev(t)], acc[45 + t][tid]);
+            }
+        }
+        acc[54][tid] -= lp3[lab] * w;
+        acc[55][tid] -= lp9[dl] * w;
+        const float dpt = L.point[ob + i] - h2f(L.point_t[ob + i]);
+        acc[56][tid] = fmaf(dpt, dpt, acc[56][tid]);
+    }
+    __syncthreads();
+    if (tid < K_SUMS) {
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s += acc[tid][k];
+        partial[((size_t)b * gridDim.x + blockIdx.x) * K_SUMS + tid] = s;
+    }
+}
+
+// coefficient block per sample (K_COEF floats): dice alpha[3], beta[3]; wdice: bsum[9], a_self[9], a_next[9], a_prev[9]
+//   a_self[j]  multiplies row i=j,        a_next[j] row i=next(j),  a_prev[j] row i=prev(j)  when the pixel's target is j
+constexpr int K_COEF = 6 + 36;
+// single block: per-sample sums -> loss terms (5 + total) and the pass-2 coefficients
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int nchunk, int B, int P,
+                                                            float *__restrict__ sums, float *__restrict__ coef,
+                                                            float *__restrict__ losses) {
+    __shared__ float s_sum[64 * K_SUMS];      // B <= 64
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < B * K_SUMS; idx += 256) {
+        const int b = idx / K_SUMS, k = idx % K_SUMS;
+        float s = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) s += partial[((size_t)b * nchunk + ch) * K_SUMS + k];
+        s_sum[idx] = s;
+        if (sums) sums[idx] = s;
+    }
+    __syncthreads();
+    const float fB = (float)B;
+    for (int b = tid; b < B; b += 256) {
+        const float *S = s_sum + b * K_SUMS;
+        float *cf = coef + (size_t)b * K_COEF;
+        for (int c = 0; c < 3; ++c) {
+            const float I = S[c], U = S[3 + c] + S[6 + c];
+            cf[c] = -2.f / (fB * (U + 1.f));
+            cf[3 + c] = 2.f * (I + 1.f) / (fB * (U + 1.f) * (U + 1.f));
+        }
+        // row i, column j terms: alpha_ij = -2/(B (U_ij+1)), beta_ij = 2 (S_ij+1)/(B (U_ij+1)^2), U_ij = Pw_i + Tw_j
+        float bsum[9];
+        for (int i = 0; i < 9; ++i) bsum[i] = 0.f;
+        for (int j = 0; j < 9; ++j) {
+            {   // (i=j, j)
+                const float U = S[9 + j] + S[18 + j], Sij = S[27 + j], m = j == 0 ? 2.f : 1.f;
+                cf[6 + 9 + j] = m * -2.f / (fB * (U + 1.f));
+                bsum[j] += m * 2.f * (Sij + 1.f) / (fB * (U + 1.f) * (U + 1.f));
+            }
+            if (j >= 1) {
+                const int in = dnext(j), ip = dprev(j);
+                {   const float U = S[9 + in] + S[18 + j], Sij = S[36 + j];
+                    cf[6 + 18 + j] = -2.f / (fB * (U + 1.f));
+                    bsum[in] += 2.f * (Sij + 1.f) / (fB * (U + 1.f) * (U + 1.f)); }
+                {   const float U = S[9 + ip] + S[18 + j], Sij = S[45 + j];
+                    cf[6 + 27 + j] = -2.f / (fB * (U + 1.f));
+                    bsum[ip] += 2.f * (Sij + 1.f) / (fB * (U + 1.f) * (U + 1.f)); }
+            } else { cf[6 + 18] = 0.f; cf[6 + 27] = 0.f; }
+        }
+        for (int i = 0; i < 9; ++i) cf[6 + i] = bsum[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float n = (float)B * (float)P;
+        float ce = 0.f, dce = 0.f, mse = 0.f;
+        for (int b = 0; b < B; ++b) { ce += s_sum[b * K_SUMS + 54]; dce += s_sum[b * K_SUMS + 55]; mse += s_sum[b * K_SUMS + 56]; }
+        ce /= n; dce /= n; mse /= n;
+        float dice = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) { const float *S = s_sum + b * K_SUMS; s += 2.f * (S[c] + 1.f) / (S[3 + c] + S[6 + c] + 1.f); }
+            dice += 1.f - s / fB;
+        }
+        float wd = 0.f;
+        for (int i = 0; i < 9; ++i) {
+            // wdice(i,j) = 1 - mean_b 2 (S_ij + 1) / (Pw_i + Tw_j + 1)
+            auto wdice = [&](int ii, int jj, int off) {
+                float s = 0.f;
+                for (int b = 0; b < B; ++b) { const float *S = s_sum + b * K_SUMS; s += 2.f * (S[off + jj] + 1.f) / (S[9 + ii] + S[18 + jj] + 1.f); }
+                return 1.f - s / fB;
+            };
+            if (i == 0) wd += 2.f * wdice(0, 0, 27);
+            else {
+                // S[i][prev(i)]: column j=prev(i), row next(j)=i -> offset 36;  S[i][next(i)]: column j=next(i), row prev(j)=i -> 45
+                wd += wdice(i, i, 27) - (1.f - wdice(i, dprev(i), 36)) - (1.f - wdice(i, dnext(i), 45));
+            }
+        }
+        wd /= 9.f;
+        losses[0] = ce + dice + dce + wd + mse;
+        losses[1] = dce; losses[2] = wd; losses[3] = mse; losses[4] = ce; losses[5] = dice;
+    }
+}
+
+// pass 2: gradients w.r.t. the logits (f32 NCHW, same layout as the logits)
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossIn L, const float *__restrict__ coef, float *__restrict__ dmask,
+                                                        float *__restrict__ dpoint, float *__restrict__ ddir) {
+    const int b = blockIdx.y;
+    const float *cf = coef + (size_t)b * K_COEF;
+    const float inv_n = 1.f / ((float)L.B * (float)L.P);
+    const size_t ob = (size_t)b * L.P;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L.P; i += gridDim.x * 256) {
+        float l3[3], p3[3], lp3[3], l9[9], p9[9], lp9[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l3[c] = L.mask[((size_t)b * 3 + c) * L.P + i];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) l9[c] = L.dirn[((size_t)b * 9 + c) * L.P + i];
+        softmax3(l3, p3, lp3);
+        softmax9(l9, p9, lp9);
+        const float w = (float)L.weight[ob + i] / 20.f;
+        const int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        // mask: dice gradient w.r.t. probabilities, through the softmax, plus the weighted CE
+        float gp[3], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gp[c] = cf[3 + c] + (c == lab ? cf[c] : 0.f); dot = fmaf(p3[c], gp[c], dot); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            dmask[((size_t)b * 3 + c) * L.P + i] = p3[c] * (gp[c] - dot) + w * inv_n * (p3[c] - (c == lab ? 1.f : 0.f));
+        // direction: weighted cyclic dice (average over 9 classes) + weighted CE
+        const int t = dice_target(L, b, i);
+        float gq[9], dot9 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) gq[c] = cf[6 + c];
+        if (t >= 0) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                float a = 0.f;
+                if (c == t) a = cf[6 + 9 + t];
+                else if (t >= 1 && c == dnext(t)) a = cf[6 + 18 + t];
+                else if (t >= 1 && c == dprev(t)) a = cf[6 + 27 + t];
+                gq[c] += a;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { gq[c] *= w * (1.f / 9.f); dot9 = fmaf(p9[c], gq[c], dot9); }
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            ddir[((size_t)b * 9 + c) * L.P + i] = p9[c] * (gq[c] - dot9) + w * inv_n * (p9[c] - (c == dl ? 1.f : 0.f));
+        dpoint[ob + i] = 2.f * inv_n * (L.point[ob + i] - h2f(L.point_t[ob + i]));
+    }
+}
+
+// ======================================================================================================
+// Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient, bias correction)
+// ======================================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, float gscale) {
+    const float step = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        gi = fmaf(wd, pi, gi);
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * (1.f - b1);
+        vi = vi * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step * (mi / denom);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+static int fill_bn_args(const cdnet_bn_bwd_args *a, BnBwdArgs &A, const char *who) {
+    CDNET_REQUIRE(a && a->raw, "%s: null pointer", who);
+    CDNET_REQUIRE(a->C % 8 == 0 && a->C >= 8 && a->C <= 2048 && 256 % (a->C / 8) == 0, "%s: C=%d unsupported", who, a->C);
+    CDNET_REQUIRE(a->ngin >= 1 && a->ngin <= 3, "%s: ngin=%d", who, a->ngin);
+    A.raw = a->raw; A.res = a->res; A.f16 = a->f16; A.scale = a->scale; A.shift = a->shift; A.relu = a->relu;
+    A.mean = a->mean; A.invstd = a->invstd;
+    for (int k = 0; k < 3; ++k) {
+        A.gin[k].g = a->gin[k].g; A.gin[k].Hg = a->gin[k].Hg; A.gin[k].Wg = a->gin[k].Wg;
+        A.gin[k].oy = a->gin[k].oy; A.gin[k].ox = a->gin[k].ox; A.gin[k].pooled = a->gin[k].pooled;
+        A.gin[k].coff = a->gin[k].coff; A.gin[k].cstride = a->gin[k].cstride ? a->gin[k].cstride : a->C;
+        if (k < a->ngin) CDNET_REQUIRE(a->gin[k].g, "%s: null gradient input %d", who, k);
+    }
+    A.ngin = a->ngin; A.N = a->N; A.H = a->H; A.W = a->W; A.C = a->C;
+    A.partial = nullptr; A.k1 = A.k2 = A.k3 = nullptr; A.draw = nullptr; A.dz_out = nullptr;
+    return CDNET_OK;
+}
+
+extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma, float *dgamma, float *dbeta, float *workspace,
+                                 size_t workspace_floats, uint16_t *draw, uint16_t *dz_out, void *stream) {
+    BnBwdArgs A;
+    int rc = fill_bn_args(a, A, "cdnet_bn_backward");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)A.N * A.H * A.W;
+    const int ppb = 256 / (A.C / 8);
+    int nb = (int)((npix + ppb - 1) / ppb);
+    if (nb > 1024) nb = 1024;
+    A.draw = draw; A.dz_out = dz_out;
+    if (A.mean) {
+        CDNET_REQUIRE(gamma && A.invstd && workspace, "cdnet_bn_backward: BatchNorm layer needs gamma/invstd/workspace");
+        const size_t need = (size_t)nb * 2 * A.C + 3 * (size_t)A.C;
+        if (workspace_floats < need) { set_error("cdnet_bn_backward: workspace %zu < %zu floats", workspace_floats, need); return CDNET_E_WORKSPACE; }
+        A.partial = workspace;
+        float *k = workspace + (size_t)nb * 2 * A.C;
+        bn_bwd_reduce_kernel<<<nb, 256, 0, st>>>(A);
+        bn_bwd_finalize_kernel<<<cdiv(A.C, 256), 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
+                                                              k + A.C, k + 2 * A.C);
+        A.k1 = k; A.k2 = k + A.C; A.k3 = k + 2 * A.C;
+    }
+    bn_bwd_apply_kernel<<<nb, 256, 0, st>>>(A);
+    return check_launch("cdnet_bn_backward");
+}
+
+extern "C" size_t cdnet_bn_backward_workspace_floats(int C) { return (size_t)1024 * 2 * C + 3 * (size_t)C; }
+
+static HeadFeat mk_hf(const cdnet_head_feat &f) {
+    HeadFeat h;
+    h.raw = f.raw; h.res = f.res; h.scale = f.scale; h.shift = f.shift; h.relu = f.relu; h.f16 = f.f16;
+    return h;
+}
+
+extern "C" int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_head_feat *f2, const cdnet_head_feat *f3,
+                                       const float *head_weights, const float *dmask, const float *dpoint, const float *ddir,
+                                       int N, int H, int W, uint16_t *df1, uint16_t *df2, uint16_t *df3, float *workspace,
+                                       size_t workspace_floats, float *dhead_weights, void *stream) {
+    CDNET_REQUIRE(f1 && f2 && f3 && head_weights && dmask && dpoint && ddir && df1 && df2 && df3 && workspace && dhead_weights,
+                  "cdnet_dam_head_backward: null pointer");
+    static_assert(HEADW_FLOATS == CDNET_HEAD_WEIGHT_FLOATS, "head weight block");
+    const size_t total = (size_t)N * H * W;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    if (workspace_floats < (size_t)nb * HEADW_FLOATS) { set_error("cdnet_dam_head_backward: workspace too small"); return CDNET_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    dam_head_bwd_kernel<<<nb, 256, 0, st>>>(mk_hf(*f1), mk_hf(*f2), mk_hf(*f3), reinterpret_cast<const HeadW *>(head_weights), dmask,
+                                            dpoint, ddir, N, H * W, df1, df2, df3, workspace);
+    reduce_partials_kernel<<<cdiv(HEADW_FLOATS, 256), 256, 0, st>>>(workspace, nb, HEADW_FLOATS, dhead_weights);
+    return check_launch("cdnet_dam_head_backward");
+}
+
+extern "C" size_t cdnet_dam_head_backward_workspace_floats(void) { return (size_t)1024 * HEADW_FLOATS; }
+
+extern "C" size_t cdnet_dam_loss_workspace_floats(int B, int P) {
+    int nchunk = cdiv(P, 256 * 8);
+    if (nchunk > 64) nchunk = 64;
+    return (size_t)B * nchunk * K_SUMS + (size_t)B * K_COEF + (size_t)B * K_SUMS + 16 + (size_t)B;   // partial | coef | sums | pad | single(int)
+}
+
+extern "C" int cdnet_dam_loss(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
+                              const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W, int quirk_sample0,
+                              float *workspace, size_t workspace_floats, float *losses, float *dmask, float *dpoint, float *ddir,
+                              void *stream) {
+    CDNET_REQUIRE(mask && point && dirn && label && dirlab && point_target_f16 && weight_u8 && workspace && losses,
+                  "cdnet_dam_loss: null pointer");
+    CDNET_REQUIRE(B >= 1 && B <= 64 && H > 0 && W > 0, "cdnet_dam_loss: batch %d not in [1,64]", B);
+    const int P = H * W;
+    if (workspace_floats < cdnet_dam_loss_workspace_floats(B, P)) { set_error("cdnet_dam_loss: workspace too small"); return CDNET_E_WORKSPACE; }
+    int nchunk = cdiv(P, 256 * 8);
+    if (nchunk > 64) nchunk = 64;
+    float *partial = workspace;
+    float *coef = partial + (size_t)B * nchunk * K_SUMS;
+    float *sums = coef + (size_t)B * K_COEF;
+    int *single = reinterpret_cast<int *>(sums + (size_t)B * K_SUMS + 16);
+    hipStream_t st = (hipStream_t)stream;
+    LossIn L;
+    L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.point_t = point_target_f16;
+    L.weight = weight_u8; L.single = single; L.B = B; L.P = P; L.quirk0 = quirk_sample0;
+    loss_single_kernel<<<B, 256, 0, st>>>(dirlab, P, single);
+    loss_reduce_kernel<<<dim3(nchunk, B), 256, 0, st>>>(L, partial);
+    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, nchunk, B, P, sums, coef, losses);
+    if (dmask) {
+        CDNET_REQUIRE(dpoint && ddir, "cdnet_dam_loss: all three gradient outputs or none");
+        loss_grad_kernel<<<dim3(lin_grid((size_t)P, 256), B), 256, 0, st>>>(L, coef, dmask, dpoint, ddir);
+    }
+    return check_launch("cdnet_dam_loss");
+}
+
+extern "C" int cdnet_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream) {
+    CDNET_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "cdnet_adam_step: bad args");
+    if (n == 0) return CDNET_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<lin_grid(n, 4096), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                                                                    weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return check_launch("cdnet_adam_step");
+}

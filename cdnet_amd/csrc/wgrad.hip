@@ -1,0 +1,307 @@
+// Backward-weight of the convolutions on the gfx950 matrix cores.
+//   dW[tap][ci][co] = sum over pixels p of  A[p + tap][ci] * G[p][co]
+// A = the layer's (transformed) input, G = gradient w.r.t. the layer's raw output (bf16).  Both live in LDS as
+// [pixel][channel] tiles - exactly what the forward staging produces - and the MFMA operands, which need eight
+// consecutive PIXELS of one channel per lane, are fetched with gfx950's transposing LDS read (ds_read_b64_tr_b16):
+// no transposed copy of any activation ever exists in HBM.
+//
+// One workgroup (4 waves) owns a (CI_T*32 input channels) x (CO_T*32 output channels) block of dW for ALL taps
+// (CI_T*CO_T = 4: each wave one 32x32 quadrant x TAPS accumulator tiles) and walks a slice of the 8x16-pixel tiles
+// (split-K over pixels).  Partial slabs are written fp32 and summed in a fixed order by wgrad_reduce (deterministic),
+// which also scatters into the PyTorch weight layout.
+//
+// Replaces the weight-gradient half of loss.backward() (train_util_dam.py:307) for nn.Conv2d / nn.ConvTranspose2d.
+#include "common.h"
+#include "conv_args.h"
+
+using namespace cdnet;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+union V16 {
+    uint4 u;
+    unsigned short h[8];
+};
+
+constexpr int TH = 8, TW = 16, HALO_W = TW + 2, NPIX_A = (TH + 2) * (TW + 2), NPIX_G = TH * TW;
+
+// LDS pixel stride for C channels such that four consecutive pixel rows x 64 B (one transposing read of a 32-lane
+// half) never share a bank: stride == 64 (mod 256) bytes
+__host__ __device__ constexpr int pstride(int C) { return C == 32 ? 64 : (C == 64 ? 192 : 320); }
+
+struct WgradArgs {
+    ConvSrc src;              // the input source this launch differentiates (one launch per concat source)
+    int src_coff;             // first input channel of this source inside the layer's weight tensor
+    const unsigned short *g;  // bf16 NHWC gradient of the raw output [N][Ho][Wo][Cout]
+    float *slab;              // f32 [ksplit][npar][ci_blocks][co_blocks][TAPS][CI][CO]
+    int N, H, W;              // logical input size
+    int Cout;
+    int taps, npar, ostride;
+    int ksplit;
+};
+
+template <int CI>
+__device__ __forceinline__ void stage_a(const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W, unsigned char *lds, int tid) {
+    constexpr int VPP = CI / 8, PSTR = pstride(CI);
+    const int slot = tid % VPP;
+    float sc[8], sh[8];
+    const bool on = s.scale != nullptr;
+    if (on && cc0 + slot * 8 < s.C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = s.scale[cc0 + slot * 8 + j]; sh[j] = s.shift[cc0 + slot * 8 + j]; }
+    }
+    const bool relu = s.relu != 0, f16 = s.f16 != 0;
+    const int Hl = s.pool ? (s.Hs + (s.pool == 2)) / 2 : s.Hs, Wl = s.pool ? (s.Ws + (s.pool == 2)) / 2 : s.Ws;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    const size_t img = (size_t)n * s.Hs * rs;
+    for (int v = tid; v < NPIX_A * VPP; v += 256) {
+        const int pix = v / VPP;
+        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        V16 val;
+        val.u = make_uint4(0, 0, 0, 0);
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        if (cc0 + slot * 8 < s.C && y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
+            float best[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q != 0 && !s.pool) break;
+                const int yy = s.pool ? 2 * ys + (q >> 1) : ys, xx = s.pool ? 2 * xs + (q & 1) : xs;
+                const bool ok = q == 0 || (yy < s.Hs && xx < s.Ws);
+                if (ok) {
+                    const size_t e = img + (size_t)yy * rs + (size_t)xx * s.C + cc0 + slot * 8;
+                    V16 raw, rr;
+                    raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
+                    rr.u = make_uint4(0, 0, 0, 0);
+                    if (s.res) rr.u = *reinterpret_cast<const uint4 *>(s.res + e);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float t = f16 ? h2f(raw.h[j]) : bf2f(raw.h[j]);
+                        if (on) t = fmaf(t, sc[j], sh[j]);
+                        if (s.res) t += f16 ? h2f(rr.h[j]) : bf2f(rr.h[j]);
+                        if (relu) t = fmaxf(t, 0.f);
+                        t = bf2f(f2bf(t));
+                        best[j] = (q == 0 || t > best[j]) ? t : best[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val.h[j] = f2bf(best[j]);
+        }
+        *reinterpret_cast<uint4 *>(lds + pix * PSTR + slot * 16) = val.u;
+    }
+}
+
+template <int CO>
+__device__ __forceinline__ void stage_g(const unsigned short *g, int co0, int Cout, int n, int y0, int x0, int H, int W,
+                                        int ostride, int pa, int pb, unsigned char *lds, int tid) {
+    constexpr int VPP = CO / 8, PSTR = pstride(CO);
+    const int Ho = H * ostride, Wo = W * ostride;
+    for (int v = tid; v < NPIX_G * VPP; v += 256) {
+        const int pix = v / VPP, slot = v % VPP;
+        const int y = y0 + pix / TW, x = x0 + pix % TW;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        const int co = co0 + slot * 8;
+        if (y < H && x < W && co < Cout) {
+            const size_t e = (((size_t)n * Ho + (y * ostride + pa)) * Wo + (x * ostride + pb)) * Cout + co;
+            val = *reinterpret_cast<const uint4 *>(g + e);          // Cout % 8 == 0 (checked by the ABI entry)
+        }
+        *reinterpret_cast<uint4 *>(lds + pix * PSTR + slot * 16) = val;
+    }
+}
+
+template <int CI_T, int CO_T, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
+    constexpr int CI = CI_T * 32, CO = CO_T * 32;
+    constexpr int PA = pstride(CI), PG = pstride(CO);
+    constexpr int A_BYTES = NPIX_A * PA;
+    static_assert(CI_T * CO_T == 4, "one 32x32 quadrant per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_a = smem, *lds_g = smem + A_BYTES;
+    typedef s16x4 __attribute__((address_space(3))) * lptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wci = wave / CO_T, wco = wave % CO_T;
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+
+    const int co_blocks = (A.Cout + CO - 1) / CO;
+    const int ci_blocks = (A.src.C + CI - 1) / CI;
+    const int cb = blockIdx.x % co_blocks, ib = blockIdx.x / co_blocks;
+    const int par = blockIdx.y;
+    const int ks = blockIdx.z;
+    const int pa = par >> 1, pb = par & 1;
+
+    int toff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        int r, c;
+        if (TAPS == 9) { r = t / 3; c = t % 3; }
+        else if (TAPS == 4) {
+            const int ty = t >> 1, tx = t & 1;
+            r = pa == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+            c = pb == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+        } else { r = 1; c = 1; }
+        toff[t] = (r * HALO_W + c) * PA;
+    }
+    // per-lane byte offsets of the transposing reads: pixel row (8*(grp>>1) + q) of the k-step, channel 16*(grp&1)+4p
+    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    const int g_lane = (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int ntiles = A.N * tiles_y * tiles_x;
+    for (int tile = ks; tile < ntiles; tile += A.ksplit) {
+        const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+        __syncthreads();
+        stage_a<CI>(A.src, ib * CI, n, y0, x0, A.H, A.W, lds_a, tid);
+        stage_g<CO>(A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, lds_g, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int ky = 0; ky < TH; ++ky) {                 // one k-step = one tile row of 16 pixels
+            const int gaddr = g_lane + ky * TW * PG;
+            s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_g + gaddr));
+            s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_g + gaddr + 4 * PG));
+            s16x8 gv;
+            gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3];
+            gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
+            const bf16x8 gf = __builtin_bit_cast(bf16x8, gv);
+            const int abase = a_lane + ky * HALO_W * PA;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + toff[t]));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + toff[t] + 4 * PA));
+                s16x8 av;
+                av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
+                av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), gf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // slab [ks][par][ib][cb][tap][CI][CO]; D rows = ci (regs + lane half), cols = co (lane & 31)
+    float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
+        }
+}
+
+// sum the split-K slabs in a fixed order and scatter into the PyTorch parameter-gradient layout
+//   mode 0: Conv2d  dW[Cout][Cin][KH][KW]  (taps = KH*KW)
+//   mode 2: ConvTranspose2d k4 s2 p1  dW[Cin][Cout][4][4]   (npar 4 x taps 4)
+//   mode 3: ConvTranspose2d k2 s2     dW[Cin][Cout][2][2]   (npar 4 x taps 1)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int ksplit, int npar, int ci_blocks,
+                                                           int co_blocks, int TAPS, int CI, int CO, int Csrc_real, int Cin_real,
+                                                           int src_coff, int Cout, int mode, float *__restrict__ dw) {
+    const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * TAPS * CI * CO;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_ks; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int co_l = r % CO; r /= CO;
+        const int ci_l = r % CI; r /= CI;
+        const int tap = r % TAPS; r /= TAPS;
+        const int cb = r % co_blocks; r /= co_blocks;
+        const int ib = r % ci_blocks; r /= ci_blocks;
+        const int par = (int)r;
+        const int co = cb * CO + co_l, ci = src_coff + ib * CI + ci_l;
+        if (co >= Cout || ib * CI + ci_l >= Csrc_real) continue;
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * per_ks + i];
+        size_t o;
+        if (mode == 0) {
+            o = ((size_t)co * Cin_real + ci) * TAPS + tap;
+        } else if (mode == 2) {
+            const int a = par >> 1, b = par & 1, ty = tap >> 1, tx = tap & 1;
+            const int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
+            const int kw = b == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+            o = (((size_t)ci * Cout + co) * 4 + kh) * 4 + kw;
+        } else {
+            o = (((size_t)ci * Cout + co) * 2 + (par >> 1)) * 2 + (par & 1);
+        }
+        dw[o] = s;
+    }
+}
+
+template <int CI_T, int CO_T, int TAPS>
+int launch_wgrad(const WgradArgs &A, hipStream_t st) {
+    constexpr int CI = CI_T * 32, CO = CO_T * 32;
+    constexpr int smem = NPIX_A * pstride(CI) + NPIX_G * pstride(CO);
+    auto kern = wgrad_kernel<CI_T, CO_T, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(wgrad)");
+        attr_done = true;
+    }
+    dim3 grid(cdiv(A.src.C, CI) * cdiv(A.Cout, CO), A.npar, A.ksplit);
+    kern<<<grid, 256, smem, st>>>(A);
+    return check_launch("wgrad_kernel");
+}
+
+template <int TAPS>
+int dispatch_wgrad(const WgradArgs &A, int ci_t, hipStream_t st) {
+    if (ci_t == 1) return launch_wgrad<1, 4, TAPS>(A, st);
+    if (ci_t == 2) return launch_wgrad<2, 2, TAPS>(A, st);
+    return launch_wgrad<4, 1, TAPS>(A, st);
+}
+
+}  // namespace
+
+extern "C" size_t cdnet_conv_wgrad_slab_floats(int C_src, int Cout, int taps, int npar, int ci_tiles, int ksplit) {
+    const int CI = ci_tiles * 32, CO = (4 / ci_tiles) * 32;
+    return (size_t)ksplit * npar * cdiv(C_src, CI) * cdiv(Cout, CO) * taps * CI * CO;
+}
+
+extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_coff, int Csrc_real, int Cin_real,
+                                          const uint16_t *grad_out,
+                                          int Cout, int N, int H, int W, int taps, int npar, int ostride, int ci_tiles,
+                                          int ksplit, float *slab, float *dw, int mode, void *stream) {
+    CDNET_REQUIRE(src && src->x && grad_out && slab && dw, "cdnet_conv_backward_weight: null pointer");
+    CDNET_REQUIRE(ci_tiles == 1 || ci_tiles == 2 || ci_tiles == 4, "cdnet_conv_backward_weight: ci_tiles=%d", ci_tiles);
+    CDNET_REQUIRE(src->C % 8 == 0, "cdnet_conv_backward_weight: source channels %d not a multiple of 8", src->C);
+    CDNET_REQUIRE(ksplit >= 1 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "cdnet_conv_backward_weight: bad size (Cout %% 8)");
+    CDNET_REQUIRE((taps == 9 && npar == 1 && ostride == 1 && mode == 0) || (taps == 1 && npar == 1 && ostride == 1 && mode == 0) ||
+                  (taps == 4 && npar == 4 && ostride == 2 && mode == 2) || (taps == 1 && npar == 4 && ostride == 2 && mode == 3),
+                  "cdnet_conv_backward_weight: taps=%d npar=%d ostride=%d mode=%d", taps, npar, ostride, mode);
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs A;
+    A.src = *reinterpret_cast<const ConvSrc *>(src);
+    A.src_coff = src_coff;
+    A.g = grad_out;
+    A.slab = slab;
+    A.N = N; A.H = H; A.W = W; A.Cout = Cout;
+    A.taps = taps; A.npar = npar; A.ostride = ostride; A.ksplit = ksplit;
+    int rc;
+    if (taps == 9) rc = dispatch_wgrad<9>(A, ci_tiles, st);
+    else if (taps == 4) rc = dispatch_wgrad<4>(A, ci_tiles, st);
+    else rc = dispatch_wgrad<1>(A, ci_tiles, st);
+    if (rc != CDNET_OK) return rc;
+    const int CI = ci_tiles * 32, CO = (4 / ci_tiles) * 32;
+    const int ci_blocks = cdiv(src->C, CI), co_blocks = cdiv(Cout, CO);
+    const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * taps * CI * CO;
+    int blocks = (int)((per_ks + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(slab, ksplit, npar, ci_blocks, co_blocks, taps, CI, CO, Csrc_real, Cin_real, src_coff, Cout,
+                                                mode, dw);
+    return check_launch("wgrad_reduce_kernel");
+}

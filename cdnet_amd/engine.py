@@ -11,7 +11,7 @@ from . import _lib
 class ConvSrc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('res', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
                 ('C', C.c_int), ('Hs', C.c_int), ('Ws', C.c_int), ('pool', C.c_int), ('relu', C.c_int),
-                ('off_y', C.c_int), ('off_x', C.c_int), ('f16', C.c_int), ('pad_', C.c_int)]
+                ('off_y', C.c_int), ('off_x', C.c_int), ('f16', C.c_int), ('row_stride', C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -28,12 +28,21 @@ def _dp(t):
 
 
 class Src:
-    """One convolution source: an NHWC bf16 tensor [N,Hs,Ws,C] plus the producer's lazily-applied transform."""
+    """One convolution source: a 16-bit NHWC tensor [N,Hs,Ws,C] (bf16, or fp16 for raw pre-BatchNorm outputs) plus the
+    producer's lazily-applied transform.  `view=(ptr_offset_elems, Hs, Ws, C, row_stride)` describes a strided window of
+    `x` instead of the dense tensor (space-to-depth view of an upsampled gradient)."""
 
-    def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0)):
-        assert x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.is_contiguous()
+    def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0), view=None):
+        assert x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
         assert res is None or res.dtype == x.dtype
         self.x, self.scale, self.shift, self.relu, self.pool, self.res, self.off = x, scale, shift, relu, pool, res, off
+        if view is None:
+            assert x.dim() == 4
+            self.N, self.Hs, self.Ws, self.Cc = x.shape
+            self.ptr_off, self.row_stride = 0, 0
+        else:
+            self.ptr_off, self.Hs, self.Ws, self.Cc, self.row_stride = view
+            self.N = x.shape[0]
 
     @property
     def f16(self):
@@ -41,14 +50,28 @@ class Src:
 
     @property
     def C(self):
-        return self.x.shape[3]
+        return self.Cc
+
+    def ptr(self):
+        return self.x.data_ptr() + 2 * self.ptr_off
 
     def logical_hw(self):
-        h, w = self.x.shape[1], self.x.shape[2]
+        h, w = self.Hs, self.Ws
         if self.pool:                      # 1/True: floor mode, 2: ceil mode
             c = 1 if int(self.pool) == 2 else 0
             return ((h + c) // 2, (w + c) // 2)
         return (h, w)
+
+    def fill(self, cs):
+        """fill a ConvSrc ctypes struct"""
+        cs.x = self.ptr()
+        cs.res = _dp(self.res)
+        cs.scale, cs.shift = _dp(self.scale), _dp(self.shift)
+        cs.C, cs.Hs, cs.Ws = self.C, self.Hs, self.Ws
+        cs.pool, cs.relu = int(self.pool), int(self.relu)
+        cs.off_y, cs.off_x = self.off
+        cs.f16 = int(self.f16)
+        cs.row_stride = int(self.row_stride)
 
 
 _SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 128), (16, 64, 64),
@@ -91,6 +114,9 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
         Cout, Cin, KH, KW = w.shape
     elif mode == 1:
         Cin, Cout, KH, KW = w.shape          # roles swap: GEMM-Cout = original in_channels
+    elif mode in (4, 5):
+        Cout, ct, KH, KW = w.shape           # backward-data of a transposed conv: GEMM-Cout = its in_channels,
+        Cin = 4 * ct                         # GEMM-Cin = space-to-depth of its out_channels
     else:
         Cin, Cout, KH, KW = w.shape
     Cin_p = Cin if Cin_pad is None else Cin_pad
@@ -102,7 +128,7 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
         else:
             raise NotImplementedError
         w, Cin = wp.contiguous(), Cin_p
-    taps = 4 if mode == 2 else (1 if mode == 3 else KH * KW)
+    taps = {2: 4, 3: 1, 4: 9, 5: 1}.get(mode, KH * KW)
     npar = 4 if mode in (2, 3) else 1
     n = packed_elems(Cout, Cin // CK, taps, CK, BN, npar)
     if out is None:
@@ -117,7 +143,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
     tile, CK, BN = cfg
     s0 = srcs[0]
-    N = s0.x.shape[0]
+    N = s0.N
     if H is None:
         H, W = s0.logical_hw()
         H, W = H + 0, W + 0
@@ -127,14 +153,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     nchunk = 0
     for i, s in enumerate(srcs):
         assert s.C % CK == 0, (s.C, CK)
-        a.src[i].x = _dp(s.x)
-        a.src[i].res = _dp(s.res)
-        a.src[i].scale = _dp(s.scale)
-        a.src[i].shift = _dp(s.shift)
-        a.src[i].C, a.src[i].Hs, a.src[i].Ws = s.C, s.x.shape[1], s.x.shape[2]
-        a.src[i].pool, a.src[i].relu = int(s.pool), int(s.relu)
-        a.src[i].off_y, a.src[i].off_x = s.off
-        a.src[i].f16 = int(s.f16)
+        s.fill(a.src[i])
         nchunk += s.C // CK
     a.nsrc = len(srcs)
     if out is None:

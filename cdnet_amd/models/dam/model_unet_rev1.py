@@ -74,6 +74,7 @@ class _RU:
         self.c1 = ConvLayer(name + '.conv1', 'conv3', m.conv1.weight, None, m.bn1)
         self.c2 = ConvLayer(name + '.conv2', 'conv3', m.conv2.weight, None, m.bn2)
         self.cr = ConvLayer(name + '.conv_1x1', 'conv1', m.conv_1x1.weight, m.conv_1x1.bias, None)
+        self.cr.bias_grad_from = self.c2          # d conv_1x1.bias = sum of dz = d bn2.bias
 
     def layers(self):
         return [self.c1, self.c2, self.cr]
@@ -84,7 +85,9 @@ class _RU:
         r = self.cr.forward([x], training, out_dtype=torch.float16)               # residual = conv_1x1(x)   (:162)
         h = self.c1.forward([x], training, relu=True)                             # relu1(bn1(conv1(x)))     (:163-165)
         y = self.c2.forward([h], training, relu=False, out_dtype=torch.float16)   # bn2(conv2(.))            (:166-167)
-        return Src(y.x, y.scale, y.shift, relu=True, res=r.x)    # relu2(out + residual)             (:168-169)
+        relu2 = not runtime.DEBUG_NORELU
+        self.c2.node_relu, self.c2.node_res = relu2, r.x         # how consumers (and backward) see the unit's output
+        return Src(y.x, y.scale, y.shift, relu=relu2, res=r.x)   # relu2(out + residual)             (:168-169)
 
 
 class Unet(nn.Module):
@@ -161,6 +164,8 @@ class Unet(nn.Module):
         """f32 device block in the CDNET_HEAD_WEIGHT_FLOATS layout (include/cdnet_hip.h)"""
         ps = [self.point_conv.weight, self.direction_conv.weight, self.mask_conv.weight, self.point_conv.bias,
               self.direction_conv.bias, self.mask_conv.bias, self.directionAtt.Conv1x1.weight, self.maskAtt.Conv1x1.weight]
+        if getattr(self, '_head_flat', None) is not None:
+            return self._head_flat                      # the trainer keeps these parameters contiguous in this layout
         ver = tuple(p._version for p in ps)
         if self._head_w is None or self._head_ver != ver:
             with torch.no_grad():
@@ -177,6 +182,8 @@ class Unet(nn.Module):
             raise RuntimeError('cdnet_amd.models.dam.model_unet_rev1.Unet runs on the MI355X only (no CPU fallback)')
         assert x.shape[1] == 3, 'the CDNet path feeds 3-channel tiles (child0/child_conv1 branches are never taken)'
         t = Src(runtime.input_pack(x.float()))
+        t.is_input = True
+        self._rt['enc'][0][1].needs_input_grad = False
         feats = {}
         for kind, layer, out_name in self._rt['enc']:              # forward_backbone (:268-287)
             if kind == 'conv':

@@ -19,6 +19,11 @@ from .engine import Src
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+import os as _os
+DEBUG_NORELU = bool(int(_os.environ.get('CDNET_DEBUG_NORELU', '0')))   # debug aid (tools/debug_train.py): linearised network
+TAPE = None              # set by cdnet_amd.trainer around a training forward: layers append themselves in execution order
+WEIGHTS_EPOCH = [0]      # bumped by the fused Adam step (it updates parameters behind torch's version counters)
+
 
 class HeadFeat(C.Structure):
     _fields_ = [('raw', C.c_void_p), ('res', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
@@ -63,6 +68,10 @@ class ConvLayer:
             self.save_invstd = torch.empty((self.Cout,), dtype=torch.float32, device=dev)
         self.stats = None
         self.saved = None                      # (srcs, raw, H, W) of the last training forward
+        self.node_relu, self.node_res = True, None   # how consumers see this layer's output (set in forward / by the RU)
+        self.needs_input_grad = True
+        self.bias_grad_from = None
+        self.wpb, self.wpb_version, self.cfg_bwd = None, None, None
 
     # -- weights ------------------------------------------------------------------------------------
     def _version(self):
@@ -75,11 +84,30 @@ class ConvLayer:
         cin_total = sum(src_channels)
         if self.cfg is None:
             self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override)
-        ver = self.weight._version
+        ver = (self.weight._version, WEIGHTS_EPOCH[0])
         if self.wp is None or self.wp_version != ver:
             pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16
             self.wp = engine.pack_weights(self.weight.detach(), self.cfg, self.pack_mode, Cin_pad=pad, out=self.wp)
             self.wp_version = ver
+
+    def backward_pack(self, cin_total, H, W):
+        """(packed weights, cfg) of the backward-data convolution: a forward convolution with flipped / transposed
+        weights (Conv2d), or a 3x3 / 1x1 convolution over the space-to-depth view of the gradient (ConvTranspose2d)."""
+        ver = (self.weight._version, WEIGHTS_EPOCH[0])
+        if self.cfg_bwd is None:
+            if self.transposed:
+                self.cfg_bwd = engine.choose_cfg([2 * self.Cout, 2 * self.Cout], self.Cin, H, W)
+            else:
+                self.cfg_bwd = engine.choose_cfg([self.Cout], cin_total, H, W)
+        if self.wpb is None or self.wpb_version != ver:
+            if self.transposed:
+                mode = 4 if self.kind == 'convT4' else 5
+                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, mode, out=self.wpb)
+            else:
+                assert cin_total == self.Cin, 'the RGB stem never needs an input gradient'
+                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, 1, out=self.wpb)
+            self.wpb_version = ver
+        return self.wpb, self.cfg_bwd
 
     def eval_fold(self):
         bn = self.bn
@@ -101,6 +129,8 @@ class ConvLayer:
         training path are stored as fp16: the consumer's affine needs more than bf16's 8 significant bits."""
         if H is None:
             H, W = srcs[0].logical_hw()
+        if DEBUG_NORELU:
+            relu = False
         self.prepare([s.C for s in srcs], H, W)
         bias = None if self.bias is None else self.bias.detach()
         if self.bn is None:
@@ -108,6 +138,9 @@ class ConvLayer:
                                          out_dtype=out_dtype)
             if training:
                 self.saved = (srcs, out, H, W)
+                self.node_relu, self.node_res = False, None
+                if TAPE is not None:
+                    TAPE.append(self)
             return Src(out)
         if not training:
             sc, sh = self.eval_fold()
@@ -115,7 +148,7 @@ class ConvLayer:
                                          oshift=sh, orelu=relu, H=H, W=W, out_dtype=out_dtype)
             return Src(out)
         tile = self.cfg[0]
-        N = srcs[0].x.shape[0]
+        N = srcs[0].N
         npar = 4 if self.transposed else 1
         T = N * npar * ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
         if self.stats is None or self.stats.shape[0] != T:
@@ -129,6 +162,9 @@ class ConvLayer:
                   _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(self.scale), _lib.ptr(self.shift),
                   _lib.ptr(self.save_mean), _lib.ptr(self.save_invstd), _lib.stream_ptr())
         self.saved = (srcs, raw, H, W)
+        self.node_relu, self.node_res = relu, None
+        if TAPE is not None:
+            TAPE.append(self)
         return Src(raw, self.scale, self.shift, relu=relu)
 
 

@@ -1,0 +1,364 @@
+"""Training step of the CDNet model on the HIP kernels: forward (batch-statistics BatchNorm), the five-term loss,
+backward, gradient all-reduce over RCCL, fused Adam - the device-side replacement of the body of the reference's
+train_util_dam.train (train_util_dam.py:54-311) with the host loops (:73-142, :278-289) moved onto the GPU.
+
+No autograd: the forward records a tape of the convolution layers it ran; backward walks the tape in reverse.  For every
+layer it (1) turns the consumers' gradients into the gradient of the raw convolution output (BatchNorm + residual + ReLU
++ max-pool/pad routing fused, cdnet_bn_backward), (2) computes dW on the matrix cores (cdnet_conv_backward_weight) and
+(3) computes the input gradient as a forward convolution with a flipped/transposed weight pack (cdnet_conv_forward).
+Parameters, gradients and the Adam moments live in flat fp32 buffers (one fused Adam launch, one all-reduce bucket
+sequence); the nn.Parameters of the model are views into them.
+"""
+import ctypes as C
+import os
+import time
+
+import torch
+
+from . import _lib, engine, runtime
+from .engine import Src
+
+HEAD_PARAMS = ['point_conv.weight', 'direction_conv.weight', 'mask_conv.weight', 'point_conv.bias',
+               'direction_conv.bias', 'mask_conv.bias', 'directionAtt.Conv1x1.weight', 'maskAtt.Conv1x1.weight']
+
+
+class GradIn(C.Structure):
+    _fields_ = [('g', C.c_void_p), ('Hg', C.c_int), ('Wg', C.c_int), ('oy', C.c_int), ('ox', C.c_int),
+                ('pooled', C.c_int), ('coff', C.c_int), ('cstride', C.c_int), ('pad_', C.c_int)]
+
+
+class BnBwdArgs(C.Structure):
+    _fields_ = [('raw', C.c_void_p), ('res', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('mean', C.c_void_p), ('invstd', C.c_void_p), ('gin', GradIn * 3), ('ngin', C.c_int),
+                ('f16', C.c_int), ('relu', C.c_int), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('C', C.c_int)]
+
+
+class _G:
+    """a gradient contribution for a stored tensor"""
+    __slots__ = ('t', 'Hg', 'Wg', 'oy', 'ox', 'pooled', 'coff', 'cstride')
+
+    def __init__(self, t, Hg, Wg, oy=0, ox=0, pooled=0, coff=0, cstride=0):
+        self.t, self.Hg, self.Wg, self.oy, self.ox, self.pooled, self.coff, self.cstride = t, Hg, Wg, oy, ox, pooled, coff, cstride
+
+
+class FlatState:
+    """fp32 flat buffers: parameters, gradients, Adam moments.  Head parameters first (in the kernel's block layout),
+    then every other parameter that takes part in forward, then the reference's never-used parameters (no gradient,
+    never stepped - torch.optim.Adam skips parameters whose .grad is None)."""
+
+    def __init__(self, model):
+        named = dict(model.named_parameters())
+        unused = [n for n in named if n.startswith(tuple(getattr(model, 'UNUSED_PREFIXES', ())))]
+        head = [n for n in HEAD_PARAMS if n in named]
+        rest = [n for n in named if n not in head and n not in unused]
+        self.order = head + rest + unused
+        sizes = [named[n].numel() for n in self.order]
+        total = sum(sizes)
+        dev = next(model.parameters()).device
+        self.P = torch.empty((total,), dtype=torch.float32, device=dev)
+        self.G = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.M = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.V = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.offsets = {}
+        off = 0
+        with torch.no_grad():
+            for n, sz in zip(self.order, sizes):
+                p = named[n]
+                self.P[off:off + sz].copy_(p.detach().reshape(-1))         # one-time host-side setup
+                p.data = self.P[off:off + sz].view(p.shape)
+                p.grad = self.G[off:off + sz].view(p.shape)
+                self.offsets[n] = (off, sz)
+                off += sz
+        self.n_used = sum(named[n].numel() for n in head + rest)
+        self.n_head = sum(named[n].numel() for n in head)
+        self.step_count = 0
+
+
+def _choose_ci_tiles(C_src, Cout):
+    best, best_cost = 2, None
+    for ci_t in (2, 1, 4):
+        CI, CO = ci_t * 32, (4 // ci_t) * 32
+        cost = -(-C_src // CI) * CI * -(-Cout // CO) * CO
+        if best_cost is None or cost < best_cost:
+            best, best_cost = ci_t, cost
+    return best
+
+
+class Trainer:
+
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.99), eps=1e-8, quirk_sample0=True,
+                 world_size=1, bucket_mb=25):
+        self.model = model
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.quirk = int(quirk_sample0)
+        self.world = world_size
+        self.bucket = int(bucket_mb * (1 << 20) // 4)
+        self.flat = FlatState(model)
+        model._head_flat = self.flat.P[:self.flat.n_head] if self.flat.n_head == 855 else None
+        self.dev = self.flat.P.device
+        self._bufs = {}
+        self._ws_bn = None
+        self._ws_slab = None
+        self._ws_head = torch.empty((_lib.load().cdnet_dam_head_backward_workspace_floats(),), dtype=torch.float32, device=self.dev)
+        self._ws_loss = None
+        self.losses = torch.zeros((6,), dtype=torch.float32, device=self.dev)
+        self.tape = []
+
+    # ------------------------------------------------------------------------------------------------
+    def buf(self, key, shape, dtype):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            b = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._bufs[key] = b
+        return b
+
+    def _bn_ws(self, Cc):
+        need = _lib.load().cdnet_bn_backward_workspace_floats(Cc)
+        if self._ws_bn is None or self._ws_bn.numel() < need:
+            self._ws_bn = torch.empty((need,), dtype=torch.float32, device=self.dev)
+        return self._ws_bn
+
+    def _slab(self, n):
+        if self._ws_slab is None or self._ws_slab.numel() < n:
+            self._ws_slab = torch.empty((n,), dtype=torch.float32, device=self.dev)
+        return self._ws_slab
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x):
+        m = self.model
+        m.train()
+        runtime.TAPE = self.tape
+        del self.tape[:]
+        try:
+            out = m(x)
+        finally:
+            runtime.TAPE = None
+        return out
+
+    def loss_and_grads(self, mask, point, direction, label, dirlab, point_t, weight):
+        B, _, H, W = mask.shape
+        lib = _lib.load()
+        need = lib.cdnet_dam_loss_workspace_floats(B, H * W)
+        if self._ws_loss is None or self._ws_loss.numel() < need:
+            self._ws_loss = torch.empty((need,), dtype=torch.float32, device=self.dev)
+        dmask = self.buf('dmask', mask.shape, torch.float32)
+        dpoint = self.buf('dpoint', point.shape, torch.float32)
+        ddir = self.buf('ddir', direction.shape, torch.float32)
+        assert label.dtype == torch.uint8 and dirlab.dtype == torch.uint8 and weight.dtype == torch.uint8
+        assert point_t.dtype == torch.float16
+        _lib.call('cdnet_dam_loss', _lib.ptr(mask), _lib.ptr(point), _lib.ptr(direction), _lib.ptr(label.contiguous()),
+                  _lib.ptr(dirlab.contiguous()), _lib.ptr(point_t.contiguous()), _lib.ptr(weight.contiguous()), B, H, W,
+                  self.quirk, _lib.ptr(self._ws_loss), self._ws_loss.numel(), _lib.ptr(self.losses), _lib.ptr(dmask),
+                  _lib.ptr(dpoint), _lib.ptr(ddir), _lib.stream_ptr())
+        return dmask, dpoint, ddir
+
+    # ------------------------------------------------------------------------------------------------
+    def backward(self, dmask, dpoint, ddir):
+        m = self.model
+        f1, f2, f3 = m._last_feats
+        N, H, W, _ = f1.x.shape
+        grads = {}                      # id(stored tensor) -> [_G]
+
+        def add(t, g):
+            grads.setdefault(id(t), []).append(g)
+
+        # head
+        df = [self.buf('dF%d' % k, (N, H, W, 64), torch.bfloat16) for k in range(3)]
+        hf = [runtime.head_feat(f) for f in (f1, f2, f3)]
+        dhead = self.flat.G[:self.flat.n_head]
+        _lib.call('cdnet_dam_head_backward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(m.head_weight_block()),
+                  _lib.ptr(dmask), _lib.ptr(dpoint), _lib.ptr(ddir), N, H, W, _lib.ptr(df[0]), _lib.ptr(df[1]),
+                  _lib.ptr(df[2]), _lib.ptr(self._ws_head), self._ws_head.numel(), _lib.ptr(dhead), _lib.stream_ptr())
+        for f, d in zip((f1, f2, f3), df):
+            add(f.x, _G(d, H, W))
+
+        for L in reversed(self.tape):
+            srcs, out, Hl, Wl = L.saved
+            gl = grads.pop(id(out), None)
+            if gl is None:
+                continue
+            No, Ho, Wo, Co = out.shape
+            if L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
+                g = self._bn_backward(L, out, gl, add)
+            else:
+                g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
+            self._conv_backward(L, srcs, g, Hl, Wl, add)
+
+    def _bn_backward(self, L, out, gl, add):
+        a = BnBwdArgs()
+        No, Ho, Wo, Co = out.shape
+        a.raw = out.data_ptr()
+        res = getattr(L, 'node_res', None)
+        a.res = None if res is None else res.data_ptr()
+        has_bn = L.bn is not None
+        a.scale = L.scale.data_ptr() if has_bn else None
+        a.shift = L.shift.data_ptr() if has_bn else None
+        a.mean = L.save_mean.data_ptr() if has_bn else None
+        a.invstd = L.save_invstd.data_ptr() if has_bn else None
+        a.ngin = len(gl)
+        assert 1 <= len(gl) <= 3, (L.name, len(gl))
+        for k, g in enumerate(gl):
+            a.gin[k].g = g.t.data_ptr()
+            a.gin[k].Hg, a.gin[k].Wg, a.gin[k].oy, a.gin[k].ox = g.Hg, g.Wg, g.oy, g.ox
+            a.gin[k].pooled, a.gin[k].coff, a.gin[k].cstride = int(g.pooled), g.coff, g.cstride or Co
+        a.f16 = int(out.dtype == torch.float16)
+        a.relu = int(getattr(L, 'node_relu', True))
+        a.N, a.H, a.W, a.C = No, Ho, Wo, Co
+        draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), torch.bfloat16)
+        dz = None
+        if res is not None:
+            dz = self.buf(('dz', L.name), (No, Ho, Wo, Co), torch.bfloat16)
+        ws = self._bn_ws(Co)
+        bn = L.bn
+        _lib.call('cdnet_bn_backward', C.byref(a), _lib.ptr(bn.weight.detach()) if has_bn else None,
+                  _lib.ptr(bn.weight.grad) if has_bn else None, _lib.ptr(bn.bias.grad) if has_bn else None,
+                  _lib.ptr(ws), ws.numel(), _lib.ptr(draw), _lib.ptr(dz), _lib.stream_ptr())
+        if res is not None:
+            add(res, _G(dz, Ho, Wo))        # gradient of the residual branch = dz; its producer (conv_1x1) is on the tape
+        return draw
+
+    def _conv_backward(self, L, srcs, g, H, W, add):
+        lib = _lib.load()
+        N = g.shape[0]
+        Cout = L.Cout
+        cin_total = sum(s.C for s in srcs)
+        cin_real = L.Cin
+        mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3}[L.kind]
+        taps, npar, ostride = L.taps, (4 if L.transposed else 1), (2 if L.transposed else 1)
+        coff = 0
+        for s in srcs:
+            ci_t = _choose_ci_tiles(s.C, Cout)
+            CI, CO = ci_t * 32, (4 // ci_t) * 32
+            other = -(-s.C // CI) * -(-Cout // CO) * npar
+            ntiles = N * (-(-H // 8)) * (-(-W // 16))
+            ksplit = max(1, min(ntiles, 512 // other if other < 512 else 1))
+            nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
+            slab = self._slab(nslab)
+            cs = engine.ConvSrc()
+            s.fill(cs)
+            csrc_real = min(s.C, cin_real - coff) if cin_total != cin_real else s.C
+            _lib.call('cdnet_conv_backward_weight', C.byref(cs), coff, csrc_real, cin_real, _lib.ptr(g), Cout, N, H, W, taps,
+                      npar, ostride, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(L.weight.grad), mode, _lib.stream_ptr())
+            coff += s.C
+        if L.bias is not None and L.bn is None:
+            # bias of a BN-less conv (ResidualUnit.conv_1x1): sum of its output gradient == dbeta of the unit's bn2
+            owner = getattr(L, 'bias_grad_from', None)
+            if owner is not None:
+                L.bias.grad.copy_(owner.bn.bias.grad)
+        if not getattr(L, 'needs_input_grad', True):
+            return
+        # input gradient: forward convolution with the backward-data pack
+        wpb, cfgb = L.backward_pack(cin_total, H, W)
+        if not L.transposed:
+            gin = self.buf(('din', L.name), (N, H, W, cin_total), torch.bfloat16)
+            engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
+        else:
+            # space-to-depth view of g [N,2H,2W,Cout]: two row-parity sources of 2*Cout channels each
+            gin = self.buf(('din', L.name), (N, H, W, cin_total), torch.bfloat16)
+            views = [Src(g, view=(a * 2 * W * Cout, H, W, 2 * Cout, 4 * W * Cout)) for a in (0, 1)]
+            engine.conv_forward(views, wpb, cin_total, cfgb, taps=(9 if L.kind == 'convT4' else 1), out=gin, H=H, W=W)
+        coff = 0
+        for s in srcs:
+            if getattr(s, 'is_input', False):
+                coff += s.C
+                continue
+            add(s.x, _G(gin, H, W, oy=s.off[0], ox=s.off[1], pooled=int(s.pool), coff=coff, cstride=cin_total))
+            coff += s.C
+
+    # ------------------------------------------------------------------------------------------------
+    def allreduce_and_step(self):
+        f = self.flat
+        gscale = 1.0
+        if self.world > 1:
+            bucketed_allreduce(f.G, f.n_used, self.bucket)
+            gscale = 1.0 / self.world
+        f.step_count += 1
+        _lib.call('cdnet_adam_step', _lib.ptr(f.P), _lib.ptr(f.G), _lib.ptr(f.M), _lib.ptr(f.V), f.n_used, self.lr,
+                  self.betas[0], self.betas[1], self.eps, self.wd, f.step_count, gscale, _lib.stream_ptr())
+        runtime.WEIGHTS_EPOCH[0] += 1
+
+    def train_step(self, x, label, dirlab, point_t, weight):
+        """x f32 [B,3,H,W]; label u8 [B,H,W] in {0,1,2}; dirlab u8 [B,H,W] 0..8; point_t f16 [B,H,W]; weight u8 [B,H,W]
+        (the png weight map; /20 on the fly).  Returns the device tensor of the 6 loss values
+        [total, direction CE, direction dice, MSE, CE, dice] (results ordering of train_util_dam.py:297-299)."""
+        mask, point, direction = self.forward(x)
+        dmask, dpoint, ddir = self.loss_and_grads(mask, point, direction, label, dirlab, point_t, weight)
+        self.backward(dmask, dpoint, ddir)
+        self.allreduce_and_step()
+        return self.losses
+
+
+def bucketed_allreduce(flat, n, bucket_elems):
+    """Sum-all-reduce of the first n elements of a flat gradient buffer in fixed-size buckets (RCCL over xGMI on the GPU,
+    gloo in the CPU tests).  The reference's nn.DataParallel reduce_add of the replicas' gradients (train.py:185) becomes
+    one process per GPU + this call; unused parameters sit beyond n and are never communicated."""
+    import torch.distributed as dist
+    works = []
+    for off in range(0, n, bucket_elems):
+        works.append(dist.all_reduce(flat[off:min(n, off + bucket_elems)], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def synthetic_batch(B, dev, seed=2022, H=256, W=256):
+    """SURVEY 8d recipe: uniform RGB tiles, ellipse instances -> 3-class label / centripetal classes / point map,
+    constant weight map 20."""
+    import numpy as np
+    from . import synth
+    rs = np.random.RandomState(seed)
+    x = (rs.randint(0, 256, size=(B, 3, H, W)).astype(np.float32) / 255.0)
+    lab = np.zeros((B, H, W), np.uint8)
+    dirn = np.zeros((B, H, W), np.uint8)
+    point = np.zeros((B, H, W), np.float16)
+    for b in range(B):
+        inst = synth.ellipse_instances(H, W, 60, rs, 5, 12, 10)
+        inside = inst > 0
+        ero = synth.erode8(inside)
+        lab[b][ero] = 1
+        lab[b][inside & ~ero] = 2
+        d, cents = synth.centroid_direction(inst)
+        d[~ero] = 0
+        dirn[b] = d
+        pt = np.zeros((H, W), np.float64)
+        for cy, cx in cents:
+            pt[cy, cx] = 255.0
+        point[b] = synth.gaussian_blur(pt, 2.0).astype(np.float16)
+    weight = np.full((B, H, W), 20, np.uint8)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return t(x), t(lab), t(dirn), t(point), t(weight)
+
+
+def make_bench_step(model, B, dev, rank, world):
+    tr = Trainer(model, world_size=world)
+    batch = synthetic_batch(B, dev, seed=2022 + rank)
+
+    def step():
+        return tr.train_step(*batch)
+    metric = 'tiles/sec (train fwd+bwd+Adam), 256x256'
+    workload = ('CDNet UNet2RevA1_vgg16 (UNet+DAM) training step: forward, 5-term loss, backward, %s fused Adam; '
+                '256x256x3 synthetic tiles, batch %d per GPU' % ('RCCL gradient all-reduce,' if world > 1 else '', B))
+    return step, metric, workload
+
+
+def cpu_baseline_train(n_tiles=2):
+    """The fp32 PyTorch-CPU oracle train iteration (oracle/train.py, pinned to the reference) on a bounded sample."""
+    import numpy as np
+    from . import synth
+    from oracle import models as om
+    from oracle import train as ot
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = om.Unet()
+    opt = ot.make_adam(net)
+    x, lab, dirn, point, weight = [t.cpu() for t in synthetic_batch(n_tiles, torch.device('cpu'))]
+    ot.train_iteration(net, opt, x, lab, dirn, point, weight)
+    t0 = time.time()
+    reps = 2
+    for _ in range(reps):
+        ot.train_iteration(net, opt, x, lab, dirn, point, weight)
+    dt = (time.time() - t0) / reps
+    return dict(value=n_tiles / dt, unit='tiles/s', cores=cores, kind='port',
+                sample='%d synthetic 256x256 tiles per iteration: oracle fp32 PyTorch-CPU train iteration (forward, 5 losses, '
+                       'autograd backward, Adam; %d threads), %d repetitions after 1 warm-up' % (n_tiles, cores, reps))

@@ -117,7 +117,8 @@ typedef struct cdnet_conv_src {
     int relu;
     int off_y, off_x;       /* F.pad: logical (y,x) reads source (y-off_y, x-off_x); outside -> 0 */
     int f16;                /* storage of x / res: 0 = bf16, 1 = fp16 (raw pre-BatchNorm outputs, residual branches) */
-    int pad_;
+    int row_stride;         /* elements between rows (0 = dense: Ws*C); images are Hs*row_stride apart.  Lets the
+                               space-to-depth view of a 2x-upsampled gradient be read without a copy. */
 } cdnet_conv_src;
 
 typedef struct cdnet_conv_args {
@@ -146,7 +147,9 @@ size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, in
 /* fp32 master weights -> packed bf16.  mode 0: Conv2d [Cout][Cin][KH][KW] forward; mode 1: Conv2d backward-data
  * (Cout/Cin are the ROLES in the backward GEMM: Cout := original in_channels, Cin := original out_channels);
  * mode 2: ConvTranspose2d [Cin][Cout][4][4] k4 s2 p1 forward (4 parities); mode 3: ConvTranspose2d [Cin][Cout][2][2]
- * k2 s2 forward (4 parities). */
+ * k2 s2 forward (4 parities); mode 4 / 5: backward-data of the k4 s2 p1 / k2 s2 transposed convolution, expressed as a
+ * 3x3 / 1x1 convolution over the space-to-depth view of the output gradient (two sources = the two row parities, each
+ * with 2*Cout_t channels ordered (column parity, channel)); Cout := transposed-conv in_channels, Cin := 4*out_channels. */
 int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode,
                             void *stream);
 int cdnet_conv_forward(const cdnet_conv_args *args, void *stream);
@@ -191,6 +194,78 @@ int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_head_feat *f2,
 /* plain UNet classifier (models/unet.py:75,104 final_conv 64->K): f32 NCHW logits from a 64-channel feature */
 int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, const float *b, int K, int N, int H, int W,
                         float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Backward-weight of a convolution (the dW half of loss.backward(), train_util_dam.py:307), one call per input
+ * source of the layer.  `src` is the layer's forward source (its lazy transform is re-applied while staging),
+ * grad_out the bf16 NHWC gradient w.r.t. the layer's raw output [N][H*ostride][W*ostride][Cout].
+ * Work is split over `ksplit` slices of the 8x16-pixel tiles; partial fp32 slabs (cdnet_conv_wgrad_slab_floats)
+ * are summed in a fixed order (bit-reproducible) and scattered into dw, the PyTorch-layout gradient:
+ *   mode 0: Conv2d [Cout][Cin_real][KH][KW]; mode 2: ConvTranspose2d k4s2p1 [Cin_real][Cout][4][4];
+ *   mode 3: ConvTranspose2d k2s2 [Cin_real][Cout][2][2].
+ * src_coff: first channel of this source inside the weight's input-channel axis (torch.cat order); Csrc_real: real
+ * channels of the source (3 for the zero-padded RGB stem).  ci_tiles in {1,2,4}: the workgroup owns
+ * ci_tiles*32 input channels x (4/ci_tiles)*32 output channels.
+ * ---------------------------------------------------------------------------------------------------- */
+size_t cdnet_conv_wgrad_slab_floats(int C_src, int Cout, int taps, int npar, int ci_tiles, int ksplit);
+int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_coff, int Csrc_real, int Cin_real,
+                               const uint16_t *grad_out, int Cout, int N, int H, int W, int taps, int npar,
+                               int ostride, int ci_tiles, int ksplit, float *slab, float *dw, int mode, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Training-only streaming kernels.  Together with cdnet_conv_forward (backward-data packs) and
+ * cdnet_conv_backward_weight they replace loss.backward() / optimizer.step() of train_util_dam.py:303-308.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct cdnet_grad_in {     /* gradient w.r.t. a tensor as delivered by ONE of its consumers */
+    const uint16_t *g;             /* bf16 NHWC [N][Hg][Wg][C] */
+    int Hg, Wg;
+    int oy, ox;                    /* the consumer read the tensor through F.pad offsets (oy, ox) */
+    int pooled;                    /* the consumer read maxpool2x2 of the tensor: route to the first maximum */
+    int coff, cstride;             /* channel slice [coff, coff+C) of a tensor with cstride channels (concat consumers) */
+    int pad_;
+} cdnet_grad_in;
+
+typedef struct cdnet_bn_bwd_args {
+    const uint16_t *raw;           /* the layer's stored forward output [N][H][W][C] (fp16 when f16 = 1, else bf16) */
+    const uint16_t *res;           /* residual that was added before the ReLU (same format) or NULL */
+    const float *scale, *shift;    /* forward per-channel affine (BatchNorm as applied), NULL = identity */
+    const float *mean, *invstd;    /* saved batch statistics; NULL = no BatchNorm (gradient passes through) */
+    cdnet_grad_in gin[3];
+    int ngin;
+    int f16, relu;
+    int N, H, W, C;
+} cdnet_bn_bwd_args;
+
+/* BatchNorm(train) + residual + ReLU backward with the consumers' max-pool / pad routing and the summation of up to
+ * three consumer gradients fused in:  dz = (sum_k g_k) * [activation > 0];  dgamma = sum dz*xhat;  dbeta = sum dz;
+ * draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) (bf16); dz_out (optional, bf16) = dz for the residual
+ * branch.  workspace: cdnet_bn_backward_workspace_floats(C) floats. */
+size_t cdnet_bn_backward_workspace_floats(int C);
+int cdnet_bn_backward(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, float *workspace,
+                      size_t workspace_floats, uint16_t *draw, uint16_t *dz_out, void *stream);
+
+/* DAM head backward (model_unet_rev1.py:258-263): gradients of the three logit maps (f32 NCHW) -> gradients of the
+ * three 64-channel features (bf16 NHWC) and of the head weights (f32, CDNET_HEAD_WEIGHT_FLOATS layout). */
+size_t cdnet_dam_head_backward_workspace_floats(void);
+int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_head_feat *f2, const cdnet_head_feat *f3,
+                            const float *head_weights, const float *dmask, const float *dpoint, const float *ddir,
+                            int N, int H, int W, uint16_t *df1, uint16_t *df2, uint16_t *df3, float *workspace,
+                            size_t workspace_floats, float *dhead_weights, void *stream);
+
+/* The five-term CDNet loss (train_util_dam.py:167-276; loss.py:131-260) and its gradient w.r.t. the logits.
+ * label u8 {0,1,2}, dirlab u8 0..8, point target f16, weight map u8 (divided by 20 on the fly, :102).
+ * quirk_sample0 = 1 reproduces train_util_dam.py:139 (direction one-hot masked by sample 0's foreground).
+ * losses[6] = {total, direction CE, direction weighted dice, MSE, CE, dice}.  dmask/dpoint/ddir may all be NULL. */
+size_t cdnet_dam_loss_workspace_floats(int B, int P);
+int cdnet_dam_loss(const float *mask, const float *point, const float *direction, const uint8_t *label,
+                   const uint8_t *dirlab, const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W,
+                   int quirk_sample0, float *workspace, size_t workspace_floats, float *losses, float *dmask,
+                   float *dpoint, float *ddir, void *stream);
+
+/* torch.optim.Adam step (utils.py:915-918: betas (0.9, 0.99), L2 weight decay added to the gradient) on flat fp32
+ * buffers; `step` is 1-based; grad_scale multiplies the gradient first (1/world_size after an all-reduce). */
+int cdnet_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }
