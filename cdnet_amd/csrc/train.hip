@@ -29,13 +29,16 @@ inline int lin_grid(size_t total, int cap = 2048) {
     return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
 }
 
-// out[k] = sum_b partial[b][k]  (fixed order)
-__global__ void reduce_partials_kernel(const float *__restrict__ partial, int nb, int K, float *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// out[k] = sum_b partial[b][k]: one wave per output, lanes stride over b, fixed butterfly -> deterministic
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nb, int K, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= K) return;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * K + k];
-    out[k] = s;
+    for (int b = lane; b < nb; b += 64) s += partial[(size_t)b * K + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[k] = s;
 }
 
 // ======================================================================================================
@@ -177,18 +180,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     }
 }
 
-// sums [nb][2][C] -> dgamma, dbeta and the apply coefficients
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int C, float M, const float *gamma,
-                                       const float *invstd, float *dgamma, float *dbeta, float *k1, float *k2, float *k3) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// sums [nb][2][C] -> dgamma, dbeta and the apply coefficients; one wave per channel, fixed butterfly (deterministic)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int C, float M, const float *gamma,
+                                                              const float *invstd, float *dgamma, float *dbeta, float *k1, float *k2,
+                                                              float *k3) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; ++b) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
-    k1[c] = gamma[c] * invstd[c];
-    k2[c] = (float)(s1 / M);
-    k3[c] = (float)(s2 / M);
+    for (int b = lane; b < nb; b += 64) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        k1[c] = gamma[c] * invstd[c];
+        k2[c] = (float)(s1 / M);
+        k3[c] = (float)(s2 / M);
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs A) {
@@ -245,6 +254,25 @@ __device__ __forceinline__ float feat1(const HeadFeat &f, size_t pix, int c, con
         x = bf2f(f2bf(x));
     }
     return x;
+}
+
+// 8 channels [c0, c0+8) of the feature at one pixel
+__device__ __forceinline__ void feat8(const HeadFeat &f, size_t pix, int c0, const float *s_sc, const float *s_sh, float *v) {
+    V16 r, rr;
+    r.u = *reinterpret_cast<const uint4 *>(f.raw + pix * 64 + c0);
+    rr.u = make_uint4(0, 0, 0, 0);
+    if (f.res) rr.u = *reinterpret_cast<const uint4 *>(f.res + pix * 64 + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = f.f16 ? h2f(r.h[j]) : bf2f(r.h[j]);
+        if (f.scale || f.res || f.relu) {
+            if (f.scale) x = fmaf(x, s_sc[c0 + j], s_sh[c0 + j]);
+            if (f.res) x += f.f16 ? h2f(rr.h[j]) : bf2f(rr.h[j]);
+            if (f.relu) x = fmaxf(x, 0.f);
+            x = bf2f(f2bf(x));
+        }
+        v[j] = x;
+    }
 }
 
 __device__ __forceinline__ void feat64(const HeadFeat &f, size_t pix, const float *s_sc, const float *s_sh, float *v) {
@@ -311,13 +339,13 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
     float sg[23];
 #pragma unroll
     for (int j = 0; j < 23; ++j) sg[j] = 0.f;
-    // weight gradient accumulators for channel c = tid & 63 over this thread's quarter of each pixel block
-    float gwm[3], gwd[9], gwp = 0.f;
+    // weight gradient accumulators: 8 channels (c8) x 13 coefficient rows, over pixels pg, pg+32, ... of each block
+    float gw[13][8];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) gwm[j] = 0.f;
+    for (int j = 0; j < 13; ++j)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) gwd[j] = 0.f;
-    const int c = tid & 63, part = tid >> 6;
+        for (int q = 0; q < 8; ++q) gw[j][q] = 0.f;
+    const int c8 = (tid & 7) * 8, pg = tid >> 3;
 
     for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {
         const size_t i = base + tid;
@@ -395,31 +423,54 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
 #pragma unroll
         for (int j = 0; j < 13; ++j) s_coef[tid][j] = coef[j];
         __syncthreads();
-        // phase 2: weight gradients for channel c over pixels part*64 .. part*64+63 of this block
-        for (int k = 0; k < 64; ++k) {
-            const int px = part * 64 + k;
+        // phase 2: weight gradients, rows = {dm[3] x F1, du[9] x F2, dpt x F3}, 16-byte feature loads
+#pragma unroll 2
+        for (int k = 0; k < 8; ++k) {
+            const int px = pg + 32 * k;
             const size_t ip = base + px;
-            if (ip >= total) break;
-            const float x1 = feat1(f1, ip, c, s_sc[0], s_sh[0]);
-            const float x2 = feat1(f2, ip, c, s_sc[1], s_sh[1]);
-            const float x3 = feat1(f3, ip, c, s_sc[2], s_sh[2]);
+            if (ip < total) {
+                float x[8];
+                feat8(f1, ip, c8, s_sc[0], s_sh[0], x);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) gwm[j] = fmaf(s_coef[px][j], x1, gwm[j]);
+                for (int j = 0; j < 3; ++j) {
+                    const float cj = s_coef[px][j];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) gwd[j] = fmaf(s_coef[px][3 + j], x2, gwd[j]);
-            gwp = fmaf(s_coef[px][12], x3, gwp);
+                    for (int q = 0; q < 8; ++q) gw[10 + j][q] = fmaf(cj, x[q], gw[10 + j][q]);
+                }
+                feat8(f2, ip, c8, s_sc[1], s_sh[1], x);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const float cj = s_coef[px][3 + j];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) gw[1 + j][q] = fmaf(cj, x[q], gw[1 + j][q]);
+                }
+                feat8(f3, ip, c8, s_sc[2], s_sh[2], x);
+                const float cp = s_coef[px][12];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gw[0][q] = fmaf(cp, x[q], gw[0][q]);
+            }
         }
         __syncthreads();
     }
     // block reduction -> partial[block][855]  (layout of HeadW)
     float *o = partial + (size_t)blockIdx.x * HEADW_FLOATS;
-    // weights: sum the 4 parts per channel
+    // weights: rows are already in HeadW order (wp | wd[9] | wm[3]); sum the 8 pixel groups of a wave by butterfly, then
+    // the 4 waves through LDS
     __shared__ float s_w[4][13][64];
-    s_w[part][0][c] = gwp;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) s_w[part][1 + j][c] = gwd[j];
+    for (int j = 0; j < 13; ++j)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s_w[part][10 + j][c] = gwm[j];
+        for (int q = 0; q < 8; ++q) {
+            float t = gw[j][q];
+            t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+            gw[j][q] = t;
+        }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_w[tid >> 6][j][c8 + q] = gw[j][q];
+    }
 #pragma unroll
     for (int j = 0; j < 23; ++j) s_red[tid][j] = sg[j];
     __syncthreads();
@@ -737,7 +788,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
         A.partial = workspace;
         float *k = workspace + (size_t)nb * 2 * A.C;
         bn_bwd_reduce_kernel<<<nb, 256, 0, st>>>(A);
-        bn_bwd_finalize_kernel<<<cdiv(A.C, 256), 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
+        bn_bwd_finalize_kernel<<<cdiv(A.C, 4), 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
                                                               k + A.C, k + 2 * A.C);
         A.k1 = k; A.k2 = k + A.C; A.k3 = k + 2 * A.C;
     }
@@ -767,7 +818,7 @@ extern "C" int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_he
     hipStream_t st = (hipStream_t)stream;
     dam_head_bwd_kernel<<<nb, 256, 0, st>>>(mk_hf(*f1), mk_hf(*f2), mk_hf(*f3), reinterpret_cast<const HeadW *>(head_weights), dmask,
                                             dpoint, ddir, N, H * W, df1, df2, df3, workspace);
-    reduce_partials_kernel<<<cdiv(HEADW_FLOATS, 256), 256, 0, st>>>(workspace, nb, HEADW_FLOATS, dhead_weights);
+    reduce_partials_kernel<<<cdiv(HEADW_FLOATS, 4), 256, 0, st>>>(workspace, nb, HEADW_FLOATS, dhead_weights);
     return check_launch("cdnet_dam_head_backward");
 }
 

@@ -214,32 +214,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int ksplit, int npar, int ci_blocks,
                                                            int co_blocks, int TAPS, int CI, int CO, int Csrc_real, int Cin_real,
                                                            int src_coff, int Cout, int mode, float *__restrict__ dw) {
+    // block = 64 consecutive slab elements x 4 interleaved k-lanes (k = kq, kq+4, ...); fixed-order combine in LDS
+    __shared__ float s_part[4][64];
     const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * TAPS * CI * CO;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_ks; i += (size_t)gridDim.x * blockDim.x) {
-        size_t r = i;
-        const int co_l = r % CO; r /= CO;
-        const int ci_l = r % CI; r /= CI;
-        const int tap = r % TAPS; r /= TAPS;
-        const int cb = r % co_blocks; r /= co_blocks;
-        const int ib = r % ci_blocks; r /= ci_blocks;
-        const int par = (int)r;
-        const int co = cb * CO + co_l, ci = src_coff + ib * CI + ci_l;
-        if (co >= Cout || ib * CI + ci_l >= Csrc_real) continue;
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * per_ks + i];
-        size_t o;
-        if (mode == 0) {
-            o = ((size_t)co * Cin_real + ci) * TAPS + tap;
-        } else if (mode == 2) {
-            const int a = par >> 1, b = par & 1, ty = tap >> 1, tx = tap & 1;
-            const int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
-            const int kw = b == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
-            o = (((size_t)ci * Cout + co) * 4 + kh) * 4 + kw;
-        } else {
-            o = (((size_t)ci * Cout + co) * 2 + (par >> 1)) * 2 + (par & 1);
+    const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;            // per_ks is a multiple of 64 (CO >= 32, CI >= 32)
+    float s = 0.f;
+    if (i < per_ks) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = kq;
+        for (; k + 12 < ksplit; k += 16) {
+            a0 += slab[(size_t)k * per_ks + i];
+            a1 += slab[(size_t)(k + 4) * per_ks + i];
+            a2 += slab[(size_t)(k + 8) * per_ks + i];
+            a3 += slab[(size_t)(k + 12) * per_ks + i];
         }
-        dw[o] = s;
+        for (; k < ksplit; k += 4) a0 += slab[(size_t)k * per_ks + i];
+        s = (a0 + a1) + (a2 + a3);
     }
+    s_part[kq][e] = s;
+    __syncthreads();
+    if (kq != 0 || i >= per_ks) return;
+    s = (s_part[0][e] + s_part[1][e]) + (s_part[2][e] + s_part[3][e]);
+    size_t r = i;
+    const int co_l = r % CO; r /= CO;
+    const int ci_l = r % CI; r /= CI;
+    const int tap = r % TAPS; r /= TAPS;
+    const int cb = r % co_blocks; r /= co_blocks;
+    const int ib = r % ci_blocks; r /= ci_blocks;
+    const int par = (int)r;
+    const int co = cb * CO + co_l, ci = src_coff + ib * CI + ci_l;
+    if (co >= Cout || ib * CI + ci_l >= Csrc_real) return;
+    size_t o;
+    if (mode == 0) {
+        o = ((size_t)co * Cin_real + ci) * TAPS + tap;
+    } else if (mode == 2) {
+        const int a = par >> 1, b = par & 1, ty = tap >> 1, tx = tap & 1;
+        const int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
+        const int kw = b == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+        o = (((size_t)ci * Cout + co) * 4 + kh) * 4 + kw;
+    } else {
+        o = (((size_t)ci * Cout + co) * 2 + (par >> 1)) * 2 + (par & 1);
+    }
+    dw[o] = s;
 }
 
 template <int CI_T, int CO_T, int TAPS>
@@ -299,8 +316,7 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     const int CI = ci_tiles * 32, CO = (4 / ci_tiles) * 32;
     const int ci_blocks = cdiv(src->C, CI), co_blocks = cdiv(Cout, CO);
     const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * taps * CI * CO;
-    int blocks = (int)((per_ks + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
+    const int blocks = (int)((per_ks + 63) / 64);
     wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(slab, ksplit, npar, ci_blocks, co_blocks, taps, CI, CO, Csrc_real, Cin_real, src_coff, Cout,
                                                 mode, dw);
     return check_launch("wgrad_reduce_kernel");
