@@ -39,6 +39,8 @@ SIGNATURES = {
     'cdnet_dam_loss_workspace_floats': (_sz, [_i, _i]),
     'cdnet_dam_loss': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    'cdnet_window_pack': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
+    'cdnet_window_stitch': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
 }
 
 _lib = None

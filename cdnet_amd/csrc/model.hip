@@ -206,6 +206,63 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(HeadFeat f, const fl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Sliding windows (utils.split_forward_dam, utils.py:658-726) with the TTA view transform folded in
+// (test_dam.py:313-385: PIL FLIP_LEFT_RIGHT / FLIP_TOP_BOTTOM / rotate(90, expand=True)).
+// view (vy,vx) -> image (iy,ix): undo vertical / horizontal flips in the view frame, then the ccw rotation.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void view_to_image(int xf, int vy, int vx, int H, int W, int &iy, int &ix) {
+    const int hv = (xf & 4) ? W : H, wv = (xf & 4) ? H : W;
+    if (xf & 2) vy = hv - 1 - vy;
+    if (xf & 1) vx = wv - 1 - vx;
+    if (xf & 4) { iy = vx; ix = W - 1 - vy; }       // r[y'][x'] = img[x'][W-1-y']
+    else { iy = vy; ix = vx; }
+}
+
+// img f32 [C][H][W] (one image) -> tiles bf16 NHWC [ny*nx][th][tw][16]; window (ky,kx) starts at (ky*stride, kx*stride)
+// of the (zero-padded) view
+__global__ __launch_bounds__(256) void window_pack_kernel(const float *__restrict__ img, int C, int H, int W, int xf, int th,
+                                                          int tw, int stride, int ny, int nx, unsigned short *__restrict__ out) {
+    const int hv = (xf & 4) ? W : H, wv = (xf & 4) ? H : W;
+    const size_t total = (size_t)ny * nx * th * tw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int tx = r % tw; r /= tw;
+        const int ty = r % th; r /= th;
+        const int kx = r % nx; const int ky = (int)(r / nx);
+        const int vy = ky * stride + ty, vx = kx * stride + tx;
+        unsigned short v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = 0;
+        if (vy < hv && vx < wv) {
+            int iy, ix;
+            view_to_image(xf, vy, vx, H, W, iy, ix);
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < C) v[c] = f2bf(img[((size_t)c * H + iy) * W + ix]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + i * 16);
+        dst[0] = *reinterpret_cast<const uint4 *>(v);
+        dst[1] = *reinterpret_cast<const uint4 *>(v + 8);
+    }
+}
+
+// tiles f32 NCHW [ny*nx][K][th][tw] -> stitched f32 [K][hv][wv] with the reference's interior rule:
+// pixel y belongs to the LAST window k with k*stride + (k ? overlap/2 : 0) <= y   (utils.py:683-712)
+__global__ __launch_bounds__(256) void window_stitch_kernel(const float *__restrict__ tiles, int K, int th, int tw, int stride,
+                                                            int half_ov, int ny, int nx, int hv, int wv, float *__restrict__ out) {
+    const size_t total = (size_t)K * hv * wv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int x = r % wv; r /= wv;
+        const int y = r % hv; const int k = (int)(r / hv);
+        int ky = y < half_ov ? 0 : (y - half_ov) / stride; ky = ky > ny - 1 ? ny - 1 : ky;
+        int kx = x < half_ov ? 0 : (x - half_ov) / stride; kx = kx > nx - 1 ? nx - 1 : kx;
+        out[i] = tiles[(((size_t)(ky * nx + kx) * K + k) * th + (y - ky * stride)) * tw + (x - kx * stride)];
+    }
+}
+
 inline int lin_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -262,4 +319,25 @@ extern "C" int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, con
     CDNET_REQUIRE(K >= 1 && K <= 16 && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1: K=%d must be in [1,16]", K);
     final_conv1x1_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(mk_feat(*f), w, b, K, N, H * W, out);
     return check_launch("cdnet_final_conv1x1");
+}
+
+extern "C" int cdnet_window_pack(const float *img, int C, int H, int W, int view_xform, int tile_h, int tile_w, int stride, int ny,
+                                 int nx, void *out_bf16_nhwc16, void *stream) {
+    CDNET_REQUIRE(img && out_bf16_nhwc16, "cdnet_window_pack: null pointer");
+    CDNET_REQUIRE(C > 0 && C <= 16 && H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && stride > 0 && ny > 0 && nx > 0 &&
+                  view_xform >= 0 && view_xform < 8, "cdnet_window_pack: bad arguments");
+    window_pack_kernel<<<lin_grid((size_t)ny * nx * tile_h * tile_w), 256, 0, (hipStream_t)stream>>>(
+        img, C, H, W, view_xform, tile_h, tile_w, stride, ny, nx, (unsigned short *)out_bf16_nhwc16);
+    return check_launch("cdnet_window_pack");
+}
+
+extern "C" int cdnet_window_stitch(const float *tiles, int K, int tile_h, int tile_w, int stride, int overlap, int ny, int nx, int Hv,
+                                   int Wv, float *out, void *stream) {
+    CDNET_REQUIRE(tiles && out, "cdnet_window_stitch: null pointer");
+    CDNET_REQUIRE(K > 0 && tile_h > 0 && tile_w > 0 && stride > 0 && ny > 0 && nx > 0 && Hv > 0 && Wv > 0 && overlap >= 0,
+                  "cdnet_window_stitch: bad arguments");
+    CDNET_REQUIRE((ny - 1) * stride + tile_h >= Hv && (nx - 1) * stride + tile_w >= Wv, "cdnet_window_stitch: windows do not cover the view");
+    window_stitch_kernel<<<lin_grid((size_t)K * Hv * Wv), 256, 0, (hipStream_t)stream>>>(tiles, K, tile_h, tile_w, stride, overlap / 2,
+                                                                                         ny, nx, Hv, Wv, out);
+    return check_launch("cdnet_window_stitch");
 }

@@ -181,7 +181,13 @@ class Unet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('cdnet_amd.models.dam.model_unet_rev1.Unet runs on the MI355X only (no CPU fallback)')
         assert x.shape[1] == 3, 'the CDNet path feeds 3-channel tiles (child0/child_conv1 branches are never taken)'
-        t = Src(runtime.input_pack(x.float()))
+        return self.forward_features_packed(runtime.input_pack(x.float()), training)
+
+    def forward_features_packed(self, x16, training):
+        """x16: bf16 NHWC [N,H,W,16] (3 real channels) - the form cdnet_input_pack / cdnet_window_pack produce"""
+        if self._rt is None:
+            self._build_runtime()
+        t = Src(x16)
         t.is_input = True
         self._rt['enc'][0][1].needs_input_grad = False
         feats = {}
@@ -208,9 +214,16 @@ class Unet(nn.Module):
 
     def forward(self, *input):
         x = input[0]
-        f1, f2, f3 = self.forward_features(x, self.training)
+        return self._head(self.forward_features(x, self.training))
+
+    def forward_packed(self, x16):
+        """forward on already packed bf16 NHWC windows (sliding-window / TTA inference)"""
+        return self._head(self.forward_features_packed(x16, self.training))
+
+    def _head(self, feats):
+        f1, f2, f3 = feats
         N, H, W, _ = f1.x.shape
-        dev = x.device
+        dev = f1.x.device
         mask = torch.empty((N, 3, H, W), dtype=torch.float32, device=dev)
         point = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
         direction = torch.empty((N, 9, H, W), dtype=torch.float32, device=dev)

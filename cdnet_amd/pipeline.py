@@ -26,3 +26,42 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False):
     r.update(cc)
     r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
     return r
+
+
+@torch.no_grad()
+def infer_image(model, image, opt=None, tta=True, all_img_test=1, patch_size=256, overlap=40, classes=9, min_area=20,
+                radius=2, want_stages=False):
+    """The reference's per-image inference (test_dam.py:297-563) for one image tensor [3,H,W] float32 on the GPU
+    (already ToTensor'd / normalised): the eight dihedral views (TTA) through the network - whole image
+    (all_img_test == 1, options.py:35) or 256/40 sliding windows (utils.split_forward_dam) - softmax / gated direction
+    argmax per view (get_probmaps), per-view direction-difference maps, their mean, the point-guided boundary boost, argmax,
+    fill holes, remove small objects, label, dilate.  Returns dict(final int32 [H,W], count, pred, ...)."""
+    from . import utils
+    if opt is not None:
+        tta, all_img_test = opt.test['tta'], opt.all_img_test
+        patch_size, overlap = opt.test['patch_size'], opt.test['overlap']
+        classes, min_area, radius = opt.direction_classes, opt.post['min_area'], opt.post['radius']
+    assert not model.training and image.dim() == 3
+    _, H, W = image.shape
+    xforms = list(postproc.TTA_XFORMS) if tta else [0]
+    if all_img_test == 1:
+        # whole-image forward: one window as large as the view
+        size = max(H, W)
+        views = utils.split_forward_views(model, image, size, 0, xforms, classes)
+    else:
+        views = utils.split_forward_views(model, image, patch_size, overlap, xforms, classes)
+    V = len(xforms)
+    plane = H * W
+    probs = torch.empty((1, V, 3 * plane), dtype=torch.float32, device=image.device)
+    points = torch.empty((1, V, plane), dtype=torch.float32, device=image.device)
+    dcms = torch.empty((1, V, plane), dtype=torch.uint8, device=image.device)
+    for v, (mask, point, direction) in enumerate(views):
+        prob, dcm = postproc.probmaps(mask[None], direction[None])
+        probs[0, v] = prob.reshape(-1)
+        points[0, v] = point.reshape(-1)
+        dcms[0, v] = dcm.reshape(-1)
+    r = postproc.postprocess_views(probs, points, dcms, xforms=xforms, H=H, W=W, classes=classes, min_area=min_area,
+                                   radius=radius, want_stages=want_stages)
+    out = {k: (v[0] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v) for k, v in r.items()}
+    out['count'] = int(r['counts'][0])
+    return out

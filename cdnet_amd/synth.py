@@ -51,10 +51,19 @@ def det_fill_state_dict(sd, bn_owners):
         v.copy_(torch.from_numpy(det_fill_array(k, tuple(v.shape), kind)))
 
 
-def det_input(shape, seed, f16_exact=False):
+def to_bf16_exact(x):
+    """round float32 to the nearest bfloat16-representable value (ties to even), still stored as float32"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & np.uint32(0xFFFF0000)
+    return u.view(np.float32)
+
+
+def det_input(shape, seed, f16_exact=False, bf16_exact=False):
     x = np.random.RandomState(seed).rand(*shape).astype(np.float32)
     if f16_exact:
         x = x.astype(np.float16).astype(np.float32)
+    if bf16_exact:
+        x = to_bf16_exact(x)
     return x
 
 

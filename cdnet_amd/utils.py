@@ -1,0 +1,120 @@
+"""Model factory, sliding-window forward and training helpers with the reference's names (utils.py).
+
+  chooseModel(opt)                                     utils.py:816-886
+  split_forward_dam(model, input, size, overlap, opt)  utils.py:658-726
+  get_optimizer(args, model)                           utils.py:907-962   (Adam path; returns the fused device optimiser)
+  AverageMeter                                         utils.py:755-774
+  adjust_learning_rate                                 utils.py:965-977
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def chooseModel(opt):
+    name = opt.model['modelName']
+    if name == 'UNet':
+        from .models.unet import UNet
+        return UNet(num_classes=opt.model['out_c'], in_channels=opt.model['in_c'])
+    if name == 'UNet2RevA1_vgg16':
+        from .models.dam.model_unet_rev1 import Unet
+        # the reference hard-codes pretrained=True (ImageNet download); weights are supplied via load_state_dict here
+        return Unet(backbone_name='vgg16_bn', pretrained=False, encoder_freeze=False, classes=opt.model['out_c'])
+    raise NotImplementedError('model {} is outside the CDNet hot path (SURVEY.md section 8: UNet, UNet2RevA1_vgg16)'.format(name))
+
+
+def window_grid(h0, w0, size, overlap):
+    """tile geometry of split_forward_dam (utils.py:664-683): padded extent, tile size, counts"""
+    stride = size - overlap
+    h = h0 + (stride - (h0 - size) % stride if h0 - size > 0 else 0)
+    w = w0 + (stride - (w0 - size) % stride if w0 - size > 0 else 0)
+    ny, nx = len(range(0, h - overlap, stride)), len(range(0, w - overlap, stride))
+    return stride, min(size, h), min(size, w), ny, nx
+
+
+def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=64):
+    """Sliding-window forward of one image [3,H,W] (cuda float32) for several TTA views at once.
+    Returns a list (one entry per view) of stitched logits (mask [3,hv,wv], point [1,hv,wv], direction [9,hv,wv])."""
+    assert image.dim() == 3 and image.is_cuda and image.dtype == torch.float32
+    Cc, H0, W0 = image.shape
+    image = image.contiguous()
+    packs, geo = [], []
+    for xf in xforms:
+        hv, wv = (W0, H0) if xf & 4 else (H0, W0)
+        stride, th, tw, ny, nx = window_grid(hv, wv, size, overlap)
+        t = torch.empty((ny * nx, th, tw, 16), dtype=torch.bfloat16, device=image.device)
+        _lib.call('cdnet_window_pack', _lib.ptr(image), Cc, H0, W0, int(xf), th, tw, stride, ny, nx, _lib.ptr(t), _lib.stream_ptr())
+        packs.append(t)
+        geo.append((hv, wv, stride, th, tw, ny, nx))
+    # batch windows of equal shape through the network
+    outs = [None] * len(xforms)
+    by_shape = {}
+    for i, t in enumerate(packs):
+        by_shape.setdefault(tuple(t.shape[1:3]), []).append(i)
+    for shape, idxs in by_shape.items():
+        tiles = torch.cat([packs[i] for i in idxs], 0) if len(idxs) > 1 else packs[idxs[0]]
+        res = []
+        for s in range(0, tiles.shape[0], max_batch):
+            res.append(model.forward_packed(tiles[s:s + max_batch]))
+        mask = torch.cat([r[0] for r in res], 0)
+        point = torch.cat([r[1] for r in res], 0)
+        direction = torch.cat([r[2] for r in res], 0)
+        off = 0
+        for i in idxs:
+            hv, wv, stride, th, tw, ny, nx = geo[i]
+            n = ny * nx
+            st = []
+            for t_, K in ((mask, mask.shape[1]), (point, 1), (direction, direction.shape[1])):
+                o = torch.empty((K, hv, wv), dtype=torch.float32, device=image.device)
+                src = t_[off:off + n].contiguous()
+                _lib.call('cdnet_window_stitch', _lib.ptr(src), K, th, tw, stride, overlap, ny, nx, hv, wv, _lib.ptr(o), _lib.stream_ptr())
+                st.append(o)
+            outs[i] = tuple(st)
+            off += n
+    return outs
+
+
+def split_forward_dam(model, input, size, overlap, opt=None):
+    """split the input image for forward process (reference signature).  input [1,C,H,W]; returns
+    (output [1,out_c,H,W], output_point [1,1,H,W], output_direction [1,classes,H,W]) on the GPU."""
+    assert input.shape[0] == 1, 'the reference calls this with one image at a time'
+    with torch.no_grad():
+        (m, p, d), = split_forward_views(model, input[0].cuda().float(), size, overlap, (0,))
+    return m[None], p[None], d[None]
+
+
+class AverageMeter(object):
+    """ Computes and stores the average and current value (utils.py:755-774) """
+
+    def __init__(self, shape=1):
+        self.shape = shape
+        self.reset()
+
+    def reset(self):
+        self.val = np.zeros(self.shape)
+        self.avg = np.zeros(self.shape)
+        self.sum = np.zeros(self.shape)
+        self.count = 0
+
+    def update(self, val, n=1):
+        val = np.array(val)
+        assert val.shape == self.val.shape
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def get_optimizer(args, model, world_size=1):
+    """utils.py:907-962 for the default 'adam' (lr, betas=(0.9, 0.99), weight_decay): returns (Trainer, None) - the
+    fused device optimiser lives inside cdnet_amd.trainer.Trainer."""
+    if args.train['optimizer'].lower() != 'adam':
+        raise NotImplementedError("only the reference's default optimizer 'adam' is on the hot path")
+    from .trainer import Trainer
+    return Trainer(model, lr=args.train['lr'], weight_decay=args.train['weight_decay'], world_size=world_size), None
+
+
+def adjust_learning_rate(args, trainer, epoch):
+    """utils.py:965-977: scheduler 'None' keeps the learning rate constant"""
+    return trainer.lr

@@ -267,6 +267,20 @@ int cdnet_dam_loss(const float *mask, const float *point, const float *direction
 int cdnet_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Sliding-window inference.  Replaces utils.split_forward_dam (utils.py:658-726) and the construction of the eight
+ * test-time-augmentation views (test_dam.py:313-385) without ever materialising a flipped / rotated / padded image.
+ * cdnet_window_pack: img f32 [C<=16][H][W] -> ny*nx windows bf16 NHWC [ny*nx][tile_h][tile_w][16] of view `view_xform`
+ *   (bit0 hflip, bit1 vflip, bit2 rot90 ccw first); window (ky,kx) starts at (ky*stride, kx*stride) of the view, pixels
+ *   beyond the view are the zero padding of utils.py:665-676.
+ * cdnet_window_stitch: window outputs f32 [ny*nx][K][tile_h][tile_w] -> out f32 [K][Hv][Wv], keeping for every pixel
+ *   the last window whose interior (overlap/2 trimmed, except at the image border) contains it (utils.py:683-712).
+ * ---------------------------------------------------------------------------------------------------- */
+int cdnet_window_pack(const float *img, int C, int H, int W, int view_xform, int tile_h, int tile_w, int stride, int ny,
+                      int nx, void *out_bf16_nhwc16, void *stream);
+int cdnet_window_stitch(const float *tiles, int K, int tile_h, int tile_w, int stride, int overlap, int ny, int nx, int Hv,
+                        int Wv, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,8 +61,8 @@ def det_fill(model):
     return model
 
 
-def det_input(shape, seed, f16_exact=False):
-    return torch.from_numpy(synth.det_input(shape, seed, f16_exact))
+def det_input(shape, seed, f16_exact=False, bf16_exact=False):
+    return torch.from_numpy(synth.det_input(shape, seed, f16_exact, bf16_exact))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -338,7 +338,7 @@ def gen_split():
              'e': (280, 300, 256, 40)}     # the reference's own size/overlap (options.py test patch 256/40)
     for name, (h, w, size, ov) in cases.items():
         seed = 31 + ord(name)
-        x = det_input((1, 3, h, w), seed, f16_exact=True)   # regenerated by synth.det_input in the tests
+        x = det_input((1, 3, h, w), seed, bf16_exact=True)  # regenerated by synth.det_input(bf16_exact=True) in the tests
         o, p, d = ref_utils.split_forward_dam(Toy(), x, size, ov, opt)
         out['cfg_' + name] = np.array([size, ov, h, w, seed])
         if name == 'e':                                       # big case: keep a strided sample of the outputs

@@ -1,0 +1,106 @@
+"""GPU parity of the inference driver: sliding windows (utils.split_forward_dam), TTA views, whole pipeline."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Opt:
+    def __init__(self):
+        self.model = dict(out_c=3, mseloss=1, direction=1)
+        self.direction_classes = 9
+
+
+class _ToyModel:
+    """the position-coding toy network of tests/golden/make_golden.py:gen_split, evaluated on packed bf16 windows
+    (torch ops here are test scaffolding, not product code)"""
+    training = False
+
+    def forward_packed(self, x16):
+        import torch
+        x = x16[..., :3].float().permute(0, 3, 1, 2)
+        b, c, h, w = x.shape
+        yy = torch.arange(h, dtype=torch.float32, device=x.device).view(1, 1, h, 1).expand(b, 1, h, w)
+        xx = torch.arange(w, dtype=torch.float32, device=x.device).view(1, 1, 1, w).expand(b, 1, h, w)
+        mask = torch.cat([x[:, :1] * 2 + yy * 1e-3, x[:, 1:2] - xx * 1e-3, x[:, 2:3] + 1], 1)
+        point = x.sum(1, keepdim=True) + yy * 1e-2 + xx * 1e-4
+        direction = torch.cat([x[:, :1] * (k + 1) + (yy + xx) * 1e-3 for k in range(9)], 1)
+        return mask.contiguous(), point.contiguous(), direction.contiguous()
+
+
+def test_split_forward_dam_matches_reference(golden):
+    import torch
+    from cdnet_amd import synth, utils
+    z = golden('split_fwd')
+    for name in z['names']:
+        size, ov, h, w, seed = [int(v) for v in z['cfg_' + name]]
+        x = torch.from_numpy(synth.det_input((1, 3, h, w), seed, bf16_exact=True))
+        o, p, d = utils.split_forward_dam(_ToyModel(), x, size, ov, _Opt())
+        assert tuple(o.shape) == (1, 3, h, w) and tuple(p.shape) == (1, 1, h, w) and tuple(d.shape) == (1, 9, h, w)
+        if name == 'e':
+            o, p, d = o[:, :, ::7, ::5], p[:, :, ::7, ::5], d[:, :, ::7, ::5]
+        np.testing.assert_allclose(o.cpu().numpy(), z['mask_' + name], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(p.cpu().numpy(), z['point_' + name], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(d.cpu().numpy(), z['dir_' + name], rtol=0, atol=4e-6)
+
+
+def test_tta_views_are_pil_transforms():
+    """window pack with a view code == the PIL transpose / rotate(90, expand) of test_dam.py:313-385 (= np.flip / rot90)"""
+    import torch
+    from cdnet_amd import _lib, synth, utils
+    H, W = 37, 53
+    img = synth.det_input((3, H, W), 4, bf16_exact=True)
+    x = torch.from_numpy(img).cuda()
+    for xf in range(8):
+        v = img
+        if xf & 4:
+            v = np.rot90(v, k=1, axes=(1, 2))
+        if xf & 1:
+            v = np.flip(v, 2)
+        if xf & 2:
+            v = np.flip(v, 1)
+        hv, wv = v.shape[1:]
+        stride, th, tw, ny, nx = utils.window_grid(hv, wv, 24, 8)
+        t = torch.empty((ny * nx, th, tw, 16), dtype=torch.bfloat16, device='cuda')
+        _lib.call('cdnet_window_pack', _lib.ptr(x), 3, H, W, xf, th, tw, stride, ny, nx, _lib.ptr(t), _lib.stream_ptr())
+        got = t.float().cpu().numpy()
+        pad = np.zeros((3, (ny - 1) * stride + th, (nx - 1) * stride + tw), np.float32)
+        pad[:, :hv, :wv] = v
+        for ky in range(ny):
+            for kx in range(nx):
+                want = pad[:, ky * stride:ky * stride + th, kx * stride:kx * stride + tw].transpose(1, 2, 0)
+                assert np.array_equal(got[ky * nx + kx, :, :, :3], want), (xf, ky, kx)
+                assert not got[ky * nx + kx, :, :, 3:].any()
+
+
+def test_infer_image_pipeline_tta_windows_vs_whole_and_oracle():
+    """the device pipeline == per-view network outputs pushed through the CPU oracle post-processing (bit-exact on the
+    integer stages given the same logits), for sliding windows + 8-view TTA on a ragged image"""
+    import torch
+    from cdnet_amd import pipeline, postproc, synth, utils
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    from oracle import postproc as orc
+    torch.manual_seed(1)
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda().eval()
+    H, W = 120, 152
+    img = torch.from_numpy(synth.det_input((3, H, W), 8)).cuda()
+    r = pipeline.infer_image(m, img, tta=True, all_img_test=0, patch_size=64, overlap=16, want_stages=True)
+    # rebuild the reference's arrays on the host from the per-view logits
+    views = utils.split_forward_views(m, img, 64, 16, postproc.TTA_XFORMS)
+    probs, points, dcms = [], [], []
+    for xf, (mask, point, direction) in zip(postproc.TTA_XFORMS, views):
+        prob, dcm = postproc.probmaps(mask[None], direction[None])
+        p, t, d = prob[0].cpu().numpy(), point.cpu().numpy(), dcm[0].cpu().numpy()
+        def unflip(a):                      # test_dam.py:356-441
+            if xf & 2: a = np.flip(a, -2)
+            if xf & 1: a = np.flip(a, -1)
+            if xf & 4: a = np.rot90(a, k=3, axes=(-2, -1))
+            return np.ascontiguousarray(a)
+        probs.append(unflip(p)); points.append(unflip(t)); dcms.append(unflip(d)[None])
+    try:
+        want = orc.postprocess_views(np.stack(probs), np.stack(points), np.stack(dcms))
+    except AssertionError:
+        pytest.skip('random-weight network produced a constant direction view')
+    assert np.array_equal(r['pred'].cpu().numpy(), want['pred'])
+    assert np.array_equal(r['final'].cpu().numpy(), want['final'])
+    assert r['count'] == want['count']
