@@ -41,6 +41,8 @@ SIGNATURES = {
     'cdnet_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'cdnet_window_pack': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
     'cdnet_window_stitch': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
+    'cdnet_label_encoding_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'cdnet_label_encoding': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

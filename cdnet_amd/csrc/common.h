@@ -32,4 +32,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr int WAVE = 64;
 
+// postproc.hip: 8-connected labelling with raster-order ids (shared with the CDM generator)
+int label8_raster(const uint8_t *mask, int N, int H, int W, int *L, int *aux, int *chunk, int32_t *labels, int32_t *counts,
+                  hipStream_t st);
+
 }  // namespace cdnet

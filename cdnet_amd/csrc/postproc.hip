@@ -597,6 +597,25 @@ inline int grid_lin(int plane) { int g = cdiv(plane, 256); return g > 2048 ? 204
 
 }  // namespace
 
+// internal (not part of the C ABI): 8-connected components of a binary mask with skimage.measure.label numbering.
+// L, aux: int32 [N*H*W] scratch; chunk: int32 [N*ceil(H*W/1024)]; labels may alias L.
+namespace cdnet {
+int label8_raster(const uint8_t *mask, int N, int H, int W, int *L, int *aux, int *chunk, int32_t *labels, int32_t *counts,
+                  hipStream_t st) {
+    const int plane = H * W, nchunk = cdiv(plane, CHUNK);
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    const dim3 gl(grid_lin(plane), N);
+    cc_init_kernel<1><<<gr, br, 0, st>>>(mask, 0, H, W, L);
+    cc_merge_kernel<1, 8><<<gr, br, 0, st>>>(mask, 0, H, W, L);
+    cc_flatten_kernel<false><<<gr, br, 0, st>>>(H, W, L, nullptr);
+    cc_count_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L, plane, nchunk, chunk);
+    cc_scan_chunks_kernel<<<N, 256, 0, st>>>(nchunk, chunk, counts);
+    cc_rank_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L, plane, nchunk, chunk, aux);
+    cc_relabel_kernel<<<gl, 256, 0, st>>>(L, aux, plane, labels);
+    return check_launch("label8_raster");
+}
+}  // namespace cdnet
+
 // ======================================================================================================
 // C ABI
 // ======================================================================================================

@@ -281,6 +281,22 @@ int cdnet_window_pack(const float *img, int C, int H, int W, int view_xform, int
 int cdnet_window_stitch(const float *tiles, int K, int tile_h, int tile_w, int stride, int overlap, int ny, int nx, int Hv,
                         int Wv, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Training-target generation.  Replaces my_transforms_direction.py:687-885 `LabelEncoding.__call__` (3-class-PNG input,
+ * do_direction = 1) with get_centerpoint2 (:650-685), Sobel.kernel (SegFix_offset_helper.py:97-132) and
+ * DTOffsetHelper.align_angle / angle_to_vector / vector_to_label (:311-341, 423-450, 486-506).
+ *   label_ch0 u8 [N][H][W] (channel 0 of the label PNG; > 127 = inside)
+ *   -> label3 u8 {0,127,255}, point f16 [N][H][W] (Gaussian sigma 2 of 255-impulses at the nucleus centres),
+ *      direction u8 0..8 (centripetal class + 1, background 0); optional inst i32 (grown instance ids), counts i32 [N].
+ * rays_host: 16 doubles {sin(2 pi k/8), cos(2 pi k/8)} k = 0..7 and gauss_host: 9 doubles (normalised half kernel,
+ * centre first) are evaluated by the HOST math library so that they equal the reference's math.sin/cos and scipy weights.
+ * max_instances: upper bound of nuclei per image (ids above it are dropped - check counts).
+ * ---------------------------------------------------------------------------------------------------- */
+size_t cdnet_label_encoding_workspace_bytes(int N, int H, int W, int max_instances);
+int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int W, int max_instances, const double *rays_host,
+                         const double *gauss_host, void *workspace, size_t workspace_bytes, uint8_t *label3,
+                         uint16_t *point_f16, uint8_t *direction, int32_t *inst_out, int32_t *counts_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

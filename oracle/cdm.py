@@ -1,0 +1,33 @@
+"""ORACLE (test infrastructure): numpy-facing wrapper over oracle/cdm_oracle.c - the reference's LabelEncoding
+(my_transforms_direction.py:687-885, 3-class-PNG branch, do_direction = 1)."""
+import ctypes as C
+import numpy as np
+from . import build as _build
+
+_lib = None
+
+
+def _l():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_build.build())
+    return _lib
+
+
+def label_encoding(label_ch0, want_aux=False):
+    """label_ch0: uint8 [H,W] (channel 0 of the 3-class label PNG).
+    Returns (label3 u8 {0,127,255}, point float16 [H,W], direction u8 [H,W] in 0..8[, inst i32, centers i32 [n,2]])."""
+    x = np.ascontiguousarray(label_ch0, dtype=np.uint8)
+    H, W = x.shape
+    label3 = np.empty((H, W), np.uint8)
+    point = np.empty((H, W), np.float32)
+    direction = np.empty((H, W), np.uint8)
+    inst = np.empty((H, W), np.int32)
+    centers = np.zeros((H * W // 4 + 1, 2), np.int32)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    n = _l().orc_label_encoding(p(x, C.c_uint8), H, W, p(label3, C.c_uint8), p(point, C.c_float), p(direction, C.c_uint8),
+                                p(inst, C.c_int32), p(centers, C.c_int32))
+    out = (label3, point.astype(np.float16), direction)
+    if want_aux:
+        out = out + (inst, centers[:n].copy())
+    return out
