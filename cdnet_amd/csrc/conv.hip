@@ -16,6 +16,7 @@
 // (training-mode BN statistics, reduced deterministically by bn_finalize).
 #include "common.h"
 #include "conv_args.h"
+#include <stdlib.h>
 
 using namespace cdnet;
 
@@ -24,6 +25,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
+
+__device__ int g_dbg_dummy;
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 __device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
@@ -188,10 +191,115 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
 }
 
 // ------------------------------------------------------------------------------------------------------
+// software pipeline: the global loads of chunk c+1 (input halo + weights) are ISSUED before the MFMA loop of chunk c
+// and only transformed / written to LDS after it, so their HBM/L2 latency hides under the matrix work (guide T14).
+// Pooled sources (4 loads + max per element) keep the synchronous path.
+// ------------------------------------------------------------------------------------------------------
+template <int TH, int TW, int CK, int BN, int TAPS>
+struct Prefetch {
+    static constexpr int VPP = CK / 8;
+    static constexpr int NPIX = (TH + 2) * (TW + 2);
+    static constexpr int NA = (NPIX * VPP + 255) / 256;
+    static constexpr int NB = (TAPS * CK * BN * 2 / 16 + 255) / 256;
+    uint4 a[NA], b[NB];
+    unsigned valid;          // bit i: vector i of `a` is inside the image / source
+    bool pooled;             // synchronous path at commit time
+};
+
+template <int TH, int TW, int CK, int BN, int TAPS>
+__device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n, int y0, int x0,
+                                            int H, int W, const unsigned short *wchunk, int tid) {
+    using PF = Prefetch<TH, TW, CK, BN, TAPS>;
+    constexpr int HW_ = TW + 2;
+    {   // weights: linear
+        const uint4 *src = reinterpret_cast<const uint4 *>(wchunk);
+#pragma unroll
+        for (int i = 0; i < PF::NB; ++i) {
+            const int v = tid + i * 256;
+            if (v < TAPS * CK * BN * 2 / 16) P.b[i] = src[v];
+        }
+    }
+    P.pooled = s.pool != 0;
+    P.valid = 0;
+    if (P.pooled) return;
+    const int slot = tid % PF::VPP;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    const size_t img = (size_t)n * s.Hs * rs;
+#pragma unroll
+    for (int i = 0; i < PF::NA; ++i) {
+        const int v = tid + i * 256;
+        if (v >= PF::NPIX * PF::VPP) break;
+        const int pix = v / PF::VPP;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        if (y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < s.Hs && xs >= 0 && xs < s.Ws) {
+            const size_t e = img + (size_t)ys * rs + (size_t)xs * s.C + cc0 + slot * 8;
+            P.a[i] = *reinterpret_cast<const uint4 *>(s.x + e);
+            P.valid |= 1u << i;
+        }
+    }
+}
+
+template <int TH, int TW, int CK, int BN, int TAPS>
+__device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n, int y0,
+                                             int x0, int H, int W, unsigned char *lds_a, unsigned char *lds_b, int tid) {
+    using PF = Prefetch<TH, TW, CK, BN, TAPS>;
+    constexpr int PSTR = CK * 2 + 16;
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_b);
+#pragma unroll
+        for (int i = 0; i < PF::NB; ++i) {
+            const int v = tid + i * 256;
+            if (v < TAPS * CK * BN * 2 / 16) dst[v] = P.b[i];
+        }
+    }
+    if (P.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid); return; }
+    const int slot = tid % PF::VPP;
+    ChanXf t;
+    t.on = s.scale != nullptr;
+    if (t.on) {
+        const float4 *ps = reinterpret_cast<const float4 *>(s.scale + cc0 + slot * 8);
+        const float4 *ph = reinterpret_cast<const float4 *>(s.shift + cc0 + slot * 8);
+        float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
+        t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
+        t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
+    }
+    const bool relu = s.relu != 0, f16 = s.f16 != 0;
+    const bool plain = !t.on && !relu && s.res == nullptr && !f16;
+    constexpr int HW_ = TW + 2;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    const size_t img = (size_t)n * s.Hs * rs;
+#pragma unroll
+    for (int i = 0; i < PF::NA; ++i) {
+        const int v = tid + i * 256;
+        if (v >= PF::NPIX * PF::VPP) break;
+        const int pix = v / PF::VPP;
+        V16 val;
+        val.u = make_uint4(0, 0, 0, 0);
+        if (P.valid & (1u << i)) {
+            V16 raw;
+            raw.u = P.a[i];
+            if (plain) val = raw;
+            else if (s.res) {
+                // the residual operand is read here (not prefetched: registers are better spent on two waves per SIMD)
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                const size_t e = img + (size_t)(y0 - 1 + hy - s.off_y) * rs + (size_t)(x0 - 1 + hx - s.off_x) * s.C + cc0 + slot * 8;
+                V16 r;
+                r.u = *reinterpret_cast<const uint4 *>(s.res + e);
+                val = xform8(raw, &r, t, relu, f16);
+            }
+            else val = xform8(raw, nullptr, t, relu, f16);
+        }
+        *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------------
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
+__global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_fwd_kernel(ConvArgs A) {
     constexpr int PSTR = CK * 2 + 16;
     constexpr int HW_ = TW + 2;
     constexpr int KC = CK / 16;
@@ -211,25 +319,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
 
-    const int tiles_x = (A.W + TW - 1) / TW;
-    const int ty_ = blockIdx.x / tiles_x, tx_ = blockIdx.x - ty_ * tiles_x;
-    const int y0 = ty_ * TH, x0 = tx_ * TW;
+    // one workgroup per (image, parity, tile_y, tile_x) tile
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total_tiles = A.N * A.npar * tiles_img;
     const int cout_tile = blockIdx.y;
-    const int n = blockIdx.z / A.npar, par = blockIdx.z - n * A.npar;
-
-    // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
-    int toff[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-        int r, c;
-        if (TAPS == 9) { r = t / 3; c = t % 3; }
-        else if (TAPS == 4) {
-            const int a = par >> 1, b = par & 1, ty = t >> 1, tx = t & 1;
-            r = a == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
-            c = b == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
-        } else { r = 1; c = 1; }
-        toff[t] = (r * HW_ + c) * PSTR;
-    }
+    const int nchunk_total = A.nchunk;
 
     // per-lane A base for each of this wave's M tiles
     int abase[MPW];
@@ -241,29 +336,66 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
     }
     const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
 
-    f32x16 acc[MPW][NPW];
-#pragma unroll
-    for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    // chunk c -> (source, first channel)
+    auto chunk_src = [&](int c, int &si, int &cc0) {
+        const int n0 = A.src[0].C / CK;
+        if (c < n0) { si = 0; cc0 = c * CK; } else { si = 1; cc0 = (c - n0) * CK; }
+    };
+    auto decode = [&](int tile, int &n, int &par, int &y0, int &x0) {
+        const int z = tile / tiles_img, r = tile - z * tiles_img;
+        n = z / A.npar; par = z - n * A.npar;
+        const int ty_ = r / tiles_x;
+        y0 = ty_ * TH; x0 = (r - ty_ * tiles_x) * TW;
+    };
+    auto wchunk = [&](int par, int chunk) {
+        return A.w + ((size_t)(par * gridDim.y + cout_tile) * nchunk_total + chunk) * (B_BYTES / 2);
+    };
 
-    const int nchunk_total = A.nchunk;
-    const unsigned short *wbase = A.w + ((size_t)(par * gridDim.y + cout_tile) * nchunk_total) * (B_BYTES / 2);
+    Prefetch<TH, TW, CK, BN, TAPS> P;
+    const int tile = blockIdx.x;
+    (void)total_tiles;
+    {
+        int n, par, y0, x0;
+        decode(tile, n, par, y0, x0);
+        {
+            int si, cc0;
+            chunk_src(0, si, cc0);
+            issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, wchunk(par, 0), tid);
+        }
+        // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
+        int toff[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            int r, c;
+            if (TAPS == 9) { r = t / 3; c = t % 3; }
+            else if (TAPS == 4) {
+                const int a = par >> 1, b = par & 1, ty = t >> 1, tx = t & 1;
+                r = a == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+                c = b == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+            } else { r = 1; c = 1; }
+            toff[t] = (r * HW_ + c) * PSTR;
+        }
+        f32x16 acc[MPW][NPW];
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    int chunk = 0;
-    for (int si = 0; si < A.nsrc; ++si) {
-        const ConvSrc &s = A.src[si];
-        for (int cc0 = 0; cc0 < s.C; cc0 += CK, ++chunk) {
+        for (int chunk = 0; chunk < nchunk_total; ++chunk) {
+            int si, cc0;
+            chunk_src(chunk, si, cc0);
+            __syncthreads();                               // previous chunk's fragment reads / previous tile's out-tile reads are done
+            commit_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid);
             __syncthreads();
-            stage_input<TH, TW, CK>(s, cc0, n, y0, x0, A.H, A.W, lds_a, tid);
-            {   // weights of this chunk: linear copy
-                const uint4 *src = reinterpret_cast<const uint4 *>(wbase + (size_t)chunk * (B_BYTES / 2));
-                uint4 *dst = reinterpret_cast<uint4 *>(lds_b);
-                for (int v = tid; v < B_BYTES / 16; v += 256) dst[v] = src[v];
+            // issue the loads of the next (tile, chunk) step now: they fly during the MFMA loop (and the epilogue)
+            if (chunk + 1 < nchunk_total) {
+                int sj, cj;
+                chunk_src(chunk + 1, sj, cj);
+                issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[sj], cj, n, y0, x0, A.H, A.W, wchunk(par, chunk + 1), tid);
             }
-            __syncthreads();
+            if (A.debug & 4) continue;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
@@ -283,79 +415,79 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs A) {
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---------------- epilogue ----------------
-    const int cout0 = cout_tile * BN;
-    unsigned char *s_out = smem;
-    const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
-    float ssum[NPW], ssq[NPW];
+        // ---------------- epilogue ----------------
+        if (A.debug & 8) { if (acc[0][0][0] == 123.456f) g_dbg_dummy = 1; return; }
+        const int cout0 = cout_tile * BN;
+        unsigned char *s_out = smem;
+        const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
+        float ssum[NPW], ssq[NPW];
 #pragma unroll
-    for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
-#pragma unroll
-    for (int ni = 0; ni < NPW; ++ni) {
-        const int col = (wn * NPW + ni) * 32 + l31;
-        const int co = cout0 + col;
-        const bool cok = co < A.Cout;
-        const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
-        const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
-        const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[mi][ni][r];
-                if (A.stats) {
-                    bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
-                    if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
-                }
-                v += bias;
-                v = fmaf(v, osc, osh);
-                if (A.orelu) v = fmaxf(v, 0.f);
-                *reinterpret_cast<unsigned short *>(s_out + m * OSTR + col * 2) = A.out_f16 ? f2h(v) : f2bf(v);
-            }
-        }
-    }
-    if (A.stats) {
+        for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
 #pragma unroll
         for (int ni = 0; ni < NPW; ++ni) {
-            ssum[ni] += __shfl_xor(ssum[ni], 32);
-            ssq[ni] += __shfl_xor(ssq[ni], 32);
-            if (half == 0) {
-                s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
-                s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
+            const int col = (wn * NPW + ni) * 32 + l31;
+            const int co = cout0 + col;
+            const bool cok = co < A.Cout;
+            const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
+            const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
+            const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[mi][ni][r];
+                    if (A.stats) {
+                        bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
+                        if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
+                    }
+                    v += bias;
+                    v = fmaf(v, osc, osh);
+                    if (A.orelu) v = fmaxf(v, 0.f);
+                    const unsigned mine = A.out_f16 ? f2h(v) : f2bf(v);
+                    const unsigned other = __shfl_xor(mine, 1);
+                    if (!(l31 & 1)) *reinterpret_cast<unsigned *>(s_out + m * OSTR + col * 2) = mine | (other << 16);
+                }
             }
         }
-    }
-    __syncthreads();
-    if (A.stats && tid < 2 * BN) {
-        const int which = tid / BN, col = tid % BN;
-        const int wn_of = col / (NPW * 32);
-        float v = 0.f;
+        if (A.stats) {
 #pragma unroll
-        for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
-        const int co = cout0 + col;
-        if (co < A.Cout) {
-            const size_t tile_lin = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
-            A.stats[(tile_lin * 2 + which) * A.Cout + co] = v;
+            for (int ni = 0; ni < NPW; ++ni) {
+                ssum[ni] += __shfl_xor(ssum[ni], 32);
+                ssq[ni] += __shfl_xor(ssq[ni], 32);
+                if (half == 0) {
+                    s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
+                    s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
+                }
+            }
         }
-    }
-    // coalesced store of the tile: 16-byte vectors, BN/8 per pixel
-    {
-        constexpr int VO = BN / 8;
-        const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
-        const int pa = par >> 1, pb = par & 1;
-        for (int v = tid; v < TH * TW * VO; v += 256) {
-            const int m = v / VO, q = v % VO;
-            const int y = y0 + m / TW, x = x0 + m % TW;
-            const int co = cout0 + q * 8;
-            if (y < A.H && x < A.W && co < A.Cout) {
-                const int oy = y * A.ostride + pa, ox = x * A.ostride + pb;
-                const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
-                unsigned short *dst = A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co;
-                *reinterpret_cast<uint4 *>(dst) = val;               // Cout % 8 == 0 (checked by the ABI entry)
+        __syncthreads();
+        if (A.stats && tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN;
+            const int wn_of = col / (NPW * 32);
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
+            const int co = cout0 + col;
+            if (co < A.Cout) A.stats[((size_t)tile * 2 + which) * A.Cout + co] = v;
+        }
+        // coalesced store of the tile: 16-byte vectors, BN/8 per pixel
+        {
+            constexpr int VO = BN / 8;
+            const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
+            const int pa = par >> 1, pb = par & 1;
+            for (int v = tid; v < TH * TW * VO; v += 256) {
+                const int m = v / VO, q = v % VO;
+                const int y = y0 + m / TW, x = x0 + m % TW;
+                const int co = cout0 + q * 8;
+                if (y < A.H && x < A.W && co < A.Cout) {
+                    const int oy = y * A.ostride + pa, ox = x * A.ostride + pb;
+                    const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
+                    unsigned short *dst = A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co;
+                    *reinterpret_cast<uint4 *>(dst) = val;               // Cout % 8 == 0 (checked by the ABI entry)
+                }
             }
         }
     }
@@ -374,7 +506,9 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
             return check_launch("hipFuncSetAttribute(conv)");
         attr_done = true;
     }
-    dim3 grid(cdiv(A.W, TW) * cdiv(A.H, TH), cdiv(A.Cout, BN), A.N * A.npar);
+    const int total_tiles = cdiv(A.W, TW) * cdiv(A.H, TH) * A.N * A.npar;
+    const int ctiles = cdiv(A.Cout, BN);
+    dim3 grid(total_tiles, ctiles, 1);
     kern<<<grid, 256, smem, st>>>(A);
     return check_launch("conv_fwd_kernel");
 }
@@ -440,6 +574,8 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
                   "cdnet_conv_forward: taps=%d npar=%d ostride=%d", A.taps, A.npar, A.ostride);
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
+    if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }
     if (A.taps == 9) return dispatch_conv<9>(A, st);
     if (A.taps == 4) return dispatch_conv<4>(A, st);
     return dispatch_conv<1>(A, st);

@@ -26,6 +26,7 @@ struct ConvArgs {
     int taps, npar, ostride, nchunk;
     int tile, CK, BN;
     int out_f16;
+    int debug;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");

@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
                 ('Cout', C.c_int), ('out_cstride', C.c_int), ('out_coff', C.c_int), ('stats', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
-                ('out_f16', C.c_int)]
+                ('out_f16', C.c_int), ('debug', C.c_int)]
 
 
 def _dp(t):

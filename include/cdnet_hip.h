@@ -140,6 +140,7 @@ typedef struct cdnet_conv_args {
     int nchunk;             /* total Cin chunks over both sources */
     int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
     int out_f16;            /* 1: store the output as fp16 instead of bf16 */
+    int debug;              /* must be 0 (kernel ablation switches used by tools/bench_conv.py) */
 } cdnet_conv_args;
 
 /* packed element count for a weight tensor; nchunk = Cin/CK over all sources */

@@ -9,7 +9,7 @@ from cdnet_amd import engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device('cuda:0')
 LAYERS = [  # name, Cin, Cout, H, cfgs
-    ('enc1_2 64->64@256', 64, 64, 256, [(16, 32, 64), (16, 64, 64)]),
+    ('enc1_2 64->64@256', 64, 64, 256, [(16, 32, 64), (16, 16, 64), (16, 32, 32)]),
     ('enc2_1 64->128@128', 64, 128, 128, [(16, 32, 64), (16, 32, 128)]),
     ('enc2_2 128->128@128', 128, 128, 128, [(16, 32, 64), (16, 32, 128)]),
     ('enc3_2 256->256@64', 256, 256, 64, [(16, 32, 64), (16, 32, 128)]),
