@@ -299,7 +299,7 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
 // the kernel
 // ------------------------------------------------------------------------------------------------------
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_fwd_kernel(ConvArgs A) {
+__global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1)) void conv_fwd_kernel(ConvArgs A) {
     constexpr int PSTR = CK * 2 + 16;
     constexpr int HW_ = TW + 2;
     constexpr int KC = CK / 16;
@@ -493,6 +493,288 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_fwd_kernel(ConvA
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Weight-stationary variant for the full-resolution layers (total Cin <= 80): the WHOLE weight tensor of the cout tile
+// (TAPS*CIN*BN bf16, <= 74 KB) is loaded into LDS once per workgroup; the workgroup is persistent (one per CU) and walks
+// a list of 16x16 tiles.  The input halo of tile t+1 is fetched into registers while the matrix cores work on tile t
+// (one wave per SIMD, up to 512 registers), the out tile has its own LDS region, so per tile there are only two
+// barriers and the only HBM traffic is the halo read and the output write.  On the 64->64 @256x256 layers this removes
+// the per-tile re-staging of 74 KB of weights that bounded the generic kernel.
+// ------------------------------------------------------------------------------------------------------
+template <int TH, int TW, int CIN, int BN, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs A) {
+    constexpr int PSTR = CIN * 2 + 16;
+    constexpr int HW_ = TW + 2;
+    constexpr int KC = CIN / 16;
+    constexpr int VPP = CIN / 8;
+    constexpr int ACTIVE = (256 / VPP) * VPP;              // staging threads (fixed channel slot per thread)
+    constexpr int NPIX = (TH + 2) * (TW + 2);
+    constexpr int NA = (NPIX * VPP + ACTIVE - 1) / ACTIVE;
+    constexpr int MT = TH * TW / 32, NT = BN / 32;
+    constexpr int MPW = MT / WM, NPW = NT / WN;
+    constexpr int W_BYTES = TAPS * CIN * BN * 2;
+    constexpr int A_BYTES = NPIX * PSTR;
+    constexpr int OSTR = BN * 2 + 8;
+    static_assert(MT % WM == 0 && NT % WN == 0 && WM * WN == 4, "wave tiling");
+    static_assert(NA <= 32, "valid mask");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_w = smem;
+    unsigned char *lds_a = smem + W_BYTES;
+    unsigned char *s_out = smem + W_BYTES + A_BYTES;
+    __shared__ float s_stats[4][2][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total_tiles = A.N * tiles_img;
+    const int cout_tile = blockIdx.y;
+    const int cout0 = cout_tile * BN;
+
+    {   // the whole weight block of this cout tile: one linear copy
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * (W_BYTES / 2));
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
+        for (int v = tid; v < W_BYTES / 16; v += 256) dst[v] = src[v];
+    }
+    // this thread's fixed 8-channel slot -> (source, channel offset) and its transform constants
+    const bool stager = tid < ACTIVE;
+    const int slot = tid % VPP;
+    const int c_glob = slot * 8;
+    const int si = (A.nsrc > 1 && c_glob >= A.src[0].C) ? 1 : 0;
+    const ConvSrc &S = A.src[si];
+    const int cc0 = c_glob - (si ? A.src[0].C : 0);
+    ChanXf t;
+    t.on = S.scale != nullptr;
+    if (t.on && stager) {
+        const float4 *ps = reinterpret_cast<const float4 *>(S.scale + cc0);
+        const float4 *ph = reinterpret_cast<const float4 *>(S.shift + cc0);
+        float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
+        t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
+        t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
+    }
+    const bool relu = S.relu != 0, f16 = S.f16 != 0;
+    const bool plain = !t.on && !relu && S.res == nullptr && !f16;
+    const int Hl = S.pool ? (S.Hs + (S.pool == 2)) / 2 : S.Hs, Wl = S.pool ? (S.Ws + (S.pool == 2)) / 2 : S.Ws;
+    const size_t rs = S.row_stride ? (size_t)S.row_stride : (size_t)S.Ws * S.C;
+
+    int toff[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) toff[tp] = TAPS == 9 ? ((tp / 3) * HW_ + tp % 3) * PSTR : (HW_ + 1) * PSTR;
+    int abase[MPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int m = (wm * MPW + mi) * 32 + l31;
+        abase[mi] = ((m / TW) * HW_ + m % TW) * PSTR + half * 16;
+    }
+    const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
+
+    auto decode = [&](int tile, int &n, int &y0, int &x0) {
+        n = tile / tiles_img;
+        const int r = tile - n * tiles_img, ty_ = r / tiles_x;
+        y0 = ty_ * TH; x0 = (r - ty_ * tiles_x) * TW;
+    };
+    uint4 pa[NA];
+    unsigned valid = 0;
+    // element offset of halo vector i of tile (n,y0,x0), or -1
+    auto issue = [&](int n, int y0, int x0) {
+        valid = 0;
+        if (!stager || S.pool) return;
+        const size_t img = (size_t)n * S.Hs * rs;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * ACTIVE;
+            if (v >= NPIX * VPP) break;
+            const int pix = v / VPP, hy = pix / HW_, hx = pix - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const int ys = y - S.off_y, xs = x - S.off_x;
+            if (y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < S.Hs && xs >= 0 && xs < S.Ws) {
+                pa[i] = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)ys * rs + (size_t)xs * S.C + cc0);
+                valid |= 1u << i;
+            }
+        }
+    };
+    auto commit = [&](int n, int y0, int x0) {
+        if (!stager) return;
+        const size_t img = (size_t)n * S.Hs * rs;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * ACTIVE;
+            if (v >= NPIX * VPP) break;
+            const int pix = v / VPP, hy = pix / HW_, hx = pix - hy * HW_;
+            V16 val;
+            val.u = make_uint4(0, 0, 0, 0);
+            if (!S.pool) {
+                if (valid & (1u << i)) {
+                    V16 raw;
+                    raw.u = pa[i];
+                    if (plain) val = raw;
+                    else if (S.res) {
+                        const size_t e = img + (size_t)(y0 - 1 + hy - S.off_y) * rs + (size_t)(x0 - 1 + hx - S.off_x) * S.C + cc0;
+                        V16 r;
+                        r.u = *reinterpret_cast<const uint4 *>(S.res + e);
+                        val = xform8(raw, &r, t, relu, f16);
+                    } else val = xform8(raw, nullptr, t, relu, f16);
+                }
+            } else {
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const int ys = y - S.off_y, xs = x - S.off_x;
+                if (y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
+                        if (q != 0 && (yy >= S.Hs || xx >= S.Ws)) continue;
+                        V16 raw;
+                        raw.u = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)yy * rs + (size_t)xx * S.C + cc0);
+                        V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
+                        val = q == 0 ? tv : max8(val, tv);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) { int n, y0, x0; decode(tile, n, y0, x0); issue(n, y0, x0); }
+    for (; tile < total_tiles; tile += gridDim.x) {
+        int n, y0, x0;
+        decode(tile, n, y0, x0);
+        commit(n, y0, x0);
+        __syncthreads();                                                        // S1: halo (and, first time, weights) visible
+        if (tile + (int)gridDim.x < total_tiles) { int n2, y2, x2; decode(tile + gridDim.x, n2, y2, x2); issue(n2, y2, x2); }
+        f32x16 acc[MPW][NPW];
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                bf16x8 af[MPW], bfr[NPW];
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi)
+                    af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + abase[mi] + toff[tp] + kc * 32);
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni)
+                    bfr[ni] = *reinterpret_cast<const bf16x8 *>(lds_w + bbase + ((tp * KC + kc) * 2) * BN * 16 + ni * 512);
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NPW; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        // ---- epilogue into the dedicated out tile ----
+        const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
+        float ssum[NPW], ssq[NPW];
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) {
+            const int col = (wn * NPW + ni) * 32 + l31;
+            const int co = cout0 + col;
+            const bool cok = co < A.Cout;
+            const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
+            const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
+            const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[mi][ni][r];
+                    if (A.stats) {
+                        bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
+                        if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
+                    }
+                    v += bias;
+                    v = fmaf(v, osc, osh);
+                    if (A.orelu) v = fmaxf(v, 0.f);
+                    const unsigned mine = A.out_f16 ? f2h(v) : f2bf(v);
+                    const unsigned other = __shfl_xor(mine, 1);
+                    if (!(l31 & 1)) *reinterpret_cast<unsigned *>(s_out + m * OSTR + col * 2) = mine | (other << 16);
+                }
+            }
+        }
+        if (A.stats) {
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) {
+                ssum[ni] += __shfl_xor(ssum[ni], 32);
+                ssq[ni] += __shfl_xor(ssq[ni], 32);
+                if (half == 0) {
+                    s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
+                    s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
+                }
+            }
+        }
+        __syncthreads();                                                        // S2: out tile complete, halo reads done
+        if (A.stats && tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN;
+            const int wn_of = col / (NPW * 32);
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
+            const int co = cout0 + col;
+            if (co < A.Cout) A.stats[((size_t)tile * 2 + which) * A.Cout + co] = v;
+        }
+        {
+            constexpr int VO = BN / 8;
+            for (int v = tid; v < TH * TW * VO; v += 256) {
+                const int m = v / VO, q = v % VO;
+                const int y = y0 + m / TW, x = x0 + m % TW;
+                const int co = cout0 + q * 8;
+                if (y < A.H && x < A.W && co < A.Cout) {
+                    const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
+                    *reinterpret_cast<uint4 *>(A.out + (((size_t)n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = val;
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int BN, int TAPS>
+int launch_conv_ws(const ConvArgs &A, hipStream_t st) {
+    constexpr int TH = 16, TW = 16;
+    constexpr int smem = TAPS * CIN * BN * 2 + (TH + 2) * (TW + 2) * (CIN * 2 + 16) + TH * TW * (BN * 2 + 8);
+    static_assert(smem + 4 * 2 * BN * 4 <= 160 * 1024, "weight-stationary configuration does not fit in LDS");
+    auto kern = conv_ws_kernel<TH, TW, CIN, BN, 4, 1, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(conv_ws)");
+        attr_done = true;
+    }
+    const int total_tiles = cdiv(A.W, TW) * cdiv(A.H, TH) * A.N;
+    const int ctiles = cdiv(A.Cout, BN);
+    int gx = 256 / ctiles;                       // one persistent workgroup per CU
+    if (gx < 1) gx = 1;
+    if (gx > total_tiles) gx = total_tiles;
+    kern<<<dim3(gx, ctiles, 1), 256, smem, st>>>(A);
+    return check_launch("conv_ws_kernel");
+}
+
+template <int TAPS>
+int dispatch_conv_ws(const ConvArgs &A, hipStream_t st) {
+    const int key = A.CK * 1000 + A.BN;
+    switch (key) {
+        case 16 * 1000 + 32: return launch_conv_ws<16, 32, TAPS>(A, st);
+        case 16 * 1000 + 64: return launch_conv_ws<16, 64, TAPS>(A, st);
+        case 32 * 1000 + 32: return launch_conv_ws<32, 32, TAPS>(A, st);
+        case 32 * 1000 + 64: return launch_conv_ws<32, 64, TAPS>(A, st);
+        case 64 * 1000 + 32: return launch_conv_ws<64, 32, TAPS>(A, st);
+        case 64 * 1000 + 64: return launch_conv_ws<64, 64, TAPS>(A, st);
+        case 80 * 1000 + 32: return launch_conv_ws<80, 32, TAPS>(A, st);
+        default:
+            set_error("cdnet_conv: unsupported weight-stationary configuration Cin=%d BN=%d", A.CK, A.BN);
+            return CDNET_E_ARG;
+    }
+}
+
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
 int launch_conv(const ConvArgs &A, hipStream_t st) {
     constexpr int PSTR = CK * 2 + 16;
@@ -561,6 +843,15 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && A.out, "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
     CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0 && A.Cout % 8 == 0, "cdnet_conv_forward: bad size (Cout must be a multiple of 8)");
+    if (A.ws) {
+        int ctot = 0;
+        for (int i = 0; i < A.nsrc; ++i) { CDNET_REQUIRE(A.src[i].x && A.src[i].C % 8 == 0, "cdnet_conv_forward: ws source channels"); ctot += A.src[i].C; }
+        CDNET_REQUIRE(ctot == A.CK && A.nchunk == 1 && A.npar == 1 && A.ostride == 1 && (A.taps == 9 || A.taps == 1) && A.tile == 16,
+                      "cdnet_conv_forward: weight-stationary mode needs CK == total Cin (%d vs %d), stride 1, 3x3 or 1x1", A.CK, ctot);
+        CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0 && A.Cout % 8 == 0, "cdnet_conv_forward: output channel slice");
+        hipStream_t st2 = (hipStream_t)stream;
+        return A.taps == 9 ? dispatch_conv_ws<9>(A, st2) : dispatch_conv_ws<1>(A, st2);
+    }
     int nchunk = 0;
     for (int i = 0; i < A.nsrc; ++i) {
         CDNET_REQUIRE(A.src[i].x && A.src[i].C % A.CK == 0, "cdnet_conv_forward: source %d channels %d not a multiple of CK=%d",

@@ -27,6 +27,8 @@ struct ConvArgs {
     int tile, CK, BN;
     int out_f16;
     int debug;
+    int ws;
+    int pad2_;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");

@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
                 ('Cout', C.c_int), ('out_cstride', C.c_int), ('out_coff', C.c_int), ('stats', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
-                ('out_f16', C.c_int), ('debug', C.c_int)]
+                ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('pad2_', C.c_int)]
 
 
 def _dp(t):
@@ -74,15 +74,23 @@ class Src:
         cs.row_stride = int(self.row_stride)
 
 
+_WS_SUPPORTED = {(16, 32), (16, 64), (32, 32), (32, 64), (64, 32), (64, 64), (80, 32)}      # (total Cin, BN)
+
 _SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 128), (16, 64, 64),
               (8, 32, 64), (8, 32, 128), (8, 64, 64)}
 
 
-def choose_cfg(src_channels, Cout, H, W, override=None):
-    """(tile, CK, BN) for a layer.  CK must divide every source's channel count."""
+def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False, allow_ws=False):
+    """(tile, CK, BN[, 'ws']) for a layer.  CK must divide every source's channel count; the 4-tuple form selects the
+    weight-stationary persistent kernel (CK = total Cin)."""
     if override is not None:
-        assert tuple(override) in _SUPPORTED, override
+        assert tuple(override[:3]) in _SUPPORTED or (len(override) == 4 and (override[1], override[2]) in _WS_SUPPORTED), override
         return tuple(override)
+    ctot = sum(src_channels)
+    if allow_ws and not transposed and taps in (9, 1) and min(H, W) >= 32:
+        bn = 64 if Cout > 32 else 32
+        if (ctot, bn) in _WS_SUPPORTED:
+            return (16, ctot, bn, 'ws')
     small = min(H, W) <= 8
     ck = 64
     while any(c % ck for c in src_channels):
@@ -96,6 +104,8 @@ def choose_cfg(src_channels, Cout, H, W, override=None):
     if ck == 64:
         ck = 32                       # 2 workgroups per CU (LDS) beat one fat one
     bn = 64 if Cout > 32 else 32
+    if ctot <= 128 and bn == 64:
+        ck = 16                       # 34 KB of LDS and <= 168 VGPRs: three workgroups per CU hide the staging latency (measured)
     if ck == 16 and bn > 64:
         bn = 64
     return (16, ck, bn)
@@ -108,7 +118,7 @@ def packed_elems(Cout, nchunk, taps, CK, BN, npar):
 def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
     """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
     Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
-    _, CK, BN = cfg
+    _, CK, BN = cfg[:3]
     assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
     if mode == 0:
         Cout, Cin, KH, KW = w.shape
@@ -141,7 +151,8 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
                  orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
-    tile, CK, BN = cfg
+    ws = len(cfg) == 4
+    tile, CK, BN = cfg[:3]
     s0 = srcs[0]
     N = s0.N
     if H is None:
@@ -152,9 +163,12 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a = ConvArgs()
     nchunk = 0
     for i, s in enumerate(srcs):
-        assert s.C % CK == 0, (s.C, CK)
+        assert ws or s.C % CK == 0, (s.C, CK)
         s.fill(a.src[i])
         nchunk += s.C // CK
+    if ws:
+        assert sum(s.C for s in srcs) == CK
+        nchunk = 1
     a.nsrc = len(srcs)
     if out is None:
         out = torch.empty((N, H * ostride, W * ostride, Cout), dtype=out_dtype, device=s0.x.device)
@@ -169,5 +183,6 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
+    a.ws = int(ws)
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

@@ -83,7 +83,7 @@ class ConvLayer:
     def prepare(self, src_channels, H, W):
         cin_total = sum(src_channels)
         if self.cfg is None:
-            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override)
+            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override, taps=self.taps, transposed=self.transposed)
         ver = (self.weight._version, WEIGHTS_EPOCH[0])
         if self.wp is None or self.wp_version != ver:
             pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16
@@ -96,9 +96,9 @@ class ConvLayer:
         ver = (self.weight._version, WEIGHTS_EPOCH[0])
         if self.cfg_bwd is None:
             if self.transposed:
-                self.cfg_bwd = engine.choose_cfg([2 * self.Cout, 2 * self.Cout], self.Cin, H, W)
+                self.cfg_bwd = engine.choose_cfg([2 * self.Cout, 2 * self.Cout], self.Cin, H, W, taps=(9 if self.kind == 'convT4' else 1))
             else:
-                self.cfg_bwd = engine.choose_cfg([self.Cout], cin_total, H, W)
+                self.cfg_bwd = engine.choose_cfg([self.Cout], cin_total, H, W, taps=self.taps)
         if self.wpb is None or self.wpb_version != ver:
             if self.transposed:
                 mode = 4 if self.kind == 'convT4' else 5
