@@ -34,7 +34,7 @@ SIGNATURES = {
     'cdnet_conv_backward_weight': (_i, [_vp, _i, _i, _i, _vp] + [_i] * 9 + [_vp, _vp, _i, _vp]),
     'cdnet_bn_backward_workspace_floats': (_sz, [_i]),
     'cdnet_bn_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
-    'cdnet_dam_head_backward_workspace_floats': (_sz, []),
+    'cdnet_dam_head_backward_workspace_floats': (_sz, [_i, _i, _i]),
     'cdnet_dam_head_backward': (_i, [_vp] * 7 + [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'cdnet_dam_loss_workspace_floats': (_sz, [_i, _i]),
     'cdnet_dam_loss': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),

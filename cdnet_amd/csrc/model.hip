@@ -125,6 +125,39 @@ __device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const
     }
 }
 
+// 16 channels [16q, 16q+16) of the feature at one pixel (q = lane & 3): four lanes share a pixel
+__device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q, const float *s_sc, const float *s_sh, float *v) {
+    const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64 + q * 16);
+    const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64 + q * 16) : nullptr;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        uint4 r = pr[h2];
+        const unsigned short *h = reinterpret_cast<const unsigned short *>(&r);
+        uint4 rr = make_uint4(0, 0, 0, 0);
+        if (ps) rr = ps[h2];
+        const unsigned short *hr = reinterpret_cast<const unsigned short *>(&rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = q * 16 + h2 * 8 + j;
+            float x = f.f16 ? h2f(h[j]) : bf2f(h[j]);
+            if (f.scale || ps || f.relu) {
+                if (f.scale) x = fmaf(x, s_sc[c], s_sh[c]);
+                if (ps) x += f.f16 ? h2f(hr[j]) : bf2f(hr[j]);
+                if (f.relu) x = fmaxf(x, 0.f);
+                x = bf2f(f2bf(x));
+            }
+            v[h2 * 8 + j] = x;
+        }
+    }
+}
+
+__device__ __forceinline__ float quad_sum(float v) {        // sum over the 4 lanes of a pixel
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
+// four lanes per pixel, 16 channels each: 4x the parallelism and a quarter of the registers of one-thread-per-pixel
 __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
                                                            int N, int plane, float *__restrict__ mask,
                                                            float *__restrict__ point, float *__restrict__ dirn) {
@@ -145,38 +178,46 @@ __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat
     }
     __syncthreads();
     const size_t total = (size_t)N * plane;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t n = i / plane, p = i - n * plane;
-        float v[64];
-        // point = point_conv(F3)
-        load_feat64(f3, i, s_sc[2], s_sh[2], v);
-        float pt = w.bp;
+    const int q = threadIdx.x & 3;
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + (threadIdx.x >> 2);
+        const bool ok = i < total;
+        const size_t ii = ok ? i : total - 1;                 // keep all lanes alive for the shuffles
+        const size_t n = ii / plane, p = ii - n * plane;
+        float v[16];
+        load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+        float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 64; ++c) pt = fmaf(w.wp[c], v[c], pt);
-        point[n * plane + p] = pt;
-        // direction = direction_conv(F2 * (1 + sigmoid(a1 * point)))
+        for (int c = 0; c < 16; ++c) s = fmaf(w.wp[q * 16 + c], v[c], s);
+        const float pt = quad_sum(s) + w.bp;
         const float g1 = 1.f + 1.f / (1.f + expf(-(w.a1 * pt)));
-        load_feat64(f2, i, s_sc[1], s_sh[1], v);
-        float d[9];
-        float q2 = 0.f;
+        load_feat16(f2, ii, q, s_sc[1], s_sh[1], v);
+        float d[9], q2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            float s = 0.f;
+            float t = 0.f;
 #pragma unroll
-            for (int c = 0; c < 64; ++c) s = fmaf(w.wd[k][c], v[c], s);
-            d[k] = fmaf(g1, s, w.bd[k]);
-            dirn[(n * 9 + k) * plane + p] = d[k];
+            for (int c = 0; c < 16; ++c) t = fmaf(w.wd[k][q * 16 + c], v[c], t);
+            d[k] = fmaf(g1, quad_sum(t), w.bd[k]);
             q2 = fmaf(w.a2[k], d[k], q2);
         }
-        // mask = mask_conv(F1 * (1 + sigmoid(maskAtt(direction))))
         const float g2 = 1.f + 1.f / (1.f + expf(-q2));
-        load_feat64(f1, i, s_sc[0], s_sh[0], v);
+        load_feat16(f1, ii, q, s_sc[0], s_sh[0], v);
+        float mk[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float s = 0.f;
+            float t = 0.f;
 #pragma unroll
-            for (int c = 0; c < 64; ++c) s = fmaf(w.wm[k][c], v[c], s);
-            mask[(n * 3 + k) * plane + p] = fmaf(g2, s, w.bm[k]);
+            for (int c = 0; c < 16; ++c) t = fmaf(w.wm[k][q * 16 + c], v[c], t);
+            mk[k] = fmaf(g2, quad_sum(t), w.bm[k]);
+        }
+        if (ok) {
+            // the 13 outputs of a pixel are spread over its 4 lanes: lane q writes outputs q, q+4, q+8, (q+12)
+            if (q == 0) { point[n * plane + p] = pt; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) if ((k & 3) == q) dirn[(n * 9 + k) * plane + p] = d[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (k + 1 == q) mask[(n * 3 + k) * plane + p] = mk[k];
         }
     }
 }
@@ -308,7 +349,7 @@ extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_hea
     CDNET_REQUIRE(f1 && f2 && f3 && head_weights && mask && point && direction, "cdnet_dam_head_forward: null pointer");
     CDNET_REQUIRE(f1->raw && f2->raw && f3->raw && N > 0 && H > 0 && W > 0, "cdnet_dam_head_forward: bad args");
     static_assert(sizeof(HeadW) == CDNET_HEAD_WEIGHT_FLOATS * 4, "head weight block layout");
-    dam_head_fwd_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(
+    dam_head_fwd_kernel<<<lin_grid((size_t)N * H * W * 4), 256, 0, (hipStream_t)stream>>>(
         mk_feat(*f1), mk_feat(*f2), mk_feat(*f3), reinterpret_cast<const HeadW *>(head_weights), N, H * W, mask, point, direction);
     return check_launch("cdnet_dam_head_forward");
 }

@@ -308,17 +308,37 @@ __device__ __forceinline__ void store64_bf16(unsigned short *dst, const float *v
     }
 }
 
-// one block = 256 consecutive pixels per iteration.  Phase 1: thread = pixel (feature gradients, the 13 per-pixel
-// coefficients, the 23 scalar gradients).  Phase 2: thread = (channel, quarter of the pixels) for the weight gradients.
+__device__ __forceinline__ void feat16(const HeadFeat &f, size_t pix, int q, const float *s_sc, const float *s_sh, float *v) {
+    feat8(f, pix, q * 16, s_sc, s_sh, v);
+    feat8(f, pix, q * 16 + 8, s_sc, s_sh, v + 8);
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+__device__ __forceinline__ void store16_bf16(unsigned short *dst, const float *v) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        V16 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = f2bf(v[h2 * 8 + j]);
+        reinterpret_cast<uint4 *>(dst)[h2] = o.u;
+    }
+}
+
+// Kernel 1: four lanes per pixel (16 channels each).  Recomputes the head, writes the three feature gradients, the 13
+// per-pixel coefficients {dpt, du[9], dm[3]} (f32 [px][16]) for the weight-gradient kernel, and per-block partial sums of
+// the 23 scalar parameter gradients (biases and gate weights).
 __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
                                                            const float *__restrict__ dmask, const float *__restrict__ dpoint,
                                                            const float *__restrict__ ddir, int N, int plane,
                                                            unsigned short *__restrict__ df1, unsigned short *__restrict__ df2,
-                                                           unsigned short *__restrict__ df3, float *__restrict__ partial) {
+                                                           unsigned short *__restrict__ df3, float *__restrict__ coef,
+                                                           float *__restrict__ partial) {
     __shared__ HeadW w;
     __shared__ float s_sc[3][64], s_sh[3][64];
-    __shared__ float s_coef[256][14];
-    __shared__ float s_red[256][24];
+    __shared__ float s_red[64][24];
     const int tid = threadIdx.x;
     {
         const float *src = reinterpret_cast<const float *>(hw);
@@ -335,128 +355,151 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
     }
     __syncthreads();
     const size_t total = (size_t)N * plane;
-    // scalar gradient accumulators: dbm[3], dbd[9], dbp, da1, da2[9]  (23)
+    const int q = tid & 3;
+    // scalar gradients accumulated by the q == 0 lane of each pixel: dbm[3] | dbd[9] | dbp | da1 | da2[9]
     float sg[23];
 #pragma unroll
     for (int j = 0; j < 23; ++j) sg[j] = 0.f;
-    // weight gradient accumulators: 8 channels (c8) x 13 coefficient rows, over pixels pg, pg+32, ... of each block
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + (tid >> 2);
+        const bool ok = i < total;
+        const size_t ii = ok ? i : total - 1;
+        const size_t n = ii / plane, p = ii - n * plane;
+        float v[16];
+        feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s = fmaf(w.wp[q * 16 + c], v[c], s);
+        const float pt = quad_sum(s) + w.bp;
+        const float sg1 = 1.f / (1.f + expf(-(w.a1 * pt)));
+        const float g1 = 1.f + sg1;
+        feat16(f2, ii, q, s_sc[1], s_sh[1], v);
+        float u[9], d[9], q2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t = fmaf(w.wd[k][q * 16 + c], v[c], t);
+            u[k] = quad_sum(t);
+            d[k] = fmaf(g1, u[k], w.bd[k]);
+            q2 = fmaf(w.a2[k], d[k], q2);
+        }
+        const float sg2 = 1.f / (1.f + expf(-q2));
+        const float g2 = 1.f + sg2;
+        feat16(f1, ii, q, s_sc[0], s_sh[0], v);
+        float dm[3], dg2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t = fmaf(w.wm[k][q * 16 + c], v[c], t);
+            const float mk = quad_sum(t);
+            const float go = ok ? dmask[(n * 3 + k) * plane + p] : 0.f;
+            dg2 = fmaf(go, mk, dg2);
+            dm[k] = go * g2;
+            sg[k] += go;
+        }
+        // dF1 = sum_k dm_k * wm_k   (this lane's 16 channels)
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            v[c] = dm[0] * w.wm[0][q * 16 + c] + dm[1] * w.wm[1][q * 16 + c] + dm[2] * w.wm[2][q * 16 + c];
+        if (ok) store16_bf16(df1 + ii * 64 + q * 16, v);
+        const float dq2 = dg2 * sg2 * (1.f - sg2);
+        float du[9], dg1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float dd = (ok ? ddir[(n * 9 + k) * plane + p] : 0.f) + dq2 * w.a2[k];
+            sg[3 + k] += dd;
+            sg[14 + k] = fmaf(dq2, d[k], sg[14 + k]);
+            dg1 = fmaf(dd, u[k], dg1);
+            du[k] = dd * g1;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) t = fmaf(du[k], w.wd[k][q * 16 + c], t);
+            v[c] = t;
+        }
+        if (ok) store16_bf16(df2 + ii * 64 + q * 16, v);
+        const float dsg1 = dg1 * sg1 * (1.f - sg1);
+        const float dpt = (ok ? dpoint[n * plane + p] : 0.f) + dsg1 * w.a1;
+        sg[12] += dpt;
+        sg[13] = fmaf(dsg1, pt, sg[13]);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = dpt * w.wp[q * 16 + c];
+        if (ok) {
+            store16_bf16(df3 + ii * 64 + q * 16, v);
+            // coefficient row [dpt | du[9] | dm[3] | 0 0 0]: lane q writes floats 4q..4q+3
+            float4 cf;
+            if (q == 0) cf = make_float4(dpt, du[0], du[1], du[2]);
+            else if (q == 1) cf = make_float4(du[3], du[4], du[5], du[6]);
+            else if (q == 2) cf = make_float4(du[7], du[8], dm[0], dm[1]);
+            else cf = make_float4(dm[2], 0.f, 0.f, 0.f);
+            reinterpret_cast<float4 *>(coef + ii * 16)[q] = cf;
+        }
+    }
+    // every lane of a pixel accumulated identical scalar sums: take the q == 0 lanes, fixed-order block reduction
+    if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < 23; ++j) s_red[tid >> 2][j] = sg[j];
+    }
+    __syncthreads();
+    if (tid < 23) {
+        float s = 0.f;
+        for (int k = 0; k < 64; ++k) s += s_red[k][tid];
+        int dst;                                     // HeadW tail: bp, bd[9], bm[3], a1, a2[9]
+        if (tid < 3) dst = 832 + 10 + tid;
+        else if (tid < 12) dst = 832 + 1 + (tid - 3);
+        else if (tid == 12) dst = 832;
+        else if (tid == 13) dst = 832 + 13;
+        else dst = 832 + 14 + (tid - 14);
+        partial[(size_t)blockIdx.x * HEADW_FLOATS + dst] = s;
+    }
+}
+
+// Kernel 2: weight gradients  dW[row][c] = sum_px coef[px][row] * F_row(px, c),  rows = {dpt x F3, du[9] x F2, dm[3] x F1}.
+// thread = (8 channels, pixel group); 104 accumulators; per-block partials in the HeadW layout.
+__global__ __launch_bounds__(256) void dam_head_wgrad_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const float *__restrict__ coef,
+                                                             int N, int plane, float *__restrict__ partial) {
+    __shared__ float s_sc[3][64], s_sh[3][64];
+    __shared__ float s_w[4][13][64];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const HeadFeat *fs[3] = {&f1, &f2, &f3};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s_sc[k][tid] = fs[k]->scale ? fs[k]->scale[tid] : 1.f;
+            s_sh[k][tid] = fs[k]->scale ? fs[k]->shift[tid] : 0.f;
+        }
+    }
+    __syncthreads();
     float gw[13][8];
 #pragma unroll
     for (int j = 0; j < 13; ++j)
 #pragma unroll
         for (int q = 0; q < 8; ++q) gw[j][q] = 0.f;
     const int c8 = (tid & 7) * 8, pg = tid >> 3;
-
-    for (size_t base = (size_t)blockIdx.x * 256; base < total; base += (size_t)gridDim.x * 256) {
-        const size_t i = base + tid;
-        float coef[13];
+    const size_t total = (size_t)N * plane;
+    for (size_t ip = (size_t)blockIdx.x * 32 + pg; ip < total; ip += (size_t)gridDim.x * 32) {
+        const float4 *cr = reinterpret_cast<const float4 *>(coef + ip * 16);
+        const float4 c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3];
+        const float cf[13] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x};
+        float x[8];
+        feat8(f3, ip, c8, s_sc[2], s_sh[2], x);
 #pragma unroll
-        for (int j = 0; j < 13; ++j) coef[j] = 0.f;
-        if (i < total) {
-            const size_t n = i / plane, p = i - n * plane;
-            float v[64];
-            feat64(f3, i, s_sc[2], s_sh[2], v);
-            float pt = w.bp;
+        for (int q = 0; q < 8; ++q) gw[0][q] = fmaf(cf[0], x[q], gw[0][q]);
+        feat8(f2, ip, c8, s_sc[1], s_sh[1], x);
 #pragma unroll
-            for (int k = 0; k < 64; ++k) pt = fmaf(w.wp[k], v[k], pt);
-            const float sg1 = 1.f / (1.f + expf(-(w.a1 * pt)));
-            const float g1 = 1.f + sg1;
-            feat64(f2, i, s_sc[1], s_sh[1], v);
-            float u[9], d[9], q2 = 0.f;
+        for (int j = 0; j < 9; ++j)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                float s = 0.f;
+            for (int q = 0; q < 8; ++q) gw[1 + j][q] = fmaf(cf[1 + j], x[q], gw[1 + j][q]);
+        feat8(f1, ip, c8, s_sc[0], s_sh[0], x);
 #pragma unroll
-                for (int cc = 0; cc < 64; ++cc) s = fmaf(w.wd[k][cc], v[cc], s);
-                u[k] = s;
-                d[k] = fmaf(g1, s, w.bd[k]);
-                q2 = fmaf(w.a2[k], d[k], q2);
-            }
-            const float sg2 = 1.f / (1.f + expf(-q2));
-            const float g2 = 1.f + sg2;
-            feat64(f1, i, s_sc[0], s_sh[0], v);
-            float dm[3], dg2 = 0.f;
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float s = 0.f;
-#pragma unroll
-                for (int cc = 0; cc < 64; ++cc) s = fmaf(w.wm[k][cc], v[cc], s);
-                const float go = dmask[(n * 3 + k) * plane + p];
-                dg2 = fmaf(go, s, dg2);
-                dm[k] = go * g2;
-                sg[k] += go;                       // d mask_conv.bias
-            }
-            // dF1 = sum_k dm_k * wm_k
-#pragma unroll
-            for (int cc = 0; cc < 64; ++cc) v[cc] = dm[0] * w.wm[0][cc] + dm[1] * w.wm[1][cc] + dm[2] * w.wm[2][cc];
-            store64_bf16(df1 + i * 64, v);
-            const float dq2 = dg2 * sg2 * (1.f - sg2);
-            float du[9], dg1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const float dd = ddir[(n * 9 + k) * plane + p] + dq2 * w.a2[k];
-                sg[3 + k] += dd;                   // d direction_conv.bias
-                sg[14 + k] = fmaf(dq2, d[k], sg[14 + k]);   // d maskAtt.Conv1x1.weight
-                dg1 = fmaf(dd, u[k], dg1);
-                du[k] = dd * g1;
-            }
-#pragma unroll
-            for (int cc = 0; cc < 64; ++cc) {
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) s = fmaf(du[k], w.wd[k][cc], s);
-                v[cc] = s;
-            }
-            store64_bf16(df2 + i * 64, v);
-            const float dsg1 = dg1 * sg1 * (1.f - sg1);
-            const float dpt = dpoint[n * plane + p] + dsg1 * w.a1;
-            sg[12] += dpt;                         // d point_conv.bias
-            sg[13] = fmaf(dsg1, pt, sg[13]);       // d directionAtt.Conv1x1.weight
-#pragma unroll
-            for (int cc = 0; cc < 64; ++cc) v[cc] = dpt * w.wp[cc];
-            store64_bf16(df3 + i * 64, v);
-            coef[0] = dm[0]; coef[1] = dm[1]; coef[2] = dm[2];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) coef[3 + k] = du[k];
-            coef[12] = dpt;
-        }
-#pragma unroll
-        for (int j = 0; j < 13; ++j) s_coef[tid][j] = coef[j];
-        __syncthreads();
-        // phase 2: weight gradients, rows = {dm[3] x F1, du[9] x F2, dpt x F3}, 16-byte feature loads
-#pragma unroll 2
-        for (int k = 0; k < 8; ++k) {
-            const int px = pg + 32 * k;
-            const size_t ip = base + px;
-            if (ip < total) {
-                float x[8];
-                feat8(f1, ip, c8, s_sc[0], s_sh[0], x);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float cj = s_coef[px][j];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) gw[10 + j][q] = fmaf(cj, x[q], gw[10 + j][q]);
-                }
-                feat8(f2, ip, c8, s_sc[1], s_sh[1], x);
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const float cj = s_coef[px][3 + j];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) gw[1 + j][q] = fmaf(cj, x[q], gw[1 + j][q]);
-                }
-                feat8(f3, ip, c8, s_sc[2], s_sh[2], x);
-                const float cp = s_coef[px][12];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) gw[0][q] = fmaf(cp, x[q], gw[0][q]);
-            }
-        }
-        __syncthreads();
+            for (int q = 0; q < 8; ++q) gw[10 + j][q] = fmaf(cf[10 + j], x[q], gw[10 + j][q]);
     }
-    // block reduction -> partial[block][855]  (layout of HeadW)
-    float *o = partial + (size_t)blockIdx.x * HEADW_FLOATS;
-    // weights: rows are already in HeadW order (wp | wd[9] | wm[3]); sum the 8 pixel groups of a wave by butterfly, then
-    // the 4 waves through LDS
-    __shared__ float s_w[4][13][64];
 #pragma unroll
     for (int j = 0; j < 13; ++j)
 #pragma unroll
@@ -471,24 +514,11 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
 #pragma unroll
             for (int q = 0; q < 8; ++q) s_w[tid >> 6][j][c8 + q] = gw[j][q];
     }
-#pragma unroll
-    for (int j = 0; j < 23; ++j) s_red[tid][j] = sg[j];
     __syncthreads();
+    float *o = partial + (size_t)blockIdx.x * HEADW_FLOATS;
     for (int idx = tid; idx < 13 * 64; idx += 256) {
         const int row = idx / 64, cc = idx % 64;
-        o[idx] = (s_w[0][row][cc] + s_w[1][row][cc]) + (s_w[2][row][cc] + s_w[3][row][cc]);   // wp | wd[9] | wm[3] contiguous
-    }
-    if (tid < 23) {
-        float s = 0.f;
-        for (int k = 0; k < 256; ++k) s += s_red[k][tid];
-        // HeadW tail: bp, bd[9], bm[3], a1, a2[9]
-        int dst;
-        if (tid < 3) dst = 832 + 10 + tid;            // bm
-        else if (tid < 12) dst = 832 + 1 + (tid - 3); // bd
-        else if (tid == 12) dst = 832;                // bp
-        else if (tid == 13) dst = 832 + 13;           // a1
-        else dst = 832 + 14 + (tid - 14);             // a2
-        o[dst] = s;
+        o[idx] = (s_w[0][row][cc] + s_w[1][row][cc]) + (s_w[2][row][cc] + s_w[3][row][cc]);
     }
 }
 
@@ -812,17 +842,21 @@ extern "C" int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_he
                   "cdnet_dam_head_backward: null pointer");
     static_assert(HEADW_FLOATS == CDNET_HEAD_WEIGHT_FLOATS, "head weight block");
     const size_t total = (size_t)N * H * W;
-    int nb = (int)((total + 255) / 256);
-    if (nb > 1024) nb = 1024;
-    if (workspace_floats < (size_t)nb * HEADW_FLOATS) { set_error("cdnet_dam_head_backward: workspace too small"); return CDNET_E_WORKSPACE; }
+    const int nb = 1024;                                    // both kernels write partial[nb][855] (disjoint column ranges)
+    const size_t need = (size_t)nb * HEADW_FLOATS + total * 16;
+    if (workspace_floats < need) { set_error("cdnet_dam_head_backward: workspace %zu < %zu floats", workspace_floats, need); return CDNET_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
+    float *partial = workspace, *coef = workspace + (size_t)nb * HEADW_FLOATS;
     dam_head_bwd_kernel<<<nb, 256, 0, st>>>(mk_hf(*f1), mk_hf(*f2), mk_hf(*f3), reinterpret_cast<const HeadW *>(head_weights), dmask,
-                                            dpoint, ddir, N, H * W, df1, df2, df3, workspace);
+                                            dpoint, ddir, N, H * W, df1, df2, df3, coef, partial);
+    dam_head_wgrad_kernel<<<nb, 256, 0, st>>>(mk_hf(*f1), mk_hf(*f2), mk_hf(*f3), coef, N, H * W, partial);
     reduce_partials_kernel<<<cdiv(HEADW_FLOATS, 4), 256, 0, st>>>(workspace, nb, HEADW_FLOATS, dhead_weights);
     return check_launch("cdnet_dam_head_backward");
 }
 
-extern "C" size_t cdnet_dam_head_backward_workspace_floats(void) { return (size_t)1024 * HEADW_FLOATS; }
+extern "C" size_t cdnet_dam_head_backward_workspace_floats(int N, int H, int W) {
+    return (size_t)1024 * HEADW_FLOATS + (size_t)N * H * W * 16;
+}
 
 extern "C" size_t cdnet_dam_loss_workspace_floats(int B, int P) {
     int nchunk = cdiv(P, 256 * 8);

@@ -99,7 +99,7 @@ class Trainer:
         self._bufs = {}
         self._ws_bn = None
         self._ws_slab = None
-        self._ws_head = torch.empty((_lib.load().cdnet_dam_head_backward_workspace_floats(),), dtype=torch.float32, device=self.dev)
+        self._ws_head = None
         self._ws_loss = None
         self.losses = torch.zeros((6,), dtype=torch.float32, device=self.dev)
         self.tape = []
@@ -166,6 +166,9 @@ class Trainer:
         df = [self.buf('dF%d' % k, (N, H, W, 64), torch.bfloat16) for k in range(3)]
         hf = [runtime.head_feat(f) for f in (f1, f2, f3)]
         dhead = self.flat.G[:self.flat.n_head]
+        need = _lib.load().cdnet_dam_head_backward_workspace_floats(N, H, W)
+        if self._ws_head is None or self._ws_head.numel() < need:
+            self._ws_head = torch.empty((need,), dtype=torch.float32, device=self.dev)
         _lib.call('cdnet_dam_head_backward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(m.head_weight_block()),
                   _lib.ptr(dmask), _lib.ptr(dpoint), _lib.ptr(ddir), N, H, W, _lib.ptr(df[0]), _lib.ptr(df[1]),
                   _lib.ptr(df[2]), _lib.ptr(self._ws_head), self._ws_head.numel(), _lib.ptr(dhead), _lib.stream_ptr())

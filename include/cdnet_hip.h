@@ -249,7 +249,7 @@ int cdnet_bn_backward(const cdnet_bn_bwd_args *args, const float *gamma, float *
 
 /* DAM head backward (model_unet_rev1.py:258-263): gradients of the three logit maps (f32 NCHW) -> gradients of the
  * three 64-channel features (bf16 NHWC) and of the head weights (f32, CDNET_HEAD_WEIGHT_FLOATS layout). */
-size_t cdnet_dam_head_backward_workspace_floats(void);
+size_t cdnet_dam_head_backward_workspace_floats(int N, int H, int W);
 int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_head_feat *f2, const cdnet_head_feat *f3,
                             const float *head_weights, const float *dmask, const float *dpoint, const float *ddir,
                             int N, int H, int W, uint16_t *df1, uint16_t *df2, uint16_t *df3, float *workspace,

@@ -271,7 +271,7 @@ def test_dam_head_backward():
     feats = [engine.Src(_nhwc(f.detach())) for f in F]
     hf = [runtime.head_feat(f) for f in feats]
     df = [torch.empty((N, H, W, 64), dtype=torch.bfloat16, device='cuda') for _ in range(3)]
-    ws = torch.empty((_lib.load().cdnet_dam_head_backward_workspace_floats(),), dtype=torch.float32, device='cuda')
+    ws = torch.empty((_lib.load().cdnet_dam_head_backward_workspace_floats(N, H, W),), dtype=torch.float32, device='cuda')
     dhw = torch.zeros(855, device='cuda')
     gmd, gpd, gdd = gm.cuda(), gp.cuda(), gd.cuda()
     _lib.call('cdnet_dam_head_backward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(hw), _lib.ptr(gmd),
