@@ -187,5 +187,5 @@ def pooled(s, ceil_mode=False):
 def pad_offsets(small_hw, big_hw):
     """F.pad(x, (dx//2, dx-dx//2, dy//2, dy-dy//2)) of model_unet_rev1.py:128-131 / unet.py:42-46 as (off_y, off_x)"""
     dy, dx = big_hw[0] - small_hw[0], big_hw[1] - small_hw[1]
-    assert dy >= 0 and dx >= 0
+    # negative differences (ceil-mode pools on odd sizes) make F.pad CROP: floor division gives the same offsets
     return (dy // 2, dx // 2)

@@ -104,3 +104,38 @@ def test_dam_unet_train_mode_forward_batch_stats():
             a, b = sd[k].cpu().numpy(), rsd[k].numpy()
             step = np.abs(b - rm0[k].numpy()).max() + 1e-6          # size of this update
             assert np.abs(a - b).max() <= 0.05 * step + 2e-3, (k, np.abs(a - b).max(), step)
+
+
+def test_plain_unet_forward_vs_oracle_and_golden(golden):
+    """models/unet.py (config 0): eval forward vs the reference's golden, ceil-mode pools / F.pad on a ragged size,
+    training-mode forward (batch statistics) vs the fp32 oracle with the reference's Kaiming init."""
+    import torch
+    from cdnet_amd import synth
+    from cdnet_amd.models.unet import UNet
+    from oracle import models as om
+    z = golden('unet_fwd')
+    ref = om.det_fill(om.UNet(3)).eval()
+    m = UNet(3)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.det_input(tuple(int(v) for v in z['x_cfg'][:4]), int(z['x_cfg'][4])))
+    with torch.no_grad():
+        _check(m(x.cuda()), z['y_eval'], 'unet eval (golden)')
+        xr = torch.from_numpy(synth.det_input(tuple(int(v) for v in z['x_ragged_cfg'][:4]), int(z['x_ragged_cfg'][4])))
+        _check(m(xr.cuda()), z['y_eval_ragged'], 'unet eval ragged (golden)')
+    torch.manual_seed(0)
+    ref = om.UNet(3)
+    for mod in ref.modules():
+        if isinstance(mod, (torch.nn.Conv2d,)):
+            torch.nn.init.kaiming_normal_(mod.weight)
+    m = UNet(3)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().train(); ref.train()
+    x = torch.from_numpy(synth.det_input((2, 3, 64, 64), 5))
+    want = ref(x).detach()
+    with torch.no_grad():
+        got = m(x.cuda()).float().cpu()
+    scale = want.abs().max()
+    err = (got - want).abs()
+    assert err.max() <= 8e-2 * scale and err.mean() <= 1e-2 * scale, (float(err.max()), float(err.mean()), float(scale))
