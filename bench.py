@@ -83,10 +83,19 @@ def time_dominant_conv(torch, B, steps=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    flops = 2.0 * B * 256 * 256 * 64 * 64 * 9             # algorithmic: 2*MACs of this layer (hooks)
-    return dict(bound='mfma', achieved=flops / ms / 1e9, peak=DENSE_BF16_PEAK_TFLOPS, unit='TFLOP/s',
-                frac=flops / ms / 1e9 / DENSE_BF16_PEAK_TFLOPS, traffic=None,
-                kernel='conv_fwd_kernel<16,16,32,64> 3x3 64->64 @256x256 x%d tiles' % B, ms_per_launch=ms)
+    flops = 2.0 * B * 256 * 256 * 64 * 64 * 9             # algorithmic: 2*MACs of this layer (forward hooks)
+    alg_bytes = B * 256 * 256 * (64 + 64) * 2             # algorithmic: input read once + output written once, bf16
+    # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 -> the HBM term bounds this layer
+    traffic = None
+    tj = os.path.join(ROOT, 'profiles', 'r01', 'dominant_conv_traffic.json')
+    if os.path.exists(tj) and B == 16:
+        with open(tj) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch')       # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes
+    gbs = alg_bytes / ms / 1e6
+    return dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, traffic=traffic,
+                kernel='conv_fwd_kernel<%s> 3x3 64->64 @256x256 x%d tiles' % (','.join(str(c) for c in cfg), B),
+                ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
+                mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / DENSE_BF16_PEAK_TFLOPS)
 
 
 def main():
