@@ -775,6 +775,322 @@ int dispatch_conv_ws(const ConvArgs &A, hipStream_t st) {
     }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a plain vector: HIP's uint4 struct copies become memcpys SROA cannot split
+template <int NB>
+struct BRegs { u32x4 r[NB]; };
+template <int NB, int B_BYTES>
+__device__ __forceinline__ void issue_b(BRegs<NB> &p, const unsigned short *w, int tid) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(w);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { const int v = tid + i * 256; if (v < B_BYTES / 16) p.r[i] = src[v]; }
+}
+template <int NB, int B_BYTES>
+__device__ __forceinline__ void commit_b(const BRegs<NB> &p, unsigned char *lds_b, int tid) {
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds_b);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { const int v = tid + i * 256; if (v < B_BYTES / 16) dst[v] = p.r[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// v2 main loop: the input halo is staged in chunks of CKA channels (full 128-byte lines per pixel when CKA = 64: the
+// 32-byte-per-pixel segments of a 16-channel chunk wasted 3/4 of every line the texture path fetched), while the
+// weights still arrive in 16-channel sub-chunks (18 KB for 64 couts) prefetched one step ahead from L2.  One barrier
+// pair per sub-chunk, the A tile is written once per CKA channels.
+// ------------------------------------------------------------------------------------------------------
+template <int TH, int TW, int CKA, int BN, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_fwd2_kernel(ConvArgs A) {
+    constexpr int PSTR = CKA * 2 + 16;
+    constexpr int HW_ = TW + 2;
+    constexpr int NPIX = (TH + 2) * (TW + 2);
+    constexpr int MT = TH * TW / 32, NT = BN / 32;
+    constexpr int MPW = MT / WM, NPW = NT / WN;
+    constexpr int A_BYTES = NPIX * PSTR;
+    constexpr int B_BYTES = TAPS * 16 * BN * 2;
+    constexpr int NA = (NPIX * (CKA / 8) + 255) / 256;
+    constexpr int NB = (B_BYTES / 16 + 255) / 256;
+    constexpr int OSTR = BN * 2 + 8;
+    static_assert(MT % WM == 0 && NT % WN == 0 && WM * WN == 4, "wave tiling");
+    static_assert(NA <= 32, "valid mask");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_a = smem;
+    unsigned char *lds_b = smem + A_BYTES;
+    __shared__ float s_stats[4][2][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int tile = blockIdx.x;
+    const int cout_tile = blockIdx.y;
+    const int z = tile / tiles_img, rr_ = tile - z * tiles_img;
+    const int n = z / A.npar, par = z - n * A.npar;
+    const int y0 = (rr_ / tiles_x) * TH, x0 = (rr_ % tiles_x) * TW;
+
+    const int par_a = par >> 1, par_b = par & 1;
+    auto tap_off = [&](int t) -> int {           // compile-time for 3x3 / 1x1; two scalar selects for the transposed-conv phases
+        if (TAPS == 9) return ((t / 3) * HW_ + t % 3) * PSTR;
+        if (TAPS == 4) {
+            const int ty = t >> 1, tx = t & 1;
+            const int r = par_a == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+            const int c = par_b == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+            return (r * HW_ + c) * PSTR;
+        }
+        return (HW_ + 1) * PSTR;
+    };
+    int abase[MPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int m = (wm * MPW + mi) * 32 + l31;
+        abase[mi] = ((m / TW) * HW_ + m % TW) * PSTR + half * 16;
+    }
+    const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
+    const unsigned short *wbase = A.w + ((size_t)(par * gridDim.y + cout_tile) * A.nchunk) * (B_BYTES / 2);
+
+    // ---- A chunk enumeration: (source, first channel, width) ----
+    auto a_chunk = [&](int idx, int &si, int &cc0, int &cw) {
+        const int c0 = A.src[0].C, n0 = (c0 + CKA - 1) / CKA;
+        if (idx < n0) { si = 0; cc0 = idx * CKA; cw = c0 - cc0 < CKA ? c0 - cc0 : CKA; }
+        else { si = 1; cc0 = (idx - n0) * CKA; const int c1 = A.src[1].C; cw = c1 - cc0 < CKA ? c1 - cc0 : CKA; }
+    };
+    int na_chunks = (A.src[0].C + CKA - 1) / CKA;
+    if (A.nsrc > 1) na_chunks += (A.src[1].C + CKA - 1) / CKA;
+
+    uint4 pa[NA];
+    BRegs<NB> pb;
+    unsigned valid = 0;
+    auto issue_a = [&](int idx) {
+        int si, cc0, cw;
+        a_chunk(idx, si, cc0, cw);
+        const ConvSrc &S = A.src[si];
+        valid = 0;
+        if (S.pool) return;
+        const int vpp = cw / 8, slot = tid % vpp;
+        const size_t rs = S.row_stride ? (size_t)S.row_stride : (size_t)S.Ws * S.C;
+        const size_t img = (size_t)n * S.Hs * rs;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * 256;
+            const int pix = v / vpp, hy = pix / HW_, hx = pix - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const int ys = y - S.off_y, xs = x - S.off_x;
+            if (v < NPIX * vpp && y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < S.Hs && xs >= 0 && xs < S.Ws) {
+                pa[i] = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)ys * rs + (size_t)xs * S.C + cc0 + slot * 8);
+                valid |= 1u << i;
+            }
+        }
+    };
+    auto commit_a = [&](int idx) {
+        int si, cc0, cw;
+        a_chunk(idx, si, cc0, cw);
+        const ConvSrc &S = A.src[si];
+        const int vpp = cw / 8, slot = tid % vpp;
+        ChanXf t;
+        t.on = S.scale != nullptr;
+        if (t.on) {
+            const float4 *ps = reinterpret_cast<const float4 *>(S.scale + cc0 + slot * 8);
+            const float4 *ph = reinterpret_cast<const float4 *>(S.shift + cc0 + slot * 8);
+            float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
+            t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
+            t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
+        }
+        const bool relu = S.relu != 0, f16 = S.f16 != 0;
+        const bool plain = !t.on && !relu && S.res == nullptr && !f16;
+        const int Hl = S.pool ? (S.Hs + (S.pool == 2)) / 2 : S.Hs, Wl = S.pool ? (S.Ws + (S.pool == 2)) / 2 : S.Ws;
+        const size_t rs = S.row_stride ? (size_t)S.row_stride : (size_t)S.Ws * S.C;
+        const size_t img = (size_t)n * S.Hs * rs;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * 256;
+            if (v >= NPIX * vpp) continue;
+            const int pix = v / vpp, hy = pix / HW_, hx = pix - hy * HW_;
+            V16 val;
+            val.u = make_uint4(0, 0, 0, 0);
+            if (!S.pool) {
+                if (valid & (1u << i)) {
+                    V16 raw;
+                    raw.u = pa[i];
+                    if (plain) val = raw;
+                    else if (S.res) {
+                        const size_t e = img + (size_t)(y0 - 1 + hy - S.off_y) * rs + (size_t)(x0 - 1 + hx - S.off_x) * S.C + cc0 + slot * 8;
+                        V16 r;
+                        r.u = *reinterpret_cast<const uint4 *>(S.res + e);
+                        val = xform8(raw, &r, t, relu, f16);
+                    } else val = xform8(raw, nullptr, t, relu, f16);
+                }
+            } else {
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const int ys = y - S.off_y, xs = x - S.off_x;
+                if (y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
+                        if (q != 0 && (yy >= S.Hs || xx >= S.Ws)) continue;
+                        V16 raw;
+                        raw.u = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)yy * rs + (size_t)xx * S.C + cc0 + slot * 8);
+                        V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
+                        val = q == 0 ? tv : max8(val, tv);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
+        }
+    };
+    f32x16 acc[MPW][NPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    issue_a(0);
+    issue_b<NB, B_BYTES>(pb, wbase, tid);
+    int g = 0;                                   // global 16-channel sub-chunk counter (= weight chunk index)
+    for (int ia = 0; ia < na_chunks; ++ia) {
+        int si, cc0, cw;
+        a_chunk(ia, si, cc0, cw);
+        const int nsub = cw / 16;
+        __syncthreads();                         // all fragment reads of the previous A chunk / B sub-chunk are done
+        commit_a(ia);
+        commit_b<NB, B_BYTES>(pb, lds_b, tid);
+        __syncthreads();
+        if (ia + 1 < na_chunks) issue_a(ia + 1);
+        for (int sb = 0; sb < nsub; ++sb, ++g) {
+            const bool more = g + 1 < A.nchunk;
+            if (more) issue_b<NB, B_BYTES>(pb, wbase + (size_t)(g + 1) * (B_BYTES / 2), tid);
+            if (!(A.debug & 4)) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    bf16x8 af[MPW], bfr[NPW];
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+                        af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + abase[mi] + tap_off(t) + sb * 32);
+#pragma unroll
+                    for (int ni = 0; ni < NPW; ++ni)
+                        bfr[ni] = *reinterpret_cast<const bf16x8 *>(lds_b + bbase + (t * 2) * BN * 16 + ni * 512);
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NPW; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+            if (sb + 1 < nsub) {                 // next weight sub-chunk of the same A chunk
+                __syncthreads();
+                commit_b<NB, B_BYTES>(pb, lds_b, tid);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- epilogue (identical to the v1 kernel) ----------------
+    const int cout0 = cout_tile * BN;
+    unsigned char *s_out = smem;
+    const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
+    float ssum[NPW], ssq[NPW];
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) {
+        const int col = (wn * NPW + ni) * 32 + l31;
+        const int co = cout0 + col;
+        const bool cok = co < A.Cout;
+        const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
+        const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
+        const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[mi][ni][r];
+                if (A.stats) {
+                    bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
+                    if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
+                }
+                v += bias;
+                v = fmaf(v, osc, osh);
+                if (A.orelu) v = fmaxf(v, 0.f);
+                const unsigned mine = A.out_f16 ? f2h(v) : f2bf(v);
+                const unsigned other = __shfl_xor(mine, 1);
+                if (!(l31 & 1)) *reinterpret_cast<unsigned *>(s_out + m * OSTR + col * 2) = mine | (other << 16);
+            }
+        }
+    }
+    if (A.stats) {
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) {
+            ssum[ni] += __shfl_xor(ssum[ni], 32);
+            ssq[ni] += __shfl_xor(ssq[ni], 32);
+            if (half == 0) {
+                s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
+                s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
+            }
+        }
+    }
+    __syncthreads();
+    if (A.stats && tid < 2 * BN) {
+        const int which = tid / BN, col = tid % BN;
+        const int wn_of = col / (NPW * 32);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
+        const int co = cout0 + col;
+        if (co < A.Cout) A.stats[((size_t)tile * 2 + which) * A.Cout + co] = v;
+    }
+    {
+        constexpr int VO = BN / 8;
+        const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
+        const int pa_ = par >> 1, pb_ = par & 1;
+        for (int v = tid; v < TH * TW * VO; v += 256) {
+            const int m = v / VO, q = v % VO;
+            const int y = y0 + m / TW, x = x0 + m % TW;
+            const int co = cout0 + q * 8;
+            if (y < A.H && x < A.W && co < A.Cout) {
+                const int oy = y * A.ostride + pa_, ox = x * A.ostride + pb_;
+                const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
+                *reinterpret_cast<uint4 *>(A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co) = val;
+            }
+        }
+    }
+}
+
+template <int TH, int TW, int CKA, int BN, int WM, int WN, int TAPS>
+int launch_conv2(const ConvArgs &A, hipStream_t st) {
+    constexpr int stage_bytes = (TH + 2) * (TW + 2) * (CKA * 2 + 16) + TAPS * 16 * BN * 2;
+    constexpr int out_bytes = TH * TW * (BN * 2 + 8);
+    constexpr int smem = stage_bytes > out_bytes ? stage_bytes : out_bytes;
+    auto kern = conv_fwd2_kernel<TH, TW, CKA, BN, WM, WN, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(conv2)");
+        attr_done = true;
+    }
+    dim3 grid(cdiv(A.W, TW) * cdiv(A.H, TH) * A.N * A.npar, cdiv(A.Cout, BN), 1);
+    kern<<<grid, 256, smem, st>>>(A);
+    return check_launch("conv_fwd2_kernel");
+}
+
+template <int TAPS>
+int dispatch_conv2(const ConvArgs &A, hipStream_t st) {
+    const int key = A.tile * 10000 + A.CK * 100 + (A.BN == 128 ? 99 : A.BN);     // A.CK carries CKA here
+    switch (key) {
+        case 16 * 10000 + 64 * 100 + 64: return launch_conv2<16, 16, 64, 64, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 64 * 100 + 32: return launch_conv2<16, 16, 64, 32, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 32 * 100 + 64: return launch_conv2<16, 16, 32, 64, 4, 1, TAPS>(A, st);
+        case 16 * 10000 + 32 * 100 + 32: return launch_conv2<16, 16, 32, 32, 4, 1, TAPS>(A, st);
+        case 8 * 10000 + 64 * 100 + 64: return launch_conv2<8, 8, 64, 64, 2, 2, TAPS>(A, st);
+        case 8 * 10000 + 64 * 100 + 99: return launch_conv2<8, 8, 64, 128, 2, 2, TAPS>(A, st);
+        default:
+            set_error("cdnet_conv: unsupported v2 configuration tile=%d CKA=%d BN=%d", A.tile, A.CK, A.BN);
+            return CDNET_E_ARG;
+    }
+}
+
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
 int launch_conv(const ConvArgs &A, hipStream_t st) {
     constexpr int PSTR = CK * 2 + 16;
@@ -843,6 +1159,16 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && A.out, "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
     CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0 && A.Cout % 8 == 0, "cdnet_conv_forward: bad size (Cout must be a multiple of 8)");
+    if (A.ws == 2) {
+        int nsub = 0;
+        for (int i = 0; i < A.nsrc; ++i) { CDNET_REQUIRE(A.src[i].x && A.src[i].C % 16 == 0, "cdnet_conv_forward: v2 source channels must be multiples of 16"); nsub += A.src[i].C / 16; }
+        CDNET_REQUIRE(nsub == A.nchunk, "cdnet_conv_forward: v2 nchunk %d != %d 16-channel sub-chunks", A.nchunk, nsub);
+        CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0 && A.Cout % 8 == 0, "cdnet_conv_forward: output channel slice");
+        hipStream_t st2 = (hipStream_t)stream;
+        if (A.taps == 9) return dispatch_conv2<9>(A, st2);
+        if (A.taps == 4) return dispatch_conv2<4>(A, st2);
+        return dispatch_conv2<1>(A, st2);
+    }
     if (A.ws) {
         int ctot = 0;
         for (int i = 0; i < A.nsrc; ++i) { CDNET_REQUIRE(A.src[i].x && A.src[i].C % 8 == 0, "cdnet_conv_forward: ws source channels"); ctot += A.src[i].C; }

@@ -143,6 +143,217 @@ __device__ __forceinline__ void load8(const float *p, int c0, float *o, float df
     for (int j = 0; j < 8; ++j) o[j] = p ? p[c0 + j] : dflt;
 }
 
+// Both passes are pure streaming (HBM bound): every thread keeps BN_U independent pixels in flight per iteration.
+constexpr int BN_U = 4;
+constexpr int BN_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ void dz8_at(const BnBwdArgs &A, unsigned p, unsigned HW, int c0, const float *sc, const float *sh, const float *mu,
+                                       const float *is, float *dz, float *xh) {
+    const unsigned n = p / HW, r = p - n * HW;
+    const unsigned y = r / (unsigned)A.W, x = r - y * (unsigned)A.W;
+    dz8<true>(A, (int)n, (int)y, (int)x, c0, sc, sh, mu, is, dz, xh);
+}
+
+// Window kernels: the layer's consumers are one 2x2 max-pool plus NF same-size un-shifted tensors (the skip connection).
+// One pooling window per thread: the four activations are read once, the pooled gradient goes to the first maximum
+// (nn.MaxPool2d backward).  All loads are unconditional (clamped coordinates) and issued before any arithmetic.
+template <int NF, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_window_kernel(BnBwdArgs A, int kp) {
+    __shared__ float s_red[APPLY ? 1 : 256][17];
+    const int VPP = A.C / 8;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 8;
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8], k3[8], s1[8], s2[8];
+    load8(A.scale, c0, sc, 1.f); load8(A.shift, c0, sh, 0.f); load8(A.mean, c0, mu, 0.f); load8(A.invstd, c0, is, 1.f);
+    if (APPLY) { load8(A.k1, c0, k1, 1.f); load8(A.k2, c0, k2, 0.f); load8(A.k3, c0, k3, 0.f); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const unsigned H = A.H, W = A.W, Hp = (H + 1) / 2, Wp = (W + 1) / 2, nwin = (unsigned)A.N * Hp * Wp;
+    const unsigned ppb = 256 / VPP;
+    const bool f16 = A.f16 != 0, relu = A.relu != 0;
+    const GradIn gp = A.gin[kp];
+    int kf[2] = {0, 0};
+    {
+        int m = 0;
+        for (int k = 0; k < A.ngin && m < NF; ++k)
+            if (k != kp) kf[m++] = k;
+    }
+    for (unsigned w = blockIdx.x * ppb + tid / VPP; w < nwin; w += gridDim.x * ppb) {
+        const unsigned n = w / (Hp * Wp), r = w - n * Hp * Wp;
+        const unsigned py = r / Wp, px = r - py * Wp;
+        V16 raw[4], g[4][NF > 0 ? NF : 1], gv;
+        unsigned pix[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned yy = 2 * py + (q >> 1), xx = 2 * px + (q & 1);
+            ok[q] = yy < H && xx < W;
+            yy = yy < H ? yy : H - 1;
+            xx = xx < W ? xx : W - 1;
+            pix[q] = (n * H + yy) * W + xx;
+            raw[q].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)pix[q] * A.C + c0);
+#pragma unroll
+            for (int m = 0; m < NF; ++m)
+                g[q][m].u = *reinterpret_cast<const uint4 *>(A.gin[kf[m]].g + (size_t)pix[q] * A.gin[kf[m]].cstride + A.gin[kf[m]].coff + c0);
+        }
+        const bool pok = py < (unsigned)gp.Hg && px < (unsigned)gp.Wg;
+        {
+            const unsigned cy = pok ? py : 0, cx = pok ? px : 0;
+            gv.u = *reinterpret_cast<const uint4 *>(gp.g + (((size_t)n * gp.Hg + cy) * gp.Wg + cx) * gp.cstride + gp.coff + c0);
+        }
+        V16 o[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x[4], a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x[q] = ld16(raw[q].h[j], f16);
+                float v = fmaf(x[q], sc[j], sh[j]);
+                if (relu) v = fmaxf(v, 0.f);
+                a[q] = bf2f(f2bf(v));
+            }
+            int bi = 0;
+            float best = a[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (ok[q] && a[q] > best) { best = a[q]; bi = q; }
+            const float gpool = pok ? bf2f(gv.h[j]) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float gs = (bi == q) ? gpool : 0.f;
+#pragma unroll
+                for (int m = 0; m < NF; ++m) gs += bf2f(g[q][m].h[j]);
+                const float dz = (!ok[q] || (relu && !(a[q] > 0.f))) ? 0.f : gs;
+                const float xh = (x[q] - mu[j]) * is[j];
+                if (APPLY) o[q].h[j] = f2bf(k1[j] * (dz - k2[j] - xh * k3[j]));
+                else { s1[j] += dz; s2[j] = fmaf(dz, xh, s2[j]); }
+            }
+        }
+        if (APPLY) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) *reinterpret_cast<uint4 *>(A.draw + (size_t)pix[q] * A.C + c0) = o[q].u;
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s_red[tid][j] = s1[j]; s_red[tid][8 + j] = s2[j]; }
+        __syncthreads();
+        for (int q = tid; q < 16 * VPP; q += 256) {
+            const int sl = q % VPP, j = q / VPP;
+            float t = 0.f;
+            for (int k = sl; k < 256; k += VPP) t += s_red[k][j];
+            float *op = A.partial + (size_t)blockIdx.x * 2 * A.C;
+            op[(j >> 3) * A.C + sl * 8 + (j & 7)] = t;
+        }
+    }
+}
+
+// Flat kernels: every gradient source is a same-size un-shifted tensor, so dz needs only the pixel index.  Loads of BN_U
+// pixels are issued back to back (clamped index, no branch), then each pixel is folded into the sums / written out.
+template <int NG, bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(BnBwdArgs A) {
+    __shared__ float s_red[256][17];
+    const int VPP = A.C / 8;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 8;
+    float sc[8], sh[8], mu[8], is[8];
+    load8(A.scale, c0, sc, 1.f); load8(A.shift, c0, sh, 0.f); load8(A.mean, c0, mu, 0.f); load8(A.invstd, c0, is, 1.f);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const unsigned npix = (unsigned)(A.N * A.H * A.W);
+    const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
+    const bool f16 = A.f16 != 0, relu = A.relu != 0;
+    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+        V16 raw[BN_U], res[BN_U], g[BN_U][NG];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            unsigned p = p0 + u * step;
+            p = p < npix ? p : npix - 1;
+            raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
+            if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+                g[u][k].u = *reinterpret_cast<const uint4 *>(A.gin[k].g + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const bool valid = p0 + u * step < npix;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = ld16(raw[u].h[j], f16);
+                float v = fmaf(x, sc[j], sh[j]);
+                if (RES) v += ld16(res[u].h[j], f16);
+                float gs = bf2f(g[u][0].h[j]);
+#pragma unroll
+                for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
+                // the forward rounds the activation to bf16 before the ReLU; rounding keeps the sign
+                const float dz = (!valid || (relu && !(bf2f(f2bf(v)) > 0.f))) ? 0.f : gs;
+                s1[j] += dz;
+                s2[j] = fmaf(dz, (x - mu[j]) * is[j], s2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_red[tid][j] = s1[j]; s_red[tid][8 + j] = s2[j]; }
+    __syncthreads();
+    for (int q = tid; q < 16 * VPP; q += 256) {
+        const int sl = q % VPP, j = q / VPP;
+        float t = 0.f;
+        for (int k = sl; k < 256; k += VPP) t += s_red[k][j];
+        float *o = A.partial + (size_t)blockIdx.x * 2 * A.C;
+        o[(j >> 3) * A.C + sl * 8 + (j & 7)] = t;
+    }
+}
+
+template <int NG, bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
+    const int VPP = A.C / 8;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 8;
+    float sc[8], sh[8], mu[8], is[8], k1[8], k2[8], k3[8];
+    load8(A.scale, c0, sc, 1.f); load8(A.shift, c0, sh, 0.f); load8(A.mean, c0, mu, 0.f); load8(A.invstd, c0, is, 1.f);
+    load8(A.k1, c0, k1, 1.f); load8(A.k2, c0, k2, 0.f); load8(A.k3, c0, k3, 0.f);
+    const unsigned npix = (unsigned)(A.N * A.H * A.W);
+    const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
+    const bool f16 = A.f16 != 0, relu = A.relu != 0;
+    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+        V16 raw[BN_U], res[BN_U], g[BN_U][NG];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            unsigned p = p0 + u * step;
+            p = p < npix ? p : npix - 1;
+            raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
+            if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+                g[u][k].u = *reinterpret_cast<const uint4 *>(A.gin[k].g + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const unsigned p = p0 + u * step;
+            V16 o, z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = ld16(raw[u].h[j], f16);
+                float v = fmaf(x, sc[j], sh[j]);
+                if (RES) v += ld16(res[u].h[j], f16);
+                float gs = bf2f(g[u][0].h[j]);
+#pragma unroll
+                for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
+                const float dz = (relu && !(bf2f(f2bf(v)) > 0.f)) ? 0.f : gs;
+                o.h[j] = f2bf(k1[j] * (dz - k2[j] - (x - mu[j]) * is[j] * k3[j]));
+                z.h[j] = f2bf(dz);
+            }
+            if (p < npix) {
+                *reinterpret_cast<uint4 *>(A.draw + (size_t)p * A.C + c0) = o.u;
+                if (RES) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)p * A.C + c0) = z.u;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     __shared__ float s_red[256][17];
     const int VPP = A.C / 8;
@@ -153,30 +364,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    const size_t npix = (size_t)A.N * A.H * A.W;
-    const size_t ppb = 256 / VPP;                                   // pixels per block per iteration
-    for (size_t p = (size_t)blockIdx.x * ppb + tid / VPP; p < npix; p += (size_t)gridDim.x * ppb) {
-        const int n = (int)(p / ((size_t)A.H * A.W));
-        const int r = (int)(p - (size_t)n * A.H * A.W);
-        float dz[8], xh[8];
-        dz8<true>(A, n, r / A.W, r % A.W, c0, sc, sh, mu, is, dz, xh);
+    const unsigned HW = (unsigned)(A.H * A.W), npix = (unsigned)A.N * HW;
+    const unsigned ppb = 256 / VPP;                                 // pixels per block per sub-iteration
+    const unsigned step = gridDim.x * ppb;
+    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+        float dz[BN_U][8], xh[BN_U][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += dz[j]; s2[j] = fmaf(dz[j], xh[j], s2[j]); }
+        for (int u = 0; u < BN_U; ++u) {
+            const unsigned p = p0 + u * step;
+            if (p < npix) dz8_at(A, p, HW, c0, sc, sh, mu, is, dz[u], xh[u]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { dz[u][j] = 0.f; xh[u][j] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += dz[u][j]; s2[j] = fmaf(dz[u][j], xh[u][j], s2[j]); }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s_red[tid][j] = s1[j]; s_red[tid][8 + j] = s2[j]; }
     __syncthreads();
-    // threads with the same slot: tid, tid+VPP, ...  -> fixed-order sum by the first VPP threads
-    if (tid < VPP) {
-        float t[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t[j] = 0.f;
-        for (int k = tid; k < 256; k += VPP)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) t[j] += s_red[k][j];
+    // threads with the same slot: tid, tid+VPP, ...  -> fixed-order sum; 16 values x VPP slots spread over the block
+    for (int q = tid; q < 16 * VPP; q += 256) {
+        const int sl = q % VPP, j = q / VPP;
+        float t = 0.f;
+        for (int k = sl; k < 256; k += VPP) t += s_red[k][j];
         float *o = A.partial + (size_t)blockIdx.x * 2 * A.C;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { o[c0 + j] = t[j]; o[A.C + c0 + j] = t[8 + j]; }
+        o[(j >> 3) * A.C + sl * 8 + (j & 7)] = t;
     }
 }
 
@@ -207,21 +423,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs A) {
     float sc[8], sh[8], mu[8], is[8], k1[8], k2[8], k3[8];
     load8(A.scale, c0, sc, 1.f); load8(A.shift, c0, sh, 0.f); load8(A.mean, c0, mu, 0.f); load8(A.invstd, c0, is, 1.f);
     load8(A.k1, c0, k1, 1.f); load8(A.k2, c0, k2, 0.f); load8(A.k3, c0, k3, 0.f);
-    const size_t npix = (size_t)A.N * A.H * A.W;
-    const size_t ppb = 256 / VPP;
-    for (size_t p = (size_t)blockIdx.x * ppb + tid / VPP; p < npix; p += (size_t)gridDim.x * ppb) {
-        const int n = (int)(p / ((size_t)A.H * A.W));
-        const int r = (int)(p - (size_t)n * A.H * A.W);
-        float dz[8], xh[8];
-        dz8<true>(A, n, r / A.W, r % A.W, c0, sc, sh, mu, is, dz, xh);
-        V16 o, z;
+    const unsigned HW = (unsigned)(A.H * A.W), npix = (unsigned)A.N * HW;
+    const unsigned ppb = 256 / VPP;
+    const unsigned step = gridDim.x * ppb;
+    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+        float dz[BN_U][8], xh[BN_U][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o.h[j] = f2bf(k1[j] * (dz[j] - k2[j] - xh[j] * k3[j]));
-            z.h[j] = f2bf(dz[j]);
+        for (int u = 0; u < BN_U; ++u) {
+            const unsigned p = p0 + u * step;
+            if (p < npix) dz8_at(A, p, HW, c0, sc, sh, mu, is, dz[u], xh[u]);
         }
-        if (A.draw) *reinterpret_cast<uint4 *>(A.draw + p * A.C + c0) = o.u;
-        if (A.dz_out) *reinterpret_cast<uint4 *>(A.dz_out + p * A.C + c0) = z.u;
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const unsigned p = p0 + u * step;
+            if (p >= npix) continue;
+            V16 o, z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o.h[j] = f2bf(k1[j] * (dz[u][j] - k2[j] - xh[u][j] * k3[j]));
+                z.h[j] = f2bf(dz[u][j]);
+            }
+            if (A.draw) *reinterpret_cast<uint4 *>(A.draw + (size_t)p * A.C + c0) = o.u;
+            if (A.dz_out) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)p * A.C + c0) = z.u;
+        }
     }
 }
 
@@ -807,26 +1031,71 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)A.N * A.H * A.W;
+    CDNET_REQUIRE(npix * (size_t)A.C < ((size_t)1 << 32) && npix < ((size_t)1 << 31), "cdnet_bn_backward: tensor too large for 32-bit pixel indexing");
     const int ppb = 256 / (A.C / 8);
-    int nb = (int)((npix + ppb - 1) / ppb);
-    if (nb > 1024) nb = 1024;
+    int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
+    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    bool simple = true, window = false;              // every gradient source a same-size, un-shifted tensor?
+    int npool = 0, kp = 0, nflat = 0;
+    for (int k = 0; k < A.ngin; ++k) {
+        const GradIn &g = A.gin[k];
+        const bool same = !g.pooled && g.oy == 0 && g.ox == 0 && g.Hg == A.H && g.Wg == A.W;
+        simple = simple && same;
+        if (g.pooled) { ++npool; kp = k; }
+        else if (same) ++nflat;
+    }
+    // window path: exactly one pooled consumer, every other one flat, a BatchNorm + ReLU layer without residual branch
+    window = npool == 1 && nflat == A.ngin - 1 && nflat <= 2 && A.mean && A.scale && !A.res && draw && !dz_out;
+    if (window) {
+        const size_t nwin = (size_t)A.N * ((A.H + 1) / 2) * ((A.W + 1) / 2);
+        nb = (int)((nwin + ppb - 1) / ppb);
+        if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    }
     A.draw = draw; A.dz_out = dz_out;
+    const bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
     if (A.mean) {
         CDNET_REQUIRE(gamma && A.invstd && workspace, "cdnet_bn_backward: BatchNorm layer needs gamma/invstd/workspace");
         const size_t need = (size_t)nb * 2 * A.C + 3 * (size_t)A.C;
         if (workspace_floats < need) { set_error("cdnet_bn_backward: workspace %zu < %zu floats", workspace_floats, need); return CDNET_E_WORKSPACE; }
         A.partial = workspace;
         float *k = workspace + (size_t)nb * 2 * A.C;
-        bn_bwd_reduce_kernel<<<nb, 256, 0, st>>>(A);
+        if (window) {
+            if (nflat == 0) bn_bwd_window_kernel<0, false><<<nb, 256, 0, st>>>(A, kp);
+            else if (nflat == 1) bn_bwd_window_kernel<1, false><<<nb, 256, 0, st>>>(A, kp);
+            else bn_bwd_window_kernel<2, false><<<nb, 256, 0, st>>>(A, kp);
+        } else if (flat) {
+            switch (A.ngin * 2 + (A.res ? 1 : 0)) {
+                case 2: bn_bwd_reduce_flat_kernel<1, false><<<nb, 256, 0, st>>>(A); break;
+                case 3: bn_bwd_reduce_flat_kernel<1, true><<<nb, 256, 0, st>>>(A); break;
+                case 4: bn_bwd_reduce_flat_kernel<2, false><<<nb, 256, 0, st>>>(A); break;
+                case 5: bn_bwd_reduce_flat_kernel<2, true><<<nb, 256, 0, st>>>(A); break;
+                case 6: bn_bwd_reduce_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
+                default: bn_bwd_reduce_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
+            }
+        } else bn_bwd_reduce_kernel<<<nb, 256, 0, st>>>(A);
         bn_bwd_finalize_kernel<<<cdiv(A.C, 4), 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
                                                               k + A.C, k + 2 * A.C);
         A.k1 = k; A.k2 = k + A.C; A.k3 = k + 2 * A.C;
     }
-    bn_bwd_apply_kernel<<<nb, 256, 0, st>>>(A);
+    if (window) {
+        if (nflat == 0) bn_bwd_window_kernel<0, true><<<nb, 256, 0, st>>>(A, kp);
+        else if (nflat == 1) bn_bwd_window_kernel<1, true><<<nb, 256, 0, st>>>(A, kp);
+        else bn_bwd_window_kernel<2, true><<<nb, 256, 0, st>>>(A, kp);
+    } else if (flat) {
+        switch (A.ngin * 2 + (A.res ? 1 : 0)) {
+            case 2: bn_bwd_apply_flat_kernel<1, false><<<nb, 256, 0, st>>>(A); break;
+            case 3: bn_bwd_apply_flat_kernel<1, true><<<nb, 256, 0, st>>>(A); break;
+            case 4: bn_bwd_apply_flat_kernel<2, false><<<nb, 256, 0, st>>>(A); break;
+            case 5: bn_bwd_apply_flat_kernel<2, true><<<nb, 256, 0, st>>>(A); break;
+            case 6: bn_bwd_apply_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
+            default: bn_bwd_apply_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
+        }
+    } else bn_bwd_apply_kernel<<<nb, 256, 0, st>>>(A);
     return check_launch("cdnet_bn_backward");
 }
 
-extern "C" size_t cdnet_bn_backward_workspace_floats(int C) { return (size_t)1024 * 2 * C + 3 * (size_t)C; }
+extern "C" size_t cdnet_bn_backward_workspace_floats(int C) { return (size_t)BN_MAX_BLOCKS * 2 * C + 3 * (size_t)C; }
 
 static HeadFeat mk_hf(const cdnet_head_feat &f) {
     HeadFeat h;

@@ -74,6 +74,7 @@ class Src:
         cs.row_stride = int(self.row_stride)
 
 
+_V2_SUPPORTED = {(16, 64, 64), (16, 64, 32), (16, 32, 64), (16, 32, 32), (8, 64, 64), (8, 64, 128)}    # (tile, CKA, BN)
 _WS_SUPPORTED = {(16, 32), (16, 64), (32, 32), (32, 64), (64, 32), (64, 64), (80, 32)}      # (total Cin, BN)
 
 _SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 128), (16, 64, 64),
@@ -84,7 +85,7 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
     """(tile, CK, BN[, 'ws']) for a layer.  CK must divide every source's channel count; the 4-tuple form selects the
     weight-stationary persistent kernel (CK = total Cin)."""
     if override is not None:
-        assert tuple(override[:3]) in _SUPPORTED or (len(override) == 4 and (override[1], override[2]) in _WS_SUPPORTED), override
+        assert tuple(override[:3]) in _SUPPORTED or (len(override) == 4 and ((override[1], override[2]) in _WS_SUPPORTED or tuple(override[:3]) in _V2_SUPPORTED)), override
         return tuple(override)
     ctot = sum(src_channels)
     if allow_ws and not transposed and taps in (9, 1) and min(H, W) >= 32:
@@ -119,6 +120,8 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
     """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
     Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
     _, CK, BN = cfg[:3]
+    if len(cfg) == 4 and cfg[3] == 'v2':
+        CK = 16                                # v2 kernels stream the weights in 16-channel sub-chunks whatever the A chunk is
     assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
     if mode == 0:
         Cout, Cin, KH, KW = w.shape
@@ -151,7 +154,8 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
                  orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
-    ws = len(cfg) == 4
+    ws = len(cfg) == 4 and cfg[3] == 'ws'
+    v2 = len(cfg) == 4 and cfg[3] == 'v2'
     tile, CK, BN = cfg[:3]
     s0 = srcs[0]
     N = s0.N
@@ -163,9 +167,9 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a = ConvArgs()
     nchunk = 0
     for i, s in enumerate(srcs):
-        assert ws or s.C % CK == 0, (s.C, CK)
+        assert ws or v2 or s.C % CK == 0, (s.C, CK)
         s.fill(a.src[i])
-        nchunk += s.C // CK
+        nchunk += s.C // (16 if v2 else CK)
     if ws:
         assert sum(s.C for s in srcs) == CK
         nchunk = 1
@@ -183,6 +187,6 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
-    a.ws = int(ws)
+    a.ws = 2 if v2 else int(ws)
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

@@ -43,6 +43,14 @@ CASES_3x3 = [
     (1, 64, 64, 8, 16, (8, 64, 64)),
     (1, 128, 64, 12, 20, (8, 32, 64)),
     (1, 64, 128, 8, 8, (8, 32, 128)),
+    # v2 kernels: A chunks of CKA channels, 16-channel weight sub-chunks
+    (2, 64, 64, 48, 40, (16, 64, 64, 'v2')),
+    (1, 128, 128, 33, 17, (16, 64, 64, 'v2')),
+    (2, 96, 64, 16, 32, (16, 64, 64, 'v2')),      # ragged last A chunk (32 of 64)
+    (1, 64, 32, 32, 32, (16, 64, 32, 'v2')),
+    (1, 32, 64, 32, 48, (16, 32, 64, 'v2')),
+    (2, 128, 256, 8, 8, (8, 64, 128, 'v2')),
+    (1, 192, 64, 12, 20, (8, 64, 64, 'v2')),
     # weight-stationary persistent kernel (CK = total Cin)
     (2, 64, 64, 48, 40, (16, 64, 64, 'ws')),
     (3, 16, 64, 33, 65, (16, 16, 64, 'ws')),
