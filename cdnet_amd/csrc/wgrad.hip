@@ -36,6 +36,7 @@ union V16 {
 };
 
 constexpr int TH = 8, TW = 16, HALO_W = TW + 2, NPIX_A = (TH + 2) * (TW + 2), NPIX_G = TH * TW;
+constexpr int NT = 512;       // threads per workgroup: 8 waves = 4 dW quadrants x 2 halves of the tile's k-steps
 
 // LDS pixel stride for C channels such that four consecutive pixel rows x 64 B (one transposing read of a 32-lane
 // half) never share a bank: stride == 64 (mod 256) bytes
@@ -52,78 +53,181 @@ struct WgradArgs {
     int ksplit;
 };
 
-template <int CI>
-__device__ __forceinline__ void stage_a(const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W, unsigned char *lds, int tid) {
-    constexpr int VPP = CI / 8, PSTR = pstride(CI);
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register staging type (HIP's uint4 struct copies defeat SROA)
+union W16 {
+    u32x4 u;
+    unsigned short h[8];
+};
+
+// ---- register prefetch of the next pixel tile: loads are issued (clamped address, no branch) right after the barrier
+// ---- that publishes the current tile and land while the MFMAs run; commit_* transforms them into LDS one tile later.
+template <int CI, bool RES>
+struct APref {
+    static constexpr int VPP = CI / 8;
+    static constexpr int NA = (NPIX_A * VPP + NT - 1) / NT;
+    u32x4 a[NA];
+    u32x4 r[RES ? NA : 1];
+    unsigned valid;
+};
+template <int CO>
+struct GPref {
+    static constexpr int VPP = CO / 8;
+    static constexpr int NG = NPIX_G * VPP / NT;
+    u32x4 g[NG];
+    unsigned valid;
+};
+
+template <int CI, bool RES>
+__device__ __forceinline__ void issue_a(APref<CI, RES> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W, int tid) {
+    constexpr int VPP = CI / 8, NA = APref<CI, RES>::NA;
+    P.valid = 0;
+    if (!RES && s.pool) return;                  // pooled sources are gathered in commit_a (4 loads per element)
     const int slot = tid % VPP;
+    const bool cok = cc0 + slot * 8 < s.C;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    const size_t img = (size_t)n * s.Hs * rs;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int v = tid + i * NT;
+        const int pix = v / VPP;
+        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        const bool ok = v < NPIX_A * VPP && cok && y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < s.Hs && xs >= 0 && xs < s.Ws;
+        const size_t e = ok ? img + (size_t)ys * rs + (size_t)xs * s.C + cc0 + slot * 8 : 0;
+        P.a[i] = *reinterpret_cast<const u32x4 *>(s.x + e);
+        if (RES) P.r[i] = *reinterpret_cast<const u32x4 *>(s.res + e);
+        P.valid |= (ok ? 1u : 0u) << i;
+    }
+}
+
+__device__ __forceinline__ u32x4 xform_a(u32x4 raw, u32x4 res, bool has_res, const float *sc, const float *sh, bool on, bool relu, bool f16) {
+    W16 r, q, o;
+    r.u = raw; q.u = res;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = f16 ? h2f(r.h[j]) : bf2f(r.h[j]);
+        if (on) t = fmaf(t, sc[j], sh[j]);
+        if (has_res) t += f16 ? h2f(q.h[j]) : bf2f(q.h[j]);
+        if (relu) t = fmaxf(t, 0.f);
+        o.h[j] = f2bf(t);
+    }
+    return o.u;
+}
+
+__device__ __forceinline__ u32x4 max_bf8(u32x4 a, u32x4 b) {
+    W16 x, y, o;
+    x.u = a; y.u = b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = bf2f(y.h[j]) > bf2f(x.h[j]) ? y.h[j] : x.h[j];
+    return o.u;
+}
+
+template <int CI, bool RES>
+__device__ __forceinline__ void commit_a(const APref<CI, RES> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
+                                         unsigned char *lds, int tid) {
+    constexpr int VPP = CI / 8, PSTR = pstride(CI), NA = APref<CI, RES>::NA;
+    const int slot = tid % VPP;
+    const bool cok = cc0 + slot * 8 < s.C;
     float sc[8], sh[8];
     const bool on = s.scale != nullptr;
-    if (on && cc0 + slot * 8 < s.C) {
+    if (on && cok) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = s.scale[cc0 + slot * 8 + j]; sh[j] = s.shift[cc0 + slot * 8 + j]; }
     }
     const bool relu = s.relu != 0, f16 = s.f16 != 0;
-    const int Hl = s.pool ? (s.Hs + (s.pool == 2)) / 2 : s.Hs, Wl = s.pool ? (s.Ws + (s.pool == 2)) / 2 : s.Ws;
+    const bool plain = !on && !relu && !f16 && !RES;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    if (RES || !s.pool) {                        // (a source with a residual branch is never pooled: checked by the ABI entry)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * NT;
+            if (v >= NPIX_A * VPP) continue;
+            const int pix = v / VPP;
+            u32x4 val = zero;
+            if (P.valid & (1u << i)) val = plain ? P.a[i] : xform_a(P.a[i], RES ? P.r[i] : zero, RES, sc, sh, on, relu, f16);
+            *reinterpret_cast<u32x4 *>(lds + pix * PSTR + slot * 16) = val;
+        }
+        return;
+    }
+    // pooled source (encoder stage inputs): window (2ys..2ys+1, 2xs..2xs+1) of the stored tensor, transform then max.
+    // Loads of a batch of elements are issued together; ceil-mode windows that stick out repeat their first pixel.
+    const int Hl = (s.Hs + (s.pool == 2)) / 2, Wl = (s.Ws + (s.pool == 2)) / 2;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
     const size_t img = (size_t)n * s.Hs * rs;
-    for (int v = tid; v < NPIX_A * VPP; v += 256) {
-        const int pix = v / VPP;
-        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        V16 val;
-        val.u = make_uint4(0, 0, 0, 0);
-        const int ys = y - s.off_y, xs = x - s.off_x;
-        if (cc0 + slot * 8 < s.C && y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
-            float best[8];
+    constexpr int BATCH = 1;
+#pragma unroll
+    for (int i0 = 0; i0 < NA; i0 += BATCH) {
+        u32x4 w[BATCH][4];
+        bool okb[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int i = i0 + b;
+            const int v = tid + i * NT;
+            const int pix = v / VPP;
+            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const int ys = y - s.off_y, xs = x - s.off_x;
+            okb[b] = i < NA && v < NPIX_A * VPP && cok && y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q != 0 && !s.pool) break;
-                const int yy = s.pool ? 2 * ys + (q >> 1) : ys, xx = s.pool ? 2 * xs + (q & 1) : xs;
-                const bool ok = q == 0 || (yy < s.Hs && xx < s.Ws);
-                if (ok) {
-                    const size_t e = img + (size_t)yy * rs + (size_t)xx * s.C + cc0 + slot * 8;
-                    V16 raw, rr;
-                    raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
-                    rr.u = make_uint4(0, 0, 0, 0);
-                    if (s.res) rr.u = *reinterpret_cast<const uint4 *>(s.res + e);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float t = f16 ? h2f(raw.h[j]) : bf2f(raw.h[j]);
-                        if (on) t = fmaf(t, sc[j], sh[j]);
-                        if (s.res) t += f16 ? h2f(rr.h[j]) : bf2f(rr.h[j]);
-                        if (relu) t = fmaxf(t, 0.f);
-                        t = bf2f(f2bf(t));
-                        best[j] = (q == 0 || t > best[j]) ? t : best[j];
-                    }
-                }
+                int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
+                if (yy >= s.Hs) yy = 2 * ys;
+                if (xx >= s.Ws) xx = 2 * xs;
+                const size_t e = okb[b] ? img + (size_t)yy * rs + (size_t)xx * s.C + cc0 + slot * 8 : 0;
+                w[b][q] = *reinterpret_cast<const u32x4 *>(s.x + e);
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) val.h[j] = f2bf(best[j]);
         }
-        *reinterpret_cast<uint4 *>(lds + pix * PSTR + slot * 16) = val.u;
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int i = i0 + b;
+            const int v = tid + i * NT;
+            if (i >= NA || v >= NPIX_A * VPP) continue;
+            const int pix = v / VPP;
+            u32x4 val = zero;
+            if (okb[b]) {
+                val = plain ? w[b][0] : xform_a(w[b][0], zero, false, sc, sh, on, relu, f16);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) val = max_bf8(val, plain ? w[b][q] : xform_a(w[b][q], zero, false, sc, sh, on, relu, f16));
+            }
+            *reinterpret_cast<u32x4 *>(lds + pix * PSTR + slot * 16) = val;
+        }
     }
 }
 
 template <int CO>
-__device__ __forceinline__ void stage_g(const unsigned short *g, int co0, int Cout, int n, int y0, int x0, int H, int W,
-                                        int ostride, int pa, int pb, unsigned char *lds, int tid) {
-    constexpr int VPP = CO / 8, PSTR = pstride(CO);
+__device__ __forceinline__ void issue_g(GPref<CO> &P, const unsigned short *g, int co0, int Cout, int n, int y0, int x0, int H, int W,
+                                        int ostride, int pa, int pb, int tid) {
+    constexpr int VPP = CO / 8, NG = GPref<CO>::NG;
     const int Ho = H * ostride, Wo = W * ostride;
-    for (int v = tid; v < NPIX_G * VPP; v += 256) {
+    P.valid = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int v = tid + i * NT;
         const int pix = v / VPP, slot = v % VPP;
         const int y = y0 + pix / TW, x = x0 + pix % TW;
-        uint4 val = make_uint4(0, 0, 0, 0);
         const int co = co0 + slot * 8;
-        if (y < H && x < W && co < Cout) {
-            const size_t e = (((size_t)n * Ho + (y * ostride + pa)) * Wo + (x * ostride + pb)) * Cout + co;
-            val = *reinterpret_cast<const uint4 *>(g + e);          // Cout % 8 == 0 (checked by the ABI entry)
-        }
-        *reinterpret_cast<uint4 *>(lds + pix * PSTR + slot * 16) = val;
+        const bool ok = y < H && x < W && co < Cout;            // Cout % 8 == 0 (checked by the ABI entry)
+        const size_t e = ok ? (((size_t)n * Ho + (y * ostride + pa)) * Wo + (x * ostride + pb)) * Cout + co : 0;
+        P.g[i] = *reinterpret_cast<const u32x4 *>(g + e);
+        P.valid |= (ok ? 1u : 0u) << i;
     }
 }
 
-template <int CI_T, int CO_T, int TAPS>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
+template <int CO>
+__device__ __forceinline__ void commit_g(const GPref<CO> &P, unsigned char *lds, int tid) {
+    constexpr int VPP = CO / 8, PSTR = pstride(CO), NG = GPref<CO>::NG;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int v = tid + i * NT;
+        const int pix = v / VPP, slot = v % VPP;
+        *reinterpret_cast<u32x4 *>(lds + pix * PSTR + slot * 16) = (P.valid & (1u << i)) ? P.g[i] : zero;
+    }
+}
+
+template <int CI_T, int CO_T, int TAPS, bool RES>
+__global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int PA = pstride(CI), PG = pstride(CO);
     constexpr int A_BYTES = NPIX_A * PA;
@@ -133,7 +237,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
     typedef s16x4 __attribute__((address_space(3))) * lptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wci = wave / CO_T, wco = wave % CO_T;
+    const int quad = wave & 3, khalf = wave >> 2;
+    const int wci = quad / CO_T, wco = quad % CO_T;
     const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
 
     const int co_blocks = (A.Cout + CO - 1) / CO;
@@ -143,21 +248,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
     const int ks = blockIdx.z;
     const int pa = par >> 1, pb = par & 1;
 
-    int toff[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-        int r, c;
-        if (TAPS == 9) { r = t / 3; c = t % 3; }
-        else if (TAPS == 4) {
+    auto tap_off = [&](int t) -> int {
+        if (TAPS == 9) return ((t / 3) * HALO_W + t % 3) * PA;
+        if (TAPS == 4) {
             const int ty = t >> 1, tx = t & 1;
-            r = pa == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
-            c = pb == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
-        } else { r = 1; c = 1; }
-        toff[t] = (r * HALO_W + c) * PA;
-    }
-    // per-lane byte offsets of the transposing reads: pixel row (8*(grp>>1) + q) of the k-step, channel 16*(grp&1)+4p
-    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2;
-    const int g_lane = (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2;
+            const int r = pa == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+            const int c = pb == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+            return (r * HALO_W + c) * PA;
+        }
+        return (HALO_W + 1) * PA;
+    };
+    // per-lane byte offsets of the transposing reads: pixel row (8*(grp>>1) + q) of the k-step, channel 16*(grp&1)+4p;
+    // this wave's k-steps are tile rows khalf*4 .. khalf*4+3
+    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2 + khalf * (TH / 2) * HALO_W * PA;
+    const int g_lane = (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2 + khalf * (TH / 2) * TW * PG;
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -167,15 +271,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
 
     const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
     const int ntiles = A.N * tiles_y * tiles_x;
+    auto coords = [&](int tile, int &n, int &y0, int &x0) {
+        n = tile / (tiles_y * tiles_x);
+        const int rem = tile - n * (tiles_y * tiles_x);
+        y0 = (rem / tiles_x) * TH;
+        x0 = (rem % tiles_x) * TW;
+    };
+    APref<CI, RES> PA_;
+    GPref<CO> PG_;
+    if (ks < ntiles) {
+        int n, y0, x0;
+        coords(ks, n, y0, x0);
+        issue_a<CI, RES>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
+        issue_g<CO>(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
+    }
     for (int tile = ks; tile < ntiles; tile += A.ksplit) {
-        const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
-        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
         __syncthreads();
-        stage_a<CI>(A.src, ib * CI, n, y0, x0, A.H, A.W, lds_a, tid);
-        stage_g<CO>(A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, lds_g, tid);
+        commit_a<CI, RES>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, lds_a, tid);
+        commit_g<CO>(PG_, lds_g, tid);
         __syncthreads();
-#pragma unroll 2
-        for (int ky = 0; ky < TH; ++ky) {                 // one k-step = one tile row of 16 pixels
+        if (tile + A.ksplit < ntiles) {
+            coords(tile + A.ksplit, n, y0, x0);
+            issue_a<CI, RES>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
+            issue_g<CO>(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
+        }
+#pragma unroll
+        for (int ky = 0; ky < TH / 2; ++ky) {             // one k-step = one tile row of 16 pixels
             const int gaddr = g_lane + ky * TW * PG;
             s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_g + gaddr));
             s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_g + gaddr + 4 * PG));
@@ -186,8 +309,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
             const int abase = a_lane + ky * HALO_W * PA;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + toff[t]));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + toff[t] + 4 * PA));
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + tap_off(t)));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + tap_off(t) + 4 * PA));
                 s16x8 av;
                 av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
                 av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
@@ -195,6 +318,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
             }
         }
     }
+    // fold the two k-halves through LDS (the staging tiles are dead now): waves 4..7 park their accumulators,
+    // waves 0..3 add them in a fixed order (deterministic) and write the slab
+    __syncthreads();
+    float *s_acc = reinterpret_cast<float *>(smem);
+    if (khalf == 1) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[((quad * TAPS + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
     // slab [ks][par][ib][cb][tap][CI][CO]; D rows = ci (regs + lane half), cols = co (lane & 31)
     float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
     const int half = lane >> 5, l31 = lane & 31;
@@ -203,7 +338,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
+            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r] + s_acc[((quad * TAPS + t) * 16 + r) * 64 + lane];
         }
 }
 
@@ -259,11 +394,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     dw[o] = s;
 }
 
-template <int CI_T, int CO_T, int TAPS>
+template <int CI_T, int CO_T, int TAPS, bool RES>
 int launch_wgrad(const WgradArgs &A, hipStream_t st) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
-    constexpr int smem = NPIX_A * pstride(CI) + NPIX_G * pstride(CO);
-    auto kern = wgrad_kernel<CI_T, CO_T, TAPS>;
+    constexpr int stage_bytes = NPIX_A * pstride(CI) + NPIX_G * pstride(CO);
+    constexpr int fold_bytes = 4 * TAPS * 16 * 64 * 4;
+    constexpr int smem = stage_bytes > fold_bytes ? stage_bytes : fold_bytes;
+    auto kern = wgrad_kernel<CI_T, CO_T, TAPS, RES>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -271,15 +408,20 @@ int launch_wgrad(const WgradArgs &A, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(cdiv(A.src.C, CI) * cdiv(A.Cout, CO), A.npar, A.ksplit);
-    kern<<<grid, 256, smem, st>>>(A);
+    kern<<<grid, NT, smem, st>>>(A);
     return check_launch("wgrad_kernel");
 }
 
 template <int TAPS>
 int dispatch_wgrad(const WgradArgs &A, int ci_t, hipStream_t st) {
-    if (ci_t == 1) return launch_wgrad<1, 4, TAPS>(A, st);
-    if (ci_t == 2) return launch_wgrad<2, 2, TAPS>(A, st);
-    return launch_wgrad<4, 1, TAPS>(A, st);
+    if (A.src.res) {
+        if (ci_t == 1) return launch_wgrad<1, 4, TAPS, true>(A, st);
+        if (ci_t == 2) return launch_wgrad<2, 2, TAPS, true>(A, st);
+        return launch_wgrad<4, 1, TAPS, true>(A, st);
+    }
+    if (ci_t == 1) return launch_wgrad<1, 4, TAPS, false>(A, st);
+    if (ci_t == 2) return launch_wgrad<2, 2, TAPS, false>(A, st);
+    return launch_wgrad<4, 1, TAPS, false>(A, st);
 }
 
 }  // namespace
@@ -296,6 +438,7 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     CDNET_REQUIRE(src && src->x && grad_out && slab && dw, "cdnet_conv_backward_weight: null pointer");
     CDNET_REQUIRE(ci_tiles == 1 || ci_tiles == 2 || ci_tiles == 4, "cdnet_conv_backward_weight: ci_tiles=%d", ci_tiles);
     CDNET_REQUIRE(src->C % 8 == 0, "cdnet_conv_backward_weight: source channels %d not a multiple of 8", src->C);
+    CDNET_REQUIRE(!(src->res && src->pool), "cdnet_conv_backward_weight: a pooled source with a residual branch is not supported");
     CDNET_REQUIRE(ksplit >= 1 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "cdnet_conv_backward_weight: bad size (Cout %% 8)");
     CDNET_REQUIRE((taps == 9 && npar == 1 && ostride == 1 && mode == 0) || (taps == 1 && npar == 1 && ostride == 1 && mode == 0) ||
                   (taps == 4 && npar == 4 && ostride == 2 && mode == 2) || (taps == 1 && npar == 4 && ostride == 2 && mode == 3),

@@ -234,7 +234,7 @@ class Trainer:
             CI, CO = ci_t * 32, (4 // ci_t) * 32
             other = -(-s.C // CI) * -(-Cout // CO) * npar
             ntiles = N * (-(-H // 8)) * (-(-W // 16))
-            ksplit = max(1, min(ntiles, 512 // other if other < 512 else 1))
+            ksplit = max(1, min(ntiles, 256 // other if other < 256 else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
             slab = self._slab(nslab)
             cs = engine.ConvSrc()
