@@ -16,6 +16,7 @@
 // (training-mode BN statistics, reduced deterministically by bn_finalize).
 #include "common.h"
 #include "conv_args.h"
+#include "xform.h"
 #include <stdlib.h>
 
 using namespace cdnet;
@@ -115,6 +116,13 @@ struct ChanXf {           // per-thread channel transform for its 8 channels of 
 
 __device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, bool relu, bool f16) {
     V16 o;
+    if (f16 && t.on && relu) {                   // the training-mode combination: packed math (xform.h)
+        const xf_u32x4 r = __builtin_bit_cast(xf_u32x4, raw.u);
+        const xf_u32x4 v = res ? xf_bnrelu_f16<true>(r, __builtin_bit_cast(xf_u32x4, res->u), t.sc, t.sh)
+                               : xf_bnrelu_f16<false>(r, r, t.sc, t.sh);
+        o.u = __builtin_bit_cast(uint4, v);
+        return o;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = ld16(raw.h[j], f16);
@@ -126,29 +134,41 @@ __device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, 
     return o;
 }
 
-__device__ __forceinline__ V16 max8(V16 a, V16 b) {
+__device__ __forceinline__ V16 max8(V16 a, V16 b, bool nonneg) {
     V16 o;
+    if (nonneg) {                                // post-ReLU values: integer order == float order
+        o.u = __builtin_bit_cast(uint4, xf_max_nonneg_bf8(__builtin_bit_cast(xf_u32x4, a.u), __builtin_bit_cast(xf_u32x4, b.u)));
+        return o;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.h[j] = bf2f(a.h[j]) >= bf2f(b.h[j]) ? a.h[j] : b.h[j];
     return o;
 }
 
+// the 8 channels' scale / shift of one thread; `xf` is the LDS copy of the source's tables ([0] scale, [XF_MAX] shift) made
+// once per workgroup (a global load here would sit in front of the chunk pipeline: vmcnt retires in order), or null
+// for callers without one
+constexpr int XF_MAX = 1024;      // source channels (both concat sources) whose scale/shift fit the LDS table
+
+__device__ __forceinline__ void load_chan_xf(ChanXf &t, const ConvSrc &s, const float *xf, int c) {
+    t.on = s.scale != nullptr;
+    if (!t.on) return;
+    const float4 *ps = reinterpret_cast<const float4 *>(xf ? xf + c : s.scale + c);
+    const float4 *ph = reinterpret_cast<const float4 *>(xf ? xf + XF_MAX + c : s.shift + c);
+    float4 a = ps[0], b = ps[1], cc = ph[0], d = ph[1];
+    t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
+    t.sh[0] = cc.x; t.sh[1] = cc.y; t.sh[2] = cc.z; t.sh[3] = cc.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
+}
+
 template <int TH, int TW, int CK>
 __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
-                                            unsigned char *lds_a, int tid) {
+                                            unsigned char *lds_a, int tid, const float *xf = nullptr) {
     constexpr int VPP = CK / 8;                  // 16-byte vectors per pixel
     constexpr int PSTR = CK * 2 + 16;            // padded pixel stride in LDS (bank-conflict free b128 reads)
     constexpr int HW_ = TW + 2, NPIX = (TH + 2) * (TW + 2);
     const int slot = tid % VPP;                  // constant per thread because 256 % VPP == 0
     ChanXf t;
-    t.on = s.scale != nullptr;
-    if (t.on) {
-        const float4 *ps = reinterpret_cast<const float4 *>(s.scale + cc0 + slot * 8);
-        const float4 *ph = reinterpret_cast<const float4 *>(s.shift + cc0 + slot * 8);
-        float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
-        t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
-        t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
-    }
+    load_chan_xf(t, s, xf, cc0 + slot * 8);
     const bool relu = s.relu != 0;
     const bool f16 = s.f16 != 0;
     const bool plain = !t.on && !relu && s.res == nullptr && !f16;
@@ -182,7 +202,7 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
                     V16 raw;
                     raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
                     V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
-                    val = q == 0 ? tv : max8(val, tv);
+                    val = q == 0 ? tv : max8(val, tv, relu);
                 }
             }
         }
@@ -243,7 +263,8 @@ __device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, c
 
 template <int TH, int TW, int CK, int BN, int TAPS>
 __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n, int y0,
-                                             int x0, int H, int W, unsigned char *lds_a, unsigned char *lds_b, int tid) {
+                                             int x0, int H, int W, unsigned char *lds_a, unsigned char *lds_b, int tid,
+                                             const float *xf) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
     constexpr int PSTR = CK * 2 + 16;
     {
@@ -254,17 +275,10 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
             if (v < TAPS * CK * BN * 2 / 16) dst[v] = P.b[i];
         }
     }
-    if (P.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid); return; }
+    if (P.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid, xf); return; }
     const int slot = tid % PF::VPP;
     ChanXf t;
-    t.on = s.scale != nullptr;
-    if (t.on) {
-        const float4 *ps = reinterpret_cast<const float4 *>(s.scale + cc0 + slot * 8);
-        const float4 *ph = reinterpret_cast<const float4 *>(s.shift + cc0 + slot * 8);
-        float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
-        t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
-        t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
-    }
+    load_chan_xf(t, s, xf, cc0 + slot * 8);
     const bool relu = s.relu != 0, f16 = s.f16 != 0;
     const bool plain = !t.on && !relu && s.res == nullptr && !f16;
     constexpr int HW_ = TW + 2;
@@ -314,10 +328,21 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
     unsigned char *lds_a = smem;
     unsigned char *lds_b = smem + A_BYTES;
     __shared__ float s_stats[4][2][BN];
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_MAX];      // scale | shift of source 0 then source 1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
+    {
+        const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
+        for (int c = tid; c < ctot; c += 256) {
+            const ConvSrc &S = c < c0n ? A.src[0] : A.src[1];
+            const int cc = c < c0n ? c : c - c0n;
+            s_xf[c] = S.scale ? S.scale[cc] : 1.f;
+            s_xf[XF_MAX + c] = S.shift ? S.shift[cc] : 0.f;
+        }
+        // (published by the barrier in front of the first commit)
+    }
 
     // one workgroup per (image, parity, tile_y, tile_x) tile
     const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
             int si, cc0;
             chunk_src(chunk, si, cc0);
             __syncthreads();                               // previous chunk's fragment reads / previous tile's out-tile reads are done
-            commit_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid);
+            commit_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid, s_xf + (si ? A.src[0].C : 0));
             __syncthreads();
             // issue the loads of the next (tile, chunk) step now: they fly during the MFMA loop (and the epilogue)
             if (chunk + 1 < nchunk_total) {
@@ -628,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs A) {
                         V16 raw;
                         raw.u = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)yy * rs + (size_t)xx * S.C + cc0);
                         V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
-                        val = q == 0 ? tv : max8(val, tv);
+                        val = q == 0 ? tv : max8(val, tv, relu);
                     }
                 }
             }
@@ -930,7 +955,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_fwd2_kernel(Conv
                         V16 raw;
                         raw.u = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)yy * rs + (size_t)xx * S.C + cc0 + slot * 8);
                         V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
-                        val = q == 0 ? tv : max8(val, tv);
+                        val = q == 0 ? tv : max8(val, tv, relu);
                     }
                 }
             }
@@ -1159,6 +1184,11 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && A.out, "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
     CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0 && A.Cout % 8 == 0, "cdnet_conv_forward: bad size (Cout must be a multiple of 8)");
+    {
+        int ctot_xf = 0;
+        for (int i = 0; i < A.nsrc; ++i) ctot_xf += A.src[i].C;
+        CDNET_REQUIRE(ctot_xf <= XF_MAX, "cdnet_conv_forward: %d source channels exceed the %d-entry scale/shift table", ctot_xf, XF_MAX);
+    }
     if (A.ws == 2) {
         int nsub = 0;
         for (int i = 0; i < A.nsrc; ++i) { CDNET_REQUIRE(A.src[i].x && A.src[i].C % 16 == 0, "cdnet_conv_forward: v2 source channels must be multiples of 16"); nsub += A.src[i].C / 16; }

@@ -11,8 +11,10 @@
 // which also scatters into the PyTorch weight layout.
 //
 // Replaces the weight-gradient half of loss.backward() (train_util_dam.py:307) for nn.Conv2d / nn.ConvTranspose2d.
+#include <stdlib.h>
 #include "common.h"
 #include "conv_args.h"
+#include "xform.h"
 
 using namespace cdnet;
 
@@ -51,6 +53,7 @@ struct WgradArgs {
     int Cout;
     int taps, npar, ostride;
     int ksplit;
+    int debug;                // ablation bits for tools/bench_wgrad.py (env CDNET_WGRAD_DEBUG): 1 no MFMA loop, 2 no loads, 4 no LDS staging
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // register staging type (HIP's uint4 struct copies defeat SROA)
@@ -59,49 +62,66 @@ union W16 {
     unsigned short h[8];
 };
 
-// ---- register prefetch of the next pixel tile: loads are issued (clamped address, no branch) right after the barrier
-// ---- that publishes the current tile and land while the MFMAs run; commit_* transforms them into LDS one tile later.
-template <int CI, bool RES>
+// ---- register prefetch of a pixel tile.  Everything that does not depend on the tile (which halo pixel / channel slot a
+// ---- thread stages, its LDS address) is computed once per kernel and kept packed in one register per staged vector;
+// ---- the loads are issued with clamped addresses and no branches, one tile ahead of their use.
+template <int CI, bool RES, int NTH = NT>
 struct APref {
     static constexpr int VPP = CI / 8;
-    static constexpr int NA = (NPIX_A * VPP + NT - 1) / NT;
+    static constexpr int NA = (NPIX_A * VPP + NTH - 1) / NTH;
     u32x4 a[NA];
     u32x4 r[RES ? NA : 1];
+    int inv[NA];              // (hy << 16) | hx of the halo pixel, -1 = this thread has no i-th vector
     unsigned valid;
 };
-template <int CO>
+template <int CO, int NTH = NT>
 struct GPref {
     static constexpr int VPP = CO / 8;
-    static constexpr int NG = NPIX_G * VPP / NT;
+    static constexpr int NG = NPIX_G * VPP / NTH;
     u32x4 g[NG];
     unsigned valid;
 };
 
-template <int CI, bool RES>
-__device__ __forceinline__ void issue_a(APref<CI, RES> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W, int tid) {
-    constexpr int VPP = CI / 8, NA = APref<CI, RES>::NA;
-    P.valid = 0;
-    if (!RES && s.pool) return;                  // pooled sources are gathered in commit_a (4 loads per element)
-    const int slot = tid % VPP;
-    const bool cok = cc0 + slot * 8 < s.C;
-    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
-    const size_t img = (size_t)n * s.Hs * rs;
+template <int CI, bool RES, int NTH>
+__device__ __forceinline__ void init_a(APref<CI, RES, NTH> &P, int tid) {
+    constexpr int VPP = CI / 8, NA = APref<CI, RES, NTH>::NA;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int v = tid + i * NT;
+        const int v = tid + i * NTH;
         const int pix = v / VPP;
         const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+        P.inv[i] = v < NPIX_A * VPP ? ((hy << 16) | hx) : -1;
+    }
+    P.valid = 0;
+}
+
+template <int CI, bool RES, int NTH>
+__device__ __forceinline__ void issue_a(APref<CI, RES, NTH> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W, int tid) {
+    constexpr int VPP = CI / 8, NA = APref<CI, RES, NTH>::NA;
+    P.valid = 0;
+    if (!RES && s.pool) return;                  // pooled sources are gathered in commit_a (4 loads per element)
+    const int cbase = cc0 + (tid % VPP) * 8;
+    const bool cok = cbase < s.C;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    const unsigned short *base = s.x + (size_t)n * s.Hs * rs + cbase;
+    const unsigned short *rbase = RES ? s.res + (size_t)n * s.Hs * rs + cbase : nullptr;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int hy = P.inv[i] >> 16, hx = P.inv[i] & 0xffff;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const int ys = y - s.off_y, xs = x - s.off_x;
-        const bool ok = v < NPIX_A * VPP && cok && y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < s.Hs && xs >= 0 && xs < s.Ws;
-        const size_t e = ok ? img + (size_t)ys * rs + (size_t)xs * s.C + cc0 + slot * 8 : 0;
-        P.a[i] = *reinterpret_cast<const u32x4 *>(s.x + e);
-        if (RES) P.r[i] = *reinterpret_cast<const u32x4 *>(s.res + e);
+        const bool ok = P.inv[i] >= 0 && cok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (unsigned)ys < (unsigned)s.Hs &&
+                        (unsigned)xs < (unsigned)s.Ws;
+        const size_t e = ok ? (size_t)ys * rs + (size_t)(xs * s.C) : 0;
+        P.a[i] = *reinterpret_cast<const u32x4 *>((ok ? base : s.x) + e);
+        if (RES) P.r[i] = *reinterpret_cast<const u32x4 *>((ok ? rbase : s.res) + e);
         P.valid |= (ok ? 1u : 0u) << i;
     }
 }
 
 __device__ __forceinline__ u32x4 xform_a(u32x4 raw, u32x4 res, bool has_res, const float *sc, const float *sh, bool on, bool relu, bool f16) {
+    if (f16 && on && relu)                       // the training-mode combination: packed math (xform.h)
+        return has_res ? xf_bnrelu_f16<true>(raw, res, sc, sh) : xf_bnrelu_f16<false>(raw, raw, sc, sh);
     W16 r, q, o;
     r.u = raw; q.u = res;
 #pragma unroll
@@ -115,7 +135,8 @@ __device__ __forceinline__ u32x4 xform_a(u32x4 raw, u32x4 res, bool has_res, con
     return o.u;
 }
 
-__device__ __forceinline__ u32x4 max_bf8(u32x4 a, u32x4 b) {
+__device__ __forceinline__ u32x4 max_bf8(u32x4 a, u32x4 b, bool nonneg) {
+    if (nonneg) return xf_max_nonneg_bf8(a, b);
     W16 x, y, o;
     x.u = a; y.u = b;
 #pragma unroll
@@ -123,117 +144,122 @@ __device__ __forceinline__ u32x4 max_bf8(u32x4 a, u32x4 b) {
     return o.u;
 }
 
-template <int CI, bool RES>
-__device__ __forceinline__ void commit_a(const APref<CI, RES> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
-                                         unsigned char *lds, int tid) {
-    constexpr int VPP = CI / 8, PSTR = pstride(CI), NA = APref<CI, RES>::NA;
+// XF selects the input transform at compile time (run-time flag tests inside the unrolled staging loops multiplied the
+// code far past the instruction cache): XF_PLAIN bf16 as stored, XF_FAST fp16 raw * scale + shift [+ residual] -> ReLU
+// (training mode, packed math), XF_GEN anything, decided per element group from the source's flags.
+enum { XF_PLAIN = 0, XF_FAST = 1, XF_GEN = 2 };
+
+template <int XF, int CI, bool RES, int NTH>
+__device__ __forceinline__ void commit_a(const APref<CI, RES, NTH> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
+                                         unsigned char *lds, int tid, const float *xf) {
+    constexpr int VPP = CI / 8, PSTR = pstride(CI), NA = APref<CI, RES, NTH>::NA;
     const int slot = tid % VPP;
-    const bool cok = cc0 + slot * 8 < s.C;
+    const int cbase = cc0 + slot * 8;
+    const bool cok = cbase < s.C;
     float sc[8], sh[8];
-    const bool on = s.scale != nullptr;
-    if (on && cok) {
+    const bool on = XF == XF_FAST || (XF == XF_GEN && s.scale != nullptr);
+    if (XF != XF_PLAIN && on) {                  // LDS copy of this block's scale | shift (see fill_xf): no vmcnt traffic here
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = s.scale[cc0 + slot * 8 + j]; sh[j] = s.shift[cc0 + slot * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { sc[j] = xf[slot * 8 + j]; sh[j] = xf[CI + slot * 8 + j]; }
     }
     const bool relu = s.relu != 0, f16 = s.f16 != 0;
-    const bool plain = !on && !relu && !f16 && !RES;
+    const bool plain = XF == XF_PLAIN || (XF == XF_GEN && !on && !relu && !f16 && !RES);
     const u32x4 zero = {0u, 0u, 0u, 0u};
-    if (RES || !s.pool) {                        // (a source with a residual branch is never pooled: checked by the ABI entry)
+    unsigned char *dst = lds + slot * 16;
+    if (XF != XF_GEN || RES || !s.pool) {        // (a source with a residual branch is never pooled: checked by the ABI entry)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int v = tid + i * NT;
-            if (v >= NPIX_A * VPP) continue;
-            const int pix = v / VPP;
+            if (P.inv[i] < 0) continue;
+            const int hy = P.inv[i] >> 16, hx = P.inv[i] & 0xffff;
             u32x4 val = zero;
-            if (P.valid & (1u << i)) val = plain ? P.a[i] : xform_a(P.a[i], RES ? P.r[i] : zero, RES, sc, sh, on, relu, f16);
-            *reinterpret_cast<u32x4 *>(lds + pix * PSTR + slot * 16) = val;
+            if (P.valid & (1u << i)) {
+                if (XF == XF_PLAIN) val = P.a[i];
+                else if (XF == XF_FAST) val = xf_bnrelu_f16<RES>(P.a[i], RES ? P.r[i] : P.a[i], sc, sh);
+                else val = plain ? P.a[i] : xform_a(P.a[i], RES ? P.r[i] : zero, RES, sc, sh, on, relu, f16);
+            }
+            *reinterpret_cast<u32x4 *>(dst + (hy * HALO_W + hx) * PSTR) = val;
         }
         return;
     }
-    // pooled source (encoder stage inputs): window (2ys..2ys+1, 2xs..2xs+1) of the stored tensor, transform then max.
-    // Loads of a batch of elements are issued together; ceil-mode windows that stick out repeat their first pixel.
+    // pooled source (encoder stage inputs): window (2ys..2ys+1, 2xs..2xs+1) of the stored tensor, transform then max;
+    // ceil-mode windows that stick out repeat their first pixel
     const int Hl = (s.Hs + (s.pool == 2)) / 2, Wl = (s.Ws + (s.pool == 2)) / 2;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
-    const size_t img = (size_t)n * s.Hs * rs;
-    constexpr int BATCH = 1;
+    const unsigned short *base = s.x + (size_t)n * s.Hs * rs + cbase;
 #pragma unroll
-    for (int i0 = 0; i0 < NA; i0 += BATCH) {
-        u32x4 w[BATCH][4];
-        bool okb[BATCH];
+    for (int i = 0; i < NA; ++i) {
+        if (P.inv[i] < 0) continue;
+        const int hy = P.inv[i] >> 16, hx = P.inv[i] & 0xffff;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        const bool ok = cok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (unsigned)ys < (unsigned)Hl && (unsigned)xs < (unsigned)Wl;
+        u32x4 w[4];
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int i = i0 + b;
-            const int v = tid + i * NT;
-            const int pix = v / VPP;
-            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const int ys = y - s.off_y, xs = x - s.off_x;
-            okb[b] = i < NA && v < NPIX_A * VPP && cok && y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
-                if (yy >= s.Hs) yy = 2 * ys;
-                if (xx >= s.Ws) xx = 2 * xs;
-                const size_t e = okb[b] ? img + (size_t)yy * rs + (size_t)xx * s.C + cc0 + slot * 8 : 0;
-                w[b][q] = *reinterpret_cast<const u32x4 *>(s.x + e);
-            }
+        for (int q = 0; q < 4; ++q) {
+            int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
+            if (yy >= s.Hs) yy = 2 * ys;
+            if (xx >= s.Ws) xx = 2 * xs;
+            const size_t e = ok ? (size_t)yy * rs + (size_t)(xx * s.C) : 0;
+            w[q] = *reinterpret_cast<const u32x4 *>((ok ? base : s.x) + e);
         }
+        u32x4 val = zero;
+        if (ok) {
+            val = plain ? w[0] : xform_a(w[0], zero, false, sc, sh, on, relu, f16);
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int i = i0 + b;
-            const int v = tid + i * NT;
-            if (i >= NA || v >= NPIX_A * VPP) continue;
-            const int pix = v / VPP;
-            u32x4 val = zero;
-            if (okb[b]) {
-                val = plain ? w[b][0] : xform_a(w[b][0], zero, false, sc, sh, on, relu, f16);
-#pragma unroll
-                for (int q = 1; q < 4; ++q) val = max_bf8(val, plain ? w[b][q] : xform_a(w[b][q], zero, false, sc, sh, on, relu, f16));
-            }
-            *reinterpret_cast<u32x4 *>(lds + pix * PSTR + slot * 16) = val;
+            for (int q = 1; q < 4; ++q) val = max_bf8(val, plain ? w[q] : xform_a(w[q], zero, false, sc, sh, on, relu, f16), relu);
         }
+        *reinterpret_cast<u32x4 *>(dst + (hy * HALO_W + hx) * PSTR) = val;
     }
 }
 
-template <int CO>
-__device__ __forceinline__ void issue_g(GPref<CO> &P, const unsigned short *g, int co0, int Cout, int n, int y0, int x0, int H, int W,
+template <int CO, int NTH>
+__device__ __forceinline__ void issue_g(GPref<CO, NTH> &P, const unsigned short *g, int co0, int Cout, int n, int y0, int x0, int H, int W,
                                         int ostride, int pa, int pb, int tid) {
-    constexpr int VPP = CO / 8, NG = GPref<CO>::NG;
+    constexpr int VPP = CO / 8, NG = GPref<CO, NTH>::NG, PPI = NTH / VPP;      // PPI pixels per i step
     const int Ho = H * ostride, Wo = W * ostride;
+    const int co = co0 + (tid % VPP) * 8;
+    const bool cok = co < Cout;                                  // Cout % 8 == 0 (checked by the ABI entry)
+    const int pix0 = tid / VPP;
+    const unsigned short *base = g + (size_t)n * Ho * Wo * Cout + co;
     P.valid = 0;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-        const int v = tid + i * NT;
-        const int pix = v / VPP, slot = v % VPP;
+        const int pix = pix0 + i * PPI;
         const int y = y0 + pix / TW, x = x0 + pix % TW;
-        const int co = co0 + slot * 8;
-        const bool ok = y < H && x < W && co < Cout;            // Cout % 8 == 0 (checked by the ABI entry)
-        const size_t e = ok ? (((size_t)n * Ho + (y * ostride + pa)) * Wo + (x * ostride + pb)) * Cout + co : 0;
-        P.g[i] = *reinterpret_cast<const u32x4 *>(g + e);
+        const bool ok = cok && y < H && x < W;
+        const size_t e = ok ? ((size_t)(y * ostride + pa) * Wo + (x * ostride + pb)) * Cout : 0;
+        P.g[i] = *reinterpret_cast<const u32x4 *>((ok ? base : g) + e);
         P.valid |= (ok ? 1u : 0u) << i;
     }
 }
 
-template <int CO>
-__device__ __forceinline__ void commit_g(const GPref<CO> &P, unsigned char *lds, int tid) {
-    constexpr int VPP = CO / 8, PSTR = pstride(CO), NG = GPref<CO>::NG;
+template <int CO, int NTH>
+__device__ __forceinline__ void commit_g(const GPref<CO, NTH> &P, unsigned char *lds, int tid) {
+    constexpr int VPP = CO / 8, PSTR = pstride(CO), NG = GPref<CO, NTH>::NG, PPI = NTH / VPP;
     const u32x4 zero = {0u, 0u, 0u, 0u};
+    unsigned char *dst = lds + (tid / VPP) * PSTR + (tid % VPP) * 16;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        const int v = tid + i * NT;
-        const int pix = v / VPP, slot = v % VPP;
-        *reinterpret_cast<u32x4 *>(lds + pix * PSTR + slot * 16) = (P.valid & (1u << i)) ? P.g[i] : zero;
+    for (int i = 0; i < NG; ++i) *reinterpret_cast<u32x4 *>(dst + i * PPI * PSTR) = (P.valid & (1u << i)) ? P.g[i] : zero;
+}
+
+// scale | shift of the CI input channels of this block -> LDS (zero-extended past the source's last channel)
+template <int CI>
+__device__ __forceinline__ void fill_xf(float *xf, const ConvSrc &s, int cc0, int tid) {
+    if (tid < CI) {
+        const bool ok = s.scale != nullptr && cc0 + tid < s.C;
+        xf[tid] = ok ? s.scale[cc0 + tid] : 1.f;
+        xf[CI + tid] = ok ? s.shift[cc0 + tid] : 0.f;
     }
+    __syncthreads();
 }
 
 template <int CI_T, int CO_T, int TAPS, bool RES>
 __global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int PA = pstride(CI), PG = pstride(CO);
-    constexpr int A_BYTES = NPIX_A * PA;
+    constexpr int A_BYTES = NPIX_A * PA, G_BYTES = NPIX_G * PG, STAGE = A_BYTES + G_BYTES;
     static_assert(CI_T * CO_T == 4, "one 32x32 quadrant per wave");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *lds_a = smem, *lds_g = smem + A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // two staging buffers [A | G]
     typedef s16x4 __attribute__((address_space(3))) * lptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
     // per-lane byte offsets of the transposing reads: pixel row (8*(grp>>1) + q) of the k-step, channel 16*(grp&1)+4p;
     // this wave's k-steps are tile rows khalf*4 .. khalf*4+3
     const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2 + khalf * (TH / 2) * HALO_W * PA;
-    const int g_lane = (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2 + khalf * (TH / 2) * TW * PG;
+    const int g_lane = A_BYTES + (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2 + khalf * (TH / 2) * TW * PG;
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -270,38 +296,58 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
-    const int ntiles = A.N * tiles_y * tiles_x;
+    const int tiles_img = tiles_y * tiles_x;
+    const int ntiles = A.N * tiles_img;
     auto coords = [&](int tile, int &n, int &y0, int &x0) {
-        n = tile / (tiles_y * tiles_x);
-        const int rem = tile - n * (tiles_y * tiles_x);
-        y0 = (rem / tiles_x) * TH;
-        x0 = (rem % tiles_x) * TW;
+        n = tile / tiles_img;
+        const int rem = tile - n * tiles_img;
+        const int ty = rem / tiles_x;
+        y0 = ty * TH;
+        x0 = (rem - ty * tiles_x) * TW;
     };
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
+    fill_xf<CI>(s_xf, A.src, ib * CI, tid);
     APref<CI, RES> PA_;
     GPref<CO> PG_;
+    init_a(PA_, tid);
+    // prologue: tile ks -> buffer 0, loads of tile ks+ksplit in flight
+    int n, y0, x0;
     if (ks < ntiles) {
-        int n, y0, x0;
         coords(ks, n, y0, x0);
-        issue_a<CI, RES>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
-        issue_g<CO>(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
-    }
-    for (int tile = ks; tile < ntiles; tile += A.ksplit) {
-        int n, y0, x0;
-        coords(tile, n, y0, x0);
-        __syncthreads();
-        commit_a<CI, RES>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, lds_a, tid);
-        commit_g<CO>(PG_, lds_g, tid);
-        __syncthreads();
-        if (tile + A.ksplit < ntiles) {
-            coords(tile + A.ksplit, n, y0, x0);
-            issue_a<CI, RES>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
-            issue_g<CO>(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
+        issue_a(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
+        issue_g(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
+        commit_a<XF_GEN>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, smem, tid, s_xf);
+        commit_g(PG_, smem + A_BYTES, tid);
+        if (ks + A.ksplit < ntiles) {
+            coords(ks + A.ksplit, n, y0, x0);
+            issue_a(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
+            issue_g(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
         }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = ks; tile < ntiles; tile += A.ksplit) {
+        // stage the next tile into the other buffer (its previous reader finished before the last barrier), then
+        // start the loads of the tile after it; (n, y0, x0) still hold the next tile's coordinates
+        if (tile + A.ksplit < ntiles) {
+            unsigned char *nb = smem + (cur ^ 1) * STAGE;
+            if (!(A.debug & 4)) {
+                commit_a<XF_GEN>(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, nb, tid, s_xf);
+                commit_g(PG_, nb + A_BYTES, tid);
+            }
+            if (tile + 2 * A.ksplit < ntiles && !(A.debug & 2)) {
+                coords(tile + 2 * A.ksplit, n, y0, x0);
+                issue_a(PA_, A.src, ib * CI, n, y0, x0, A.H, A.W, tid);
+                issue_g(PG_, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, tid);
+            }
+        }
+        const unsigned char *buf = smem + cur * STAGE;
+        if (!(A.debug & 1))
 #pragma unroll
         for (int ky = 0; ky < TH / 2; ++ky) {             // one k-step = one tile row of 16 pixels
             const int gaddr = g_lane + ky * TW * PG;
-            s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_g + gaddr));
-            s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_g + gaddr + 4 * PG));
+            s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + gaddr));
+            s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + gaddr + 4 * PG));
             s16x8 gv;
             gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3];
             gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
@@ -309,18 +355,19 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
             const int abase = a_lane + ky * HALO_W * PA;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + tap_off(t)));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds_a + abase + tap_off(t) + 4 * PA));
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + abase + tap_off(t)));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + abase + tap_off(t) + 4 * PA));
                 s16x8 av;
                 av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
                 av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), gf, acc[t], 0, 0, 0);
             }
         }
+        __syncthreads();
+        cur ^= 1;
     }
     // fold the two k-halves through LDS (the staging tiles are dead now): waves 4..7 park their accumulators,
     // waves 0..3 add them in a fixed order (deterministic) and write the slab
-    __syncthreads();
     float *s_acc = reinterpret_cast<float *>(smem);
     if (khalf == 1) {
 #pragma unroll
@@ -339,6 +386,134 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
         for (int r = 0; r < 16; ++r) {
             const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r] + s_acc[((quad * TAPS + t) * 16 + r) * 64 + lane];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Specialised-wave variant for un-pooled sources.  Waves 0..3 only run the matrix cores (one dW quadrant each, all eight
+// k-steps of a tile), waves 4..7 only move data: they keep the global loads of two tiles in flight in registers,
+// transform them and fill the other LDS buffer while the consumers work.  One barrier per tile; each SIMD hosts one
+// consumer and one producer wave, so staging VALU work and MFMAs overlap instead of alternating.
+// ------------------------------------------------------------------------------------------------------
+constexpr int NTP = 256;      // producer threads
+
+template <int CI_T, int CO_T, int TAPS, bool RES, int XF>
+__global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
+    constexpr int CI = CI_T * 32, CO = CO_T * 32;
+    constexpr int PA = pstride(CI), PG = pstride(CO);
+    constexpr int A_BYTES = NPIX_A * PA, G_BYTES = NPIX_G * PG, STAGE = A_BYTES + G_BYTES;
+    static_assert(CI_T * CO_T == 4, "one 32x32 quadrant per consumer wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // two staging buffers [A | G]
+    typedef s16x4 __attribute__((address_space(3))) * lptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_blocks = (A.Cout + CO - 1) / CO;
+    const int ci_blocks = (A.src.C + CI - 1) / CI;
+    const int cb = blockIdx.x % co_blocks, ib = blockIdx.x / co_blocks;
+    const int par = blockIdx.y;
+    const int ks = blockIdx.z;
+    const int pa = par >> 1, pb = par & 1;
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_img = tiles_y * tiles_x;
+    const int ntiles = A.N * tiles_img;
+    const int ntl = ks < ntiles ? (ntiles - ks + A.ksplit - 1) / A.ksplit : 0;      // tiles of this workgroup
+
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
+    fill_xf<CI>(s_xf, A.src, ib * CI, tid);
+    if (wave >= 4) {
+        // ------------------------------- producers -------------------------------
+        const int ptid = tid - NTP;
+        APref<CI, RES, NTP> P0, P1;
+        GPref<CO, NTP> G0, G1;
+        init_a(P0, ptid);
+        init_a(P1, ptid);
+        auto issue = [&](APref<CI, RES, NTP> &P, GPref<CO, NTP> &G, int j) {
+            const int tile = ks + j * A.ksplit;
+            const int n = tile / tiles_img, rem = tile - n * tiles_img;
+            const int ty = rem / tiles_x;
+            const int y0 = ty * TH, x0 = (rem - ty * tiles_x) * TW;
+            issue_a(P, A.src, ib * CI, n, y0, x0, A.H, A.W, ptid);
+            issue_g(G, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, ptid);
+        };
+        auto commit = [&](const APref<CI, RES, NTP> &P, const GPref<CO, NTP> &G, int bufi) {
+            unsigned char *nb = smem + bufi * STAGE;
+            commit_a<XF>(P, A.src, ib * CI, 0, 0, 0, A.H, A.W, nb, ptid, s_xf);
+            commit_g(G, nb + A_BYTES, ptid);
+        };
+        if (ntl > 0) issue(P0, G0, 0);
+        if (ntl > 1) issue(P1, G1, 1);
+        if (ntl > 0) commit(P0, G0, 0);
+        if (ntl > 2) issue(P0, G0, 2);
+        __syncthreads();
+        for (int j = 0; j < ntl; j += 2) {
+            // consumers are on tile j (buffer 0): fill buffer 1 with tile j+1, then start the loads of tile j+3
+            if (j + 1 < ntl) commit(P1, G1, 1);
+            if (j + 3 < ntl) issue(P1, G1, j + 3);
+            __syncthreads();
+            if (j + 1 >= ntl) break;
+            // consumers are on tile j+1 (buffer 1): fill buffer 0 with tile j+2, start the loads of tile j+4
+            if (j + 2 < ntl) commit(P0, G0, 0);
+            if (j + 4 < ntl) issue(P0, G0, j + 4);
+            __syncthreads();
+        }
+        return;
+    }
+    // ------------------------------- consumers -------------------------------
+    const int quad = wave;
+    const int wci = quad / CO_T, wco = quad % CO_T;
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    auto tap_off = [&](int t) -> int {
+        if (TAPS == 9) return ((t / 3) * HALO_W + t % 3) * PA;
+        if (TAPS == 4) {
+            const int ty = t >> 1, tx = t & 1;
+            const int r = pa == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+            const int c = pb == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+            return (r * HALO_W + c) * PA;
+        }
+        return (HALO_W + 1) * PA;
+    };
+    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    const int g_lane = A_BYTES + (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
+    for (int j = 0; j < ntl; ++j) {
+        const unsigned char *buf = smem + (j & 1) * STAGE;
+        if (!(A.debug & 1))
+#pragma unroll 2
+        for (int ky = 0; ky < TH; ++ky) {                 // one k-step = one tile row of 16 pixels
+            const int gaddr = g_lane + ky * TW * PG;
+            s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + gaddr));
+            s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + gaddr + 4 * PG));
+            s16x8 gv;
+            gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3];
+            gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
+            const bf16x8 gf = __builtin_bit_cast(bf16x8, gv);
+            const int abase = a_lane + ky * HALO_W * PA;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + abase + tap_off(t)));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + abase + tap_off(t) + 4 * PA));
+                s16x8 av;
+                av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
+                av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), gf, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // slab [ks][par][ib][cb][tap][CI][CO]; D rows = ci (regs + lane half), cols = co (lane & 31)
+    float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
         }
 }
 
@@ -394,12 +569,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     dw[o] = s;
 }
 
+template <int CI_T, int CO_T, int TAPS, bool RES, int XF>
+int launch_wgrad_ws(const WgradArgs &A, hipStream_t st) {
+    constexpr int CI = CI_T * 32, CO = CO_T * 32;
+    constexpr int smem = 2 * (NPIX_A * pstride(CI) + NPIX_G * pstride(CO));
+    auto kern = wgrad_ws_kernel<CI_T, CO_T, TAPS, RES, XF>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(wgrad_ws)");
+        attr_done = true;
+    }
+    dim3 grid(cdiv(A.src.C, CI) * cdiv(A.Cout, CO), A.npar, A.ksplit);
+    kern<<<grid, NT, smem, st>>>(A);
+    return check_launch("wgrad_ws_kernel");
+}
+
 template <int CI_T, int CO_T, int TAPS, bool RES>
-int launch_wgrad(const WgradArgs &A, hipStream_t st) {
+int launch_wgrad_gen(const WgradArgs &A, hipStream_t st) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int stage_bytes = NPIX_A * pstride(CI) + NPIX_G * pstride(CO);
     constexpr int fold_bytes = 4 * TAPS * 16 * 64 * 4;
-    constexpr int smem = stage_bytes > fold_bytes ? stage_bytes : fold_bytes;
+    constexpr int smem = 2 * stage_bytes > fold_bytes ? 2 * stage_bytes : fold_bytes;
     auto kern = wgrad_kernel<CI_T, CO_T, TAPS, RES>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -412,16 +603,27 @@ int launch_wgrad(const WgradArgs &A, hipStream_t st) {
     return check_launch("wgrad_kernel");
 }
 
+// kernel choice: un-pooled sources with CI <= 64 take the specialised-wave kernel with a compile-time transform
+// (plain / training-mode fast path / generic); pooled sources, CI = 128 blocks and generic-with-residual the 8-wave one
+template <int CI_T, int CO_T, int TAPS>
+int launch_wgrad(const WgradArgs &A, hipStream_t st) {
+    const ConvSrc &s = A.src;
+    const bool res = s.res != nullptr;
+    if (CI_T != 4 && !s.pool && !(A.debug & 8)) {
+        const bool plain = !s.scale && !s.relu && !s.f16 && !res;
+        const bool fast = s.scale && s.relu && s.f16;
+        if (plain) return launch_wgrad_ws<CI_T, CO_T, TAPS, false, XF_PLAIN>(A, st);
+        if (fast) return res ? launch_wgrad_ws<CI_T, CO_T, TAPS, true, XF_FAST>(A, st) : launch_wgrad_ws<CI_T, CO_T, TAPS, false, XF_FAST>(A, st);
+        if (!res) return launch_wgrad_ws<CI_T, CO_T, TAPS, false, XF_GEN>(A, st);
+    }
+    return res ? launch_wgrad_gen<CI_T, CO_T, TAPS, true>(A, st) : launch_wgrad_gen<CI_T, CO_T, TAPS, false>(A, st);
+}
+
 template <int TAPS>
 int dispatch_wgrad(const WgradArgs &A, int ci_t, hipStream_t st) {
-    if (A.src.res) {
-        if (ci_t == 1) return launch_wgrad<1, 4, TAPS, true>(A, st);
-        if (ci_t == 2) return launch_wgrad<2, 2, TAPS, true>(A, st);
-        return launch_wgrad<4, 1, TAPS, true>(A, st);
-    }
-    if (ci_t == 1) return launch_wgrad<1, 4, TAPS, false>(A, st);
-    if (ci_t == 2) return launch_wgrad<2, 2, TAPS, false>(A, st);
-    return launch_wgrad<4, 1, TAPS, false>(A, st);
+    if (ci_t == 1) return launch_wgrad<1, 4, TAPS>(A, st);
+    if (ci_t == 2) return launch_wgrad<2, 2, TAPS>(A, st);
+    return launch_wgrad<4, 1, TAPS>(A, st);
 }
 
 }  // namespace
@@ -451,6 +653,8 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     A.slab = slab;
     A.N = N; A.H = H; A.W = W; A.Cout = Cout;
     A.taps = taps; A.npar = npar; A.ostride = ostride; A.ksplit = ksplit;
+    static const int dbg = getenv("CDNET_WGRAD_DEBUG") ? atoi(getenv("CDNET_WGRAD_DEBUG")) : 0;
+    A.debug = dbg;
     int rc;
     if (taps == 9) rc = dispatch_wgrad<9>(A, ci_tiles, st);
     else if (taps == 4) rc = dispatch_wgrad<4>(A, ci_tiles, st);

@@ -3,7 +3,8 @@ usage: python tools/bench_bn.py [B]"""
 import ctypes as C
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cdnet_amd import _lib
 from cdnet_amd.trainer import BnBwdArgs
 

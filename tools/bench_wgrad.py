@@ -3,7 +3,8 @@ usage: python tools/bench_wgrad.py [B] [reps]"""
 import ctypes as C
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cdnet_amd import _lib, engine, trainer
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
