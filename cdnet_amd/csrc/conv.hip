@@ -14,6 +14,7 @@
 // applied on the fly, so none of those ever makes its own pass over HBM.  The epilogue either applies a folded
 // eval-mode BN (+ReLU) or emits the raw convolution output together with per-tile channel sums / sums of squares
 // (training-mode BN statistics, reduced deterministically by bn_finalize).
+#include <type_traits>
 #include "common.h"
 #include "conv_args.h"
 #include "xform.h"
@@ -222,15 +223,38 @@ struct Prefetch {
     static constexpr int NA = (NPIX * VPP + 255) / 256;
     static constexpr int NB = (TAPS * CK * BN * 2 / 16 + 255) / 256;
     uint4 a[NA], b[NB];
-    unsigned valid;          // bit i: vector i of `a` is inside the image / source
+    // per (tile, source) staging geometry, computed once by prep_source and reused by every chunk of that source:
+    int eoff[NA];            // element offset of the thread's i-th vector inside the image (channel 0 of its slot), -1 = zero fill
+    unsigned tvalid;         // bit i: eoff[i] >= 0
+    unsigned valid;          // snapshot of tvalid taken by issue_chunk (the source may change before the commit)
     bool pooled;             // synchronous path at commit time
 };
 
 template <int TH, int TW, int CK, int BN, int TAPS>
-__device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n, int y0, int x0,
-                                            int H, int W, const unsigned short *wchunk, int tid) {
+__device__ __forceinline__ void prep_source(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int y0, int x0, int H, int W, int tid) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
     constexpr int HW_ = TW + 2;
+    const int slot = tid % PF::VPP;
+    const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
+    P.tvalid = 0;
+#pragma unroll
+    for (int i = 0; i < PF::NA; ++i) {
+        const int v = tid + i * 256;
+        const int pix = v / PF::VPP;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        const bool inr = v < PF::NPIX * PF::VPP;
+        const bool ok = inr && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
+        P.eoff[i] = ok ? ys * rs + xs * s.C + slot * 8 : -1;
+        P.tvalid |= (ok ? 1u : 0u) << i;
+    }
+}
+
+template <int TH, int TW, int CK, int BN, int TAPS>
+__device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n,
+                                            const unsigned short *wchunk, int tid) {
+    using PF = Prefetch<TH, TW, CK, BN, TAPS>;
     {   // weights: linear
         const uint4 *src = reinterpret_cast<const uint4 *>(wchunk);
 #pragma unroll
@@ -242,23 +266,12 @@ __device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, c
     P.pooled = s.pool != 0;
     P.valid = 0;
     if (P.pooled) return;
-    const int slot = tid % PF::VPP;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
-    const size_t img = (size_t)n * s.Hs * rs;
+    const unsigned short *base = s.x + (size_t)n * s.Hs * rs + cc0;
+    P.valid = P.tvalid;
 #pragma unroll
-    for (int i = 0; i < PF::NA; ++i) {
-        const int v = tid + i * 256;
-        if (v >= PF::NPIX * PF::VPP) break;
-        const int pix = v / PF::VPP;
-        const int hy = pix / HW_, hx = pix - hy * HW_;
-        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        const int ys = y - s.off_y, xs = x - s.off_x;
-        if (y >= 0 && y < H && x >= 0 && x < W && ys >= 0 && ys < s.Hs && xs >= 0 && xs < s.Ws) {
-            const size_t e = img + (size_t)ys * rs + (size_t)xs * s.C + cc0 + slot * 8;
-            P.a[i] = *reinterpret_cast<const uint4 *>(s.x + e);
-            P.valid |= 1u << i;
-        }
-    }
+    for (int i = 0; i < PF::NA; ++i)
+        if (P.eoff[i] >= 0) P.a[i] = *reinterpret_cast<const uint4 *>(base + P.eoff[i]);
 }
 
 template <int TH, int TW, int CK, int BN, int TAPS>
@@ -266,7 +279,6 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
                                              int x0, int H, int W, unsigned char *lds_a, unsigned char *lds_b, int tid,
                                              const float *xf) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
-    constexpr int PSTR = CK * 2 + 16;
     {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_b);
 #pragma unroll
@@ -281,31 +293,31 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
     load_chan_xf(t, s, xf, cc0 + slot * 8);
     const bool relu = s.relu != 0, f16 = s.f16 != 0;
     const bool plain = !t.on && !relu && s.res == nullptr && !f16;
-    constexpr int HW_ = TW + 2;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
-    const size_t img = (size_t)n * s.Hs * rs;
+    // the residual operand is read here (not prefetched: registers are better spent on more waves per SIMD); the
+    // loads of all vectors are issued before the first use
+    V16 rr[PF::NA];
+    if (s.res) {
+        const unsigned short *rbase = s.res + (size_t)n * s.Hs * rs + cc0;
+#pragma unroll
+        for (int i = 0; i < PF::NA; ++i) rr[i].u = *reinterpret_cast<const uint4 *>(rbase + ((P.valid & (1u << i)) ? P.eoff[i] : 0));
+    }
+    // LDS address of vector i: pixel (tid / VPP + i * 256 / VPP), slot tid % VPP - affine in i
+    constexpr int PSTR = CK * 2 + 16;
+    unsigned char *dst0 = lds_a + (tid / PF::VPP) * PSTR + slot * 16;
 #pragma unroll
     for (int i = 0; i < PF::NA; ++i) {
-        const int v = tid + i * 256;
-        if (v >= PF::NPIX * PF::VPP) break;
-        const int pix = v / PF::VPP;
+        if (tid + i * 256 >= PF::NPIX * PF::VPP) continue;
         V16 val;
         val.u = make_uint4(0, 0, 0, 0);
         if (P.valid & (1u << i)) {
             V16 raw;
             raw.u = P.a[i];
             if (plain) val = raw;
-            else if (s.res) {
-                // the residual operand is read here (not prefetched: registers are better spent on two waves per SIMD)
-                const int hy = pix / HW_, hx = pix - hy * HW_;
-                const size_t e = img + (size_t)(y0 - 1 + hy - s.off_y) * rs + (size_t)(x0 - 1 + hx - s.off_x) * s.C + cc0 + slot * 8;
-                V16 r;
-                r.u = *reinterpret_cast<const uint4 *>(s.res + e);
-                val = xform8(raw, &r, t, relu, f16);
-            }
+            else if (s.res) val = xform8(raw, &rr[i], t, relu, f16);
             else val = xform8(raw, nullptr, t, relu, f16);
         }
-        *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
+        *reinterpret_cast<uint4 *>(dst0 + i * (256 / PF::VPP) * PSTR) = val.u;
     }
 }
 
@@ -385,7 +397,8 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
         {
             int si, cc0;
             chunk_src(0, si, cc0);
-            issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, wchunk(par, 0), tid);
+            prep_source<TH, TW, CK, BN, TAPS>(P, A.src[si], y0, x0, A.H, A.W, tid);
+            issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, wchunk(par, 0), tid);
         }
         // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
         int toff[TAPS];
@@ -418,7 +431,8 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
             if (chunk + 1 < nchunk_total) {
                 int sj, cj;
                 chunk_src(chunk + 1, sj, cj);
-                issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[sj], cj, n, y0, x0, A.H, A.W, wchunk(par, chunk + 1), tid);
+                if (sj != si) prep_source<TH, TW, CK, BN, TAPS>(P, A.src[sj], y0, x0, A.H, A.W, tid);     // second concat source
+                issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[sj], cj, n, wchunk(par, chunk + 1), tid);
             }
             if (A.debug & 4) continue;
 #pragma unroll
@@ -450,33 +464,66 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
         float ssum[NPW], ssq[NPW];
 #pragma unroll
         for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
+        // BatchNorm statistics of the raw accumulators (before bias / scale).  Full tiles take the branch-free loop.
+        if (A.stats) {
+            if (full) {
 #pragma unroll
-        for (int ni = 0; ni < NPW; ++ni) {
-            const int col = (wn * NPW + ni) * 32 + l31;
-            const int co = cout0 + col;
-            const bool cok = co < A.Cout;
-            const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
-            const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
-            const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
+                for (int ni = 0; ni < NPW; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < MPW; ++mi) {
+                    for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[mi][ni][r];
-                    if (A.stats) {
-                        bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
-                        if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
-                    }
-                    v += bias;
-                    v = fmaf(v, osc, osh);
-                    if (A.orelu) v = fmaxf(v, 0.f);
-                    const unsigned mine = A.out_f16 ? f2h(v) : f2bf(v);
-                    const unsigned other = __shfl_xor(mine, 1);
-                    if (!(l31 & 1)) *reinterpret_cast<unsigned *>(s_out + m * OSTR + col * 2) = mine | (other << 16);
-                }
+                        for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const float v = ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W) ? acc[mi][ni][r] : 0.f;
+                            ssum[ni] += v;
+                            ssq[ni] = fmaf(v, v, ssq[ni]);
+                        }
             }
         }
+        // accumulators -> 16-bit out tile in LDS.  A lane owns one output channel (column) of 16 pixel rows; two
+        // neighbouring lanes swap one value per register pair through DPP (quad_perm [1,0,3,2]) so that each lane
+        // ends up with the (even column, odd column) pair of ONE row and stores a packed dword: no LDS permutes, half
+        // the stores.  bias, scale and shift fold into one fma; the ReLU is taken on the packed 16-bit patterns.
+        auto write_tile = [&](auto f16c) {
+            constexpr bool F16 = decltype(f16c)::value;
+            const bool odd = (l31 & 1) != 0;
+            const xf_s16x2 lo = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) {
+                const int col = (wn * NPW + ni) * 32 + l31;
+                const int co = cout0 + col;
+                const bool cok = co < A.Cout;
+                const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
+                const float osh = fmaf((A.bias && cok) ? A.bias[co] : 0.f, osc, (A.oshift && cok) ? A.oshift[co] : 0.f);
+                unsigned char *dst = s_out + (col & ~1) * 2 + (odd ? OSTR : 0);
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi) {
+#pragma unroll
+                    for (int rp = 0; rp < 8; ++rp) {
+                        const int r = 2 * rp;
+                        const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;     // row of register r
+                        const float v0 = fmaf(acc[mi][ni][r], osc, osh), v1 = fmaf(acc[mi][ni][r + 1], osc, osh);
+                        const float send = odd ? v0 : v1;
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                        const xf_f32x2 pr = {odd ? got : v0, odd ? v1 : got};      // (even column, odd column) of row m (+1 on odd lanes)
+                        xf_s16x2 pk;
+                        if (F16) pk = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(pr, xf_h16x2));
+                        else pk = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(pr, xf_bf16x2));
+                        pk = __builtin_elementwise_max(pk, lo);
+                        *reinterpret_cast<unsigned *>(dst + m * OSTR) = __builtin_bit_cast(unsigned, pk);
+                    }
+                }
+            }
+        };
+        if (A.out_f16) write_tile(std::true_type{});
+        else write_tile(std::false_type{});
         if (A.stats) {
 #pragma unroll
             for (int ni = 0; ni < NPW; ++ni) {
