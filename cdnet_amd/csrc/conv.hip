@@ -15,6 +15,7 @@
 // eval-mode BN (+ReLU) or emits the raw convolution output together with per-tile channel sums / sums of squares
 // (training-mode BN statistics, reduced deterministically by bn_finalize).
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "conv_args.h"
 #include "xform.h"
@@ -58,11 +59,20 @@ union V16 {
 // mode 3: ConvTranspose2d weight [Cin][Cout][2][2] forward, parity (a,b): single tap (kh=a, kw=b)
 // Channels beyond the real Cin/Cout (padding to CK / BN multiples) are zero.
 // ------------------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout, int Cin,
-                                    int KH, int KW, int CK, int BN, int nchunk, int ntile, int TAPS, int mode,
-                                    int parity) {
-    const size_t total = (size_t)ntile * nchunk * TAPS * (CK / 16) * 2 * BN * 8;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+struct PackDesc {            // one (layer, sub-pixel parity) packing job
+    const float *w;
+    unsigned short *out;
+    int Cout, Cin, KH, KW, CK, BN, nchunk, ntile, TAPS, mode, parity;
+    unsigned block0, nblocks; // its slice of the batched launch
+};
+
+__device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size_t stride) {
+    const float *__restrict__ w = d.w;
+    unsigned short *__restrict__ out = d.out;
+    const int Cout = d.Cout, Cin = d.Cin, KH = d.KH, KW = d.KW, CK = d.CK, BN = d.BN, nchunk = d.nchunk, TAPS = d.TAPS, mode = d.mode,
+              parity = d.parity;
+    const size_t total = (size_t)d.ntile * nchunk * TAPS * (CK / 16) * 2 * BN * 8;
+    for (size_t i = first; i < total; i += stride) {
         size_t r = i;
         int j = r % 8; r /= 8;
         int col = r % BN; r /= BN;
@@ -105,6 +115,22 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, unsigned short 
         }
         out[i] = f2bf(v);
     }
+}
+
+__global__ void pack_weights_kernel(PackDesc d) {
+    pack_range(d, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
+// every layer's forward and backward-data packs in ONE launch (the training step re-packs ~80 small tensors after each
+// Adam update; separate launches cost more than the work)
+__global__ void pack_weights_batch_kernel(const PackDesc *__restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                          // last descriptor whose block0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = table[lo];
+    pack_range(d, (size_t)(blockIdx.x - d.block0) * blockDim.x + threadIdx.x, (size_t)d.nblocks * blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1209,21 +1235,64 @@ extern "C" size_t cdnet_conv_packed_weight_elems(int Cout, int Cin_padded_chunks
     return (size_t)npar * cdiv(Cout, BN) * Cin_padded_chunks * taps * CK * BN;
 }
 
-extern "C" int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN,
-                                       int mode, void *stream) {
-    CDNET_REQUIRE(w && packed, "cdnet_pack_conv_weights: null pointer");
-    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0, "cdnet_pack_conv_weights: Cin=%d CK=%d BN=%d", Cin, CK, BN);
+static int fill_pack_desc(PackDesc &d, const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode, int p,
+                          const char *who) {
+    CDNET_REQUIRE(w && packed, "%s: null pointer", who);
+    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0 && mode >= 0 && mode <= 5, "%s: Cin=%d CK=%d BN=%d mode=%d", who, Cin, CK, BN, mode);
     const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : (mode == 4 ? 9 : (mode == 5 ? 1 : KH * KW)));
-    const int npar = (mode == 2 || mode == 3) ? 4 : 1;
     const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
     const size_t per = (size_t)ntile * nchunk * taps * CK * BN;
+    d.w = w; d.out = (unsigned short *)packed + (size_t)p * per;
+    d.Cout = Cout; d.Cin = Cin; d.KH = KH; d.KW = KW; d.CK = CK; d.BN = BN; d.nchunk = nchunk; d.ntile = ntile; d.TAPS = taps; d.mode = mode;
+    d.parity = p;
+    d.block0 = 0;
+    d.nblocks = (unsigned)((per + 2047) / 2048);          // 8 elements per thread
+    if (d.nblocks > 4096) d.nblocks = 4096;
+    return CDNET_OK;
+}
+
+extern "C" int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN,
+                                       int mode, void *stream) {
+    const int npar = (mode == 2 || mode == 3) ? 4 : 1;
     for (int p = 0; p < npar; ++p) {
-        int blocks = (int)((per + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        pack_weights_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, (unsigned short *)packed + p * per, Cout, Cin, KH,
-                                                                   KW, CK, BN, nchunk, ntile, taps, mode, p);
+        PackDesc d;
+        int rc = fill_pack_desc(d, w, packed, Cout, Cin, KH, KW, CK, BN, mode, p, "cdnet_pack_conv_weights");
+        if (rc) return rc;
+        pack_weights_kernel<<<d.nblocks, 256, 0, (hipStream_t)stream>>>(d);
     }
     return check_launch("cdnet_pack_conv_weights");
+}
+
+extern "C" size_t cdnet_pack_batch_table_bytes(int n_jobs) { return (size_t)n_jobs * 4 * sizeof(PackDesc); }
+
+extern "C" int cdnet_pack_conv_weights_batch(const cdnet_pack_job *jobs, int n_jobs, void *table, size_t table_bytes, int upload,
+                                             void *stream) {
+    CDNET_REQUIRE(jobs && n_jobs > 0 && table, "cdnet_pack_conv_weights_batch: null pointer / no jobs");
+    CDNET_REQUIRE(table_bytes >= cdnet_pack_batch_table_bytes(n_jobs), "cdnet_pack_conv_weights_batch: table too small");
+    static thread_local std::vector<PackDesc> host;
+    host.clear();
+    unsigned blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const cdnet_pack_job &J = jobs[j];
+        const int npar = (J.mode == 2 || J.mode == 3) ? 4 : 1;
+        for (int p = 0; p < npar; ++p) {
+            PackDesc d;
+            int rc = fill_pack_desc(d, J.w, J.packed, J.Cout, J.Cin, J.KH, J.KW, J.CK, J.BN, J.mode, p, "cdnet_pack_conv_weights_batch");
+            if (rc) return rc;
+            d.block0 = blocks;
+            blocks += d.nblocks;
+            host.push_back(d);
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (upload) {
+        // (synchronous with respect to the host buffer: the table is rebuilt on every call)
+        if (hipMemcpyAsync(table, host.data(), host.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return check_launch("cdnet_pack_conv_weights_batch(upload)");
+    }
+    pack_weights_batch_kernel<<<blocks, 256, 0, st>>>((const PackDesc *)table, (int)host.size());
+    return check_launch("cdnet_pack_conv_weights_batch");
 }
 
 extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {

@@ -116,13 +116,11 @@ def packed_elems(Cout, nchunk, taps, CK, BN, npar):
     return _lib.load().cdnet_conv_packed_weight_elems(Cout, nchunk, taps, CK, BN, npar)
 
 
-def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
-    """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
-    Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
+def _pack_dims(w, cfg, mode):
+    """(Cout, Cin, KH, KW, CK, BN, taps, npar) as cdnet_pack_conv_weights wants them (GEMM roles, see include/cdnet_hip.h)"""
     _, CK, BN = cfg[:3]
     if len(cfg) == 4 and cfg[3] == 'v2':
         CK = 16                                # v2 kernels stream the weights in 16-channel sub-chunks whatever the A chunk is
-    assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
     if mode == 0:
         Cout, Cin, KH, KW = w.shape
     elif mode == 1:
@@ -132,6 +130,30 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
         Cin = 4 * ct                         # GEMM-Cin = space-to-depth of its out_channels
     else:
         Cin, Cout, KH, KW = w.shape
+    taps = {2: 4, 3: 1, 4: 9, 5: 1}.get(mode, KH * KW)
+    npar = 4 if mode in (2, 3) else 1
+    return Cout, Cin, KH, KW, CK, BN, taps, npar
+
+
+class PackJob(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('packed', C.c_void_p), ('Cout', C.c_int), ('Cin', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
+                ('CK', C.c_int), ('BN', C.c_int), ('mode', C.c_int), ('pad_', C.c_int)]
+
+
+def pack_job(w, cfg, mode, out):
+    """descriptor of one re-pack of `w` into the existing packed buffer `out` (cdnet_pack_conv_weights_batch)"""
+    Cout, Cin, KH, KW, CK, BN, taps, npar = _pack_dims(w, cfg, mode)
+    assert out.numel() == packed_elems(Cout, Cin // CK, taps, CK, BN, npar)
+    j = PackJob()
+    j.w, j.packed, j.Cout, j.Cin, j.KH, j.KW, j.CK, j.BN, j.mode = w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, CK, BN, mode
+    return j
+
+
+def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
+    """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
+    Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
+    assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
+    Cout, Cin, KH, KW, CK, BN, taps, npar = _pack_dims(w, cfg, mode)
     Cin_p = Cin if Cin_pad is None else Cin_pad
     if Cin_p != Cin:
         # zero-extend the reduction channels (only the RGB stem needs this)
@@ -141,8 +163,6 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
         else:
             raise NotImplementedError
         w, Cin = wp.contiguous(), Cin_p
-    taps = {2: 4, 3: 1, 4: 9, 5: 1}.get(mode, KH * KW)
-    npar = 4 if mode in (2, 3) else 1
     n = packed_elems(Cout, Cin // CK, taps, CK, BN, npar)
     if out is None:
         out = torch.empty((n,), dtype=torch.int16, device=w.device)

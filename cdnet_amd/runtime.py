@@ -11,6 +11,7 @@ in train mode they store the raw convolution output and emit BN statistics, and 
 relu(raw*scale+shift).
 """
 import ctypes as C
+import weakref
 import torch
 
 from . import _lib, engine
@@ -23,6 +24,7 @@ import os as _os
 DEBUG_NORELU = bool(int(_os.environ.get('CDNET_DEBUG_NORELU', '0')))   # debug aid (tools/debug_train.py): linearised network
 TAPE = None              # set by cdnet_amd.trainer around a training forward: layers append themselves in execution order
 WEIGHTS_EPOCH = [0]      # bumped by the fused Adam step (it updates parameters behind torch's version counters)
+LAYERS = weakref.WeakSet()   # every live ConvLayer (the trainer batches their weight re-packs)
 
 
 class HeadFeat(C.Structure):
@@ -72,6 +74,8 @@ class ConvLayer:
         self.needs_input_grad = True
         self.bias_grad_from = None
         self.wpb, self.wpb_version, self.cfg_bwd = None, None, None
+        self.wp_padded = False                 # forward pack zero-extends Cin (RGB stem): not batchable
+        LAYERS.add(self)
 
     # -- weights ------------------------------------------------------------------------------------
     def _version(self):
@@ -87,6 +91,7 @@ class ConvLayer:
         ver = (self.weight._version, WEIGHTS_EPOCH[0])
         if self.wp is None or self.wp_version != ver:
             pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16
+            self.wp_padded = pad is not None
             self.wp = engine.pack_weights(self.weight.detach(), self.cfg, self.pack_mode, Cin_pad=pad, out=self.wp)
             self.wp_version = ver
 

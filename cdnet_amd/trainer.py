@@ -89,6 +89,7 @@ class Trainer:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.99), eps=1e-8, quirk_sample0=True,
                  world_size=1, bucket_mb=25):
         self.model = model
+        self._pack_jobs = None
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.quirk = int(quirk_sample0)
         self.world = world_size
@@ -279,6 +280,36 @@ class Trainer:
         _lib.call('cdnet_adam_step', _lib.ptr(f.P), _lib.ptr(f.G), _lib.ptr(f.M), _lib.ptr(f.V), f.n_used, self.lr,
                   self.betas[0], self.betas[1], self.eps, self.wd, f.step_count, gscale, _lib.stream_ptr())
         runtime.WEIGHTS_EPOCH[0] += 1
+        self._repack_all()
+
+    def _repack_all(self):
+        """Re-pack every layer's forward / backward-data weights in one launch (they would otherwise be re-packed one by
+        one, lazily, by the next forward and backward).  The job table is built after the first step, once every layer
+        has its packed buffers."""
+        f = self.flat
+        lo, hi = f.P.data_ptr(), f.P.data_ptr() + f.P.numel() * 4
+        if self._pack_jobs is None:
+            jobs, owners = [], []
+            for L in runtime.LAYERS:
+                if not (lo <= L.weight.data_ptr() < hi):
+                    continue
+                w = L.weight.detach()
+                if L.wp is not None and not L.wp_padded:
+                    jobs.append(engine.pack_job(w, L.cfg, L.pack_mode, L.wp)); owners.append((L, 'wp_version'))
+                if L.wpb is not None:
+                    mode = (4 if L.kind == 'convT4' else 5) if L.transposed else 1
+                    jobs.append(engine.pack_job(w, L.cfg_bwd, mode, L.wpb)); owners.append((L, 'wpb_version'))
+            if not jobs or self.flat.step_count < 1:
+                return
+            arr = (engine.PackJob * len(jobs))(*jobs)
+            nbytes = _lib.load().cdnet_pack_batch_table_bytes(len(jobs))
+            table = torch.empty((nbytes,), dtype=torch.uint8, device=f.P.device)
+            self._pack_jobs = (arr, len(jobs), table, owners, [True])
+        arr, n, table, owners, first = self._pack_jobs
+        _lib.call('cdnet_pack_conv_weights_batch', C.byref(arr), n, _lib.ptr(table), table.numel(), int(first[0]), _lib.stream_ptr())
+        first[0] = False
+        for L, attr in owners:
+            setattr(L, attr, (L.weight._version, runtime.WEIGHTS_EPOCH[0]))
 
     def train_step(self, x, label, dirlab, point_t, weight):
         """x f32 [B,3,H,W]; label u8 [B,H,W] in {0,1,2}; dirlab u8 [B,H,W] 0..8; point_t f16 [B,H,W]; weight u8 [B,H,W]

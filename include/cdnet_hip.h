@@ -155,6 +155,18 @@ size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, in
  * with 2*Cout_t channels ordered (column parity, channel)); Cout := transposed-conv in_channels, Cin := 4*out_channels. */
 int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode,
                             void *stream);
+/* The same packing for many tensors in one launch (the training step re-packs every layer's forward and backward-data
+ * weights after each optimizer update - train_util_dam.py:308 optimizer.step()).  `table` is device scratch of
+ * cdnet_pack_batch_table_bytes(n_jobs) bytes; upload = 1 copies the job table there (first call, or whenever the jobs
+ * changed), upload = 0 re-runs the table uploaded before. */
+typedef struct cdnet_pack_job {
+    const float *w;
+    void *packed;
+    int Cout, Cin, KH, KW, CK, BN, mode, pad_;
+} cdnet_pack_job;
+size_t cdnet_pack_batch_table_bytes(int n_jobs);
+int cdnet_pack_conv_weights_batch(const cdnet_pack_job *jobs, int n_jobs, void *table, size_t table_bytes, int upload,
+                                  void *stream);
 int cdnet_conv_forward(const cdnet_conv_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
