@@ -172,16 +172,16 @@ __device__ __forceinline__ V16 max8(V16 a, V16 b, bool nonneg) {
     return o;
 }
 
-// the 8 channels' scale / shift of one thread; `xf` is the LDS copy of the source's tables ([0] scale, [XF_MAX] shift) made
+// the 8 channels' scale / shift of one thread; `xf` is the LDS copy of the source's tables ([0] scale, [xfs] shift) made
 // once per workgroup (a global load here would sit in front of the chunk pipeline: vmcnt retires in order), or null
 // for callers without one
 constexpr int XF_MAX = 1024;      // source channels (both concat sources) whose scale/shift fit the LDS table
 
-__device__ __forceinline__ void load_chan_xf(ChanXf &t, const ConvSrc &s, const float *xf, int c) {
+__device__ __forceinline__ void load_chan_xf(ChanXf &t, const ConvSrc &s, const float *xf, int xfs, int c) {
     t.on = s.scale != nullptr;
     if (!t.on) return;
     const float4 *ps = reinterpret_cast<const float4 *>(xf ? xf + c : s.scale + c);
-    const float4 *ph = reinterpret_cast<const float4 *>(xf ? xf + XF_MAX + c : s.shift + c);
+    const float4 *ph = reinterpret_cast<const float4 *>(xf ? xf + xfs + c : s.shift + c);
     float4 a = ps[0], b = ps[1], cc = ph[0], d = ph[1];
     t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
     t.sh[0] = cc.x; t.sh[1] = cc.y; t.sh[2] = cc.z; t.sh[3] = cc.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
@@ -189,13 +189,13 @@ __device__ __forceinline__ void load_chan_xf(ChanXf &t, const ConvSrc &s, const 
 
 template <int TH, int TW, int CK>
 __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
-                                            unsigned char *lds_a, int tid, const float *xf = nullptr) {
+                                            unsigned char *lds_a, int tid, const float *xf = nullptr, int xfs = 0) {
     constexpr int VPP = CK / 8;                  // 16-byte vectors per pixel
     constexpr int PSTR = CK * 2 + 16;            // padded pixel stride in LDS (bank-conflict free b128 reads)
     constexpr int HW_ = TW + 2, NPIX = (TH + 2) * (TW + 2);
     const int slot = tid % VPP;                  // constant per thread because 256 % VPP == 0
     ChanXf t;
-    load_chan_xf(t, s, xf, cc0 + slot * 8);
+    load_chan_xf(t, s, xf, xfs, cc0 + slot * 8);
     const bool relu = s.relu != 0;
     const bool f16 = s.f16 != 0;
     const bool plain = !t.on && !relu && s.res == nullptr && !f16;
@@ -242,13 +242,29 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
 // and only transformed / written to LDS after it, so their HBM/L2 latency hides under the matrix work (guide T14).
 // Pooled sources (4 loads + max per element) keep the synchronous path.
 // ------------------------------------------------------------------------------------------------------
+// LDS layout of conv_fwd_kernel (dynamic): [A halo tile][B chunk (x2 when the weights arrive by LDS-DMA)] aliased by the
+// out tile + the BatchNorm partial sums, followed by the scale|shift table of the source channels.
+template <int TH, int TW, int CK, int BN, int TAPS>
+struct ConvLds {
+    static constexpr bool GLDS = (CK == 16 && TH == 16);      // weights by global_load_lds into a double buffer
+    static constexpr int PSTR = CK * 2 + 16;
+    static constexpr int A_BYTES = (TH + 2) * (TW + 2) * PSTR;
+    static constexpr int B_BYTES = TAPS * CK * BN * 2;
+    static constexpr int STAGE = A_BYTES + (GLDS ? 2 : 1) * B_BYTES;
+    static constexpr int OUT_BYTES = TH * TW * (BN * 2 + 8);
+    static constexpr int STATS_BYTES = 4 * 2 * BN * 4;
+    static constexpr int MAIN = ((STAGE > OUT_BYTES + STATS_BYTES ? STAGE : OUT_BYTES + STATS_BYTES) + 15) / 16 * 16;
+    static int bytes(int ctot) { return MAIN + 2 * ((ctot + 7) / 8 * 8) * 4; }
+};
+
 template <int TH, int TW, int CK, int BN, int TAPS>
 struct Prefetch {
     static constexpr int VPP = CK / 8;
     static constexpr int NPIX = (TH + 2) * (TW + 2);
     static constexpr int NA = (NPIX * VPP + 255) / 256;
+    static constexpr bool GLDS = ConvLds<TH, TW, CK, BN, TAPS>::GLDS;
     static constexpr int NB = (TAPS * CK * BN * 2 / 16 + 255) / 256;
-    uint4 a[NA], b[NB];
+    uint4 a[NA], b[GLDS ? 1 : NB];
     // per (tile, source) staging geometry, computed once by prep_source and reused by every chunk of that source:
     int eoff[NA];            // element offset of the thread's i-th vector inside the image (channel 0 of its slot), -1 = zero fill
     unsigned tvalid;         // bit i: eoff[i] >= 0
@@ -279,9 +295,22 @@ __device__ __forceinline__ void prep_source(Prefetch<TH, TW, CK, BN, TAPS> &P, c
 
 template <int TH, int TW, int CK, int BN, int TAPS>
 __device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n,
-                                            const unsigned short *wchunk, int tid) {
+                                            const unsigned short *wchunk, int tid, unsigned char *lds_b_next) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
-    {   // weights: linear
+    if (PF::GLDS) {
+        // weights: the packed chunk is the LDS image - LDS-DMA, one 1 KB wave-instruction per 64 vectors, no registers.
+        // (destination = wave-uniform base + lane * 16; drained by the vmcnt(0) of the barrier before the next commit)
+        constexpr int NVEC = TAPS * CK * BN * 2 / 16;
+        static_assert(NVEC % 64 == 0, "whole wave-instructions");
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int i = 0; i < PF::NB; ++i) {
+            const int v0 = (i * 4 + wave) * 64;                          // first vector of this wave-instruction
+            if (v0 < NVEC)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wchunk + (size_t)(v0 + lane) * 8),
+                                                 (__attribute__((address_space(3))) void *)(lds_b_next + v0 * 16), 16, 0, 0);
+        }
+    } else {   // weights: linear, through registers
         const uint4 *src = reinterpret_cast<const uint4 *>(wchunk);
 #pragma unroll
         for (int i = 0; i < PF::NB; ++i) {
@@ -303,9 +332,9 @@ __device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, c
 template <int TH, int TW, int CK, int BN, int TAPS>
 __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n, int y0,
                                              int x0, int H, int W, unsigned char *lds_a, unsigned char *lds_b, int tid,
-                                             const float *xf) {
+                                             const float *xf, int xfs) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
-    {
+    if (!PF::GLDS) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_b);
 #pragma unroll
         for (int i = 0; i < PF::NB; ++i) {
@@ -313,10 +342,10 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
             if (v < TAPS * CK * BN * 2 / 16) dst[v] = P.b[i];
         }
     }
-    if (P.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid, xf); return; }
+    if (P.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid, xf, xfs); return; }
     const int slot = tid % PF::VPP;
     ChanXf t;
-    load_chan_xf(t, s, xf, cc0 + slot * 8);
+    load_chan_xf(t, s, xf, xfs, cc0 + slot * 8);
     const bool relu = s.relu != 0, f16 = s.f16 != 0;
     const bool plain = !t.on && !relu && s.res == nullptr && !f16;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
@@ -357,27 +386,30 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
     constexpr int KC = CK / 16;
     constexpr int MT = TH * TW / 32, NT = BN / 32;
     constexpr int MPW = MT / WM, NPW = NT / WN;
-    constexpr int A_BYTES = (TH + 2) * (TW + 2) * PSTR;
-    constexpr int B_BYTES = TAPS * CK * BN * 2;
+    using LDS = ConvLds<TH, TW, CK, BN, TAPS>;
+    constexpr bool GLDS = LDS::GLDS;
+    constexpr int A_BYTES = LDS::A_BYTES;
+    constexpr int B_BYTES = LDS::B_BYTES;
     constexpr int OSTR = BN * 2 + 8;             // out staging row stride (bytes)
     static_assert(MT % WM == 0 && NT % WN == 0 && WM * WN == 4, "wave tiling");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_a = smem;
-    unsigned char *lds_b = smem + A_BYTES;
-    __shared__ float s_stats[4][2][BN];
-    __shared__ __attribute__((aligned(16))) float s_xf[2 * XF_MAX];      // scale | shift of source 0 then source 1
+    unsigned char *lds_b0 = smem + A_BYTES;
+    float (*s_stats)[2][BN] = reinterpret_cast<float (*)[2][BN]>(smem + LDS::OUT_BYTES);      // epilogue only
+    float *s_xf = reinterpret_cast<float *>(smem + LDS::MAIN);          // scale | shift of source 0 then source 1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
+    const int xfs = ((A.src[0].C + (A.nsrc > 1 ? A.src[1].C : 0)) + 7) / 8 * 8;      // table stride (floats)
     {
         const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
         for (int c = tid; c < ctot; c += 256) {
             const ConvSrc &S = c < c0n ? A.src[0] : A.src[1];
             const int cc = c < c0n ? c : c - c0n;
             s_xf[c] = S.scale ? S.scale[cc] : 1.f;
-            s_xf[XF_MAX + c] = S.shift ? S.shift[cc] : 0.f;
+            s_xf[xfs + c] = S.shift ? S.shift[cc] : 0.f;
         }
         // (published by the barrier in front of the first commit)
     }
@@ -424,7 +456,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
             int si, cc0;
             chunk_src(0, si, cc0);
             prep_source<TH, TW, CK, BN, TAPS>(P, A.src[si], y0, x0, A.H, A.W, tid);
-            issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, wchunk(par, 0), tid);
+            issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, wchunk(par, 0), tid, lds_b0);
         }
         // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
         int toff[TAPS];
@@ -451,14 +483,15 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
             int si, cc0;
             chunk_src(chunk, si, cc0);
             __syncthreads();                               // previous chunk's fragment reads / previous tile's out-tile reads are done
-            commit_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid, s_xf + (si ? A.src[0].C : 0));
+            unsigned char *lds_b = lds_b0 + (GLDS ? (chunk & 1) * B_BYTES : 0);
+            commit_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid, s_xf + (si ? A.src[0].C : 0), xfs);
             __syncthreads();
             // issue the loads of the next (tile, chunk) step now: they fly during the MFMA loop (and the epilogue)
             if (chunk + 1 < nchunk_total) {
                 int sj, cj;
                 chunk_src(chunk + 1, sj, cj);
                 if (sj != si) prep_source<TH, TW, CK, BN, TAPS>(P, A.src[sj], y0, x0, A.H, A.W, tid);     // second concat source
-                issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[sj], cj, n, wchunk(par, chunk + 1), tid);
+                issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[sj], cj, n, wchunk(par, chunk + 1), tid, lds_b0 + ((chunk + 1) & 1) * B_BYTES);
             }
             if (A.debug & 4) continue;
 #pragma unroll
@@ -591,614 +624,16 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Weight-stationary variant for the full-resolution layers (total Cin <= 80): the WHOLE weight tensor of the cout tile
-// (TAPS*CIN*BN bf16, <= 74 KB) is loaded into LDS once per workgroup; the workgroup is persistent (one per CU) and walks
-// a list of 16x16 tiles.  The input halo of tile t+1 is fetched into registers while the matrix cores work on tile t
-// (one wave per SIMD, up to 512 registers), the out tile has its own LDS region, so per tile there are only two
-// barriers and the only HBM traffic is the halo read and the output write.  On the 64->64 @256x256 layers this removes
-// the per-tile re-staging of 74 KB of weights that bounded the generic kernel.
-// ------------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CIN, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256, 1) void conv_ws_kernel(ConvArgs A) {
-    constexpr int PSTR = CIN * 2 + 16;
-    constexpr int HW_ = TW + 2;
-    constexpr int KC = CIN / 16;
-    constexpr int VPP = CIN / 8;
-    constexpr int ACTIVE = (256 / VPP) * VPP;              // staging threads (fixed channel slot per thread)
-    constexpr int NPIX = (TH + 2) * (TW + 2);
-    constexpr int NA = (NPIX * VPP + ACTIVE - 1) / ACTIVE;
-    constexpr int MT = TH * TW / 32, NT = BN / 32;
-    constexpr int MPW = MT / WM, NPW = NT / WN;
-    constexpr int W_BYTES = TAPS * CIN * BN * 2;
-    constexpr int A_BYTES = NPIX * PSTR;
-    constexpr int OSTR = BN * 2 + 8;
-    static_assert(MT % WM == 0 && NT % WN == 0 && WM * WN == 4, "wave tiling");
-    static_assert(NA <= 32, "valid mask");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *lds_w = smem;
-    unsigned char *lds_a = smem + W_BYTES;
-    unsigned char *s_out = smem + W_BYTES + A_BYTES;
-    __shared__ float s_stats[4][2][BN];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
-    const int tiles_img = tiles_x * tiles_y;
-    const int total_tiles = A.N * tiles_img;
-    const int cout_tile = blockIdx.y;
-    const int cout0 = cout_tile * BN;
-
-    {   // the whole weight block of this cout tile: one linear copy
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * (W_BYTES / 2));
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
-        for (int v = tid; v < W_BYTES / 16; v += 256) dst[v] = src[v];
-    }
-    // this thread's fixed 8-channel slot -> (source, channel offset) and its transform constants
-    const bool stager = tid < ACTIVE;
-    const int slot = tid % VPP;
-    const int c_glob = slot * 8;
-    const int si = (A.nsrc > 1 && c_glob >= A.src[0].C) ? 1 : 0;
-    const ConvSrc &S = A.src[si];
-    const int cc0 = c_glob - (si ? A.src[0].C : 0);
-    ChanXf t;
-    t.on = S.scale != nullptr;
-    if (t.on && stager) {
-        const float4 *ps = reinterpret_cast<const float4 *>(S.scale + cc0);
-        const float4 *ph = reinterpret_cast<const float4 *>(S.shift + cc0);
-        float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
-        t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
-        t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
-    }
-    const bool relu = S.relu != 0, f16 = S.f16 != 0;
-    const bool plain = !t.on && !relu && S.res == nullptr && !f16;
-    const int Hl = S.pool ? (S.Hs + (S.pool == 2)) / 2 : S.Hs, Wl = S.pool ? (S.Ws + (S.pool == 2)) / 2 : S.Ws;
-    const size_t rs = S.row_stride ? (size_t)S.row_stride : (size_t)S.Ws * S.C;
-
-    int toff[TAPS];
-#pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) toff[tp] = TAPS == 9 ? ((tp / 3) * HW_ + tp % 3) * PSTR : (HW_ + 1) * PSTR;
-    int abase[MPW];
-#pragma unroll
-    for (int mi = 0; mi < MPW; ++mi) {
-        const int m = (wm * MPW + mi) * 32 + l31;
-        abase[mi] = ((m / TW) * HW_ + m % TW) * PSTR + half * 16;
-    }
-    const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
-
-    auto decode = [&](int tile, int &n, int &y0, int &x0) {
-        n = tile / tiles_img;
-        const int r = tile - n * tiles_img, ty_ = r / tiles_x;
-        y0 = ty_ * TH; x0 = (r - ty_ * tiles_x) * TW;
-    };
-    uint4 pa[NA];
-    unsigned valid = 0;
-    // element offset of halo vector i of tile (n,y0,x0), or -1
-    auto issue = [&](int n, int y0, int x0) {
-        valid = 0;
-        if (!stager || S.pool) return;
-        const size_t img = (size_t)n * S.Hs * rs;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int v = tid + i * ACTIVE;
-            if (v >= NPIX * VPP) break;
-            const int pix = v / VPP, hy = pix / HW_, hx = pix - hy * HW_;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const int ys = y - S.off_y, xs = x - S.off_x;
-            if (y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < S.Hs && xs >= 0 && xs < S.Ws) {
-                pa[i] = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)ys * rs + (size_t)xs * S.C + cc0);
-                valid |= 1u << i;
-            }
-        }
-    };
-    auto commit = [&](int n, int y0, int x0) {
-        if (!stager) return;
-        const size_t img = (size_t)n * S.Hs * rs;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int v = tid + i * ACTIVE;
-            if (v >= NPIX * VPP) break;
-            const int pix = v / VPP, hy = pix / HW_, hx = pix - hy * HW_;
-            V16 val;
-            val.u = make_uint4(0, 0, 0, 0);
-            if (!S.pool) {
-                if (valid & (1u << i)) {
-                    V16 raw;
-                    raw.u = pa[i];
-                    if (plain) val = raw;
-                    else if (S.res) {
-                        const size_t e = img + (size_t)(y0 - 1 + hy - S.off_y) * rs + (size_t)(x0 - 1 + hx - S.off_x) * S.C + cc0;
-                        V16 r;
-                        r.u = *reinterpret_cast<const uint4 *>(S.res + e);
-                        val = xform8(raw, &r, t, relu, f16);
-                    } else val = xform8(raw, nullptr, t, relu, f16);
-                }
-            } else {
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                const int ys = y - S.off_y, xs = x - S.off_x;
-                if (y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
-                        if (q != 0 && (yy >= S.Hs || xx >= S.Ws)) continue;
-                        V16 raw;
-                        raw.u = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)yy * rs + (size_t)xx * S.C + cc0);
-                        V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
-                        val = q == 0 ? tv : max8(val, tv, relu);
-                    }
-                }
-            }
-            *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < total_tiles) { int n, y0, x0; decode(tile, n, y0, x0); issue(n, y0, x0); }
-    for (; tile < total_tiles; tile += gridDim.x) {
-        int n, y0, x0;
-        decode(tile, n, y0, x0);
-        commit(n, y0, x0);
-        __syncthreads();                                                        // S1: halo (and, first time, weights) visible
-        if (tile + (int)gridDim.x < total_tiles) { int n2, y2, x2; decode(tile + gridDim.x, n2, y2, x2); issue(n2, y2, x2); }
-        f32x16 acc[MPW][NPW];
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-#pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp) {
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                bf16x8 af[MPW], bfr[NPW];
-#pragma unroll
-                for (int mi = 0; mi < MPW; ++mi)
-                    af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + abase[mi] + toff[tp] + kc * 32);
-#pragma unroll
-                for (int ni = 0; ni < NPW; ++ni)
-                    bfr[ni] = *reinterpret_cast<const bf16x8 *>(lds_w + bbase + ((tp * KC + kc) * 2) * BN * 16 + ni * 512);
-#pragma unroll
-                for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NPW; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
-            }
-        }
-        // ---- epilogue into the dedicated out tile ----
-        const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
-        float ssum[NPW], ssq[NPW];
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni) {
-            const int col = (wn * NPW + ni) * 32 + l31;
-            const int co = cout0 + col;
-            const bool cok = co < A.Cout;
-            const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
-            const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
-            const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MPW; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[mi][ni][r];
-                    if (A.stats) {
-                        bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
-                        if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
-                    }
-                    v += bias;
-                    v = fmaf(v, osc, osh);
-                    if (A.orelu) v = fmaxf(v, 0.f);
-                    const unsigned mine = A.out_f16 ? f2h(v) : f2bf(v);
-                    const unsigned other = __shfl_xor(mine, 1);
-                    if (!(l31 & 1)) *reinterpret_cast<unsigned *>(s_out + m * OSTR + col * 2) = mine | (other << 16);
-                }
-            }
-        }
-        if (A.stats) {
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni) {
-                ssum[ni] += __shfl_xor(ssum[ni], 32);
-                ssq[ni] += __shfl_xor(ssq[ni], 32);
-                if (half == 0) {
-                    s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
-                    s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
-                }
-            }
-        }
-        __syncthreads();                                                        // S2: out tile complete, halo reads done
-        if (A.stats && tid < 2 * BN) {
-            const int which = tid / BN, col = tid % BN;
-            const int wn_of = col / (NPW * 32);
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
-            const int co = cout0 + col;
-            if (co < A.Cout) A.stats[((size_t)tile * 2 + which) * A.Cout + co] = v;
-        }
-        {
-            constexpr int VO = BN / 8;
-            for (int v = tid; v < TH * TW * VO; v += 256) {
-                const int m = v / VO, q = v % VO;
-                const int y = y0 + m / TW, x = x0 + m % TW;
-                const int co = cout0 + q * 8;
-                if (y < A.H && x < A.W && co < A.Cout) {
-                    const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
-                    *reinterpret_cast<uint4 *>(A.out + (((size_t)n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = val;
-                }
-            }
-        }
-    }
-}
-
-template <int CIN, int BN, int TAPS>
-int launch_conv_ws(const ConvArgs &A, hipStream_t st) {
-    constexpr int TH = 16, TW = 16;
-    constexpr int smem = TAPS * CIN * BN * 2 + (TH + 2) * (TW + 2) * (CIN * 2 + 16) + TH * TW * (BN * 2 + 8);
-    static_assert(smem + 4 * 2 * BN * 4 <= 160 * 1024, "weight-stationary configuration does not fit in LDS");
-    auto kern = conv_ws_kernel<TH, TW, CIN, BN, 4, 1, TAPS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(conv_ws)");
-        attr_done = true;
-    }
-    const int total_tiles = cdiv(A.W, TW) * cdiv(A.H, TH) * A.N;
-    const int ctiles = cdiv(A.Cout, BN);
-    int gx = 256 / ctiles;                       // one persistent workgroup per CU
-    if (gx < 1) gx = 1;
-    if (gx > total_tiles) gx = total_tiles;
-    kern<<<dim3(gx, ctiles, 1), 256, smem, st>>>(A);
-    return check_launch("conv_ws_kernel");
-}
-
-template <int TAPS>
-int dispatch_conv_ws(const ConvArgs &A, hipStream_t st) {
-    const int key = A.CK * 1000 + A.BN;
-    switch (key) {
-        case 16 * 1000 + 32: return launch_conv_ws<16, 32, TAPS>(A, st);
-        case 16 * 1000 + 64: return launch_conv_ws<16, 64, TAPS>(A, st);
-        case 32 * 1000 + 32: return launch_conv_ws<32, 32, TAPS>(A, st);
-        case 32 * 1000 + 64: return launch_conv_ws<32, 64, TAPS>(A, st);
-        case 64 * 1000 + 32: return launch_conv_ws<64, 32, TAPS>(A, st);
-        case 64 * 1000 + 64: return launch_conv_ws<64, 64, TAPS>(A, st);
-        case 80 * 1000 + 32: return launch_conv_ws<80, 32, TAPS>(A, st);
-        default:
-            set_error("cdnet_conv: unsupported weight-stationary configuration Cin=%d BN=%d", A.CK, A.BN);
-            return CDNET_E_ARG;
-    }
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a plain vector: HIP's uint4 struct copies become memcpys SROA cannot split
-template <int NB>
-struct BRegs { u32x4 r[NB]; };
-template <int NB, int B_BYTES>
-__device__ __forceinline__ void issue_b(BRegs<NB> &p, const unsigned short *w, int tid) {
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(w);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) { const int v = tid + i * 256; if (v < B_BYTES / 16) p.r[i] = src[v]; }
-}
-template <int NB, int B_BYTES>
-__device__ __forceinline__ void commit_b(const BRegs<NB> &p, unsigned char *lds_b, int tid) {
-    u32x4 *dst = reinterpret_cast<u32x4 *>(lds_b);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) { const int v = tid + i * 256; if (v < B_BYTES / 16) dst[v] = p.r[i]; }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// v2 main loop: the input halo is staged in chunks of CKA channels (full 128-byte lines per pixel when CKA = 64: the
-// 32-byte-per-pixel segments of a 16-channel chunk wasted 3/4 of every line the texture path fetched), while the
-// weights still arrive in 16-channel sub-chunks (18 KB for 64 couts) prefetched one step ahead from L2.  One barrier
-// pair per sub-chunk, the A tile is written once per CKA channels.
-// ------------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CKA, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256, (BN <= 64 ? 2 : 1)) void conv_fwd2_kernel(ConvArgs A) {
-    constexpr int PSTR = CKA * 2 + 16;
-    constexpr int HW_ = TW + 2;
-    constexpr int NPIX = (TH + 2) * (TW + 2);
-    constexpr int MT = TH * TW / 32, NT = BN / 32;
-    constexpr int MPW = MT / WM, NPW = NT / WN;
-    constexpr int A_BYTES = NPIX * PSTR;
-    constexpr int B_BYTES = TAPS * 16 * BN * 2;
-    constexpr int NA = (NPIX * (CKA / 8) + 255) / 256;
-    constexpr int NB = (B_BYTES / 16 + 255) / 256;
-    constexpr int OSTR = BN * 2 + 8;
-    static_assert(MT % WM == 0 && NT % WN == 0 && WM * WN == 4, "wave tiling");
-    static_assert(NA <= 32, "valid mask");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *lds_a = smem;
-    unsigned char *lds_b = smem + A_BYTES;
-    __shared__ float s_stats[4][2][BN];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
-    const int tiles_img = tiles_x * tiles_y;
-    const int tile = blockIdx.x;
-    const int cout_tile = blockIdx.y;
-    const int z = tile / tiles_img, rr_ = tile - z * tiles_img;
-    const int n = z / A.npar, par = z - n * A.npar;
-    const int y0 = (rr_ / tiles_x) * TH, x0 = (rr_ % tiles_x) * TW;
-
-    const int par_a = par >> 1, par_b = par & 1;
-    auto tap_off = [&](int t) -> int {           // compile-time for 3x3 / 1x1; two scalar selects for the transposed-conv phases
-        if (TAPS == 9) return ((t / 3) * HW_ + t % 3) * PSTR;
-        if (TAPS == 4) {
-            const int ty = t >> 1, tx = t & 1;
-            const int r = par_a == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
-            const int c = par_b == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
-            return (r * HW_ + c) * PSTR;
-        }
-        return (HW_ + 1) * PSTR;
-    };
-    int abase[MPW];
-#pragma unroll
-    for (int mi = 0; mi < MPW; ++mi) {
-        const int m = (wm * MPW + mi) * 32 + l31;
-        abase[mi] = ((m / TW) * HW_ + m % TW) * PSTR + half * 16;
-    }
-    const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
-    const unsigned short *wbase = A.w + ((size_t)(par * gridDim.y + cout_tile) * A.nchunk) * (B_BYTES / 2);
-
-    // ---- A chunk enumeration: (source, first channel, width) ----
-    auto a_chunk = [&](int idx, int &si, int &cc0, int &cw) {
-        const int c0 = A.src[0].C, n0 = (c0 + CKA - 1) / CKA;
-        if (idx < n0) { si = 0; cc0 = idx * CKA; cw = c0 - cc0 < CKA ? c0 - cc0 : CKA; }
-        else { si = 1; cc0 = (idx - n0) * CKA; const int c1 = A.src[1].C; cw = c1 - cc0 < CKA ? c1 - cc0 : CKA; }
-    };
-    int na_chunks = (A.src[0].C + CKA - 1) / CKA;
-    if (A.nsrc > 1) na_chunks += (A.src[1].C + CKA - 1) / CKA;
-
-    uint4 pa[NA];
-    BRegs<NB> pb;
-    unsigned valid = 0;
-    auto issue_a = [&](int idx) {
-        int si, cc0, cw;
-        a_chunk(idx, si, cc0, cw);
-        const ConvSrc &S = A.src[si];
-        valid = 0;
-        if (S.pool) return;
-        const int vpp = cw / 8, slot = tid % vpp;
-        const size_t rs = S.row_stride ? (size_t)S.row_stride : (size_t)S.Ws * S.C;
-        const size_t img = (size_t)n * S.Hs * rs;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int v = tid + i * 256;
-            const int pix = v / vpp, hy = pix / HW_, hx = pix - hy * HW_;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const int ys = y - S.off_y, xs = x - S.off_x;
-            if (v < NPIX * vpp && y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < S.Hs && xs >= 0 && xs < S.Ws) {
-                pa[i] = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)ys * rs + (size_t)xs * S.C + cc0 + slot * 8);
-                valid |= 1u << i;
-            }
-        }
-    };
-    auto commit_a = [&](int idx) {
-        int si, cc0, cw;
-        a_chunk(idx, si, cc0, cw);
-        const ConvSrc &S = A.src[si];
-        const int vpp = cw / 8, slot = tid % vpp;
-        ChanXf t;
-        t.on = S.scale != nullptr;
-        if (t.on) {
-            const float4 *ps = reinterpret_cast<const float4 *>(S.scale + cc0 + slot * 8);
-            const float4 *ph = reinterpret_cast<const float4 *>(S.shift + cc0 + slot * 8);
-            float4 a = ps[0], b = ps[1], c = ph[0], d = ph[1];
-            t.sc[0] = a.x; t.sc[1] = a.y; t.sc[2] = a.z; t.sc[3] = a.w; t.sc[4] = b.x; t.sc[5] = b.y; t.sc[6] = b.z; t.sc[7] = b.w;
-            t.sh[0] = c.x; t.sh[1] = c.y; t.sh[2] = c.z; t.sh[3] = c.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
-        }
-        const bool relu = S.relu != 0, f16 = S.f16 != 0;
-        const bool plain = !t.on && !relu && S.res == nullptr && !f16;
-        const int Hl = S.pool ? (S.Hs + (S.pool == 2)) / 2 : S.Hs, Wl = S.pool ? (S.Ws + (S.pool == 2)) / 2 : S.Ws;
-        const size_t rs = S.row_stride ? (size_t)S.row_stride : (size_t)S.Ws * S.C;
-        const size_t img = (size_t)n * S.Hs * rs;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int v = tid + i * 256;
-            if (v >= NPIX * vpp) continue;
-            const int pix = v / vpp, hy = pix / HW_, hx = pix - hy * HW_;
-            V16 val;
-            val.u = make_uint4(0, 0, 0, 0);
-            if (!S.pool) {
-                if (valid & (1u << i)) {
-                    V16 raw;
-                    raw.u = pa[i];
-                    if (plain) val = raw;
-                    else if (S.res) {
-                        const size_t e = img + (size_t)(y0 - 1 + hy - S.off_y) * rs + (size_t)(x0 - 1 + hx - S.off_x) * S.C + cc0 + slot * 8;
-                        V16 r;
-                        r.u = *reinterpret_cast<const uint4 *>(S.res + e);
-                        val = xform8(raw, &r, t, relu, f16);
-                    } else val = xform8(raw, nullptr, t, relu, f16);
-                }
-            } else {
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                const int ys = y - S.off_y, xs = x - S.off_x;
-                if (y >= 0 && y < A.H && x >= 0 && x < A.W && ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
-                        if (q != 0 && (yy >= S.Hs || xx >= S.Ws)) continue;
-                        V16 raw;
-                        raw.u = *reinterpret_cast<const uint4 *>(S.x + img + (size_t)yy * rs + (size_t)xx * S.C + cc0 + slot * 8);
-                        V16 tv = plain ? raw : xform8(raw, nullptr, t, relu, f16);
-                        val = q == 0 ? tv : max8(val, tv, relu);
-                    }
-                }
-            }
-            *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
-        }
-    };
-    f32x16 acc[MPW][NPW];
-#pragma unroll
-    for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    issue_a(0);
-    issue_b<NB, B_BYTES>(pb, wbase, tid);
-    int g = 0;                                   // global 16-channel sub-chunk counter (= weight chunk index)
-    for (int ia = 0; ia < na_chunks; ++ia) {
-        int si, cc0, cw;
-        a_chunk(ia, si, cc0, cw);
-        const int nsub = cw / 16;
-        __syncthreads();                         // all fragment reads of the previous A chunk / B sub-chunk are done
-        commit_a(ia);
-        commit_b<NB, B_BYTES>(pb, lds_b, tid);
-        __syncthreads();
-        if (ia + 1 < na_chunks) issue_a(ia + 1);
-        for (int sb = 0; sb < nsub; ++sb, ++g) {
-            const bool more = g + 1 < A.nchunk;
-            if (more) issue_b<NB, B_BYTES>(pb, wbase + (size_t)(g + 1) * (B_BYTES / 2), tid);
-            if (!(A.debug & 4)) {
-#pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    bf16x8 af[MPW], bfr[NPW];
-#pragma unroll
-                    for (int mi = 0; mi < MPW; ++mi)
-                        af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + abase[mi] + tap_off(t) + sb * 32);
-#pragma unroll
-                    for (int ni = 0; ni < NPW; ++ni)
-                        bfr[ni] = *reinterpret_cast<const bf16x8 *>(lds_b + bbase + (t * 2) * BN * 16 + ni * 512);
-#pragma unroll
-                    for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NPW; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
-                }
-            }
-            if (sb + 1 < nsub) {                 // next weight sub-chunk of the same A chunk
-                __syncthreads();
-                commit_b<NB, B_BYTES>(pb, lds_b, tid);
-                __syncthreads();
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---------------- epilogue (identical to the v1 kernel) ----------------
-    const int cout0 = cout_tile * BN;
-    unsigned char *s_out = smem;
-    const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
-    float ssum[NPW], ssq[NPW];
-#pragma unroll
-    for (int ni = 0; ni < NPW; ++ni) { ssum[ni] = 0.f; ssq[ni] = 0.f; }
-#pragma unroll
-    for (int ni = 0; ni < NPW; ++ni) {
-        const int col = (wn * NPW + ni) * 32 + l31;
-        const int co = cout0 + col;
-        const bool cok = co < A.Cout;
-        const float bias = (A.bias && cok) ? A.bias[co] : 0.f;
-        const float osc = (A.oscale && cok) ? A.oscale[co] : 1.f;
-        const float osh = (A.oshift && cok) ? A.oshift[co] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[mi][ni][r];
-                if (A.stats) {
-                    bool ok = full || ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W);
-                    if (ok) { ssum[ni] += v; ssq[ni] = fmaf(v, v, ssq[ni]); }
-                }
-                v += bias;
-                v = fmaf(v, osc, osh);
-                if (A.orelu) v = fmaxf(v, 0.f);
-                const unsigned mine = A.out_f16 ? f2h(v) : f2bf(v);
-                const unsigned other = __shfl_xor(mine, 1);
-                if (!(l31 & 1)) *reinterpret_cast<unsigned *>(s_out + m * OSTR + col * 2) = mine | (other << 16);
-            }
-        }
-    }
-    if (A.stats) {
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni) {
-            ssum[ni] += __shfl_xor(ssum[ni], 32);
-            ssq[ni] += __shfl_xor(ssq[ni], 32);
-            if (half == 0) {
-                s_stats[wave][0][(wn * NPW + ni) * 32 + l31] = ssum[ni];
-                s_stats[wave][1][(wn * NPW + ni) * 32 + l31] = ssq[ni];
-            }
-        }
-    }
-    __syncthreads();
-    if (A.stats && tid < 2 * BN) {
-        const int which = tid / BN, col = tid % BN;
-        const int wn_of = col / (NPW * 32);
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < WM; ++k) v += s_stats[k * WN + wn_of][which][col];
-        const int co = cout0 + col;
-        if (co < A.Cout) A.stats[((size_t)tile * 2 + which) * A.Cout + co] = v;
-    }
-    {
-        constexpr int VO = BN / 8;
-        const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
-        const int pa_ = par >> 1, pb_ = par & 1;
-        for (int v = tid; v < TH * TW * VO; v += 256) {
-            const int m = v / VO, q = v % VO;
-            const int y = y0 + m / TW, x = x0 + m % TW;
-            const int co = cout0 + q * 8;
-            if (y < A.H && x < A.W && co < A.Cout) {
-                const int oy = y * A.ostride + pa_, ox = x * A.ostride + pb_;
-                const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
-                *reinterpret_cast<uint4 *>(A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co) = val;
-            }
-        }
-    }
-}
-
-template <int TH, int TW, int CKA, int BN, int WM, int WN, int TAPS>
-int launch_conv2(const ConvArgs &A, hipStream_t st) {
-    constexpr int stage_bytes = (TH + 2) * (TW + 2) * (CKA * 2 + 16) + TAPS * 16 * BN * 2;
-    constexpr int out_bytes = TH * TW * (BN * 2 + 8);
-    constexpr int smem = stage_bytes > out_bytes ? stage_bytes : out_bytes;
-    auto kern = conv_fwd2_kernel<TH, TW, CKA, BN, WM, WN, TAPS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(conv2)");
-        attr_done = true;
-    }
-    dim3 grid(cdiv(A.W, TW) * cdiv(A.H, TH) * A.N * A.npar, cdiv(A.Cout, BN), 1);
-    kern<<<grid, 256, smem, st>>>(A);
-    return check_launch("conv_fwd2_kernel");
-}
-
-template <int TAPS>
-int dispatch_conv2(const ConvArgs &A, hipStream_t st) {
-    const int key = A.tile * 10000 + A.CK * 100 + (A.BN == 128 ? 99 : A.BN);     // A.CK carries CKA here
-    switch (key) {
-        case 16 * 10000 + 64 * 100 + 64: return launch_conv2<16, 16, 64, 64, 4, 1, TAPS>(A, st);
-        case 16 * 10000 + 64 * 100 + 32: return launch_conv2<16, 16, 64, 32, 4, 1, TAPS>(A, st);
-        case 16 * 10000 + 32 * 100 + 64: return launch_conv2<16, 16, 32, 64, 4, 1, TAPS>(A, st);
-        case 16 * 10000 + 32 * 100 + 32: return launch_conv2<16, 16, 32, 32, 4, 1, TAPS>(A, st);
-        case 8 * 10000 + 64 * 100 + 64: return launch_conv2<8, 8, 64, 64, 2, 2, TAPS>(A, st);
-        case 8 * 10000 + 64 * 100 + 99: return launch_conv2<8, 8, 64, 128, 2, 2, TAPS>(A, st);
-        default:
-            set_error("cdnet_conv: unsupported v2 configuration tile=%d CKA=%d BN=%d", A.tile, A.CK, A.BN);
-            return CDNET_E_ARG;
-    }
-}
-
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
 int launch_conv(const ConvArgs &A, hipStream_t st) {
-    constexpr int PSTR = CK * 2 + 16;
-    constexpr int stage_bytes = (TH + 2) * (TW + 2) * PSTR + TAPS * CK * BN * 2;
-    constexpr int out_bytes = TH * TW * (BN * 2 + 8);          // the out tile reuses the staging buffers
-    constexpr int smem = stage_bytes > out_bytes ? stage_bytes : out_bytes;
+    using LDS = ConvLds<TH, TW, CK, BN, TAPS>;
+    int ctot = 0;
+    for (int i = 0; i < A.nsrc; ++i) ctot += A.src[i].C;
+    const int smem = LDS::bytes(ctot);
     auto kern = conv_fwd_kernel<TH, TW, CK, BN, WM, WN, TAPS>;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS::bytes(XF_MAX)) != hipSuccess)
             return check_launch("hipFuncSetAttribute(conv)");
         attr_done = true;
     }
@@ -1305,25 +740,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         for (int i = 0; i < A.nsrc; ++i) ctot_xf += A.src[i].C;
         CDNET_REQUIRE(ctot_xf <= XF_MAX, "cdnet_conv_forward: %d source channels exceed the %d-entry scale/shift table", ctot_xf, XF_MAX);
     }
-    if (A.ws == 2) {
-        int nsub = 0;
-        for (int i = 0; i < A.nsrc; ++i) { CDNET_REQUIRE(A.src[i].x && A.src[i].C % 16 == 0, "cdnet_conv_forward: v2 source channels must be multiples of 16"); nsub += A.src[i].C / 16; }
-        CDNET_REQUIRE(nsub == A.nchunk, "cdnet_conv_forward: v2 nchunk %d != %d 16-channel sub-chunks", A.nchunk, nsub);
-        CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0 && A.Cout % 8 == 0, "cdnet_conv_forward: output channel slice");
-        hipStream_t st2 = (hipStream_t)stream;
-        if (A.taps == 9) return dispatch_conv2<9>(A, st2);
-        if (A.taps == 4) return dispatch_conv2<4>(A, st2);
-        return dispatch_conv2<1>(A, st2);
-    }
-    if (A.ws) {
-        int ctot = 0;
-        for (int i = 0; i < A.nsrc; ++i) { CDNET_REQUIRE(A.src[i].x && A.src[i].C % 8 == 0, "cdnet_conv_forward: ws source channels"); ctot += A.src[i].C; }
-        CDNET_REQUIRE(ctot == A.CK && A.nchunk == 1 && A.npar == 1 && A.ostride == 1 && (A.taps == 9 || A.taps == 1) && A.tile == 16,
-                      "cdnet_conv_forward: weight-stationary mode needs CK == total Cin (%d vs %d), stride 1, 3x3 or 1x1", A.CK, ctot);
-        CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0 && A.Cout % 8 == 0, "cdnet_conv_forward: output channel slice");
-        hipStream_t st2 = (hipStream_t)stream;
-        return A.taps == 9 ? dispatch_conv_ws<9>(A, st2) : dispatch_conv_ws<1>(A, st2);
-    }
+    CDNET_REQUIRE(A.ws == 0, "cdnet_conv_forward: ws must be 0 (reserved)");
     int nchunk = 0;
     for (int i = 0; i < A.nsrc; ++i) {
         CDNET_REQUIRE(A.src[i].x && A.src[i].C % A.CK == 0, "cdnet_conv_forward: source %d channels %d not a multiple of CK=%d",

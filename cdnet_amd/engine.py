@@ -74,34 +74,25 @@ class Src:
         cs.row_stride = int(self.row_stride)
 
 
-_V2_SUPPORTED = {(16, 64, 64), (16, 64, 32), (16, 32, 64), (16, 32, 32), (8, 64, 64), (8, 64, 128)}    # (tile, CKA, BN)
-_WS_SUPPORTED = {(16, 32), (16, 64), (32, 32), (32, 64), (64, 32), (64, 64), (80, 32)}      # (total Cin, BN)
-
 _SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 128), (16, 64, 64),
               (8, 32, 64), (8, 32, 128), (8, 64, 64)}
 
 
-def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False, allow_ws=False):
-    """(tile, CK, BN[, 'ws']) for a layer.  CK must divide every source's channel count; the 4-tuple form selects the
-    weight-stationary persistent kernel (CK = total Cin)."""
+def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False, N=16):
+    """(tile, CK, BN) for a layer.  CK must divide every source's channel count.  N = images per launch."""
     if override is not None:
-        assert tuple(override[:3]) in _SUPPORTED or (len(override) == 4 and ((override[1], override[2]) in _WS_SUPPORTED or tuple(override[:3]) in _V2_SUPPORTED)), override
+        assert tuple(override) in _SUPPORTED, override
         return tuple(override)
     ctot = sum(src_channels)
-    if allow_ws and not transposed and taps in (9, 1) and min(H, W) >= 32:
-        bn = 64 if Cout > 32 else 32
-        if (ctot, bn) in _WS_SUPPORTED:
-            return (16, ctot, bn, 'ws')
-    small = min(H, W) <= 8
+    # few pixels: 8x8 tiles give the grid more workgroups (measured: 16x16 layers at 16 images, 8x8 layers always)
+    small = min(H, W) <= 8 or (min(H, W) <= 16 and N <= 32)
     ck = 64
     while any(c % ck for c in src_channels):
         ck //= 2
     assert ck >= 16, 'source channels must be multiples of 16: %s' % (src_channels,)
     if small:
-        assert ck >= 32
-        if Cout >= 128:
-            return (8, 32, 128)
-        return (8, ck, 64)
+        if ck >= 32:
+            return (8, 32, 64)
     if ck == 64:
         ck = 32                       # 2 workgroups per CU (LDS) beat one fat one
     bn = 64 if Cout > 32 else 32
@@ -119,8 +110,6 @@ def packed_elems(Cout, nchunk, taps, CK, BN, npar):
 def _pack_dims(w, cfg, mode):
     """(Cout, Cin, KH, KW, CK, BN, taps, npar) as cdnet_pack_conv_weights wants them (GEMM roles, see include/cdnet_hip.h)"""
     _, CK, BN = cfg[:3]
-    if len(cfg) == 4 and cfg[3] == 'v2':
-        CK = 16                                # v2 kernels stream the weights in 16-channel sub-chunks whatever the A chunk is
     if mode == 0:
         Cout, Cin, KH, KW = w.shape
     elif mode == 1:
@@ -174,8 +163,6 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
                  orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
-    ws = len(cfg) == 4 and cfg[3] == 'ws'
-    v2 = len(cfg) == 4 and cfg[3] == 'v2'
     tile, CK, BN = cfg[:3]
     s0 = srcs[0]
     N = s0.N
@@ -187,12 +174,9 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a = ConvArgs()
     nchunk = 0
     for i, s in enumerate(srcs):
-        assert ws or v2 or s.C % CK == 0, (s.C, CK)
+        assert s.C % CK == 0, (s.C, CK)
         s.fill(a.src[i])
-        nchunk += s.C // (16 if v2 else CK)
-    if ws:
-        assert sum(s.C for s in srcs) == CK
-        nchunk = 1
+        nchunk += s.C // CK
     a.nsrc = len(srcs)
     if out is None:
         out = torch.empty((N, H * ostride, W * ostride, Cout), dtype=out_dtype, device=s0.x.device)
@@ -207,6 +191,6 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
-    a.ws = 2 if v2 else int(ws)
+    a.ws = 0
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

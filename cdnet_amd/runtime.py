@@ -84,10 +84,10 @@ class ConvLayer:
             v = (v, self.bias._version)
         return v
 
-    def prepare(self, src_channels, H, W):
+    def prepare(self, src_channels, H, W, N=16):
         cin_total = sum(src_channels)
         if self.cfg is None:
-            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override, taps=self.taps, transposed=self.transposed)
+            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override, taps=self.taps, transposed=self.transposed, N=N)
         ver = (self.weight._version, WEIGHTS_EPOCH[0])
         if self.wp is None or self.wp_version != ver:
             pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16
@@ -136,7 +136,7 @@ class ConvLayer:
             H, W = srcs[0].logical_hw()
         if DEBUG_NORELU:
             relu = False
-        self.prepare([s.C for s in srcs], H, W)
+        self.prepare([s.C for s in srcs], H, W, srcs[0].N)
         bias = None if self.bias is None else self.bias.detach()
         if self.bn is None:
             out, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, bias=bias, H=H, W=W,

@@ -141,7 +141,7 @@ typedef struct cdnet_conv_args {
     int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
     int out_f16;            /* 1: store the output as fp16 instead of bf16 */
     int debug;              /* must be 0 (kernel ablation switches used by tools/bench_conv.py) */
-    int ws;                 /* 1: weight-stationary persistent kernel (total Cin == CK <= 80, 3x3 / 1x1, stride 1) */
+    int ws;                 /* reserved, must be 0 */
     int pad2_;
 } cdnet_conv_args;
 

@@ -43,20 +43,6 @@ CASES_3x3 = [
     (1, 64, 64, 8, 16, (8, 64, 64)),
     (1, 128, 64, 12, 20, (8, 32, 64)),
     (1, 64, 128, 8, 8, (8, 32, 128)),
-    # v2 kernels: A chunks of CKA channels, 16-channel weight sub-chunks
-    (2, 64, 64, 48, 40, (16, 64, 64, 'v2')),
-    (1, 128, 128, 33, 17, (16, 64, 64, 'v2')),
-    (2, 96, 64, 16, 32, (16, 64, 64, 'v2')),      # ragged last A chunk (32 of 64)
-    (1, 64, 32, 32, 32, (16, 64, 32, 'v2')),
-    (1, 32, 64, 32, 48, (16, 32, 64, 'v2')),
-    (2, 128, 256, 8, 8, (8, 64, 128, 'v2')),
-    (1, 192, 64, 12, 20, (8, 64, 64, 'v2')),
-    # weight-stationary persistent kernel (CK = total Cin)
-    (2, 64, 64, 48, 40, (16, 64, 64, 'ws')),
-    (3, 16, 64, 33, 65, (16, 16, 64, 'ws')),
-    (1, 64, 32, 32, 32, (16, 64, 32, 'ws')),
-    (2, 64, 128, 32, 48, (16, 64, 64, 'ws')),
-    (20, 32, 64, 64, 64, (16, 32, 64, 'ws')),    # more tiles than persistent workgroups
 ]
 
 
@@ -175,31 +161,3 @@ def test_conv_backward_data_pack():
     wp = engine.pack_weights(w.cuda(), cfg, 1)
     out, _ = engine.conv_forward([engine.Src(_nhwc(dy))], wp, Cin, cfg)
     _close(_nchw(out), want, 'bwd-data')
-
-
-def test_conv_ws_two_sources_transforms_stats():
-    """weight-stationary kernel with the dec4 shape: sources [16 (fp16 raw, affine+relu, pad offset), 64 (fp16 raw + residual)]"""
-    import torch
-    import torch.nn.functional as F
-    from cdnet_amd import engine
-    g = torch.Generator().manual_seed(23)
-    N, Ca, Cb, Cout, H, W = 3, 16, 64, 16, 40, 56
-    a = torch.randn((N, Ca, H - 2, W - 1), generator=g).half().float()
-    b = torch.randn((N, Cb, H, W), generator=g).half().float()
-    res = torch.randn((N, Cb, H, W), generator=g).half().float()
-    sa, ha = torch.rand((Ca,), generator=g) + 0.5, torch.randn((Ca,), generator=g) * 0.3
-    sb, hb = torch.rand((Cb,), generator=g) + 0.5, torch.randn((Cb,), generator=g) * 0.3
-    w = _bf(torch.randn((Cout, Ca + Cb, 3, 3), generator=g) * (2.0 / (9 * (Ca + Cb))) ** 0.5)
-    ta = F.pad(_bf(F.relu(a * sa.view(1, -1, 1, 1) + ha.view(1, -1, 1, 1))), (0, 1, 1, 1))
-    tb = _bf(F.relu(b * sb.view(1, -1, 1, 1) + hb.view(1, -1, 1, 1) + res))
-    want = F.conv2d(torch.cat([ta, tb], 1), w, None, padding=1)
-    cfg = (16, 80, 32, 'ws')
-    wp = engine.pack_weights(w.cuda(), cfg, 0)
-    srcs = [engine.Src(_nhwc(a, torch.float16), sa.cuda(), ha.cuda(), relu=True, off=(1, 0)),
-            engine.Src(_nhwc(b, torch.float16), sb.cuda(), hb.cuda(), relu=True, res=_nhwc(res, torch.float16))]
-    out, stats = engine.conv_forward(srcs, wp, Cout, cfg, stats=True, H=H, W=W, out_dtype=torch.float16)
-    got = out.float().cpu().permute(0, 3, 1, 2)
-    err = (got - want).abs()
-    assert float((err - (want.abs() * 2 ** -9 + 2e-3)).max()) <= 0, float(err.max())
-    np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), want.sum((0, 2, 3)).numpy(), rtol=2e-4, atol=3e-2)
-    np.testing.assert_allclose(stats.sum(0)[1].cpu().numpy(), (want * want).sum((0, 2, 3)).numpy(), rtol=2e-4, atol=3e-2)
