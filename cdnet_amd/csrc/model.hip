@@ -51,17 +51,24 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(const float *__r
                                                                 float eps, float momentum, float *rm, float *rv,
                                                                 float *scale, float *shift, float *mean_out,
                                                                 float *invstd_out) {
-    // one wave per channel: deterministic tree over the tiles
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    // one workgroup per channel (C workgroups keep every CU busy; the 4-byte reads of different channels share cache
+    // lines in L2): thread i sums tiles i, i+256, ... in order, then a fixed LDS tree - deterministic
+    __shared__ double s_s[256], s_q[256];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < T; t += 256) {
         s += (double)stats[((size_t)t * 2) * C + c];
         q += (double)stats[((size_t)t * 2 + 1) * C + c];
     }
+    s_s[lane] = s; s_q[lane] = q;
+    __syncthreads();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    for (int o = 128; o > 0; o >>= 1) {
+        if (lane < o) { s_s[lane] += s_s[lane + o]; s_q[lane] += s_q[lane + o]; }
+        __syncthreads();
+    }
+    s = s_s[0]; q = s_q[0];
     if (lane == 0) {
         double mean = s / count;
         double var = q / count - mean * mean;
@@ -331,7 +338,7 @@ extern "C" int cdnet_bn_finalize_train(const float *stats, int T, int C, float c
                                        float *running_var, float *scale, float *shift, float *save_mean,
                                        float *save_invstd, void *stream) {
     CDNET_REQUIRE(stats && gamma && beta && scale && shift && T > 0 && C > 0 && count > 0, "cdnet_bn_finalize_train: bad args");
-    bn_finalize_train_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(stats, T, C, count, gamma, beta, conv_bias, eps, momentum,
+    bn_finalize_train_kernel<<<C, 256, 0, (hipStream_t)stream>>>(stats, T, C, count, gamma, beta, conv_bias, eps, momentum,
                                                                          running_mean, running_var, scale, shift, save_mean,
                                                                          save_invstd);
     return check_launch("cdnet_bn_finalize_train");

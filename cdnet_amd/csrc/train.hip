@@ -396,17 +396,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     }
 }
 
-// sums [nb][2][C] -> dgamma, dbeta and the apply coefficients; one wave per channel, fixed butterfly (deterministic)
+// sums [nb][2][C] -> dgamma, dbeta and the apply coefficients; one workgroup per channel, fixed LDS tree (deterministic)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int C, float M, const float *gamma,
                                                               const float *invstd, float *dgamma, float *dbeta, float *k1, float *k2,
                                                               float *k3) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double s_a[256], s_b[256];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nb; b += 64) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nb; b += 256) { s1 += (double)partial[((size_t)b * 2) * C + c]; s2 += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    s_a[lane] = s1; s_b[lane] = s2;
+    __syncthreads();
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    for (int o = 128; o > 0; o >>= 1) {
+        if (lane < o) { s_a[lane] += s_a[lane + o]; s_b[lane] += s_b[lane + o]; }
+        __syncthreads();
+    }
+    s1 = s_a[0]; s2 = s_b[0];
     if (lane == 0) {
         if (dbeta) dbeta[c] = (float)s1;
         if (dgamma) dgamma[c] = (float)s2;
@@ -1074,7 +1080,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
                 default: bn_bwd_reduce_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
             }
         } else bn_bwd_reduce_kernel<<<nb, 256, 0, st>>>(A);
-        bn_bwd_finalize_kernel<<<cdiv(A.C, 4), 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
+        bn_bwd_finalize_kernel<<<A.C, 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
                                                               k + A.C, k + 2 * A.C);
         A.k1 = k; A.k2 = k + A.C; A.k3 = k + 2 * A.C;
     }
