@@ -6,6 +6,7 @@
 //   DAM head: point_conv, directionAtt, direction_conv, maskAtt, mask_conv fused per pixel
 //     (models/dam/model_unet_rev1.py:8-17, 227-231, 258-263)
 #include "common.h"
+#include "xform.h"
 
 using namespace cdnet;
 
@@ -136,12 +137,20 @@ __device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const
 __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q, const float *s_sc, const float *s_sh, float *v) {
     const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64 + q * 16);
     const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64 + q * 16) : nullptr;
+    const bool fast = f.f16 && f.scale && f.relu;        // training-mode feature: packed math (xform.h)
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
         uint4 r = pr[h2];
-        const unsigned short *h = reinterpret_cast<const unsigned short *>(&r);
         uint4 rr = make_uint4(0, 0, 0, 0);
         if (ps) rr = ps[h2];
+        if (fast) {
+            const xf_u32x4 a = __builtin_bit_cast(xf_u32x4, r), b = __builtin_bit_cast(xf_u32x4, rr);
+            const int c0 = q * 16 + h2 * 8;
+            if (ps) xf_bnrelu_f16_to_f32<true>(a, b, s_sc + c0, s_sh + c0, v + h2 * 8);
+            else xf_bnrelu_f16_to_f32<false>(a, a, s_sc + c0, s_sh + c0, v + h2 * 8);
+            continue;
+        }
+        const unsigned short *h = reinterpret_cast<const unsigned short *>(&r);
         const unsigned short *hr = reinterpret_cast<const unsigned short *>(&rr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -158,11 +167,7 @@ __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q
     }
 }
 
-__device__ __forceinline__ float quad_sum(float v) {        // sum over the 4 lanes of a pixel
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    return v;
-}
+__device__ __forceinline__ float quad_sum(float v) { return xf_quad_sum(v); }        // sum over the 4 lanes of a pixel
 
 // four lanes per pixel, 16 channels each: 4x the parallelism and a quarter of the registers of one-thread-per-pixel
 __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,

@@ -6,6 +6,7 @@
 //   loss terms :167-276 with loss.py:131-260 (dice / weighted cyclic dice), nn.NLLLoss(reduction='none') x weight map,
 //   nn.MSELoss; loss.backward() :307 (non-convolution parts); optimizer.step() :308 with utils.py:915-918 (Adam).
 #include "common.h"
+#include "xform.h"
 
 using namespace cdnet;
 
@@ -492,6 +493,12 @@ __device__ __forceinline__ void feat8(const HeadFeat &f, size_t pix, int c0, con
     r.u = *reinterpret_cast<const uint4 *>(f.raw + pix * 64 + c0);
     rr.u = make_uint4(0, 0, 0, 0);
     if (f.res) rr.u = *reinterpret_cast<const uint4 *>(f.res + pix * 64 + c0);
+    if (f.f16 && f.scale && f.relu) {            // training-mode feature: packed math (xform.h)
+        const xf_u32x4 a = __builtin_bit_cast(xf_u32x4, r.u), b = __builtin_bit_cast(xf_u32x4, rr.u);
+        if (f.res) xf_bnrelu_f16_to_f32<true>(a, b, s_sc + c0, s_sh + c0, v);
+        else xf_bnrelu_f16_to_f32<false>(a, a, s_sc + c0, s_sh + c0, v);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float x = f.f16 ? h2f(r.h[j]) : bf2f(r.h[j]);
@@ -542,11 +549,7 @@ __device__ __forceinline__ void feat16(const HeadFeat &f, size_t pix, int q, con
     feat8(f, pix, q * 16, s_sc, s_sh, v);
     feat8(f, pix, q * 16 + 8, s_sc, s_sh, v + 8);
 }
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    return v;
-}
+__device__ __forceinline__ float quad_sum(float v) { return xf_quad_sum(v); }
 __device__ __forceinline__ void store16_bf16(unsigned short *dst, const float *v) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {

@@ -48,4 +48,24 @@ __device__ __forceinline__ xf_u32x4 xf_max_nonneg_bf8(xf_u32x4 a, xf_u32x4 b) {
     return O.u;
 }
 
+
+// the same transform, result widened to 8 floats (the values the MFMA kernels see: bf16-rounded)
+template <bool RES>
+__device__ __forceinline__ void xf_bnrelu_f16_to_f32(xf_u32x4 raw, xf_u32x4 res, const float *sc, const float *sh, float *out) {
+    XfWords O;
+    O.u = xf_bnrelu_f16<RES>(raw, res, sc, sh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out[2 * k] = __builtin_bit_cast(float, O.w[k] << 16);
+        out[2 * k + 1] = __builtin_bit_cast(float, O.w[k] & 0xffff0000u);
+    }
+}
+
+// sum over the 4 lanes of a quad with two DPP moves (no LDS permute)
+__device__ __forceinline__ float xf_quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // lanes ^ 1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // lanes ^ 2
+    return v;
+}
+
 }  // namespace cdnet
