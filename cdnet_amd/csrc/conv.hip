@@ -242,11 +242,19 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
 // and only transformed / written to LDS after it, so their HBM/L2 latency hides under the matrix work (guide T14).
 // Pooled sources (4 loads + max per element) keep the synchronous path.
 // ------------------------------------------------------------------------------------------------------
+#ifndef CDNET_CONV_GLDS
+#define CDNET_CONV_GLDS 1
+#endif
+#ifndef CDNET_CONV_ADEPTH
+#define CDNET_CONV_ADEPTH 1
+#endif
 // LDS layout of conv_fwd_kernel (dynamic): [A halo tile][B chunk (x2 when the weights arrive by LDS-DMA)] aliased by the
 // out tile + the BatchNorm partial sums, followed by the scale|shift table of the source channels.
 template <int TH, int TW, int CK, int BN, int TAPS>
 struct ConvLds {
-    static constexpr bool GLDS = (CK == 16 && TH == 16);      // weights by global_load_lds into a double buffer
+    static constexpr bool DEEP = (CK == 16 && TH == 16);      // 16-channel chunks: prefetch ring of ADEPTH halo chunks
+    static constexpr bool GLDS = CDNET_CONV_GLDS && DEEP;     // weights by global_load_lds into a double buffer
+    static constexpr int ADEPTH = DEEP ? CDNET_CONV_ADEPTH : 1;
     static constexpr int PSTR = CK * 2 + 16;
     static constexpr int A_BYTES = (TH + 2) * (TW + 2) * PSTR;
     static constexpr int B_BYTES = TAPS * CK * BN * 2;
@@ -264,21 +272,26 @@ struct Prefetch {
     static constexpr int NA = (NPIX * VPP + 255) / 256;
     static constexpr bool GLDS = ConvLds<TH, TW, CK, BN, TAPS>::GLDS;
     static constexpr int NB = (TAPS * CK * BN * 2 / 16 + 255) / 256;
-    uint4 a[NA], b[GLDS ? 1 : NB];
+    static constexpr int ADEPTH = ConvLds<TH, TW, CK, BN, TAPS>::ADEPTH;
+    struct ASlot {
+        uint4 a[NA];
+        unsigned valid;      // snapshot of the source's tvalid taken at issue time
+        bool pooled;         // synchronous path at commit time
+    };
+    ASlot s[ADEPTH];         // ring of halo-chunk prefetches: chunk c lives in slot c % ADEPTH
+    uint4 b[GLDS ? 1 : NB];
     // per (tile, source) staging geometry, computed once by prep_source and reused by every chunk of that source:
-    int eoff[NA];            // element offset of the thread's i-th vector inside the image (channel 0 of its slot), -1 = zero fill
-    unsigned tvalid;         // bit i: eoff[i] >= 0
-    unsigned valid;          // snapshot of tvalid taken by issue_chunk (the source may change before the commit)
-    bool pooled;             // synchronous path at commit time
+    int eoff[2][NA];         // element offset of the thread's i-th vector inside the image (channel 0 of its slot), -1 = zero fill
+    unsigned tvalid[2];      // bit i: eoff[i] >= 0
 };
 
-template <int TH, int TW, int CK, int BN, int TAPS>
+template <int SI, int TH, int TW, int CK, int BN, int TAPS>
 __device__ __forceinline__ void prep_source(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int y0, int x0, int H, int W, int tid) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
     constexpr int HW_ = TW + 2;
     const int slot = tid % PF::VPP;
     const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
-    P.tvalid = 0;
+    P.tvalid[SI] = 0;
 #pragma unroll
     for (int i = 0; i < PF::NA; ++i) {
         const int v = tid + i * 256;
@@ -288,14 +301,13 @@ __device__ __forceinline__ void prep_source(Prefetch<TH, TW, CK, BN, TAPS> &P, c
         const int ys = y - s.off_y, xs = x - s.off_x;
         const bool inr = v < PF::NPIX * PF::VPP;
         const bool ok = inr && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
-        P.eoff[i] = ok ? ys * rs + xs * s.C + slot * 8 : -1;
-        P.tvalid |= (ok ? 1u : 0u) << i;
+        P.eoff[SI][i] = ok ? ys * rs + xs * s.C + slot * 8 : -1;
+        P.tvalid[SI] |= (ok ? 1u : 0u) << i;
     }
 }
 
 template <int TH, int TW, int CK, int BN, int TAPS>
-__device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n,
-                                            const unsigned short *wchunk, int tid, unsigned char *lds_b_next) {
+__device__ __forceinline__ void issue_b(Prefetch<TH, TW, CK, BN, TAPS> &P, const unsigned short *wchunk, int tid, unsigned char *lds_b_next) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
     if (PF::GLDS) {
         // weights: the packed chunk is the LDS image - LDS-DMA, one 1 KB wave-instruction per 64 vectors, no registers.
@@ -318,19 +330,27 @@ __device__ __forceinline__ void issue_chunk(Prefetch<TH, TW, CK, BN, TAPS> &P, c
             if (v < TAPS * CK * BN * 2 / 16) P.b[i] = src[v];
         }
     }
-    P.pooled = s.pool != 0;
-    P.valid = 0;
-    if (P.pooled) return;
+}
+
+// halo chunk of source `si` (channels cc0..cc0+CK) -> the registers of one ring slot
+template <typename PF>
+__device__ __forceinline__ void issue_a(PF &P, typename PF::ASlot &S, const ConvSrc &s, int si, int cc0, int n) {
+    S.pooled = s.pool != 0;
+    S.valid = 0;
+    if (S.pooled) return;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
     const unsigned short *base = s.x + (size_t)n * s.Hs * rs + cc0;
-    P.valid = P.tvalid;
+    S.valid = si ? P.tvalid[1] : P.tvalid[0];
 #pragma unroll
-    for (int i = 0; i < PF::NA; ++i)
-        if (P.eoff[i] >= 0) P.a[i] = *reinterpret_cast<const uint4 *>(base + P.eoff[i]);
+    for (int i = 0; i < PF::NA; ++i) {
+        const int e = si ? P.eoff[1][i] : P.eoff[0][i];
+        if (e >= 0) S.a[i] = *reinterpret_cast<const uint4 *>(base + e);
+    }
 }
 
 template <int TH, int TW, int CK, int BN, int TAPS>
-__device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS> &P, const ConvSrc &s, int cc0, int n, int y0,
+__device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS> &P, const typename Prefetch<TH, TW, CK, BN, TAPS>::ASlot &S,
+                                             const ConvSrc &s, int si, int cc0, int n, int y0,
                                              int x0, int H, int W, unsigned char *lds_a, unsigned char *lds_b, int tid,
                                              const float *xf, int xfs) {
     using PF = Prefetch<TH, TW, CK, BN, TAPS>;
@@ -342,7 +362,7 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
             if (v < TAPS * CK * BN * 2 / 16) dst[v] = P.b[i];
         }
     }
-    if (P.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid, xf, xfs); return; }
+    if (S.pooled) { stage_input<TH, TW, CK>(s, cc0, n, y0, x0, H, W, lds_a, tid, xf, xfs); return; }
     const int slot = tid % PF::VPP;
     ChanXf t;
     load_chan_xf(t, s, xf, xfs, cc0 + slot * 8);
@@ -355,7 +375,7 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
     if (s.res) {
         const unsigned short *rbase = s.res + (size_t)n * s.Hs * rs + cc0;
 #pragma unroll
-        for (int i = 0; i < PF::NA; ++i) rr[i].u = *reinterpret_cast<const uint4 *>(rbase + ((P.valid & (1u << i)) ? P.eoff[i] : 0));
+        for (int i = 0; i < PF::NA; ++i) rr[i].u = *reinterpret_cast<const uint4 *>(rbase + ((S.valid & (1u << i)) ? (si ? P.eoff[1][i] : P.eoff[0][i]) : 0));
     }
     // LDS address of vector i: pixel (tid / VPP + i * 256 / VPP), slot tid % VPP - affine in i
     constexpr int PSTR = CK * 2 + 16;
@@ -365,9 +385,9 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
         if (tid + i * 256 >= PF::NPIX * PF::VPP) continue;
         V16 val;
         val.u = make_uint4(0, 0, 0, 0);
-        if (P.valid & (1u << i)) {
+        if (S.valid & (1u << i)) {
             V16 raw;
-            raw.u = P.a[i];
+            raw.u = S.a[i];
             if (plain) val = raw;
             else if (s.res) val = xform8(raw, &rr[i], t, relu, f16);
             else val = xform8(raw, nullptr, t, relu, f16);
@@ -380,7 +400,7 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
 // the kernel
 // ------------------------------------------------------------------------------------------------------
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1)) void conv_fwd_kernel(ConvArgs A) {
+__global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CONV_ADEPTH <= 2 ? 3 : 2) : 1)) void conv_fwd_kernel(ConvArgs A) {
     constexpr int PSTR = CK * 2 + 16;
     constexpr int HW_ = TW + 2;
     constexpr int KC = CK / 16;
@@ -452,12 +472,19 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
     {
         int n, par, y0, x0;
         decode(tile, n, par, y0, x0);
-        {
-            int si, cc0;
-            chunk_src(0, si, cc0);
-            prep_source<TH, TW, CK, BN, TAPS>(P, A.src[si], y0, x0, A.H, A.W, tid);
-            issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, wchunk(par, 0), tid, lds_b0);
-        }
+        using PF = Prefetch<TH, TW, CK, BN, TAPS>;
+        constexpr int AD = PF::ADEPTH;
+        prep_source<0>(P, A.src[0], y0, x0, A.H, A.W, tid);
+        if (A.nsrc > 1) prep_source<1>(P, A.src[1], y0, x0, A.H, A.W, tid);
+        // prologue: the first AD halo chunks and the first weight chunk
+        issue_b(P, wchunk(par, 0), tid, lds_b0);
+#pragma unroll
+        for (int k = 0; k < AD; ++k)
+            if (k < nchunk_total) {
+                int si, cc0;
+                chunk_src(k, si, cc0);
+                issue_a(P, P.s[k], A.src[si], si, cc0, n);
+            }
         // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
         int toff[TAPS];
 #pragma unroll
@@ -479,21 +506,23 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-        for (int chunk = 0; chunk < nchunk_total; ++chunk) {
+        // one chunk step; K = ring slot of this chunk (compile-time so that the prefetch registers stay registers)
+        auto step = [&](auto kc_, int chunk) {
+            constexpr int K = decltype(kc_)::value;
             int si, cc0;
             chunk_src(chunk, si, cc0);
             __syncthreads();                               // previous chunk's fragment reads / previous tile's out-tile reads are done
             unsigned char *lds_b = lds_b0 + (GLDS ? (chunk & 1) * B_BYTES : 0);
-            commit_chunk<TH, TW, CK, BN, TAPS>(P, A.src[si], cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid, s_xf + (si ? A.src[0].C : 0), xfs);
+            commit_chunk<TH, TW, CK, BN, TAPS>(P, P.s[K], A.src[si], si, cc0, n, y0, x0, A.H, A.W, lds_a, lds_b, tid, s_xf + (si ? A.src[0].C : 0), xfs);
             __syncthreads();
-            // issue the loads of the next (tile, chunk) step now: they fly during the MFMA loop (and the epilogue)
-            if (chunk + 1 < nchunk_total) {
+            // refill: the weights of the next chunk and the halo chunk AD steps ahead fly during the MFMA loops
+            if (chunk + 1 < nchunk_total) issue_b(P, wchunk(par, chunk + 1), tid, lds_b0 + ((chunk + 1) & 1) * B_BYTES);
+            if (chunk + AD < nchunk_total) {
                 int sj, cj;
-                chunk_src(chunk + 1, sj, cj);
-                if (sj != si) prep_source<TH, TW, CK, BN, TAPS>(P, A.src[sj], y0, x0, A.H, A.W, tid);     // second concat source
-                issue_chunk<TH, TW, CK, BN, TAPS>(P, A.src[sj], cj, n, wchunk(par, chunk + 1), tid, lds_b0 + ((chunk + 1) & 1) * B_BYTES);
+                chunk_src(chunk + AD, sj, cj);
+                issue_a(P, P.s[K], A.src[sj], sj, cj, n);
             }
-            if (A.debug & 4) continue;
+            if (A.debug & 4) return;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
@@ -512,7 +541,14 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 ? 3 : 2) : 1
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
                 }
             }
+        };
+        for (int c0 = 0; c0 < nchunk_total; c0 += AD) {
+            step(std::integral_constant<int, 0>{}, c0);
+            if (AD > 1 && c0 + 1 < nchunk_total) step(std::integral_constant<int, (AD > 1 ? 1 : 0)>{}, c0 + 1);
+            if (AD > 2 && c0 + 2 < nchunk_total) step(std::integral_constant<int, (AD > 2 ? 2 : 0)>{}, c0 + 2);
+            if (AD > 3 && c0 + 3 < nchunk_total) step(std::integral_constant<int, (AD > 3 ? 3 : 0)>{}, c0 + 3);
         }
+        static_assert(AD <= 4, "ring depth");
         __syncthreads();
 
         // ---------------- epilogue ----------------
