@@ -743,3 +743,257 @@ extern "C" int cdnet_cc_chain(const uint8_t *pred, int fg_value, int N, int H, i
     dilate_disk_kernel<<<gr, br, 0, st>>>(lab, H, W, radius, final_);
     return check_launch("cdnet_cc_chain");
 }
+
+// ======================================================================================================
+// Watershed variant of the post-processing (postproc_other.py:15-99, ws branch :36-48)
+//   dist   = per-instance Euclidean distance transform scaled to 0..255 (gen_inst_dst_map :16-27)
+//   marker = label4(erode4(fill_holes(dist > 125))) with labels smaller than min_size dropped
+//   out    = watershed(-dist as uint8, marker, mask = pred), labels smaller than min_size dropped
+// Every step is integer / exactly-rounded fp64, so the result is bit-exact against the restatement in
+// oracle/postproc_oracle.c; steps up to the marker are pinned against scipy itself (tests/test_oracle_watershed.py).
+// The flood reproduces skimage's priority (value, then age); only its tie-break between marker pixels of equal value
+// and age 0 is unpinned (skimage absent): here raster order.
+// ======================================================================================================
+namespace {
+
+constexpr int WS_INF = 1 << 14;
+
+// h[p] = horizontal distance from p to the nearest pixel of its row whose component differs (WS_INF if none)
+__global__ __launch_bounds__(256) void ws_rowdist_kernel(const int *__restrict__ L, int H, int W, int *__restrict__ h) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const int k = L[base + i];
+        int best = WS_INF;
+        if (k >= 0) {
+            const int *row = L + base + (size_t)y * W;
+            for (int d = 1; d < best; ++d) {
+                const bool l = x - d >= 0, r = x + d < W;
+                if (!l && !r) break;
+                if ((l && row[x - d] != k) || (r && row[x + d] != k)) { best = d; break; }
+            }
+        }
+        h[base + i] = best;
+    }
+}
+
+// exact squared distance to the nearest pixel outside the own component: min over rows y' of dy^2 + (same ? h^2 : 0);
+// per-component maximum by atomicMax on the component's root slot
+__global__ __launch_bounds__(256) void ws_edt_kernel(const int *__restrict__ L, const int *__restrict__ h, int H, int W,
+                                                     int *__restrict__ d2, int *__restrict__ maxd2) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const int k = L[base + i];
+        if (k < 0) { d2[base + i] = 0; continue; }
+        long long best = (long long)h[base + i] * h[base + i];
+        for (int dy = 1; (long long)dy * dy < best; ++dy) {
+            bool any = false;
+#pragma unroll
+            for (int s = -1; s <= 1; s += 2) {
+                const int yy = y + s * dy;
+                if (yy < 0 || yy >= H) continue;
+                any = true;
+                const size_t q = base + (size_t)yy * W + x;
+                const long long c = (long long)dy * dy + (L[q] == k ? (long long)h[q] * h[q] : 0);
+                best = c < best ? c : best;
+            }
+            if (!any) break;
+        }
+        const int v = best > 0x3fffffff ? 0x3fffffff : (int)best;
+        d2[base + i] = v;
+        atomicMax(maxd2 + base + k, v);
+    }
+}
+
+// canvas = uint8(255 * (sqrt(d2) / sqrt(max d2))) in fp64 (numpy: 255 * (nuc_dst / np.amax(nuc_dst)), astype uint8);
+// marker mask = canvas > 125
+__global__ __launch_bounds__(256) void ws_canvas_kernel(const int *__restrict__ L, const int *__restrict__ d2,
+                                                        const int *__restrict__ maxd2, int plane, uint8_t *__restrict__ canvas,
+                                                        uint8_t *__restrict__ mk) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const int k = L[base + i];
+        uint8_t c = 0;
+        if (k >= 0) {
+            const double d = sqrt((double)d2[base + i]), m = sqrt((double)maxd2[base + k]);
+            c = (uint8_t)(255.0 * (d / m));
+        }
+        canvas[base + i] = c;
+        mk[base + i] = c > 125 ? 1 : 0;
+    }
+}
+
+// binary erosion by the 4-neighbour cross, outside = 0 (scipy binary_erosion defaults)
+__global__ __launch_bounds__(256) void ws_erode4_kernel(const uint8_t *__restrict__ a, int H, int W, uint8_t *__restrict__ out) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const uint8_t *p = a + base;
+        const bool v = p[i] && y > 0 && y < H - 1 && x > 0 && x < W - 1 && p[i - W] && p[i + W] && p[i - 1] && p[i + 1];
+        out[base + i] = v ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ws_hist_kernel(const int32_t *__restrict__ lab, int plane, int *__restrict__ area) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const int l = lab[base + i];
+        if (l > 0) atomicAdd(area + base + l, 1);          // labels <= plane / 2 < plane
+    }
+}
+
+// remove_small_objects on a label image: labels with fewer than min_size pixels -> 0 (ids are kept); also records the
+// last pixel (raster order) of every component of `comp` for the flood
+__global__ __launch_bounds__(256) void ws_drop_small_kernel(int32_t *__restrict__ lab, const int *__restrict__ area, int plane,
+                                                            int min_size) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const int l = lab[base + i];
+        if (l > 0 && area[base + l] < min_size) lab[base + i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ws_last_kernel(const int *__restrict__ L, int plane, int *__restrict__ last) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const int k = L[base + i];
+        if (k >= 0) atomicMax(last + base + k, i);
+    }
+}
+
+// The flood.  4-connected components of the mask are independent, so one thread owns one component (its root is its
+// raster-first pixel) and runs skimage's sequential algorithm on it: seeds = the component's marker pixels in raster
+// order; pop the smallest (value, age); every unlabelled 4-neighbour inside the mask (order: up, left, right, down)
+// takes the label and is pushed with its own value.  Values are uint8, so the priority queue is 256 FIFO buckets
+// (linked through next[]): FIFO order inside a bucket IS age order.
+__global__ __launch_bounds__(64) void ws_flood_kernel(const int *__restrict__ L, const int *__restrict__ last,
+                                                      const uint8_t *__restrict__ canvas, const int32_t *__restrict__ marker,
+                                                      int H, int W, int *__restrict__ next, int32_t *__restrict__ out) {
+    const int n = blockIdx.y;
+    const int plane = H * W;
+    const size_t base = (size_t)n * plane;
+    const int root = blockIdx.x * blockDim.x + threadIdx.x;
+    if (root >= plane || L[base + root] != root) return;
+    const int *Ln = L + base;
+    const uint8_t *cv = canvas + base;
+    int *nx = next + base;
+    int32_t *o = out + base;
+    int head[256], tail[256];
+    for (int b = 0; b < 256; ++b) head[b] = -1;
+    int lo = 256;
+    const int end = last[base + root];
+    for (int i = root; i <= end; ++i) {
+        if (Ln[i] != root) continue;
+        const int m = marker[base + i];
+        if (m <= 0) continue;
+        o[i] = m;
+        const int v = (256 - cv[i]) & 255;                 // uint8 negation of the distance map (postproc_other.py:47)
+        nx[i] = -1;
+        if (head[v] < 0) head[v] = i; else nx[tail[v]] = i;
+        tail[v] = i;
+        lo = v < lo ? v : lo;
+    }
+    while (true) {
+        while (lo < 256 && head[lo] < 0) ++lo;
+        if (lo >= 256) break;
+        const int p = head[lo];
+        head[lo] = nx[p];
+        const int lab = o[p];
+        const int y = p / W, x = p - y * W;
+        const int nb[4] = {y > 0 ? p - W : -1, x > 0 ? p - 1 : -1, x < W - 1 ? p + 1 : -1, y < H - 1 ? p + W : -1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = nb[j];
+            if (q < 0 || Ln[q] != root || o[q] != 0) continue;     // outside the mask component / already labelled
+            o[q] = lab;
+            const int v = (256 - cv[q]) & 255;
+            nx[q] = -1;
+            if (head[v] < 0) head[v] = q; else nx[tail[v]] = q;
+            tail[v] = q;
+            lo = v < lo ? v : lo;
+        }
+    }
+}
+
+size_t ws_layout(int N, int H, int W, size_t o[10]) {
+    const size_t P = (size_t)N * H * W;
+    size_t off = 0;
+    for (int k = 0; k < 6; ++k) { o[k] = off; off = align_up(off + P * 4, 256); }      // L1, L2, aux, h/area, d2/next, maxd2/last
+    for (int k = 6; k < 9; ++k) { o[k] = off; off = align_up(off + P, 256); }          // canvas, m, m2
+    o[9] = off; off = align_up(off + (size_t)N * cdiv(H * W, CHUNK) * 4, 256);          // chunk counters
+    return off;
+}
+
+// 4-connected components of a u8 mask: roots in L (raster-first pixel of each component, -1 off-mask)
+void label4_roots(const uint8_t *mask, int N, int H, int W, int *L, hipStream_t st) {
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    cc_init_kernel<1><<<gr, br, 0, st>>>(mask, 0, H, W, L);
+    cc_merge_kernel<1, 4><<<gr, br, 0, st>>>(mask, 0, H, W, L);
+    cc_flatten_kernel<false><<<gr, br, 0, st>>>(H, W, L, nullptr);
+}
+
+}  // namespace
+
+extern "C" size_t cdnet_watershed_workspace_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    size_t o[10];
+    return ws_layout(N, H, W, o);
+}
+
+extern "C" int cdnet_watershed_process(const uint8_t *pred, int N, int H, int W, int min_size, void *workspace, size_t workspace_bytes,
+                                       uint8_t *dist_out, int32_t *marker_out, int32_t *labels, void *stream) {
+    CDNET_REQUIRE(pred && labels && workspace, "cdnet_watershed_process: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0 && (size_t)H * W < (1u << 30) && H < WS_INF && W < WS_INF, "cdnet_watershed_process: bad size");
+    size_t o[10];
+    const size_t need = ws_layout(N, H, W, o);
+    if (workspace_bytes < need) { set_error("cdnet_watershed_process: workspace %zu < %zu bytes", workspace_bytes, need); return CDNET_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int *L1 = (int *)(ws + o[0]), *L2 = (int *)(ws + o[1]), *aux = (int *)(ws + o[2]), *hb = (int *)(ws + o[3]), *d2 = (int *)(ws + o[4]),
+        *mx = (int *)(ws + o[5]), *chunk = (int *)(ws + o[9]);
+    uint8_t *canvas = dist_out ? dist_out : (uint8_t *)(ws + o[6]), *m = (uint8_t *)(ws + o[7]), *m2 = (uint8_t *)(ws + o[8]);
+    const int plane = H * W, nchunk = cdiv(plane, CHUNK);
+    const size_t P = (size_t)N * plane;
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    const dim3 gl(grid_lin(plane), N);
+    int32_t *marker = marker_out ? marker_out : (int32_t *)L2;
+
+    // 1. components of the prediction (measurements.label, 4-connected), exact EDT per component, scaled distance map
+    label4_roots(pred, N, H, W, L1, st);
+    if (hipMemsetAsync(mx, 0, P * 4, st) != hipSuccess) return check_launch("memset");
+    ws_rowdist_kernel<<<gl, 256, 0, st>>>(L1, H, W, hb);
+    ws_edt_kernel<<<gl, 256, 0, st>>>(L1, hb, H, W, d2, mx);
+    ws_canvas_kernel<<<gl, 256, 0, st>>>(L1, d2, mx, plane, canvas, m);
+    // 2. marker: fill holes, erode, label (raster numbering), drop small labels
+    cc_init_kernel<0><<<gr, br, 0, st>>>(m, 1, H, W, L2);
+    cc_merge_kernel<0, 4><<<gr, br, 0, st>>>(m, 1, H, W, L2);
+    cc_flatten_kernel<false><<<gr, br, 0, st>>>(H, W, L2, nullptr);
+    fill_mark_border_kernel<<<dim3(cdiv(2 * (H + W), 256), N), 256, 0, st>>>(H, W, L2);
+    fill_output_kernel<<<gl, 256, 0, st>>>(m, 1, plane, L2, m2);
+    ws_erode4_kernel<<<gl, 256, 0, st>>>(m2, H, W, m);
+    label4_roots(m, N, H, W, L2, st);
+    cc_count_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L2, plane, nchunk, chunk);
+    cc_scan_chunks_kernel<<<N, 256, 0, st>>>(nchunk, chunk, nullptr);
+    cc_rank_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L2, plane, nchunk, chunk, aux);
+    cc_relabel_kernel<<<gl, 256, 0, st>>>(L2, aux, plane, marker);          // in place when marker aliases L2
+    if (hipMemsetAsync(hb, 0, P * 4, st) != hipSuccess) return check_launch("memset");
+    ws_hist_kernel<<<gl, 256, 0, st>>>(marker, plane, hb);
+    ws_drop_small_kernel<<<gl, 256, 0, st>>>(marker, hb, plane, min_size);
+    // 3. flood per component of the prediction, then drop small labels
+    if (hipMemsetAsync(mx, 0xff, P * 4, st) != hipSuccess) return check_launch("memset");      // last = -1
+    if (hipMemsetAsync(labels, 0, P * 4, st) != hipSuccess) return check_launch("memset");
+    ws_last_kernel<<<gl, 256, 0, st>>>(L1, plane, mx);
+    ws_flood_kernel<<<dim3(cdiv(plane, 64), N), 64, 0, st>>>(L1, mx, canvas, marker, H, W, d2, labels);
+    if (hipMemsetAsync(hb, 0, P * 4, st) != hipSuccess) return check_launch("memset");
+    ws_hist_kernel<<<gl, 256, 0, st>>>(labels, plane, hb);
+    ws_drop_small_kernel<<<gl, 256, 0, st>>>(labels, hb, plane, min_size);
+    return check_launch("cdnet_watershed_process");
+}

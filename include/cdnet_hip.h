@@ -82,6 +82,20 @@ int cdnet_tta_boost_argmax(const float *probs, const float *points, const uint8_
                            float *pmax_ws, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Watershed variant of the instance post-processing.   Replaces postproc_other.py:15-99 `process(pred, model_mode,
+ * min_size, ws=True)` for the non-'dcan' modes, steps :36-48:
+ *   scipy.ndimage.measurements.label (4-connected) -> gen_inst_dst_map (:16-27: per-instance distance_transform_edt
+ *   scaled to 0..255 uint8) -> marker = label(binary_erosion(binary_fill_holes(dist > 125))) with labels smaller than
+ *   min_size removed -> skimage.segmentation.watershed(-dist [uint8 wrap], marker, mask=pred) -> remove small labels.
+ * pred u8 [N][H][W] already thresholded (0 / non-zero = `pred > 0.5`, :33-34).
+ * Outputs: labels i32 [N][H][W] (required, marker ids are kept like the reference does); dist u8 and marker i32 stage
+ * outputs (each may be NULL).  workspace: cdnet_watershed_workspace_bytes(N, H, W) bytes.
+ * ---------------------------------------------------------------------------------------------------- */
+size_t cdnet_watershed_workspace_bytes(int N, int H, int W);
+int cdnet_watershed_process(const uint8_t *pred, int N, int H, int W, int min_size, void *workspace, size_t workspace_bytes,
+                            uint8_t *dist, int32_t *marker, int32_t *labels, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Connected-component chain.   Replaces test_dam.py:546-563:
  *   scipy.ndimage.binary_fill_holes -> skimage.morphology.remove_small_objects(min_area)
  *   -> skimage.measure.label (8-connectivity, ids in raster order) -> skimage.morphology.dilation(disk(radius)).

@@ -147,3 +147,59 @@ def postprocess_views(probs, points, dcms, classes=9, min_area=20, radius=2):
     r.update(cc_chain(r['pred'] == 1, min_area, radius))
     r['ddms'] = ddms
     return r
+
+
+# ---------------------------------------------------------------------------------------------------------
+# watershed variant: postproc_other.py:15-99 (ws branch :36-48)
+# ---------------------------------------------------------------------------------------------------------
+def ws_dist(lab):
+    """gen_inst_dst_map (postproc_other.py:16-27) restated in C (brute-force exact EDT)"""
+    lab = np.ascontiguousarray(lab, dtype=np.int32)
+    out = np.empty(lab.shape, np.uint8)
+    lib().orc_ws_dist(_p(lab, C.c_int32), lab.shape[0], lab.shape[1], _p(out, C.c_uint8))
+    return out
+
+
+def watershed(image_u8, markers, mask):
+    image_u8 = np.ascontiguousarray(image_u8, dtype=np.uint8)
+    markers = np.ascontiguousarray(markers, dtype=np.int32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.empty(markers.shape, np.int32)
+    lib().orc_watershed(_p(image_u8, C.c_uint8), _p(markers, C.c_int32), _p(mask, C.c_uint8), markers.shape[0], markers.shape[1],
+                        _p(out, C.c_int32))
+    return out
+
+
+def remove_small_labels(lab, min_size):
+    """skimage.morphology.remove_small_objects on an integer label image (documented behaviour: labels whose pixel count
+    is below min_size are zeroed, the other ids are kept)"""
+    sizes = np.bincount(lab.ravel())
+    out = lab.copy()
+    small = sizes < min_size
+    small[0] = False
+    out[small[lab]] = 0
+    return out
+
+
+def watershed_process(pred, min_size=10, use_scipy=True):
+    """postproc_other.process(pred, model_mode != 'dcan'/'unet'/'micronet', ws=True), steps :31-48.  With use_scipy the
+    distance map and the marker come from the very scipy calls the reference makes; otherwise from the C restatement
+    (tests assert both agree).  Returns dict(dist, marker, labels)."""
+    from scipy import ndimage as ndi
+    pred = (np.asarray(pred) > 0.5).astype(np.uint8)
+    lab = ndi.label(pred)[0].astype(np.int32)                                    # measurements.label (:37)
+    if use_scipy:
+        canvas = np.zeros(pred.shape, np.uint8)                                  # gen_inst_dst_map (:16-27)
+        for k in range(1, int(lab.max()) + 1):
+            d = ndi.distance_transform_edt(lab == k)
+            canvas += (255 * (d / np.amax(d))).astype('uint8')
+    else:
+        canvas = ws_dist(lab)
+    marker = canvas > 125                                                         # (:39-41)
+    marker = ndi.binary_fill_holes(marker)
+    marker = ndi.binary_erosion(marker, iterations=1)
+    marker = ndi.label(marker)[0].astype(np.int32)
+    marker = remove_small_labels(marker, min_size)                                # (:46)
+    out = watershed((-canvas.astype(np.int32) & 255).astype(np.uint8), marker, pred)   # -dist on uint8 wraps (:47)
+    out = remove_small_labels(out, min_size)                                      # (:48)
+    return dict(dist=canvas, marker=marker, labels=out)

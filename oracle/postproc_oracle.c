@@ -245,3 +245,98 @@ void orc_probmaps(const float *mask_logits, const float *dir_logits, int C, int 
         dcm[i] = (uint8_t)a;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------
+ * Watershed variant (postproc_other.py:15-99, ws branch :36-48).  ORACLE - test infrastructure only.
+ *
+ * orc_ws_dist: gen_inst_dst_map (:16-27) for a 4-connected label image: per instance the exact Euclidean distance to
+ *   the nearest pixel outside the instance (scipy distance_transform_edt of the instance mask), scaled by 255 / max and
+ *   truncated to uint8.  Brute force over growing square rings.
+ * orc_watershed: skimage.segmentation.watershed(image, markers, mask=mask) with connectivity 1, non-compact, no
+ *   watershed line, as published in skimage/segmentation/_watershed_cy.pyx (watershed_raveled): marker pixels are
+ *   pushed in raster order; the smallest (value, age) is popped; each unlabelled neighbour inside the mask (raveled
+ *   offsets -W, -1, +1, +W) takes the label and is pushed with its own image value and the next age.  skimage gives all
+ *   marker pixels age 0 and leaves their mutual order to its heap; here they get ages 0, 1, 2, ... in raster order
+ *   (PARITY UNPINNED for that tie-break: scikit-image is not available in this image).  A real binary heap on
+ *   (value, age) - deliberately a different data structure from the HIP kernel's FIFO buckets.
+ * ------------------------------------------------------------------------------------------------------ */
+void orc_ws_dist(const int32_t *lab, int H, int W, uint8_t *canvas)
+{
+    int nlab = 0;
+    for (int i = 0; i < H * W; ++i) if (lab[i] > nlab) nlab = lab[i];
+    long long *d2 = (long long *)malloc(sizeof(long long) * (size_t)H * W);
+    long long *mx = (long long *)calloc((size_t)nlab + 1, sizeof(long long));
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int k = lab[y * W + x];
+            long long best = -1;
+            if (k > 0) {
+                const int rmax = (H > W ? H : W);
+                for (int r = 1; r <= rmax; ++r) {
+                    if (best >= 0 && (long long)r * r >= best) break;
+                    for (int dy = -r; dy <= r; ++dy) {
+                        const int yy = y + dy;
+                        if (yy < 0 || yy >= H) continue;
+                        const int step = (dy == -r || dy == r) ? 1 : 2 * r;
+                        for (int dx = -r; dx <= r; dx += step) {
+                            const int xx = x + dx;
+                            if (xx < 0 || xx >= W) continue;
+                            if (lab[yy * W + xx] != k) {
+                                const long long c = (long long)dy * dy + (long long)dx * dx;
+                                if (best < 0 || c < best) best = c;
+                            }
+                        }
+                    }
+                }
+                if (best < 0) best = 0;
+                if (best > mx[k]) mx[k] = best;
+            }
+            d2[y * W + x] = best < 0 ? 0 : best;
+        }
+    for (int i = 0; i < H * W; ++i) {
+        const int k = lab[i];
+        canvas[i] = k > 0 ? (uint8_t)(255.0 * (sqrt((double)d2[i]) / sqrt((double)mx[k]))) : 0;
+    }
+    free(d2);
+    free(mx);
+}
+
+typedef struct { int value; long long age; int index; } ws_elem;
+
+static int ws_less(const ws_elem *a, const ws_elem *b) { return a->value != b->value ? a->value < b->value : a->age < b->age; }
+
+void orc_watershed(const uint8_t *image, const int32_t *markers, const uint8_t *mask, int H, int W, int32_t *out)
+{
+    const int P = H * W;
+    ws_elem *heap = (ws_elem *)malloc(sizeof(ws_elem) * (size_t)(P + 1));
+    int n = 0;
+    long long age = 0;
+    for (int i = 0; i < P; ++i) out[i] = (markers[i] > 0 && mask[i]) ? markers[i] : 0;
+#define WS_PUSH(V, I) do { ws_elem e_ = {(V), age++, (I)}; int c_ = n++; \
+        while (c_ > 0) { int p_ = (c_ - 1) / 2; if (!ws_less(&e_, &heap[p_])) break; heap[c_] = heap[p_]; c_ = p_; } heap[c_] = e_; } while (0)
+    for (int i = 0; i < P; ++i) if (out[i]) WS_PUSH(image[i], i);
+    while (n > 0) {
+        const ws_elem top = heap[0];
+        const ws_elem lastv = heap[--n];
+        int c = 0;
+        while (1) {
+            int l = 2 * c + 1, r = l + 1, m = -1;
+            if (l < n) m = l;
+            if (r < n && ws_less(&heap[r], &heap[l])) m = r;
+            if (m < 0 || !ws_less(&heap[m], &lastv)) break;
+            heap[c] = heap[m];
+            c = m;
+        }
+        if (n > 0) heap[c] = lastv;
+        const int p = top.index, y = p / W, x = p - y * W;
+        const int nb[4] = {y > 0 ? p - W : -1, x > 0 ? p - 1 : -1, x < W - 1 ? p + 1 : -1, y < H - 1 ? p + W : -1};
+        for (int j = 0; j < 4; ++j) {
+            const int q = nb[j];
+            if (q < 0 || !mask[q] || out[q]) continue;
+            out[q] = out[p];
+            WS_PUSH(image[q], q);
+        }
+    }
+#undef WS_PUSH
+    free(heap);
+}
