@@ -174,6 +174,7 @@ def main():
                 line['cpu_baseline'] = trainer.cpu_baseline_train()
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                    # rank 0 times the roofline kernel after the timed region: leave together
         dist.destroy_process_group()
 
 
