@@ -34,6 +34,10 @@ SIGNATURES = {
     'cdnet_bn_finalize_train': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_dam_head_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_final_conv1x1': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_bias_grad_workspace_floats': (_sz, [_i]),
+    'cdnet_bias_grad': (_i, [_vp, _sz, _i, _vp, _sz, _vp, _vp]),
+    'cdnet_final_conv1x1_backward_workspace_floats': (_sz, []),
+    'cdnet_final_conv1x1_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     'cdnet_conv_wgrad_slab_floats': (_sz, [_i] * 6),
     'cdnet_conv_backward_weight': (_i, [_vp, _i, _i, _i, _vp] + [_i] * 9 + [_vp, _vp, _i, _vp]),
     'cdnet_bn_backward_workspace_floats': (_sz, [_i]),

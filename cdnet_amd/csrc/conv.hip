@@ -175,7 +175,7 @@ __device__ __forceinline__ V16 max8(V16 a, V16 b, bool nonneg) {
 // the 8 channels' scale / shift of one thread; `xf` is the LDS copy of the source's tables ([0] scale, [xfs] shift) made
 // once per workgroup (a global load here would sit in front of the chunk pipeline: vmcnt retires in order), or null
 // for callers without one
-constexpr int XF_MAX = 1024;      // source channels (both concat sources) whose scale/shift fit the LDS table
+constexpr int XF_MAX = 2048;      // source channels (both concat sources) whose scale/shift fit the LDS table
 
 __device__ __forceinline__ void load_chan_xf(ChanXf &t, const ConvSrc &s, const float *xf, int xfs, int c) {
     t.on = s.scale != nullptr;

@@ -1011,6 +1011,111 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+
+// ======================================================================================================
+// Backward of the plain UNet's 64 -> K classifier (models/unet.py:75,104).  Four lanes per pixel (16 channels each):
+//   dF[c] = sum_k dlogit_k * w[k][c];  dW[k][c] = sum_px dlogit_k * F[c];  db[k] = sum_px dlogit_k.
+// Per-block partial sums [K*64 | K], reduced in a fixed order by reduce_partials_kernel (deterministic).
+// ======================================================================================================
+constexpr int FC_KMAX = 4;
+
+__global__ __launch_bounds__(256) void final_conv_bwd_kernel(HeadFeat f, const float *__restrict__ w, const float *__restrict__ dl,
+                                                             int K, int N, int plane, unsigned short *__restrict__ df,
+                                                             float *__restrict__ partial) {
+    __shared__ float s_w[FC_KMAX * 64], s_sc[64], s_sh[64];
+    __shared__ float s_red[4][FC_KMAX * 64 + FC_KMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < K * 64; i += 256) s_w[i] = w[i];
+    if (tid < 64) { s_sc[tid] = f.scale ? f.scale[tid] : 1.f; s_sh[tid] = f.scale ? f.shift[tid] : 0.f; }
+    __syncthreads();
+    const int q = tid & 3;
+    float gw[FC_KMAX][16], gb[FC_KMAX];
+#pragma unroll
+    for (int k = 0; k < FC_KMAX; ++k) {
+        gb[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) gw[k][c] = 0.f;
+    }
+    const size_t total = (size_t)N * plane;
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + (tid >> 2);
+        const bool ok = i < total;
+        const size_t ii = ok ? i : total - 1;
+        const size_t n = ii / plane, p = ii - n * plane;
+        float v[16], d[FC_KMAX];
+        feat16(f, ii, q, s_sc, s_sh, v);
+#pragma unroll
+        for (int k = 0; k < FC_KMAX; ++k) d[k] = (ok && k < K) ? dl[(n * K + k) * plane + p] : 0.f;
+        float o[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < FC_KMAX; ++k) {
+                t = fmaf(d[k], s_w[(k < K ? k : 0) * 64 + q * 16 + c], t);
+                gw[k][c] = fmaf(d[k], v[c], gw[k][c]);
+            }
+            o[c] = t;
+        }
+#pragma unroll
+        for (int k = 0; k < FC_KMAX; ++k) gb[k] += d[k];
+        if (ok) store16_bf16(df + ii * 64 + q * 16, o);
+    }
+    // lanes with the same q own the same channels: butterfly over the 16 pixel slots of the wave, then one row per wave
+#pragma unroll
+    for (int k = 0; k < FC_KMAX; ++k) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float t = gw[k][c];
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) t += __shfl_xor(t, m);
+            if (lane < 4) s_red[wave][k * 64 + lane * 16 + c] = t;
+        }
+        float t = gb[k];
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) t += __shfl_xor(t, m);
+        if (lane == 0) s_red[wave][FC_KMAX * 64 + k] = t;
+    }
+    __syncthreads();
+    for (int j = tid; j < FC_KMAX * 64 + FC_KMAX; j += 256)
+        partial[(size_t)blockIdx.x * (FC_KMAX * 64 + FC_KMAX) + j] = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
+}
+
+__global__ void final_conv_scatter_kernel(const float *__restrict__ sums, int K, float *__restrict__ dw, float *__restrict__ db) {
+    const int t = threadIdx.x + blockIdx.x * blockDim.x;
+    if (t < K * 64) dw[t] = sums[t];
+    if (t < K) db[t] = sums[FC_KMAX * 64 + t];
+}
+
+
+// bias gradient of a BatchNorm-less convolution (the plain UNet's ConvTranspose2d, models/unet.py:30):
+// db[c] = sum over pixels of the bf16 NHWC output gradient.  thread = (8 channels, pixel group); per-block partials.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short *__restrict__ g, unsigned npix, int C,
+                                                        float *__restrict__ partial) {
+    __shared__ float s_red[256][9];
+    const int VPP = C / 8, tid = threadIdx.x;
+    const int slot = tid % VPP;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const unsigned ppb = 256 / VPP;
+    for (unsigned p = blockIdx.x * ppb + tid / VPP; p < npix; p += gridDim.x * ppb) {
+        V16 v;
+        v.u = *reinterpret_cast<const uint4 *>(g + (size_t)p * C + slot * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v.h[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_red[tid][j] = acc[j];
+    __syncthreads();
+    for (int q = tid; q < C; q += 256) {
+        const int sl = q / 8, j = q % 8;
+        float t = 0.f;
+        for (int k = sl; k < 256; k += VPP) t += s_red[k][j];
+        partial[(size_t)blockIdx.x * C + q] = t;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
@@ -1180,4 +1285,40 @@ extern "C" int cdnet_adam_step(float *param, const float *grad, float *exp_avg, 
     adam_kernel<<<lin_grid(n, 4096), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                                                                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
     return check_launch("cdnet_adam_step");
+}
+
+extern "C" size_t cdnet_final_conv1x1_backward_workspace_floats(void) { return (size_t)1025 * (FC_KMAX * 64 + FC_KMAX); }
+
+extern "C" int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
+                                            uint16_t *df, float *workspace, size_t workspace_floats, float *dw, float *db, void *stream) {
+    CDNET_REQUIRE(f && f->raw && w && dlogits && df && workspace && dw && db, "cdnet_final_conv1x1_backward: null pointer");
+    CDNET_REQUIRE(K >= 1 && K <= FC_KMAX && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1_backward: K=%d must be in [1,%d]", K, FC_KMAX);
+    if (workspace_floats < cdnet_final_conv1x1_backward_workspace_floats()) { set_error("cdnet_final_conv1x1_backward: workspace too small"); return CDNET_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)N * H * W;
+    int nb = (int)((npix + 63) / 64);
+    if (nb > 1024) nb = 1024;
+    constexpr int ROW = FC_KMAX * 64 + FC_KMAX;
+    float *sums = workspace + (size_t)1024 * ROW;
+    final_conv_bwd_kernel<<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
+    reduce_partials_kernel<<<cdiv(ROW, 4), 256, 0, st>>>(workspace, nb, ROW, sums);
+    final_conv_scatter_kernel<<<1, 256, 0, st>>>(sums, K, dw, db);
+    return check_launch("cdnet_final_conv1x1_backward");
+}
+
+extern "C" size_t cdnet_bias_grad_workspace_floats(int C) { return (size_t)512 * C; }
+
+extern "C" int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db,
+                               void *stream) {
+    CDNET_REQUIRE(grad_out && workspace && db, "cdnet_bias_grad: null pointer");
+    CDNET_REQUIRE(C >= 8 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && npix > 0 && npix < ((size_t)1 << 31), "cdnet_bias_grad: C=%d unsupported", C);
+    if (workspace_floats < cdnet_bias_grad_workspace_floats(C)) { set_error("cdnet_bias_grad: workspace too small"); return CDNET_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned ppb = 256 / (C / 8);
+    int nb = (int)((npix + ppb * 8 - 1) / (ppb * 8));
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    bias_grad_kernel<<<nb, 256, 0, st>>>(grad_out, (unsigned)npix, C, workspace);
+    reduce_partials_kernel<<<cdiv(C, 4), 256, 0, st>>>(workspace, nb, C, db);
+    return check_launch("cdnet_bias_grad");
 }

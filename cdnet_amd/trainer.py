@@ -175,7 +175,11 @@ class Trainer:
                   _lib.ptr(df[2]), _lib.ptr(self._ws_head), self._ws_head.numel(), _lib.ptr(dhead), _lib.stream_ptr())
         for f, d in zip((f1, f2, f3), df):
             add(f.x, _G(d, H, W))
+        self._backward_tape(grads, add)
 
+    def _backward_tape(self, grads, add):
+        """walk the forward tape backwards: BatchNorm(+ReLU, residual, pool/pad/concat routing) backward, then the
+        weight and input gradients of every convolution that received a gradient"""
         for L in reversed(self.tape):
             srcs, out, Hl, Wl = L.saved
             gl = grads.pop(id(out), None)
@@ -249,6 +253,12 @@ class Trainer:
             owner = getattr(L, 'bias_grad_from', None)
             if owner is not None:
                 L.bias.grad.copy_(owner.bn.bias.grad)
+            else:
+                # stand-alone biased convolution (plain UNet's ConvTranspose2d): db = sum of the output gradient
+                need = lib.cdnet_bias_grad_workspace_floats(Cout)
+                ws = self._slab(need)
+                _lib.call('cdnet_bias_grad', _lib.ptr(g), g.numel() // Cout, Cout, _lib.ptr(ws), ws.numel(), _lib.ptr(L.bias.grad),
+                          _lib.stream_ptr())
         if not getattr(L, 'needs_input_grad', True):
             return
         # input gradient: forward convolution with the backward-data pack
@@ -320,6 +330,58 @@ class Trainer:
         self.backward(dmask, dpoint, ddir)
         self.allreduce_and_step()
         return self.losses
+
+
+class UNetTrainer(Trainer):
+    """Body of the plain-UNet train iteration (train_util.py:58-200 with the default options: log-softmax + NLL x weight
+    map mean, + MulticlassDiceLoss on the softmax, alpha = 0, no boundary loss) -> backward -> Adam.
+    The two loss terms are exactly the mask terms of the DAM loss kernel, which is fed constant point / direction
+    branches here; `losses` = [total, CE x weight, dice]."""
+
+    def __init__(self, model, **kw):
+        super().__init__(model, **kw)
+        self.unet_losses = torch.zeros((3,), dtype=torch.float32, device=self.dev)
+
+    def loss_and_grads(self, logits, label, weight):
+        B, K, H, W = logits.shape
+        assert K == 3, 'the fused loss serves the 3-class configuration (options.py: out_c = 3)'
+        z = lambda shape, dt: self.buf(('zero',) + tuple(shape) + (dt,), shape, dt)
+        point, dirn = z((B, 1, H, W), torch.float32), z((B, 9, H, W), torch.float32)
+        dirlab, point_t = z((B, H, W), torch.uint8), z((B, H, W), torch.float16)
+        for t in (point, dirn, dirlab, point_t):
+            t.zero_()
+        dmask, _, _ = super().loss_and_grads(logits, point, dirn, label, dirlab, point_t, weight)
+        self.unet_losses[1:3] = self.losses[4:6]
+        self.unet_losses[0] = self.losses[4] + self.losses[5]
+        return dmask
+
+    def backward(self, dlogits):
+        m = self.model
+        feat = m._last_feat
+        N, H, W, _ = feat.x.shape
+        grads = {}
+
+        def add(t, g):
+            grads.setdefault(id(t), []).append(g)
+        K = m.num_classes
+        df = self.buf('dF', (N, H, W, 64), torch.bfloat16)
+        lib = _lib.load()
+        ws = self._slab(lib.cdnet_final_conv1x1_backward_workspace_floats())
+        hf = runtime.head_feat(feat)
+        w = m.final_conv.weight.detach().reshape(K, 64)
+        _lib.call('cdnet_final_conv1x1_backward', C.byref(hf), _lib.ptr(w), _lib.ptr(dlogits), K, N, H, W, _lib.ptr(df), _lib.ptr(ws),
+                  ws.numel(), _lib.ptr(m.final_conv.weight.grad), _lib.ptr(m.final_conv.bias.grad), _lib.stream_ptr())
+        add(feat.x, _G(df, H, W))
+        self._backward_tape(grads, add)
+
+    def train_step(self, x, label, weight):
+        """x f32 [B,3,H,W]; label u8 [B,H,W] in {0,1,2}; weight u8 [B,H,W] (png weight map, /20 on the fly,
+        train_util.py:109).  Returns the device tensor [total, CE, dice]."""
+        logits = self.forward(x)
+        dlogits = self.loss_and_grads(logits, label, weight)
+        self.backward(dlogits)
+        self.allreduce_and_step()
+        return self.unet_losses
 
 
 def bucketed_allreduce(flat, n, bucket_elems):

@@ -223,6 +223,16 @@ int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_head_feat *f2,
 /* plain UNet classifier (models/unet.py:75,104 final_conv 64->K): f32 NCHW logits from a 64-channel feature */
 int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, const float *b, int K, int N, int H, int W,
                         float *out, void *stream);
+/* bias gradient of a convolution that is not followed by BatchNorm (plain UNet's ConvTranspose2d, models/unet.py:30):
+ * db[c] = sum over the npix pixels of grad_out (bf16 NHWC [npix][C]).  workspace: cdnet_bias_grad_workspace_floats(C). */
+size_t cdnet_bias_grad_workspace_floats(int C);
+int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);
+/* backward of that classifier (plain-UNet training, train_util.py:126-200 loss.backward()): dlogits f32 [N][K][H][W] ->
+ * df bf16 NHWC [N][H][W][64] (gradient of the activated feature), dw f32 [K][64], db f32 [K].  K <= 4.
+ * workspace: cdnet_final_conv1x1_backward_workspace_floats() floats. */
+size_t cdnet_final_conv1x1_backward_workspace_floats(void);
+int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
+                                 uint16_t *df, float *workspace, size_t workspace_floats, float *dw, float *db, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Backward-weight of a convolution (the dW half of loss.backward(), train_util_dam.py:307), one call per input

@@ -96,3 +96,26 @@ def train_iteration(model, optimizer, x, label, direction, point_target, weight_
     L['total'].backward()
     optimizer.step()
     return {k: float(v) for k, v in L.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# plain UNet (train_util.py:58-260, default options: add_weightMap, dice = 1, alpha = 0, boundary_loss = 0)
+# ---------------------------------------------------------------------------------------------------------
+def unet_losses(logits, label, weight_png):
+    w = weight_png.float().div(20)                                   # train_util.py:109
+    if w.dim() == 4:
+        w = w.squeeze(1)
+    label = label.long()
+    ce = (F.nll_loss(F.log_softmax(logits, 1), label, reduction='none') * w).mean()      # :128-136
+    onehot3 = F.one_hot(label, 3).permute(0, 3, 1, 2).float()
+    dice = multiclass_dice(F.softmax(logits, 1), onehot3)                                 # :183-186
+    return dict(ce=ce, dice=dice, total=ce + dice)
+
+
+def unet_train_iteration(model, optimizer, x, label, weight_png):
+    model.train()
+    L = unet_losses(model(x), label, weight_png)
+    optimizer.zero_grad()
+    L['total'].backward()
+    optimizer.step()
+    return {k: float(v) for k, v in L.items()}

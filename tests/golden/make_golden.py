@@ -282,6 +282,37 @@ def gen_train_iter():
     save('train_iter', **out)
 
 
+def gen_unet_train_iter():
+    """two iterations of the reference's plain-UNet train loop (train_util.train, default options) on one batch"""
+    import train_util
+    import utils as ref_utils
+    from models.unet import UNet
+    B, H, W = 2, 64, 64
+    lab, _, _, weight = _synthetic_targets(B, H, W, 31)
+    x = det_input((B, 3, H, W), 12)
+    target0 = torch.from_numpy(lab * 127 + (lab == 2)).long().unsqueeze(1)   # {0,127,255} as ToTensor emits
+    sample = (x, torch.from_numpy(weight), target0)
+    m = det_fill(UNet(num_classes=3, in_channels=3))
+    opt = _Opt()
+    opt.model['modelName'] = 'UNet'
+    opt.train['num_epochs'] = 1
+    optimizer, _ = ref_utils.get_optimizer(opt, m)
+    crit = torch.nn.NLLLoss(reduction='none')
+    pick = ['down1.down_conv.0.weight', 'down1.down_conv.1.weight', 'down4.down_conv.3.weight', 'middle_conv.0.weight',
+            'up1.up.weight', 'up1.up.bias', 'up4.up_conv.3.weight', 'up4.up_conv.4.bias', 'final_conv.weight', 'final_conv.bias']
+    sd = dict(m.named_parameters())
+    res, snaps = [], []
+    for it in range(2):
+        r = train_util.train([sample], m, optimizer, crit, it, opt, _Logger())
+        res.append(np.array(r, dtype=np.float64))
+        snaps.append({k: sd[k].detach().reshape(-1)[:96].numpy().copy() for k in pick})
+    out = {'x_cfg': np.array([B, 3, H, W, 12]), 'tgt_cfg': np.array([B, H, W, 31]), 'results': np.stack(res), 'pick': np.array(pick)}
+    for it in range(2):
+        for k in pick:
+            out['p%d_%s' % (it, k)] = snaps[it][k]
+    save('unet_train_iter', **out)
+
+
 # ----------------------------------------------------------------------------------------------
 _ellipse_instances = synth.ellipse_instances
 
@@ -469,7 +500,7 @@ def gen_aji():
     save('aji', **out)
 
 
-ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter,
+ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter,
        'cdm': gen_cdm, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':

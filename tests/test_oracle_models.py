@@ -116,3 +116,21 @@ def test_train_iteration_matches_reference(golden):
             np.testing.assert_allclose(got, z['p%d_%s' % (it, k)], rtol=2e-3, atol=2e-5, err_msg=str(k))
     np.testing.assert_allclose(m.state_dict()['backbone.1.running_mean'].numpy(), z['rm_backbone.1.running_mean'],
                                rtol=1e-4, atol=1e-6)
+
+
+def test_unet_train_iteration_matches_reference(golden):
+    """two iterations of train_util.train (reference, plain UNet, default options) == oracle unet_train_iteration"""
+    z = golden('unet_train_iter')
+    B, _, H, W, xseed = [int(v) for v in z['x_cfg']]
+    lab, _, _, weight = synth.train_targets(B, H, W, int(z['tgt_cfg'][3]))
+    x = torch.from_numpy(synth.det_input((B, 3, H, W), xseed))
+    m = om.det_fill(om.UNet(3))
+    opt = ot.make_adam(m)
+    sd = dict(m.named_parameters())
+    for it in range(2):
+        L = ot.unet_train_iteration(m, opt, x, torch.from_numpy(lab), torch.from_numpy(weight))
+        r = z['results'][it]          # [loss, loss_CE, ssim(-1), pixel metrics ...] (train_util.py:225)
+        assert abs(L['total'] - r[0]) < 5e-5 and abs(L['ce'] - r[1]) < 2e-5
+        for k in z['pick']:
+            got = sd[str(k)].detach().reshape(-1)[:96].numpy()
+            np.testing.assert_allclose(got, z['p%d_%s' % (it, k)], rtol=2e-3, atol=2e-5, err_msg=str(k))
