@@ -763,7 +763,8 @@ __global__ __launch_bounds__(256) void dam_head_wgrad_kernel(HeadFeat f1, HeadFe
 //   9..17 Pw_i  sum w q_i               18..26 Tw_j sum w t_j
 //   27..35 S[j][j]  36..44 S[next(j)][j]  45..53 S[prev(j)][j]   (S[i][j] = sum w q_i t_j, j = target class)
 //   54 ce  55 dce  56 mse
-constexpr int K_SUMS = 57;
+//   57 tp  58 fp  59 fn   of the pixel-level metric (argmax direction == 1 vs direction label == 1, train_util_dam.py:279-281)
+constexpr int K_SUMS = 60;
 __device__ __forceinline__ int dnext(int i) { return i == 8 ? 1 : i + 1; }      // cyclic over 1..8 (loss.py:231-258)
 __device__ __forceinline__ int dprev(int i) { return i == 1 ? 8 : i - 1; }
 
@@ -855,6 +856,16 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossIn L, float *__res
         acc[55][tid] -= lp9[dl] * w;
         const float dpt = L.point[ob + i] - h2f(L.point_t[ob + i]);
         acc[56][tid] = fmaf(dpt, dpt, acc[56][tid]);
+        {   // np.argmax over the 9 direction classes (first maximum), "inside" = class 1 (utils.py:76-78)
+            int am = 0;
+            float best = l9[0];
+#pragma unroll
+            for (int c = 1; c < 9; ++c) if (l9[c] > best) { best = l9[c]; am = c; }
+            const bool pi = am == 1, ti = dl == 1;
+            if (pi && ti) acc[57][tid] += 1.f;
+            if (pi && !ti) acc[58][tid] += 1.f;
+            if (!pi && ti) acc[59][tid] += 1.f;
+        }
     }
     __syncthreads();
     if (tid < K_SUMS) {
@@ -940,6 +951,19 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
         wd /= 9.f;
         losses[0] = ce + dice + dce + wd + mse;
         losses[1] = dce; losses[2] = wd; losses[3] = mse; losses[4] = ce; losses[5] = dice;
+        // pixel-level metrics, mean over the samples (utils.py:67-110): accuracy, IoU, recall, precision, F1
+        double m[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < B; ++b) {
+            const double tp = s_sum[b * K_SUMS + 57], fp = s_sum[b * K_SUMS + 58], fn = s_sum[b * K_SUMS + 59];
+            const double tn = (double)P - tp - fp - fn;
+            const double precision = tp / (tp + fp + 1e-10), recall = tp / (tp + fn + 1e-10);
+            m[0] += (tp + tn) / (tp + fp + tn + fn + 1e-10);
+            m[1] += tp / (tp + fp + fn + 1e-10);
+            m[2] += recall;
+            m[3] += precision;
+            m[4] += 2 * precision * recall / (precision + recall + 1e-10);
+        }
+        for (int k = 0; k < 5; ++k) losses[6 + k] = (float)(m[k] / B);
     }
 }
 

@@ -102,7 +102,7 @@ class Trainer:
         self._ws_slab = None
         self._ws_head = None
         self._ws_loss = None
-        self.losses = torch.zeros((6,), dtype=torch.float32, device=self.dev)
+        self.losses = torch.zeros((11,), dtype=torch.float32, device=self.dev)     # 6 loss values + 5 pixel metrics
         self.tape = []
 
     # ------------------------------------------------------------------------------------------------
@@ -323,8 +323,9 @@ class Trainer:
 
     def train_step(self, x, label, dirlab, point_t, weight):
         """x f32 [B,3,H,W]; label u8 [B,H,W] in {0,1,2}; dirlab u8 [B,H,W] 0..8; point_t f16 [B,H,W]; weight u8 [B,H,W]
-        (the png weight map; /20 on the fly).  Returns the device tensor of the 6 loss values
-        [total, direction CE, direction dice, MSE, CE, dice] (results ordering of train_util_dam.py:297-299)."""
+        (the png weight map; /20 on the fly).  Returns the device tensor of 11 values: [total, direction CE, direction dice,
+        MSE, CE, dice, pixel accuracy, IoU, recall, precision, F1] (train_util_dam.py:297-299; slot 5 holds the mask dice
+        term where the reference logs its unused variance term)."""
         mask, point, direction = self.forward(x)
         dmask, dpoint, ddir = self.loss_and_grads(mask, point, direction, label, dirlab, point_t, weight)
         self.backward(dmask, dpoint, ddir)

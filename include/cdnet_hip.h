@@ -294,7 +294,9 @@ int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_head_feat *f2
 /* The five-term CDNet loss (train_util_dam.py:167-276; loss.py:131-260) and its gradient w.r.t. the logits.
  * label u8 {0,1,2}, dirlab u8 0..8, point target f16, weight map u8 (divided by 20 on the fly, :102).
  * quirk_sample0 = 1 reproduces train_util_dam.py:139 (direction one-hot masked by sample 0's foreground).
- * losses[6] = {total, direction CE, direction weighted dice, MSE, CE, dice}.  dmask/dpoint/ddir may all be NULL. */
+ * losses[11] = {total, direction CE, direction weighted dice, MSE, CE, dice, then the pixel-level metrics of
+ * train_util_dam.py:279-293 (argmax direction class == 1 vs direction label == 1, utils.py:67-110), averaged over the batch:
+ * accuracy, IoU, recall, precision, F1}.  dmask/dpoint/ddir may all be NULL. */
 size_t cdnet_dam_loss_workspace_floats(int B, int P);
 int cdnet_dam_loss(const float *mask, const float *point, const float *direction, const uint8_t *label,
                    const uint8_t *dirlab, const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W,

@@ -87,15 +87,34 @@ def make_adam(model, lr=1e-3, weight_decay=1e-4):
     return torch.optim.Adam(model.parameters(), lr=lr, betas=(0.9, 0.99), weight_decay=weight_decay)
 
 
+def pixel_metrics(pred, target):
+    """utils.accuracy_pixel_level (utils.py:67-110): per-sample tp/fp/fn/tn of (pred == 1) vs (target == 1), the derived
+    [accuracy, IoU, recall, precision, F1] averaged over the batch (float64)."""
+    import numpy as np
+    pred, target = np.asarray(pred), np.asarray(target)
+    res = np.zeros(5)
+    for i in range(target.shape[0]):
+        p, t = (pred[i] == 1).astype(np.float64), (target[i] == 1).astype(np.float64)
+        tp, tn, fp, fn = (p * t).sum(), ((1 - p) * (1 - t)).sum(), (p * (1 - t)).sum(), ((1 - p) * t).sum()
+        precision, recall = tp / (tp + fp + 1e-10), tp / (tp + fn + 1e-10)
+        res += [(tp + tn) / (tp + fp + tn + fn + 1e-10), tp / (tp + fp + fn + 1e-10), recall, precision,
+                2 * precision * recall / (precision + recall + 1e-10)]
+    return res / target.shape[0]
+
+
 def train_iteration(model, optimizer, x, label, direction, point_target, weight_png):
-    """One reference iteration; returns the loss dict (floats)."""
+    """One reference iteration; returns the loss dict (floats) + 'metrics' (train_util_dam.py:279-293, default options:
+    argmax of the direction branch against the direction target)."""
     model.train()
     mask, point, dirn = model(x)
     L = dam_losses(mask, point, dirn, label, direction, point_target, weight_png)
+    metrics = pixel_metrics(dirn.detach().argmax(1).numpy(), direction.numpy())
     optimizer.zero_grad()
     L['total'].backward()
     optimizer.step()
-    return {k: float(v) for k, v in L.items()}
+    out = {k: float(v) for k, v in L.items()}
+    out['metrics'] = metrics
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------

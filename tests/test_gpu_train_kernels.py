@@ -221,14 +221,15 @@ def test_loss_values_and_gradients(golden):
         L['total'].backward()
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
         ws = torch.empty((_lib.load().cdnet_dam_loss_workspace_floats(B, H * W),), dtype=torch.float32, device='cuda')
-        losses = torch.zeros(6, device='cuda')
+        losses = torch.zeros(11, device='cuda')
         dm, dp, dd = torch.empty_like(lm, device='cuda'), torch.empty_like(lp, device='cuda'), torch.empty_like(ld, device='cuda')
         keep = [lm.detach().cuda(), lp.detach().cuda(), ld.detach().cuda(), dev(lab), dev(dirn), dev(point), dev(weight[:, 0])]
         _lib.call('cdnet_dam_loss', *[_lib.ptr(t) for t in keep], B, H, W, quirk,
                   _lib.ptr(ws), ws.numel(), _lib.ptr(losses), _lib.ptr(dm), _lib.ptr(dp), _lib.ptr(dd), _lib.stream_ptr())
-        got = losses.cpu().numpy()
+        got = losses.cpu().numpy()[:6]
         want = [float(L[k]) for k in ('total', 'dce', 'wdice', 'mse', 'ce', 'dice')]
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(losses.cpu().numpy()[6:], ot.pixel_metrics(ld.detach().argmax(1).numpy(), dirn), rtol=1e-6, atol=1e-7)
         assert _rel(dm.cpu(), lm.grad) < 1e-4 and _rel(dd.cpu(), ld.grad) < 1e-4 and _rel(dp.cpu(), lp.grad) < 1e-4
 
 

@@ -60,7 +60,7 @@ def test_loss_values_match_fp32_oracle():
     m, ref, x, t = _setup()
     tr, _ = _hip_grads(m, x, t)
     L, _ = _oracle_grads(ref, x, t, emulated=False)
-    got = tr.losses.cpu().numpy()
+    got = tr.losses.cpu().numpy()[:6]
     want = [L[k] for k in ('total', 'dce', 'wdice', 'mse', 'ce', 'dice')]
     np.testing.assert_allclose(got, want, rtol=2e-3)
 

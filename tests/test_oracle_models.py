@@ -111,6 +111,7 @@ def test_train_iteration_matches_reference(golden):
         r = z['results'][it]          # [loss, dirCE, dirDice, mse, CE, var, ...] (train_util_dam.py:297-299)
         assert abs(L['total'] - r[0]) < 5e-5 and abs(L['dce'] - r[1]) < 2e-5 and abs(L['wdice'] - r[2]) < 2e-5
         assert abs(L['mse'] - r[3]) < 2e-5 and abs(L['ce'] - r[4]) < 2e-5
+        np.testing.assert_allclose(L['metrics'], r[6:11], rtol=1e-9, atol=1e-12)     # pixel accuracy, IoU, recall, precision, F1
         for k in z['pick']:
             got = sd[str(k)].detach().reshape(-1)[:96].numpy()
             np.testing.assert_allclose(got, z['p%d_%s' % (it, k)], rtol=2e-3, atol=2e-5, err_msg=str(k))
