@@ -20,6 +20,8 @@ SIGNATURES = {
     'cdnet_ddm_normalize': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'cdnet_probmaps': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'cdnet_tta_boost_argmax': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_label_pair_histogram': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_remap_label': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_watershed_workspace_bytes': (_sz, [_i, _i, _i]),
     'cdnet_watershed_process': (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     'cdnet_cc_workspace_bytes': (_sz, [_i, _i, _i]),

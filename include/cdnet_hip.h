@@ -338,6 +338,19 @@ int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int W, int max_
                          const double *gauss_host, void *workspace, size_t workspace_bytes, uint8_t *label3,
                          uint16_t *point_f16, uint8_t *direction, int32_t *inst_out, int32_t *counts_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Instance metrics (stats_utils.py): one pass over a ground-truth and a predicted label image [N][plane] i32 gives the
+ * per-label areas (area_*[N][cap], ids must be < cap <= 65536) and a sparse table of pairwise intersections (open
+ * addressing, hash_slots a power of two >= 2 x expected pairs: hash_keys[N][slots] = (true_id << 16) | pred_id, 0 = empty;
+ * hash_counts = pixels).  get_fast_aji :7-106, get_fast_pq :182-276 and get_dice_1 :323-335 are finished on the host from
+ * these (cdnet_amd/stats_utils.py).  err_flag (1 int): 1 = id out of range, 2 = table full.
+ * cdnet_remap_label = remap_label :361-392 (by_size = False); scratch i32 [N][cap].
+ * ---------------------------------------------------------------------------------------------------- */
+int cdnet_label_pair_histogram(const int32_t *true_lab, const int32_t *pred_lab, int N, int plane, int cap, int hash_slots,
+                               int32_t *area_true, int32_t *area_pred, uint32_t *hash_keys, int32_t *hash_counts, int32_t *err_flag,
+                               void *stream);
+int cdnet_remap_label(const int32_t *lab, int N, int plane, int cap, int32_t *scratch, int32_t *out, int32_t *err_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
