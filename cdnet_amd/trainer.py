@@ -90,6 +90,7 @@ class Trainer:
                  world_size=1, bucket_mb=25):
         self.model = model
         self._pack_jobs = None
+        self._ar_works = None
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.quirk = int(quirk_sample0)
         self.world = world_size
@@ -175,6 +176,8 @@ class Trainer:
                   _lib.ptr(df[2]), _lib.ptr(self._ws_head), self._ws_head.numel(), _lib.ptr(dhead), _lib.stream_ptr())
         for f, d in zip((f1, f2, f3), df):
             add(f.x, _G(d, H, W))
+        self._overlap_begin()
+        self._overlap_done(None)
         self._backward_tape(grads, add)
 
     def _backward_tape(self, grads, add):
@@ -191,6 +194,7 @@ class Trainer:
             else:
                 g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
             self._conv_backward(L, srcs, g, Hl, Wl, add)
+            self._overlap_done((L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias))
 
     def _bn_backward(self, L, out, gl, add):
         a = BnBwdArgs()
@@ -280,11 +284,68 @@ class Trainer:
             coff += s.C
 
     # ------------------------------------------------------------------------------------------------
+    # Gradient all-reduce overlapped with backward.  The flat gradient buffer is laid out in forward order, backward
+    # fills it from the end: after every layer, each fixed-size bucket that lies completely above the highest parameter
+    # still waiting for its gradient is handed to RCCL (async: the collective waits for the kernels already queued on
+    # the compute stream and runs beside the rest of backward).  CDNET_ALLREDUCE_OVERLAP=0 keeps the single
+    # post-backward pass.
+    def _overlap_begin(self):
+        self._ar_works = None
+        if not self._reduce_active() or os.environ.get('CDNET_ALLREDUCE_OVERLAP', '1') == '0':
+            return
+        f = self.flat
+        base = f.G.data_ptr()
+        pend = {}
+        owners = [p for L in self.tape for p in (L.weight, L.bias, None if L.bn is None else L.bn.weight,
+                                                 None if L.bn is None else L.bn.bias) if p is not None]
+        for p in owners:
+            off = (p.grad.data_ptr() - base) // 4
+            if 0 <= off < f.n_used:
+                pend[off] = off + p.numel()
+        if f.n_head:
+            pend[0] = f.n_head                       # the head block, written by the head backward kernel
+        self._ar_pending = pend
+        self._ar_works = []
+        self._ar_next = -(-f.n_used // self.bucket)  # buckets [k*bucket, (k+1)*bucket) with k >= _ar_next are in flight
+
+    def _overlap_done(self, params):
+        """the gradients of `params` (or the head block when None) are final: launch every bucket now complete"""
+        if self._ar_works is None:
+            return
+        f = self.flat
+        if params is None:
+            self._ar_pending.pop(0, None)
+        else:
+            base = f.G.data_ptr()
+            for p in params:
+                if p is not None:
+                    self._ar_pending.pop((p.grad.data_ptr() - base) // 4, None)
+        top = max(self._ar_pending.values()) if self._ar_pending else 0
+        self._launch_buckets(top)
+
+    def _launch_buckets(self, top):
+        import torch.distributed as dist
+        f = self.flat
+        while self._ar_next > 0 and (self._ar_next - 1) * self.bucket >= top:
+            k = self._ar_next - 1
+            a, b = k * self.bucket, min(f.n_used, (k + 1) * self.bucket)
+            self._ar_works.append(dist.all_reduce(f.G[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self._ar_next = k
+
+    def _reduce_active(self):
+        return self.world > 1 or os.environ.get('CDNET_FORCE_ALLREDUCE', '0') == '1'
+
     def allreduce_and_step(self):
         f = self.flat
         gscale = 1.0
-        if self.world > 1:
-            bucketed_allreduce(f.G, f.n_used, self.bucket)
+        if self._reduce_active():
+            if getattr(self, '_ar_works', None) is not None:
+                self._launch_buckets(0)                  # whatever backward did not release yet
+                for w in self._ar_works:
+                    w.wait()
+                self._ar_works = None
+            else:
+                bucketed_allreduce(f.G, f.n_used, self.bucket)
             gscale = 1.0 / self.world
         f.step_count += 1
         _lib.call('cdnet_adam_step', _lib.ptr(f.P), _lib.ptr(f.G), _lib.ptr(f.M), _lib.ptr(f.V), f.n_used, self.lr,
@@ -373,6 +434,8 @@ class UNetTrainer(Trainer):
         _lib.call('cdnet_final_conv1x1_backward', C.byref(hf), _lib.ptr(w), _lib.ptr(dlogits), K, N, H, W, _lib.ptr(df), _lib.ptr(ws),
                   ws.numel(), _lib.ptr(m.final_conv.weight.grad), _lib.ptr(m.final_conv.bias.grad), _lib.stream_ptr())
         add(feat.x, _G(df, H, W))
+        self._overlap_begin()
+        self._overlap_done([m.final_conv.weight, m.final_conv.bias])
         self._backward_tape(grads, add)
 
     def train_step(self, x, label, weight):

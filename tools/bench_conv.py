@@ -18,22 +18,24 @@ LAYERS = [  # name, Cin, Cout, H, cfgs
     ('dec3 160->32@128', 160, 32, 128, [(16, 32, 32), (16, 16, 32)]),
 ]
 print('B =', B)
+LAYERS.append(('1x1 64->64@256', 64, 64, 256, [(16, 16, 64), (16, 32, 64), (16, 64, 64)]))
 for name, Cin, Cout, H, cfgs in LAYERS:
+    K = 1 if name.startswith('1x1') else 3
     x = torch.randn((B, H, H, Cin), device=dev).to(torch.bfloat16)
-    w = torch.randn((Cout, Cin, 3, 3), device=dev) * 0.05
-    flops = 2.0 * B * H * H * Cin * Cout * 9
+    w = torch.randn((Cout, Cin, K, K), device=dev) * 0.05
+    flops = 2.0 * B * H * H * Cin * Cout * K * K
     byts = B * H * H * (Cin + Cout) * 2
     for cfg in cfgs:
         wp = engine.pack_weights(w, cfg, 0)
         out = torch.empty((B, H, H, Cout), dtype=torch.bfloat16, device=dev)
         for _ in range(3):
-            engine.conv_forward([engine.Src(x)], wp, Cout, cfg, out=out)
+            engine.conv_forward([engine.Src(x)], wp, Cout, cfg, taps=K * K, out=out)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            engine.conv_forward([engine.Src(x)], wp, Cout, cfg, out=out)
+            engine.conv_forward([engine.Src(x)], wp, Cout, cfg, taps=K * K, out=out)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
