@@ -198,19 +198,13 @@ __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat
         const size_t n = ii / plane, p = ii - n * plane;
         float v[16];
         load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s = fmaf(w.wp[q * 16 + c], v[c], s);
-        const float pt = quad_sum(s) + w.bp;
+        const float pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         const float g1 = 1.f + 1.f / (1.f + expf(-(w.a1 * pt)));
         load_feat16(f2, ii, q, s_sc[1], s_sh[1], v);
         float d[9], q2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            float t = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t = fmaf(w.wd[k][q * 16 + c], v[c], t);
-            d[k] = fmaf(g1, quad_sum(t), w.bd[k]);
+            d[k] = fmaf(g1, quad_sum(xf_dot16(w.wd[k] + q * 16, v)), w.bd[k]);
             q2 = fmaf(w.a2[k], d[k], q2);
         }
         const float g2 = 1.f + 1.f / (1.f + expf(-q2));
@@ -218,10 +212,7 @@ __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat
         float mk[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float t = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t = fmaf(w.wm[k][q * 16 + c], v[c], t);
-            mk[k] = fmaf(g2, quad_sum(t), w.bm[k]);
+            mk[k] = fmaf(g2, quad_sum(xf_dot16(w.wm[k] + q * 16, v)), w.bm[k]);
         }
         if (ok) {
             // the 13 outputs of a pixel are spread over its 4 lanes: lane q writes outputs q, q+4, q+8, (q+12)

@@ -600,20 +600,14 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         const size_t n = ii / plane, p = ii - n * plane;
         float v[16];
         feat16(f3, ii, q, s_sc[2], s_sh[2], v);
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s = fmaf(w.wp[q * 16 + c], v[c], s);
-        const float pt = quad_sum(s) + w.bp;
+        const float pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         const float sg1 = 1.f / (1.f + expf(-(w.a1 * pt)));
         const float g1 = 1.f + sg1;
         feat16(f2, ii, q, s_sc[1], s_sh[1], v);
         float u[9], d[9], q2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            float t = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t = fmaf(w.wd[k][q * 16 + c], v[c], t);
-            u[k] = quad_sum(t);
+            u[k] = quad_sum(xf_dot16(w.wd[k] + q * 16, v));
             d[k] = fmaf(g1, u[k], w.bd[k]);
             q2 = fmaf(w.a2[k], d[k], q2);
         }
@@ -623,19 +617,16 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         float dm[3], dg2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float t = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t = fmaf(w.wm[k][q * 16 + c], v[c], t);
-            const float mk = quad_sum(t);
+            const float mk = quad_sum(xf_dot16(w.wm[k] + q * 16, v));
             const float go = ok ? dmask[(n * 3 + k) * plane + p] : 0.f;
             dg2 = fmaf(go, mk, dg2);
             dm[k] = go * g2;
             sg[k] += go;
         }
         // dF1 = sum_k dm_k * wm_k   (this lane's 16 channels)
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            v[c] = dm[0] * w.wm[0][q * 16 + c] + dm[1] * w.wm[1][q * 16 + c] + dm[2] * w.wm[2][q * 16 + c];
+        xf_axpy16(dm[0], w.wm[0] + q * 16, v, false);
+        xf_axpy16(dm[1], w.wm[1] + q * 16, v, true);
+        xf_axpy16(dm[2], w.wm[2] + q * 16, v, true);
         if (ok) store16_bf16(df1 + ii * 64 + q * 16, v);
         const float dq2 = dg2 * sg2 * (1.f - sg2);
         float du[9], dg1 = 0.f;
@@ -648,19 +639,13 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
             du[k] = dd * g1;
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) t = fmaf(du[k], w.wd[k][q * 16 + c], t);
-            v[c] = t;
-        }
+        for (int k = 0; k < 9; ++k) xf_axpy16(du[k], w.wd[k] + q * 16, v, k != 0);
         if (ok) store16_bf16(df2 + ii * 64 + q * 16, v);
         const float dsg1 = dg1 * sg1 * (1.f - sg1);
         const float dpt = (ok ? dpoint[n * plane + p] : 0.f) + dsg1 * w.a1;
         sg[12] += dpt;
         sg[13] = fmaf(dsg1, pt, sg[13]);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = dpt * w.wp[q * 16 + c];
+        xf_axpy16(dpt, w.wp + q * 16, v, false);
         if (ok) {
             store16_bf16(df3 + ii * 64 + q * 16, v);
             // coefficient row [dpt | du[9] | dm[3] | 0 0 0]: lane q writes floats 4q..4q+3

@@ -68,4 +68,29 @@ __device__ __forceinline__ float xf_quad_sum(float v) {
     return v;
 }
 
+
+// 16-term dot product with packed fp32 FMAs (v_pk_fma_f32: two lanes of the sum per instruction)
+__device__ __forceinline__ float xf_dot16(const float *__restrict__ w, const float *__restrict__ v) {
+    xf_f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const xf_f32x2 a = {w[2 * c], w[2 * c + 1]}, b = {v[2 * c], v[2 * c + 1]};
+        acc = __builtin_elementwise_fma(a, b, acc);
+    }
+    return acc[0] + acc[1];
+}
+
+// out[c] (+)= s * w[c] for 16 channels, two per instruction
+__device__ __forceinline__ void xf_axpy16(float s, const float *__restrict__ w, float *__restrict__ out, bool accumulate) {
+    const xf_f32x2 ss = {s, s};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const xf_f32x2 a = {w[2 * c], w[2 * c + 1]};
+        xf_f32x2 o = {accumulate ? out[2 * c] : 0.f, accumulate ? out[2 * c + 1] : 0.f};
+        o = __builtin_elementwise_fma(ss, a, o);
+        out[2 * c] = o[0];
+        out[2 * c + 1] = o[1];
+    }
+}
+
 }  // namespace cdnet
