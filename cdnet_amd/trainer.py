@@ -90,7 +90,7 @@ class Trainer:
                  world_size=1, bucket_mb=25):
         self.model = model
         self._pack_jobs = None
-        self._ar_works = None
+        self._ar = None
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.quirk = int(quirk_sample0)
         self.world = world_size
@@ -290,7 +290,7 @@ class Trainer:
     # the compute stream and runs beside the rest of backward).  CDNET_ALLREDUCE_OVERLAP=0 keeps the single
     # post-backward pass.
     def _overlap_begin(self):
-        self._ar_works = None
+        self._ar = None
         if not self._reduce_active() or os.environ.get('CDNET_ALLREDUCE_OVERLAP', '1') == '0':
             return
         f = self.flat
@@ -304,33 +304,17 @@ class Trainer:
                 pend[off] = off + p.numel()
         if f.n_head:
             pend[0] = f.n_head                       # the head block, written by the head backward kernel
-        self._ar_pending = pend
-        self._ar_works = []
-        self._ar_next = -(-f.n_used // self.bucket)  # buckets [k*bucket, (k+1)*bucket) with k >= _ar_next are in flight
+        self._ar = BucketReducer(f.G, f.n_used, self.bucket, pend)
 
     def _overlap_done(self, params):
         """the gradients of `params` (or the head block when None) are final: launch every bucket now complete"""
-        if self._ar_works is None:
+        if self._ar is None:
             return
-        f = self.flat
         if params is None:
-            self._ar_pending.pop(0, None)
+            self._ar.done([0])
         else:
-            base = f.G.data_ptr()
-            for p in params:
-                if p is not None:
-                    self._ar_pending.pop((p.grad.data_ptr() - base) // 4, None)
-        top = max(self._ar_pending.values()) if self._ar_pending else 0
-        self._launch_buckets(top)
-
-    def _launch_buckets(self, top):
-        import torch.distributed as dist
-        f = self.flat
-        while self._ar_next > 0 and (self._ar_next - 1) * self.bucket >= top:
-            k = self._ar_next - 1
-            a, b = k * self.bucket, min(f.n_used, (k + 1) * self.bucket)
-            self._ar_works.append(dist.all_reduce(f.G[a:b], op=dist.ReduceOp.SUM, async_op=True))
-            self._ar_next = k
+            base = self.flat.G.data_ptr()
+            self._ar.done([(p.grad.data_ptr() - base) // 4 for p in params if p is not None])
 
     def _reduce_active(self):
         return self.world > 1 or os.environ.get('CDNET_FORCE_ALLREDUCE', '0') == '1'
@@ -339,11 +323,9 @@ class Trainer:
         f = self.flat
         gscale = 1.0
         if self._reduce_active():
-            if getattr(self, '_ar_works', None) is not None:
-                self._launch_buckets(0)                  # whatever backward did not release yet
-                for w in self._ar_works:
-                    w.wait()
-                self._ar_works = None
+            if getattr(self, '_ar', None) is not None:
+                self._ar.finish()                        # whatever backward did not release yet, then wait for all
+                self._ar = None
             else:
                 bucketed_allreduce(f.G, f.n_used, self.bucket)
             gscale = 1.0 / self.world
@@ -446,6 +428,41 @@ class UNetTrainer(Trainer):
         self.backward(dlogits)
         self.allreduce_and_step()
         return self.unet_losses
+
+
+class BucketReducer:
+    """Releases fixed-size buckets of a flat gradient buffer to the all-reduce as soon as they are complete.
+    The buffer is laid out in forward order and backward fills it from the end: `pending` maps the start offset of
+    every tensor that still waits for its gradient to its end offset; a bucket [k*B, (k+1)*B) is launched (async
+    all-reduce, top-down) once no pending tensor reaches into or above it.  Every rank runs the same schedule, so the
+    collectives are issued in the same order everywhere.  Backend-agnostic (RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, flat, n_used, bucket_elems, pending):
+        self.flat, self.n, self.bucket = flat, n_used, bucket_elems
+        self.pending = dict(pending)
+        self.works = []
+        self.next = -(-n_used // bucket_elems)       # buckets with index >= next are in flight
+        self.early = 0                               # buckets released before finish() (overlap actually happened)
+
+    def _launch(self, top):
+        import torch.distributed as dist
+        while self.next > 0 and (self.next - 1) * self.bucket >= top:
+            k = self.next - 1
+            a, b = k * self.bucket, min(self.n, (k + 1) * self.bucket)
+            self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self.next = k
+
+    def done(self, offsets):
+        for off in offsets:
+            self.pending.pop(off, None)
+        before = len(self.works)
+        self._launch(max(self.pending.values()) if self.pending else 0)
+        self.early += len(self.works) - before
+
+    def finish(self):
+        self._launch(0)
+        for w in self.works:
+            w.wait()
 
 
 def bucketed_allreduce(flat, n, bucket_elems):

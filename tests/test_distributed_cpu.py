@@ -58,3 +58,55 @@ def test_flat_state_layout_cpu():
     off, sz = fs.offsets['mask_conv.weight']
     fs.P[off] = 123.0
     assert float(p.reshape(-1)[0]) == 123.0 and p.grad.data_ptr() == fs.G[off:].data_ptr()
+
+
+def _overlap_worker(rank, world, port, sizes, n_tail, bucket, out):
+    """the schedule of the overlapped all-reduce: tensors complete in reverse (backward) order, buckets are released as
+    they become whole"""
+    import torch.distributed as dist
+    from cdnet_amd.trainer import BucketReducer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n_used = sum(sizes)
+    flat = torch.zeros(n_used + n_tail)
+    offs, o = [], 0
+    for sz in sizes:
+        offs.append(o)
+        o += sz
+    red = BucketReducer(flat, n_used, bucket, {a: a + sz for a, sz in zip(offs, sizes)})
+    g = torch.Generator().manual_seed(200 + rank)
+    early = 0
+    for a, sz in reversed(list(zip(offs, sizes))):        # "backward": last layer first
+        early = red.early                                  # buckets already in flight before this tensor completed
+        flat[a:a + sz] = torch.randn(sz, generator=g)
+        red.done([a])
+    red.finish()
+    if rank == 0:
+        out.put((flat.numpy().copy(), early, len(red.works)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_schedule_two_ranks():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    sizes, n_tail, bucket = [855, 1728, 64, 64, 36864, 64, 9000, 5, 300, 2048], 77, 4096
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, sizes, n_tail, bucket, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, early, total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = np.zeros(sum(sizes) + n_tail, np.float32)
+    for r in range(2):
+        g = torch.Generator().manual_seed(200 + r)
+        o = sum(sizes)
+        for sz in reversed(sizes):
+            o -= sz
+            want[o:o + sz] += torch.randn(sz, generator=g).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert total == -(-sum(sizes) // bucket)               # every bucket reduced exactly once
+    assert 0 < early < total                               # most buckets were in flight before the first layer's gradient existed
