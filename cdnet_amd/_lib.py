@@ -20,6 +20,7 @@ SIGNATURES = {
     'cdnet_ddm_normalize': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'cdnet_probmaps': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'cdnet_tta_boost_argmax': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_fuse_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'cdnet_label_pair_histogram': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_remap_label': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_watershed_workspace_bytes': (_sz, [_i, _i, _i]),

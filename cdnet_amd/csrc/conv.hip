@@ -108,8 +108,14 @@ __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size
                 if (mode == 4) {
                     const int kh = 2 * (tap / 3) + a - 1, kw = 2 * (tap % 3) + b - 1;      // 3x3 taps (ky, kx)
                     if (kh >= 0 && kh < 4 && kw >= 0 && kw < 4) v = w[(((size_t)co * Ct + c) * 4 + kh) * 4 + kw];
-                } else {
+                } else if (mode == 5) {
                     v = w[(((size_t)co * Ct + c) * 2 + a) * 2 + b];
+                } else {
+                    // mode 6: FORWARD 3x3 stride-2 pad-1 convolution [Cout][Ct][3][3] as a 3x3 convolution over the
+                    // space-to-depth view of its input: in(2y+ky-1, 2x+kx-1) = view(y+dy, x+dx; parity a, b) with
+                    // ky = 2*dy + a + 1 (tap row r = dy + 1), only dy in {-1, 0} contribute
+                    const int kh = 2 * (tap / 3 - 1) + a + 1, kw = 2 * (tap % 3 - 1) + b + 1;
+                    if (kh >= 0 && kh < 3 && kw >= 0 && kw < 3) v = w[(((size_t)co * Ct + c) * 3 + kh) * 3 + kw];
                 }
             }
         }
@@ -709,8 +715,8 @@ extern "C" size_t cdnet_conv_packed_weight_elems(int Cout, int Cin_padded_chunks
 static int fill_pack_desc(PackDesc &d, const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode, int p,
                           const char *who) {
     CDNET_REQUIRE(w && packed, "%s: null pointer", who);
-    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0 && mode >= 0 && mode <= 5, "%s: Cin=%d CK=%d BN=%d mode=%d", who, Cin, CK, BN, mode);
-    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : (mode == 4 ? 9 : (mode == 5 ? 1 : KH * KW)));
+    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0 && mode >= 0 && mode <= 6, "%s: Cin=%d CK=%d BN=%d mode=%d", who, Cin, CK, BN, mode);
+    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : ((mode == 4 || mode == 6) ? 9 : (mode == 5 ? 1 : KH * KW)));
     const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
     const size_t per = (size_t)ntile * nchunk * taps * CK * BN;
     d.w = w; d.out = (unsigned short *)packed + (size_t)p * per;

@@ -312,6 +312,68 @@ inline int lin_grid(size_t total) {
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// HRNet fuse / residual sums (seg_hrnet_rev1.py:256-283, 76-92, 113-133, 528-533): out = [relu]( sum_j term_j ) where a
+// term is a same-size bf16 NHWC tensor or the bilinear up-sampling (F.interpolate / F.upsample mode='bilinear',
+// align_corners=False) of a lower-resolution one.  The output may be a channel slice of a wider tensor (the final
+// torch.cat of the four branches).  8 channels per thread, fp32 arithmetic, one rounding at the end.
+// ------------------------------------------------------------------------------------------------------
+struct FuseTerm { const unsigned short *x; int Hs, Ws; };
+struct FuseArgs { FuseTerm t[4]; int nterm; int N, H, W, C; int relu; unsigned short *out; int out_cstride, out_coff; };
+
+__device__ __forceinline__ void bf8_to_f32(uint4 u, float *v) {
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+}
+
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
+    const int VPP = A.C / 8;
+    const size_t total = (size_t)A.N * A.H * A.W * VPP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i % VPP);
+        const size_t pix = i / VPP;
+        const int x = (int)(pix % A.W), y = (int)((pix / A.W) % A.H), n = (int)(pix / ((size_t)A.W * A.H));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int k = 0; k < A.nterm; ++k) {
+            const FuseTerm &T = A.t[k];
+            const unsigned short *base = T.x + (size_t)n * T.Hs * T.Ws * A.C + slot * 8;
+            float v[8];
+            if (T.Hs == A.H && T.Ws == A.W) {
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y * A.W + x) * A.C), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            } else {
+                // PyTorch upsample_bilinear2d, align_corners=False: src = max(0, (dst + 0.5) * scale - 0.5), scale = in/out
+                const float sy = (float)T.Hs / (float)A.H, sx = (float)T.Ws / (float)A.W;
+                float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+                fy = fy < 0.f ? 0.f : fy;
+                fx = fx < 0.f ? 0.f : fx;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < T.Hs - 1 ? 1 : 0), x1 = x0 + (x0 < T.Ws - 1 ? 1 : 0);
+                const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+                float a[8], b[8], c[8], d[8];
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y0 * T.Ws + x0) * A.C), a);
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y0 * T.Ws + x1) * A.C), b);
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y1 * T.Ws + x0) * A.C), c);
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y1 * T.Ws + x1) * A.C), d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += hy * (hx * a[j] + lx * b[j]) + ly * (hx * c[j] + lx * d[j]);
+            }
+        }
+        unsigned short oh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oh[j] = f2bf(A.relu ? fmaxf(acc[j], 0.f) : acc[j]);
+        uint4 ou;
+        ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
+        ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
+        *reinterpret_cast<uint4 *>(A.out + pix * A.out_cstride + A.out_coff + slot * 8) = ou;
+    }
+}
+
 }  // namespace
 
 extern "C" int cdnet_input_pack(const float *x, int N, int C, int H, int W, void *out, void *stream) {
@@ -384,4 +446,23 @@ extern "C" int cdnet_window_stitch(const float *tiles, int K, int tile_h, int ti
     window_stitch_kernel<<<lin_grid((size_t)K * Hv * Wv), 256, 0, (hipStream_t)stream>>>(tiles, K, tile_h, tile_w, stride, overlap / 2,
                                                                                          ny, nx, Hv, Wv, out);
     return check_launch("cdnet_window_stitch");
+}
+
+
+extern "C" int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, uint16_t *out, int out_cstride,
+                              int out_coff, void *stream) {
+    CDNET_REQUIRE(terms && out && nterm >= 1 && nterm <= 4, "cdnet_fuse_sum: 1..4 terms");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "cdnet_fuse_sum: bad size (C %% 8)");
+    FuseArgs A;
+    for (int k = 0; k < 4; ++k) {
+        if (k < nterm) {
+            CDNET_REQUIRE(terms[k].x && terms[k].Hs > 0 && terms[k].Ws > 0 && terms[k].Hs <= H && terms[k].Ws <= W, "cdnet_fuse_sum: term %d", k);
+            A.t[k].x = terms[k].x; A.t[k].Hs = terms[k].Hs; A.t[k].Ws = terms[k].Ws;
+        } else { A.t[k].x = nullptr; A.t[k].Hs = A.t[k].Ws = 0; }
+    }
+    A.nterm = nterm; A.N = N; A.H = H; A.W = W; A.C = C; A.relu = relu; A.out = out;
+    A.out_cstride = out_cstride ? out_cstride : C; A.out_coff = out_coff;
+    CDNET_REQUIRE(A.out_cstride % 8 == 0 && out_coff % 8 == 0 && out_coff + C <= A.out_cstride, "cdnet_fuse_sum: output channel slice");
+    fuse_sum_kernel<<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    return check_launch("cdnet_fuse_sum");
 }

@@ -114,12 +114,12 @@ def _pack_dims(w, cfg, mode):
         Cout, Cin, KH, KW = w.shape
     elif mode == 1:
         Cin, Cout, KH, KW = w.shape          # roles swap: GEMM-Cout = original in_channels
-    elif mode in (4, 5):
+    elif mode in (4, 5, 6):
         Cout, ct, KH, KW = w.shape           # backward-data of a transposed conv: GEMM-Cout = its in_channels,
-        Cin = 4 * ct                         # GEMM-Cin = space-to-depth of its out_channels
+        Cin = 4 * ct                         # GEMM-Cin = space-to-depth of its out_channels (6: stride-2 forward conv)
     else:
         Cin, Cout, KH, KW = w.shape
-    taps = {2: 4, 3: 1, 4: 9, 5: 1}.get(mode, KH * KW)
+    taps = {2: 4, 3: 1, 4: 9, 5: 1, 6: 9}.get(mode, KH * KW)
     npar = 4 if mode in (2, 3) else 1
     return Cout, Cin, KH, KW, CK, BN, taps, npar
 

@@ -47,16 +47,18 @@ class ConvLayer:
     """One convolution (optionally followed by BatchNorm) of a network."""
 
     def __init__(self, name, kind, weight, bias=None, bn=None, cfg_override=None):
-        assert kind in ('conv3', 'conv1', 'convT4', 'convT2')
+        assert kind in ('conv3', 'conv1', 'convT4', 'convT2', 'conv3s2')
         self.name, self.kind, self.weight, self.bias, self.bn = name, kind, weight, bias, bn
         self.cfg_override = cfg_override
-        if kind in ('conv3', 'conv1'):
+        if kind == 'conv3s2':                 # stride-2 3x3 conv over the space-to-depth view of its input (pack mode 6)
+            self.Cout, self.Cin = weight.shape[0], 4 * weight.shape[1]
+        elif kind in ('conv3', 'conv1'):
             self.Cout, self.Cin = weight.shape[0], weight.shape[1]
         else:
             self.Cin, self.Cout = weight.shape[0], weight.shape[1]
-        self.taps = {'conv3': 9, 'conv1': 1, 'convT4': 4, 'convT2': 1}[kind]
+        self.taps = {'conv3': 9, 'conv1': 1, 'convT4': 4, 'convT2': 1, 'conv3s2': 9}[kind]
         self.transposed = kind in ('convT4', 'convT2')
-        self.pack_mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3}[kind]
+        self.pack_mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3, 'conv3s2': 6}[kind]
         self.cfg = None
         self.wp = None
         self.wp_version = None

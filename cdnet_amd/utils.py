@@ -21,7 +21,10 @@ def chooseModel(opt):
         from .models.dam.model_unet_rev1 import Unet
         # the reference hard-codes pretrained=True (ImageNet download); weights are supplied via load_state_dict here
         return Unet(backbone_name='vgg16_bn', pretrained=False, encoder_freeze=False, classes=opt.model['out_c'])
-    raise NotImplementedError('model {} is outside the CDNet hot path (SURVEY.md section 8: UNet, UNet2RevA1_vgg16)'.format(name))
+    if name == 'HRNet18_rev1':                       # utils.py:880-882
+        from .models.dam.seg_hrnet_rev1 import HighResolutionNet
+        return HighResolutionNet(opt)
+    raise NotImplementedError('model {} is outside the CDNet hot path (SURVEY.md section 8: UNet, UNet2RevA1_vgg16, HRNet18_rev1)'.format(name))
 
 
 def window_grid(h0, w0, size, overlap):

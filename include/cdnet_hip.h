@@ -166,7 +166,9 @@ size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, in
  * mode 2: ConvTranspose2d [Cin][Cout][4][4] k4 s2 p1 forward (4 parities); mode 3: ConvTranspose2d [Cin][Cout][2][2]
  * k2 s2 forward (4 parities); mode 4 / 5: backward-data of the k4 s2 p1 / k2 s2 transposed convolution, expressed as a
  * 3x3 / 1x1 convolution over the space-to-depth view of the output gradient (two sources = the two row parities, each
- * with 2*Cout_t channels ordered (column parity, channel)); Cout := transposed-conv in_channels, Cin := 4*out_channels. */
+ * with 2*Cout_t channels ordered (column parity, channel)); Cout := transposed-conv in_channels, Cin := 4*out_channels.
+ * mode 6: forward Conv2d [Cout][C][3][3] stride 2 pad 1 (HRNet transition / fuse layers, seg_hrnet_rev1.py:228-247,
+ * 436-443) as a 3x3 convolution over the same space-to-depth view of its INPUT; Cin := 4*C. */
 int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode,
                             void *stream);
 /* The same packing for many tensors in one launch (the training step re-packs every layer's forward and backward-data
@@ -337,6 +339,17 @@ size_t cdnet_label_encoding_workspace_bytes(int N, int H, int W, int max_instanc
 int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int W, int max_instances, const double *rays_host,
                          const double *gauss_host, void *workspace, size_t workspace_bytes, uint8_t *label3,
                          uint16_t *point_f16, uint8_t *direction, int32_t *inst_out, int32_t *counts_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * HRNet fuse / residual sums.  Replaces the y = y + x[j] / y = y + F.interpolate(..., mode='bilinear') / relu(y) chains of
+ * seg_hrnet_rev1.py:256-283, the residual adds of BasicBlock / Bottleneck (:76-92, :113-133) and the F.upsample + torch.cat
+ * of the four branches (:528-533).  out[N][H][W] = [relu](sum of 1..4 terms), every term a bf16 NHWC tensor with C
+ * channels, either [H][W] or a lower resolution that is up-sampled bilinearly (align_corners = False).  The output may be a
+ * channel slice [out_coff, out_coff + C) of pixels out_cstride wide (0 = C).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct cdnet_fuse_term { const uint16_t *x; int Hs, Ws; } cdnet_fuse_term;
+int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, uint16_t *out, int out_cstride,
+                   int out_coff, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Instance metrics (stats_utils.py): one pass over a ground-truth and a predicted label image [N][plane] i32 gives the

@@ -282,6 +282,29 @@ def gen_train_iter():
     save('train_iter', **out)
 
 
+def gen_hrnet():
+    """HRNet18_rev1 (seg_hrnet_rev1.HighResolutionNet) eval forward; closed-form weights with every Conv2d scaled by 0.45
+    (the un-scaled fill overflows through the 30 residual additions)"""
+    from models.dam.seg_hrnet_rev1 import HighResolutionNet
+
+    class _O:
+        model = {'out_c': 3}
+    m = det_fill(HighResolutionNet(_O())).eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.mul_(0.45)
+        out = {'gain': np.float64(0.45)}
+        for tag, shape, seed in (('a', (1, 3, 64, 64), 5), ('b', (2, 3, 32, 96), 6)):
+            x = det_input(shape, seed, bf16_exact=True)
+            for n, o in zip(('mask', 'point', 'direction'), m(x)):
+                out['%s_%s' % (n, tag)] = o.numpy()
+            out['x_cfg_' + tag] = np.array(list(shape) + [seed])
+    out['param_count'] = np.int64(sum(p.numel() for p in m.parameters()))
+    out['n_keys'] = np.int64(len(m.state_dict()))
+    save('hrnet_fwd', **out)
+
+
 def gen_unet_train_iter():
     """two iterations of the reference's plain-UNet train loop (train_util.train, default options) on one batch"""
     import train_util
@@ -500,7 +523,7 @@ def gen_aji():
     save('aji', **out)
 
 
-ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter,
+ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet,
        'cdm': gen_cdm, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':
