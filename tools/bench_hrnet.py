@@ -1,0 +1,28 @@
+"""HRNet18_rev1 inference forward (BASELINE config 5 shape: 512x512 tiles) timing.  usage: python tools/bench_hrnet.py [B]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cdnet_amd.models.dam.seg_hrnet_rev1 import HighResolutionNet
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+
+
+class O:
+    model = {'out_c': 3}
+
+
+torch.manual_seed(0)
+m = HighResolutionNet(O()).cuda().eval()
+x = torch.rand((B, 3, 512, 512), device='cuda')
+with torch.no_grad():
+    for _ in range(2):
+        m(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        m(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+print('HRNet18_rev1 eval forward, %d tiles 512x512: %.2f ms = %.1f tiles/s' % (B, dt * 1e3, B / dt))
