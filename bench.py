@@ -99,6 +99,31 @@ def time_dominant_conv(torch, B, steps=20):
                 mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / DENSE_BF16_PEAK_TFLOPS)
 
 
+def cpu_baseline_train(n_tiles=2):
+    """The fp32 PyTorch-CPU oracle train iteration (oracle/train.py, pinned to the reference) on a bounded sample."""
+    import numpy as np
+    import torch
+    from cdnet_amd import synth
+    from cdnet_amd.trainer import synthetic_batch
+    from oracle import models as om
+    from oracle import train as ot
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = om.Unet()
+    opt = ot.make_adam(net)
+    x, lab, dirn, point, weight = [t.cpu() for t in synthetic_batch(n_tiles, torch.device('cpu'))]
+    ot.train_iteration(net, opt, x, lab, dirn, point, weight)
+    t0 = time.time()
+    reps = 2
+    for _ in range(reps):
+        ot.train_iteration(net, opt, x, lab, dirn, point, weight)
+    dt = (time.time() - t0) / reps
+    return dict(value=n_tiles / dt, unit='tiles/s', cores=cores, kind='port',
+                sample='%d synthetic 256x256 tiles per iteration: oracle fp32 PyTorch-CPU train iteration (forward, 5 losses, '
+                       'autograd backward, Adam; %d threads), %d repetitions after 1 warm-up' % (n_tiles, cores, reps))
+
+
 def main():
     a = parse()
     import numpy as np
@@ -201,8 +226,7 @@ def main():
             if mode == 'infer':
                 line['cpu_baseline'] = cpu_baseline_infer()
             else:
-                from cdnet_amd import trainer
-                line['cpu_baseline'] = trainer.cpu_baseline_train()
+                line['cpu_baseline'] = cpu_baseline_train()
         print(json.dumps(line))
     if world > 1:
         dist.barrier()                    # rank 0 times the roofline kernel after the timed region: leave together

@@ -516,26 +516,3 @@ def make_bench_step(model, B, dev, rank, world):
     workload = ('CDNet UNet2RevA1_vgg16 (UNet+DAM) training step: forward, 5-term loss, backward, %s fused Adam; '
                 '256x256x3 synthetic tiles, batch %d per GPU' % ('RCCL gradient all-reduce,' if world > 1 else '', B))
     return step, metric, workload
-
-
-def cpu_baseline_train(n_tiles=2):
-    """The fp32 PyTorch-CPU oracle train iteration (oracle/train.py, pinned to the reference) on a bounded sample."""
-    import numpy as np
-    from . import synth
-    from oracle import models as om
-    from oracle import train as ot
-    cores = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    net = om.Unet()
-    opt = ot.make_adam(net)
-    x, lab, dirn, point, weight = [t.cpu() for t in synthetic_batch(n_tiles, torch.device('cpu'))]
-    ot.train_iteration(net, opt, x, lab, dirn, point, weight)
-    t0 = time.time()
-    reps = 2
-    for _ in range(reps):
-        ot.train_iteration(net, opt, x, lab, dirn, point, weight)
-    dt = (time.time() - t0) / reps
-    return dict(value=n_tiles / dt, unit='tiles/s', cores=cores, kind='port',
-                sample='%d synthetic 256x256 tiles per iteration: oracle fp32 PyTorch-CPU train iteration (forward, 5 losses, '
-                       'autograd backward, Adam; %d threads), %d repetitions after 1 warm-up' % (n_tiles, cores, reps))
