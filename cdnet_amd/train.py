@@ -1,0 +1,94 @@
+"""Training entry point with the reference's shape (train.py:59-530, the part that is the hot path): options -> seeds ->
+`chooseModel` -> optimiser -> epochs of `train_util_dam.train` (or the plain-UNet step) -> checkpoint.
+
+    python -m cdnet_amd.train --synthetic 64 --epochs 2              # synthetic tiles (no dataset needed)
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m cdnet_amd.train ...   # one process per GPU, RCCL all-reduce
+
+The reference's augmentation pipeline (albumentations / PIL RNG streams) and its CSV / tensorboard logging are outside
+the accelerated path: with a real dataset the loader below applies only random 256x256 crops,
+`LabelEncoding` (on the GPU) and `ToTensor`; `nn.DataParallel` (train.py:185) is replaced by one process per GPU."""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import synth, train_util_dam, utils
+from .options import Options
+from .trainer import synthetic_batch, UNetTrainer
+
+
+class _SyntheticLoader:
+    """`n` batches of the SURVEY 8d recipe in the sample layout of the reference's DataLoader"""
+
+    def __init__(self, n_batches, batch, dev, seed):
+        self.items = []
+        for k in range(n_batches):
+            x, lab, dirn, point, weight = synthetic_batch(batch, dev, seed=seed + k)
+            target0 = (lab.to(torch.int64) * 127 + (lab == 2).to(torch.int64)).unsqueeze(1)      # {0,127,255} as ToTensor emits
+            self.items.append((x, weight.unsqueeze(1), target0, point, dirn))
+
+    def __iter__(self):
+        return iter(self.items)
+
+    def __len__(self):
+        return len(self.items)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument('--synthetic', type=int, default=0, help='number of synthetic batches per epoch (0 = read the dataset folders)')
+    own, rest = ap.parse_known_args(argv)
+    opt = Options(isTrain=True).parse(rest)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format='%(message)s', stream=sys.stdout)
+    logger = logging.getLogger('cdnet_amd.train')
+    torch.manual_seed(opt.train['seed'])                   # train.py:75-81 (same seed on every rank = same initial weights)
+    np.random.seed(opt.train['seed'])
+    model = utils.chooseModel(opt).to(dev)
+    plain_unet = opt.model['modelName'] == 'UNet'
+    if plain_unet:
+        trainer = UNetTrainer(model, lr=opt.train['lr'], weight_decay=opt.train['weight_decay'], world_size=world)
+    else:
+        trainer, _ = utils.get_optimizer(opt, model, world_size=world)
+    B = opt.train['batch_size']
+    if own.synthetic <= 0:
+        raise SystemExit("dataset folders are read by the reference's DataFolder + augmentation pipeline, which is outside the "
+                         "accelerated path; run with --synthetic N, or feed train_util_dam.train your own loader")
+    loader = _SyntheticLoader(own.synthetic, B, dev, seed=opt.train['seed'] + 1000 * rank)
+    for epoch in range(opt.train['start_epoch'], opt.train['num_epochs']):
+        t0 = time.time()
+        if plain_unet:
+            tot = np.zeros(3)
+            for x, w, target0, _, _ in loader:
+                tot += trainer.train_step(x, train_util_dam._label3(target0), w[:, 0].contiguous()).cpu().numpy()
+            res = tot / len(loader)
+        else:
+            res = train_util_dam.train(loader, model, trainer, None, epoch, opt, logger)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        logger.info('epoch {:d}: loss {:.4f}  ({:.1f} tiles/s on {:d} GPU(s))'.format(epoch + 1, float(res[0]), world * B * len(loader) / dt, world))
+    if rank == 0 and opt.train.get('save_dir'):
+        os.makedirs(opt.train['save_dir'], exist_ok=True)
+        torch.save({'epoch': opt.train['num_epochs'], 'state_dict': {'module.' + k: v.detach().cpu() for k, v in model.state_dict().items()}},
+                   os.path.join(opt.train['save_dir'], 'checkpoint_last.pth.tar'))          # DataParallel key prefix (train.py:476-487)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == '__main__':
+    main()
