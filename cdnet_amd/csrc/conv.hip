@@ -149,6 +149,10 @@ struct ChanXf {           // per-thread channel transform for its 8 channels of 
 
 __device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, bool relu, bool f16) {
     V16 o;
+    if (f16 && !t.on && relu && res) {           // eval-mode residual unit: relu(raw + res), packed math
+        o.u = __builtin_bit_cast(uint4, xf_addrelu_f16(__builtin_bit_cast(xf_u32x4, raw.u), __builtin_bit_cast(xf_u32x4, res->u)));
+        return o;
+    }
     if (f16 && t.on && relu) {                   // the training-mode combination: packed math (xform.h)
         const xf_u32x4 r = __builtin_bit_cast(xf_u32x4, raw.u);
         const xf_u32x4 v = res ? xf_bnrelu_f16<true>(r, __builtin_bit_cast(xf_u32x4, res->u), t.sc, t.sh)

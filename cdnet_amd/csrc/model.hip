@@ -143,6 +143,10 @@ __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q
         uint4 r = pr[h2];
         uint4 rr = make_uint4(0, 0, 0, 0);
         if (ps) rr = ps[h2];
+        if (f.f16 && !f.scale && f.relu && ps) {           // eval-mode residual unit output: relu(raw + res)
+            xf_addrelu_f16_to_f32(__builtin_bit_cast(xf_u32x4, r), __builtin_bit_cast(xf_u32x4, rr), v + h2 * 8);
+            continue;
+        }
         if (fast) {
             const xf_u32x4 a = __builtin_bit_cast(xf_u32x4, r), b = __builtin_bit_cast(xf_u32x4, rr);
             const int c0 = q * 16 + h2 * 8;

@@ -49,6 +49,33 @@ __device__ __forceinline__ xf_u32x4 xf_max_nonneg_bf8(xf_u32x4 a, xf_u32x4 b) {
 }
 
 
+
+// eval-mode residual unit output: relu(raw + res), both fp16, no affine (the BatchNorm is folded into the producer) -> bf16
+__device__ __forceinline__ xf_u32x4 xf_addrelu_f16(xf_u32x4 raw, xf_u32x4 res) {
+    XfWords I, R, O;
+    I.u = raw;
+    R.u = res;
+    const xf_s16x2 zero = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const xf_f32x2 t = __builtin_convertvector(__builtin_bit_cast(xf_h16x2, I.w[k]), xf_f32x2) +
+                           __builtin_convertvector(__builtin_bit_cast(xf_h16x2, R.w[k]), xf_f32x2);
+        const xf_bf16x2 r = __builtin_convertvector(t, xf_bf16x2);
+        O.w[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(xf_s16x2, r), zero));
+    }
+    return O.u;
+}
+
+__device__ __forceinline__ void xf_addrelu_f16_to_f32(xf_u32x4 raw, xf_u32x4 res, float *out) {
+    XfWords O;
+    O.u = xf_addrelu_f16(raw, res);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out[2 * k] = __builtin_bit_cast(float, O.w[k] << 16);
+        out[2 * k + 1] = __builtin_bit_cast(float, O.w[k] & 0xffff0000u);
+    }
+}
+
 // the same transform, result widened to 8 floats (the values the MFMA kernels see: bf16-rounded)
 template <bool RES>
 __device__ __forceinline__ void xf_bnrelu_f16_to_f32(xf_u32x4 raw, xf_u32x4 res, const float *sc, const float *sh, float *out) {
