@@ -21,6 +21,8 @@ SIGNATURES = {
     'cdnet_probmaps': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'cdnet_tta_boost_argmax': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_fuse_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    'cdnet_upsample_bilinear_backward': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_s2d_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_label_pair_histogram': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_remap_label': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_watershed_workspace_bytes': (_sz, [_i, _i, _i]),

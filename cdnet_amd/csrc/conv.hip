@@ -99,6 +99,14 @@ __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size
             } else if (mode == 3) {
                 int a = parity >> 1, b = parity & 1;
                 v = w[(((size_t)ci * Cout + co) * 2 + a) * 2 + b];
+            } else if (mode == 7) {
+                // backward-data of mode 6: GEMM co = (a, b, c) of the view (Cout = 4*Ct), ci = the conv's out channel,
+                // taps flipped: dV[y'][x'][(a,b,c)] = sum_t dY[y' - dy_t][x' - dx_t][ci] * W[ci][c][ky][kx]
+                const int Ct = Cout / 4;
+                const int a = co / (2 * Ct), b = (co / Ct) & 1, c = co % Ct;
+                const int tf = 8 - tap;
+                const int kh = 2 * (tf / 3 - 1) + a + 1, kw = 2 * (tf % 3 - 1) + b + 1;
+                if (kh >= 0 && kh < 3 && kw >= 0 && kw < 3) v = w[(((size_t)ci * Ct + c) * 3 + kh) * 3 + kw];
             } else {
                 // modes 4/5: backward-data of a stride-2 transposed convolution as a convolution over the space-to-depth
                 // view of the output gradient.  GEMM "cin" ci = a*(2*Ct) + b*Ct + c (row parity a = source, column parity
@@ -719,8 +727,8 @@ extern "C" size_t cdnet_conv_packed_weight_elems(int Cout, int Cin_padded_chunks
 static int fill_pack_desc(PackDesc &d, const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode, int p,
                           const char *who) {
     CDNET_REQUIRE(w && packed, "%s: null pointer", who);
-    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0 && mode >= 0 && mode <= 6, "%s: Cin=%d CK=%d BN=%d mode=%d", who, Cin, CK, BN, mode);
-    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : ((mode == 4 || mode == 6) ? 9 : (mode == 5 ? 1 : KH * KW)));
+    CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0 && mode >= 0 && mode <= 7, "%s: Cin=%d CK=%d BN=%d mode=%d", who, Cin, CK, BN, mode);
+    const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : ((mode == 4 || mode == 6 || mode == 7) ? 9 : (mode == 5 ? 1 : KH * KW)));
     const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
     const size_t per = (size_t)ntile * nchunk * taps * CK * BN;
     d.w = w; d.out = (unsigned short *)packed + (size_t)p * per;

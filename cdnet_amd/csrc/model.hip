@@ -323,13 +323,31 @@ inline int lin_grid(size_t total) {
 // align_corners=False) of a lower-resolution one.  The output may be a channel slice of a wider tensor (the final
 // torch.cat of the four branches).  8 channels per thread, fp32 arithmetic, one rounding at the end.
 // ------------------------------------------------------------------------------------------------------
-struct FuseTerm { const unsigned short *x; int Hs, Ws; };
+struct FuseTerm { const unsigned short *x; int Hs, Ws; const float *scale, *shift; int f16; };
 struct FuseArgs { FuseTerm t[4]; int nterm; int N, H, W, C; int relu; unsigned short *out; int out_cstride, out_coff; };
 
 __device__ __forceinline__ void bf8_to_f32(uint4 u, float *v) {
     const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+}
+
+// 8 channels of one term at one source pixel: bf16 / fp16 storage, optional per-channel affine (training mode: the raw
+// convolution output with its BatchNorm scale / shift)
+__device__ __forceinline__ void term8(const FuseTerm &T, const unsigned short *p, int c0, float *v) {
+    const uint4 u = *reinterpret_cast<const uint4 *>(p);
+    if (T.f16) {
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[k] & 0xffffu));
+            v[2 * k + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[k] >> 16));
+        }
+    } else bf8_to_f32(u, v);
+    if (T.scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], T.scale[c0 + j], T.shift[c0 + j]);
+    }
 }
 
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
             const unsigned short *base = T.x + (size_t)n * T.Hs * T.Ws * A.C + slot * 8;
             float v[8];
             if (T.Hs == A.H && T.Ws == A.W) {
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y * A.W + x) * A.C), v);
+                term8(T, base + ((size_t)y * A.W + x) * A.C, slot * 8, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += v[j];
             } else {
@@ -360,10 +378,10 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
                 const int y1 = y0 + (y0 < T.Hs - 1 ? 1 : 0), x1 = x0 + (x0 < T.Ws - 1 ? 1 : 0);
                 const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
                 float a[8], b[8], c[8], d[8];
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y0 * T.Ws + x0) * A.C), a);
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y0 * T.Ws + x1) * A.C), b);
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y1 * T.Ws + x0) * A.C), c);
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + ((size_t)y1 * T.Ws + x1) * A.C), d);
+                term8(T, base + ((size_t)y0 * T.Ws + x0) * A.C, slot * 8, a);
+                term8(T, base + ((size_t)y0 * T.Ws + x1) * A.C, slot * 8, b);
+                term8(T, base + ((size_t)y1 * T.Ws + x0) * A.C, slot * 8, c);
+                term8(T, base + ((size_t)y1 * T.Ws + x1) * A.C, slot * 8, d);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += hy * (hx * a[j] + lx * b[j]) + ly * (hx * c[j] + lx * d[j]);
             }
@@ -375,6 +393,72 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
         ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
         ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
         *reinterpret_cast<uint4 *>(A.out + pix * A.out_cstride + A.out_coff + slot * 8) = ou;
+    }
+}
+
+
+// transpose of the bilinear up-sampling inside fuse_sum (gather form, deterministic): din[ys][xs] = sum over the output
+// pixels (y, x) whose interpolation reads (ys, xs) of their weight x dout[y][x].  dout may be a channel slice.
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const unsigned short *__restrict__ dout, int N, int H, int W, int C, int cstride,
+                                                           int coff, int Hs, int Ws, unsigned short *__restrict__ din) {
+    const int VPP = C / 8;
+    const size_t total = (size_t)N * Hs * Ws * VPP;
+    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    const int ry = (H + Hs - 1) / Hs, rx = (W + Ws - 1) / Ws;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i % VPP);
+        const size_t pix = i / VPP;
+        const int xs = (int)(pix % Ws), ys = (int)((pix / Ws) % Hs), n = (int)(pix / ((size_t)Ws * Hs));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const int ylo = (ys - 1) * ry < 0 ? 0 : (ys - 1) * ry, yhi = (ys + 2) * ry > H ? H : (ys + 2) * ry;
+        const int xlo = (xs - 1) * rx < 0 ? 0 : (xs - 1) * rx, xhi = (xs + 2) * rx > W ? W : (xs + 2) * rx;
+        for (int y = ylo; y < yhi; ++y) {
+            float fy = ((float)y + 0.5f) * sy - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+            const float ly = fy - (float)y0;
+            const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int x = xlo; x < xhi; ++x) {
+                float fx = ((float)x + 0.5f) * sx - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = (int)fx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                const float lx = fx - (float)x0;
+                const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float v[8];
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(dout + (((size_t)n * H + y) * W + x) * cstride + coff + slot * 8), v);
+                const float wgt = wy * wx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(wgt, v[j], acc[j]);
+            }
+        }
+        unsigned short oh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oh[j] = f2bf(acc[j]);
+        uint4 ou;
+        ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
+        ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
+        *reinterpret_cast<uint4 *>(din + pix * C + slot * 8) = ou;
+    }
+}
+
+// space-to-depth gradient [N][H2][W2][(a, b, c)] -> NHWC [N][2*H2][2*W2][C] (the input gradient of a stride-2 convolution
+// computed through the space-to-depth view)
+__global__ __launch_bounds__(256) void s2d_to_nhwc_kernel(const unsigned short *__restrict__ in, int N, int H2, int W2, int C,
+                                                          unsigned short *__restrict__ out) {
+    const int VPP = C / 8;
+    const size_t total = (size_t)N * H2 * W2 * 4 * VPP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i % VPP);
+        size_t r = i / VPP;
+        const int ab = (int)(r & 3); r >>= 2;
+        const int x2 = (int)(r % W2), y2 = (int)((r / W2) % H2), n = (int)(r / ((size_t)W2 * H2));
+        const int a = ab >> 1, b = ab & 1;
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + (((size_t)n * H2 + y2) * W2 + x2) * 4 * C + (size_t)ab * C + slot * 8);
+        *reinterpret_cast<uint4 *>(out + (((size_t)n * 2 * H2 + 2 * y2 + a) * 2 * W2 + 2 * x2 + b) * C + slot * 8) = v;
     }
 }
 
@@ -462,11 +546,28 @@ extern "C" int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, in
         if (k < nterm) {
             CDNET_REQUIRE(terms[k].x && terms[k].Hs > 0 && terms[k].Ws > 0 && terms[k].Hs <= H && terms[k].Ws <= W, "cdnet_fuse_sum: term %d", k);
             A.t[k].x = terms[k].x; A.t[k].Hs = terms[k].Hs; A.t[k].Ws = terms[k].Ws;
-        } else { A.t[k].x = nullptr; A.t[k].Hs = A.t[k].Ws = 0; }
+            A.t[k].scale = terms[k].scale; A.t[k].shift = terms[k].shift; A.t[k].f16 = terms[k].f16;
+            CDNET_REQUIRE((terms[k].scale == nullptr) == (terms[k].shift == nullptr), "cdnet_fuse_sum: scale and shift come together");
+        } else { A.t[k].x = nullptr; A.t[k].Hs = A.t[k].Ws = 0; A.t[k].scale = A.t[k].shift = nullptr; A.t[k].f16 = 0; }
     }
     A.nterm = nterm; A.N = N; A.H = H; A.W = W; A.C = C; A.relu = relu; A.out = out;
     A.out_cstride = out_cstride ? out_cstride : C; A.out_coff = out_coff;
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && out_coff % 8 == 0 && out_coff + C <= A.out_cstride, "cdnet_fuse_sum: output channel slice");
     fuse_sum_kernel<<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
     return check_launch("cdnet_fuse_sum");
+}
+
+extern "C" int cdnet_upsample_bilinear_backward(const uint16_t *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws,
+                                                uint16_t *din, void *stream) {
+    CDNET_REQUIRE(dout && din && N > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C % 8 == 0 && C >= 8, "cdnet_upsample_bilinear_backward: bad args");
+    const int cs = dout_cstride ? dout_cstride : C;
+    CDNET_REQUIRE(cs % 8 == 0 && dout_coff % 8 == 0 && dout_coff + C <= cs, "cdnet_upsample_bilinear_backward: channel slice");
+    upsample_bwd_kernel<<<lin_grid((size_t)N * Hs * Ws * (C / 8)), 256, 0, (hipStream_t)stream>>>(dout, N, H, W, C, cs, dout_coff, Hs, Ws, din);
+    return check_launch("cdnet_upsample_bilinear_backward");
+}
+
+extern "C" int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int C, uint16_t *out, void *stream) {
+    CDNET_REQUIRE(in && out && N > 0 && H2 > 0 && W2 > 0 && C % 8 == 0 && C >= 8, "cdnet_s2d_to_nhwc: bad args");
+    s2d_to_nhwc_kernel<<<lin_grid((size_t)N * H2 * W2 * 4 * (C / 8)), 256, 0, (hipStream_t)stream>>>(in, N, H2, W2, C, out);
+    return check_launch("cdnet_s2d_to_nhwc");
 }

@@ -558,6 +558,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     size_t o;
     if (mode == 0) {
         o = ((size_t)co * Cin_real + ci) * TAPS + tap;
+    } else if (mode == 6) {
+        // stride-2 3x3 conv through the space-to-depth view: GEMM ci = (a, b, c), Cin_real = 4*Ct; dW[co][c][ky][kx] with
+        // ky = 2*(tap/3 - 1) + a + 1 (the other tap / parity combinations multiply structural zeros)
+        const int Ct = Cin_real / 4;
+        const int a = ci / (2 * Ct), b = (ci / Ct) & 1, c = ci % Ct;
+        const int kh = 2 * (tap / 3 - 1) + a + 1, kw = 2 * (tap % 3 - 1) + b + 1;
+        if (kh < 0 || kh > 2 || kw < 0 || kw > 2) return;
+        o = (((size_t)co * Ct + c) * 3 + kh) * 3 + kw;
     } else if (mode == 2) {
         const int a = par >> 1, b = par & 1, ty = tap >> 1, tx = tap & 1;
         const int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
@@ -643,6 +651,7 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     CDNET_REQUIRE(!(src->res && src->pool), "cdnet_conv_backward_weight: a pooled source with a residual branch is not supported");
     CDNET_REQUIRE(ksplit >= 1 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "cdnet_conv_backward_weight: bad size (Cout %% 8)");
     CDNET_REQUIRE((taps == 9 && npar == 1 && ostride == 1 && mode == 0) || (taps == 1 && npar == 1 && ostride == 1 && mode == 0) ||
+                  (taps == 9 && npar == 1 && ostride == 1 && mode == 6) ||
                   (taps == 4 && npar == 4 && ostride == 2 && mode == 2) || (taps == 1 && npar == 4 && ostride == 2 && mode == 3),
                   "cdnet_conv_backward_weight: taps=%d npar=%d ostride=%d mode=%d", taps, npar, ostride, mode);
     hipStream_t st = (hipStream_t)stream;

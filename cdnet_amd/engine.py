@@ -117,9 +117,12 @@ def _pack_dims(w, cfg, mode):
     elif mode in (4, 5, 6):
         Cout, ct, KH, KW = w.shape           # backward-data of a transposed conv: GEMM-Cout = its in_channels,
         Cin = 4 * ct                         # GEMM-Cin = space-to-depth of its out_channels (6: stride-2 forward conv)
+    elif mode == 7:
+        Cin, ct, KH, KW = w.shape            # backward-data of the stride-2 conv (mode 6): GEMM-Cout = 4 * its in_channels
+        Cout = 4 * ct
     else:
         Cin, Cout, KH, KW = w.shape
-    taps = {2: 4, 3: 1, 4: 9, 5: 1, 6: 9}.get(mode, KH * KW)
+    taps = {2: 4, 3: 1, 4: 9, 5: 1, 6: 9, 7: 9}.get(mode, KH * KW)
     npar = 4 if mode in (2, 3) else 1
     return Cout, Cin, KH, KW, CK, BN, taps, npar
 

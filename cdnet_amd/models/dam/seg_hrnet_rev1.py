@@ -340,4 +340,5 @@ class HighResolutionNet(nn.Module):
 
 
 class FuseTerm(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('Hs', C.c_int), ('Ws', C.c_int)]
+    _fields_ = [('x', C.c_void_p), ('Hs', C.c_int), ('Ws', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('f16', C.c_int), ('pad_', C.c_int)]

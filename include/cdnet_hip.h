@@ -164,7 +164,8 @@ size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, in
 /* fp32 master weights -> packed bf16.  mode 0: Conv2d [Cout][Cin][KH][KW] forward; mode 1: Conv2d backward-data
  * (Cout/Cin are the ROLES in the backward GEMM: Cout := original in_channels, Cin := original out_channels);
  * mode 2: ConvTranspose2d [Cin][Cout][4][4] k4 s2 p1 forward (4 parities); mode 3: ConvTranspose2d [Cin][Cout][2][2]
- * k2 s2 forward (4 parities); mode 4 / 5: backward-data of the k4 s2 p1 / k2 s2 transposed convolution, expressed as a
+ * k2 s2 forward (4 parities); mode 7: backward-data of mode 6 (Cout := 4*C of the view, Cin := the conv's out_channels);
+ * mode 4 / 5: backward-data of the k4 s2 p1 / k2 s2 transposed convolution, expressed as a
  * 3x3 / 1x1 convolution over the space-to-depth view of the output gradient (two sources = the two row parities, each
  * with 2*Cout_t channels ordered (column parity, channel)); Cout := transposed-conv in_channels, Cin := 4*out_channels.
  * mode 6: forward Conv2d [Cout][C][3][3] stride 2 pad 1 (HRNet transition / fuse layers, seg_hrnet_rev1.py:228-247,
@@ -344,12 +345,28 @@ int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int W, int max_
  * HRNet fuse / residual sums.  Replaces the y = y + x[j] / y = y + F.interpolate(..., mode='bilinear') / relu(y) chains of
  * seg_hrnet_rev1.py:256-283, the residual adds of BasicBlock / Bottleneck (:76-92, :113-133) and the F.upsample + torch.cat
  * of the four branches (:528-533).  out[N][H][W] = [relu](sum of 1..4 terms), every term a bf16 NHWC tensor with C
- * channels, either [H][W] or a lower resolution that is up-sampled bilinearly (align_corners = False).  The output may be a
+ * channels (optionally with a per-channel affine), either [H][W] or a lower resolution that is up-sampled bilinearly
+ * (align_corners = False).  The output may be a
  * channel slice [out_coff, out_coff + C) of pixels out_cstride wide (0 = C).
  * ---------------------------------------------------------------------------------------------------- */
-typedef struct cdnet_fuse_term { const uint16_t *x; int Hs, Ws; } cdnet_fuse_term;
+typedef struct cdnet_fuse_term {
+    const uint16_t *x;      /* bf16 (or fp16 when f16 = 1) NHWC [N][Hs][Ws][C] */
+    int Hs, Ws;
+    const float *scale;     /* optional per-channel affine applied to the term (training mode: raw conv output x BatchNorm */
+    const float *shift;     /* scale / shift), both NULL or both set */
+    int f16, pad_;
+} cdnet_fuse_term;
 int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, uint16_t *out, int out_cstride,
                    int out_coff, void *stream);
+
+/* backward pieces of the HRNet training step (loss.backward() through seg_hrnet_rev1.py:256-283, 436-443):
+ * cdnet_upsample_bilinear_backward: transpose of the bilinear up-sampling done inside cdnet_fuse_sum: dout bf16 NHWC
+ *   [N][H][W] (channel slice coff / cstride allowed) -> din bf16 [N][Hs][Ws][C];
+ * cdnet_s2d_to_nhwc: gradient computed in the space-to-depth view [N][H2][W2][(a, b, c)] -> [N][2*H2][2*W2][C]
+ *   (input gradient of a stride-2 convolution; weight pack mode 7 = backward-data of mode 6). */
+int cdnet_upsample_bilinear_backward(const uint16_t *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws,
+                                     uint16_t *din, void *stream);
+int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int C, uint16_t *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Instance metrics (stats_utils.py): one pass over a ground-truth and a predicted label image [N][plane] i32 gives the
