@@ -305,6 +305,52 @@ def gen_hrnet():
     save('hrnet_fwd', **out)
 
 
+def gen_hrnet_train():
+    """Two iterations of the reference's train() (train_util_dam.py:17-160) on HRNet18_rev1: closed-form weights with the
+    convolutions scaled by 0.45, BatchNorm in batch-statistics mode, Adam from get_optimizer"""
+    import train_util_dam
+    import utils as ref_utils
+    from models.dam.seg_hrnet_rev1 import HighResolutionNet
+
+    class _O:
+        model = {'out_c': 3}
+    m = det_fill(HighResolutionNet(_O()))
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                mod.weight.mul_(0.45)
+    B, H, W = 2, 64, 64
+    lab, dirn, point, weight = _synthetic_targets(B, H, W, 41)
+    x = det_input((B, 3, H, W), 15, bf16_exact=True)
+    target0 = torch.from_numpy(lab * 127 + (lab == 2)).long().unsqueeze(1)
+    sample = (x, torch.from_numpy(weight), target0, torch.from_numpy(point), torch.from_numpy(dirn))
+    opt = _Opt()
+    optimizer, _ = ref_utils.get_optimizer(opt, m)
+    crit = torch.nn.NLLLoss(reduction='none')
+    pick = ['conv1.weight', 'bn1.weight', 'conv2.weight', 'layer1.0.conv1.weight', 'layer1.0.downsample.0.weight', 'layer1.1.conv3.weight',
+            'transition1.0.0.weight', 'transition1.1.0.0.weight', 'stage2.0.branches.1.1.conv2.weight', 'stage2.0.fuse_layers.0.1.0.weight',
+            'stage2.0.fuse_layers.1.0.0.0.weight', 'stage3.1.fuse_layers.2.0.0.0.weight', 'stage3.2.fuse_layers.2.0.1.0.weight',
+            'transition3.3.0.0.weight', 'stage4.0.branches.3.0.bn1.bias', 'stage4.1.fuse_layers.0.3.1.weight',
+            'stage4.1.fuse_layers.3.0.2.0.weight', 'stage4.1.branches.0.1.conv1.weight', 'mask_feature.conv1.weight',
+            'mask_feature.conv_1x1.weight', 'point_conv.weight', 'directionAtt.Conv1x1.weight', 'mask_conv.bias']
+    sd = dict(m.named_parameters())
+    p0 = {k: sd[k].detach().reshape(-1)[:96].numpy().copy() for k in pick}
+    res, snaps = [], []
+    for it in range(2):
+        r = train_util_dam.train([sample], m, optimizer, crit, it, opt, _Logger())
+        res.append(np.array(r, dtype=np.float64))
+        snaps.append({k: sd[k].detach().reshape(-1)[:96].numpy().copy() for k in pick})
+    out = {'x_cfg': np.array([B, 3, H, W, 15]), 'tgt_cfg': np.array([B, H, W, 41]), 'gain': np.float64(0.45),
+           'results': np.stack(res), 'pick': np.array(pick), 'lr': np.float64(opt.train['lr'])}
+    for k in pick:
+        out['p_init_' + k] = p0[k]
+        for it in range(2):
+            out['p%d_%s' % (it, k)] = snaps[it][k]
+    out['rm_bn1.running_mean'] = m.state_dict()['bn1.running_mean'].numpy().copy()
+    out['rm_stage4.1.branches.3.1.bn2.running_var'] = m.state_dict()['stage4.1.branches.3.1.bn2.running_var'].numpy().copy()
+    save('hrnet_train', **out)
+
+
 def gen_unet_train_iter():
     """two iterations of the reference's plain-UNet train loop (train_util.train, default options) on one batch"""
     import train_util
@@ -523,7 +569,7 @@ def gen_aji():
     save('aji', **out)
 
 
-ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet,
+ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
        'cdm': gen_cdm, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':
