@@ -462,6 +462,41 @@ __global__ __launch_bounds__(256) void s2d_to_nhwc_kernel(const unsigned short *
     }
 }
 
+// gradient of a fuse / residual sum: out = [mask > 0] * (sum of up to 6 gradient contributions, each possibly a channel slice)
+struct GradSumArgs { const unsigned short *g[6]; int cstride[6], coff[6]; int nterm; const unsigned short *mask; size_t npix; int C; unsigned short *out; };
+
+__global__ __launch_bounds__(256) void grad_sum_kernel(const GradSumArgs A) {
+    const int VPP = A.C / 8;
+    const size_t total = A.npix * VPP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i % VPP);
+        const size_t pix = i / VPP;
+        float acc[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k < A.nterm) {
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(A.g[k] + pix * A.cstride[k] + A.coff[k] + slot * 8), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        }
+        if (A.mask) {
+            bf8_to_f32(*reinterpret_cast<const uint4 *>(A.mask + pix * A.C + slot * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = v[j] > 0.f ? acc[j] : 0.f;
+        }
+        unsigned short oh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oh[j] = f2bf(acc[j]);
+        uint4 ou;
+        ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
+        ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
+        *reinterpret_cast<uint4 *>(A.out + pix * A.C + slot * 8) = ou;
+    }
+}
+
 }  // namespace
 
 extern "C" int cdnet_input_pack(const float *x, int N, int C, int H, int W, void *out, void *stream) {
@@ -570,4 +605,19 @@ extern "C" int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int 
     CDNET_REQUIRE(in && out && N > 0 && H2 > 0 && W2 > 0 && C % 8 == 0 && C >= 8, "cdnet_s2d_to_nhwc: bad args");
     s2d_to_nhwc_kernel<<<lin_grid((size_t)N * H2 * W2 * 4 * (C / 8)), 256, 0, (hipStream_t)stream>>>(in, N, H2, W2, C, out);
     return check_launch("cdnet_s2d_to_nhwc");
+}
+
+extern "C" int cdnet_grad_sum(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream) {
+    CDNET_REQUIRE(terms && out && nterm >= 1 && nterm <= 6 && npix > 0 && C % 8 == 0 && C >= 8, "cdnet_grad_sum: bad args");
+    GradSumArgs A;
+    for (int k = 0; k < 6; ++k) { A.g[k] = nullptr; A.cstride[k] = C; A.coff[k] = 0; }
+    for (int k = 0; k < nterm; ++k) {
+        A.g[k] = terms[k].g;
+        A.cstride[k] = terms[k].cstride ? terms[k].cstride : C;
+        A.coff[k] = terms[k].coff;
+        CDNET_REQUIRE(A.g[k] && A.cstride[k] % 8 == 0 && A.coff[k] % 8 == 0 && A.coff[k] + C <= A.cstride[k], "cdnet_grad_sum: channel slice");
+    }
+    A.nterm = nterm; A.mask = mask; A.npix = (size_t)npix; A.C = C; A.out = out;
+    grad_sum_kernel<<<lin_grid((size_t)npix * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    return check_launch("cdnet_grad_sum");
 }

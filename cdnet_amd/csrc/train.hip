@@ -31,6 +31,12 @@ inline int lin_grid(size_t total, int cap = 2048) {
 }
 
 // out[k] = sum_b partial[b][k]: one wave per output, lanes stride over b, fixed butterfly -> deterministic
+// first pixel (or pool window) of a thread in the "VPP threads per pixel, 256 / VPP pixels per block" layouts below; when VPP does
+// not divide 256 (HRNet's 48 / 80 / 144 channels) the left-over threads of the block sit the loop out
+__device__ __forceinline__ unsigned first_pixel(unsigned ppb, int VPP) {
+    return (int)threadIdx.x < (int)ppb * VPP ? blockIdx.x * ppb + threadIdx.x / VPP : 0xffffffffu;
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nb, int K, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_bwd_window_kernel(BnBwdArgs A, int kp)
         for (int k = 0; k < A.ngin && m < NF; ++k)
             if (k != kp) kf[m++] = k;
     }
-    for (unsigned w = blockIdx.x * ppb + tid / VPP; w < nwin; w += gridDim.x * ppb) {
+    for (unsigned w = first_pixel(ppb, VPP); w < nwin; w += gridDim.x * ppb) {
         const unsigned n = w / (Hp * Wp), r = w - n * Hp * Wp;
         const unsigned py = r / Wp, px = r - py * Wp;
         V16 raw[4], g[4][NF > 0 ? NF : 1], gv;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(BnBwdArgs A) {
     const unsigned npix = (unsigned)(A.N * A.H * A.W);
     const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
     const bool f16 = A.f16 != 0, relu = A.relu != 0;
-    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
         V16 raw[BN_U], res[BN_U], g[BN_U][NG];
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
     const unsigned npix = (unsigned)(A.N * A.H * A.W);
     const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
     const bool f16 = A.f16 != 0, relu = A.relu != 0;
-    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
         V16 raw[BN_U], res[BN_U], g[BN_U][NG];
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     const unsigned HW = (unsigned)(A.H * A.W), npix = (unsigned)A.N * HW;
     const unsigned ppb = 256 / VPP;                                 // pixels per block per sub-iteration
     const unsigned step = gridDim.x * ppb;
-    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
         float dz[BN_U][8], xh[BN_U][8];
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs A) {
     const unsigned HW = (unsigned)(A.H * A.W), npix = (unsigned)A.N * HW;
     const unsigned ppb = 256 / VPP;
     const unsigned step = gridDim.x * ppb;
-    for (unsigned p0 = blockIdx.x * ppb + tid / VPP; p0 < npix; p0 += step * BN_U) {
+    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
         float dz[BN_U][8], xh[BN_U][8];
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short *__
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const unsigned ppb = 256 / VPP;
-    for (unsigned p = blockIdx.x * ppb + tid / VPP; p < npix; p += gridDim.x * ppb) {
+    for (unsigned p = first_pixel(ppb, VPP); p < npix; p += gridDim.x * ppb) {
         V16 v;
         v.u = *reinterpret_cast<const uint4 *>(g + (size_t)p * C + slot * 8);
 #pragma unroll
@@ -1132,7 +1138,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short *__
 // ------------------------------------------------------------------------------------------------------
 static int fill_bn_args(const cdnet_bn_bwd_args *a, BnBwdArgs &A, const char *who) {
     CDNET_REQUIRE(a && a->raw, "%s: null pointer", who);
-    CDNET_REQUIRE(a->C % 8 == 0 && a->C >= 8 && a->C <= 2048 && 256 % (a->C / 8) == 0, "%s: C=%d unsupported", who, a->C);
+    CDNET_REQUIRE(a->C % 8 == 0 && a->C >= 8 && a->C <= 2048 , "%s: C=%d unsupported", who, a->C);
     CDNET_REQUIRE(a->ngin >= 1 && a->ngin <= 3, "%s: ngin=%d", who, a->ngin);
     A.raw = a->raw; A.res = a->res; A.f16 = a->f16; A.scale = a->scale; A.shift = a->shift; A.relu = a->relu;
     A.mean = a->mean; A.invstd = a->invstd;
@@ -1320,7 +1326,7 @@ extern "C" size_t cdnet_bias_grad_workspace_floats(int C) { return (size_t)512 *
 extern "C" int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db,
                                void *stream) {
     CDNET_REQUIRE(grad_out && workspace && db, "cdnet_bias_grad: null pointer");
-    CDNET_REQUIRE(C >= 8 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && npix > 0 && npix < ((size_t)1 << 31), "cdnet_bias_grad: C=%d unsupported", C);
+    CDNET_REQUIRE(C >= 8 && C % 8 == 0 && C <= 2048 && npix > 0 && npix < ((size_t)1 << 31), "cdnet_bias_grad: C=%d unsupported", C);
     if (workspace_floats < cdnet_bias_grad_workspace_floats(C)) { set_error("cdnet_bias_grad: workspace too small"); return CDNET_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const unsigned ppb = 256 / (C / 8);

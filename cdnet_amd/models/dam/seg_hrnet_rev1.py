@@ -1,5 +1,5 @@
 """`HighResolutionNet` - HRNet-W18 + DAM head (reference: models/dam/seg_hrnet_rev1.py:289-548, `HRNet18_rev1` of
-utils.chooseModel :880-882, BASELINE config 5), host-side mirror for INFERENCE.
+utils.chooseModel :880-882, BASELINE config 5), host-side mirror (inference and training).
 
 Same constructor argument (`config` with `config.model['out_c']`), same `forward(x) -> (mask, point, direction)`, same
 state_dict keys (conv1/bn1/conv2/bn2, layer1.*, transition1-3.*, stage2-4.*.{branches,fuse_layers}.*, the never-used
@@ -10,7 +10,7 @@ HIP kernels of the UNet path plus two additions:
   * `cdnet_fuse_sum`: the residual adds of BasicBlock / Bottleneck (:76-92, :113-133), the fuse sums with bilinear
     up-sampling (:256-283) and the final F.upsample + torch.cat (:528-533).
 Branch widths 18 / 36 / 72 are carried zero-padded to 32 / 48 / 80 channels (padded weights and BatchNorm rows are
-zero / identity, so the padding stays exactly zero).  Training of this model is not wired (raises)."""
+zero, so the padding stays exactly zero through forward, backward and Adam).  Training: cdnet_amd.trainer.Trainer."""
 import ctypes as C
 import types
 
@@ -137,42 +137,62 @@ class HighResolutionNet(nn.Module):
         return nn.ModuleList(layers)
 
     # ---------------------------------------------------------------------------------------------------
-    # runtime (eval): padded parameter copies + ConvLayers
+    # runtime: zero-padded parameter storage + ConvLayers
+    #
+    # The kernels want channel counts in multiples of 16, so every parameter with an 18 / 36 / 72 (or RGB 3) dimension is
+    # held zero-padded (`compute parameter`); the module's own nn.Parameter / BatchNorm buffer becomes a strided VIEW of the
+    # leading corner of that storage, so state_dict() / load_state_dict() keep working on the reference's shapes with no
+    # copies.  Two exceptions: mask_feature.conv1 / conv_1x1 read the concatenation of the four padded branches (their
+    # input channels are scattered over four segments) - those are synchronised by copy (sync_real_parameters()).
     # ---------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _padded(conv, bn, cin_segments=None, stride=1):
-        """ConvLayer over zero-padded copies of conv / bn.  cin_segments: [(real_start, count, padded_start)] placing the
-        real input channels in the padded layout (default: one segment at 0)."""
-        w = conv.weight.detach()
-        cout, cin, k, _ = w.shape
+    def _compute_param(self, real, pshape, segs=None):
+        """the parameter the kernels use for `real`: `real` itself when no padding is needed, else a zero-padded copy"""
+        if tuple(real.shape) == tuple(pshape):
+            return real
+        pp = nn.Parameter(torch.zeros(pshape, dtype=torch.float32, device=real.device), requires_grad=False)
+        with torch.no_grad():
+            if segs is None:
+                pp[tuple(slice(0, n) for n in real.shape)] = real.detach()
+            else:
+                for r0, n, p0 in segs:
+                    pp[:, p0:p0 + n] = real.detach()[:, r0:r0 + n]
+        self._slots.append((real, pp, segs))
+        self._pmap[id(real)] = pp
+        return pp
+
+    def _padded(self, conv, bn, cin_segments=None, stride=1, name='hrnet'):
+        """ConvLayer over the compute parameters of conv / bn.  cin_segments: [(real_start, count, padded_start)] placing
+        the real input channels in the padded layout (default: one segment at 0)."""
+        cout, cin, k, _ = conv.weight.shape
         cin_p = _pad16(cin) if cin_segments is None else _pad16(max(p + n for _, n, p in cin_segments))
-        segs = cin_segments or [(0, cin, 0)]
         cout_p = _pad16(cout)
-        wp = torch.zeros((cout_p, cin_p, k, k), dtype=torch.float32, device=w.device)
-        for r0, n, p0 in segs:
-            wp[:cout, p0:p0 + n] = w[:, r0:r0 + n]
+        w = self._compute_param(conv.weight, (cout_p, cin_p, k, k), cin_segments)
         bnp = None
         if bn is not None:
-            bnp = nn.BatchNorm2d(cout_p).to(w.device).eval()
-            with torch.no_grad():
-                bnp.weight[:cout] = bn.weight
-                bnp.bias.zero_()
-                bnp.bias[:cout] = bn.bias
-                bnp.running_mean.zero_()
-                bnp.running_mean[:cout] = bn.running_mean
-                bnp.running_var.fill_(1.0)
-                bnp.running_var[:cout] = bn.running_var
-                bnp.eps = bn.eps
-        bias = None
-        if conv.bias is not None:
-            bias = torch.zeros((cout_p,), dtype=torch.float32, device=w.device)
-            bias[:cout] = conv.bias.detach()
+            bnp = bn
+            if cout_p != cout:
+                # shell module over the padded rows: gamma = beta = mean = 0, var = 1 there, so padded channels stay exactly 0
+                bnp = nn.BatchNorm2d(cout_p, momentum=bn.momentum, eps=bn.eps).to(conv.weight.device)
+                bnp.weight = self._compute_param(bn.weight, (cout_p,))
+                bnp.bias = self._compute_param(bn.bias, (cout_p,))
+                with torch.no_grad():
+                    bnp.running_mean[:cout] = bn.running_mean
+                    bnp.running_var[:cout] = bn.running_var
+                bn._buffers['running_mean'] = bnp.running_mean[:cout]
+                bn._buffers['running_var'] = bnp.running_var[:cout]
+                bnp.train(bn.training)
+        bias = None if conv.bias is None else self._compute_param(conv.bias, (cout_p,))
         kind = 'conv1' if k == 1 else ('conv3s2' if stride == 2 else 'conv3')
-        return ConvLayer('hrnet', kind, wp.contiguous(), bias, bnp)
+        return ConvLayer(name, kind, w, bias, bnp)
 
     def _build_runtime(self):
-        P = self._padded
+        self._slots, self._pmap, self._nodes = [], {}, {}
+        names = {id(m): n for n, m in self.named_modules()}
+
+        def P(conv, bn, segs=None, stride=1):
+            return self._padded(conv, bn, segs, stride, name=names[id(conv)])
         rt = {'stem': [P(self.conv1, self.bn1), P(self.conv2, self.bn2)]}
+        rt['stem'][0].needs_input_grad = False
         rt['layer1'] = []
         for b in self.layer1:
             ds = None if b.downsample is None else P(b.downsample[0], b.downsample[1])
@@ -211,64 +231,116 @@ class HighResolutionNet(nn.Module):
             p0 += _pad16(c)
         self._cat_layout = [(p, _pad16(c)) for (_, c, p) in segs]
         mf = self.mask_feature
-        shim = types.SimpleNamespace(conv1=types.SimpleNamespace(weight=P(mf.conv1, None, segs).weight), bn1=mf.bn1, conv2=mf.conv2,
-                                     bn2=mf.bn2, conv_1x1=types.SimpleNamespace(weight=P(mf.conv_1x1, None, segs).weight,
-                                                                                bias=mf.conv_1x1.bias))
+        ctot = p0
+        shim = types.SimpleNamespace(conv1=types.SimpleNamespace(weight=self._compute_param(mf.conv1.weight, (64, ctot, 3, 3), segs)),
+                                     bn1=mf.bn1, conv2=mf.conv2, bn2=mf.bn2,
+                                     conv_1x1=types.SimpleNamespace(weight=self._compute_param(mf.conv_1x1.weight, (64, ctot, 1, 1), segs),
+                                                                    bias=mf.conv_1x1.bias))
         rt['ru'] = [_RU('mask_feature', shim), _RU('direction_feature', self.direction_feature),
                     _RU('point_feature', self.point_feature)]
         self._rt = rt
+        self.rebind_views()
         self._rt_ver = self._param_version()
+
+    def rebind_views(self):
+        """point the module's own parameters at the leading corner of their padded compute storage (and gradient)"""
+        for real, pp, segs in self._slots:
+            if segs is None:
+                idx = tuple(slice(0, n) for n in real.shape)
+                real.data = pp.data[idx]
+                real.grad = None if pp.grad is None else pp.grad[idx]
+
+    def sync_real_parameters(self):
+        """copy the two concatenation-reading weights from their padded compute storage back into the module's parameters
+        (the trained values live in the compute storage; every other parameter is a view and needs no copy)"""
+        if self._rt is None:
+            return
+        with torch.no_grad():
+            for real, pp, segs in self._slots:
+                if segs is not None:
+                    for r0, n, p0 in segs:
+                        real[:, r0:r0 + n] = pp.detach()[:, p0:p0 + n]
+        self._rt_ver = self._param_version()
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_real_parameters()
+        return super().state_dict(*args, **kwargs)
+
+    def trainer_named_parameters(self):
+        """name -> compute parameter, in forward order where it matters to the trainer (cdnet_amd.trainer.FlatState)"""
+        self._ensure_runtime()
+        return {n: self._pmap.get(id(p), p) for n, p in self.named_parameters()}
 
     def _param_version(self):
         return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
 
+    def _ensure_runtime(self):
+        dev_moved = False
+        if self._rt is not None:
+            views = [(real, pp) for real, pp, segs in self._slots if segs is None]
+            real, pp = views[0]
+            dev_moved = real.untyped_storage().data_ptr() != pp.untyped_storage().data_ptr()     # .to() / .cuda() re-made the parameters
+        if self._rt is None or dev_moved:
+            self._build_runtime()
+        elif self._rt_ver != self._param_version():
+            # load_state_dict / in-place edits went through the views; the segment-mapped weights need their scatter
+            with torch.no_grad():
+                for real, pp, segs in self._slots:
+                    if segs is not None:
+                        for r0, n, p0 in segs:
+                            pp[:, p0:p0 + n] = real.detach()[:, r0:r0 + n]
+            runtime.WEIGHTS_EPOCH[0] += 1                  # every packed weight / BatchNorm fold is stale
+            self._rt_ver = self._param_version()
+
     # ---------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _fuse(terms, relu, out=None, out_coff=0):
-        """terms: list of Src (plain bf16 NHWC); the first full-size one fixes H, W.  Returns Src of the sum."""
-        xs = [t.x for t in terms]
-        for t in terms:
-            assert t.scale is None and t.res is None and not t.pool and not t.relu and t.x.dtype == torch.bfloat16
-        N, _, _, Cc = xs[0].shape
-        H, W = max(x.shape[1] for x in xs), max(x.shape[2] for x in xs)
-        arr = (FuseTerm * len(xs))()
-        for k, x in enumerate(xs):
-            assert x.shape[3] == Cc and x.is_contiguous()
-            arr[k].x, arr[k].Hs, arr[k].Ws = x.data_ptr(), x.shape[1], x.shape[2]
-        if out is None:
-            o = torch.empty((N, H, W, Cc), dtype=torch.bfloat16, device=xs[0].device)
-            cs = Cc
-        else:
-            o, cs = out, out.shape[3]
-        _lib.call('cdnet_fuse_sum', C.byref(arr), len(xs), N, H, W, Cc, int(relu), _lib.ptr(o), cs, out_coff, _lib.stream_ptr())
-        return Src(o)
+    def _node(self, key):
+        n = self._nodes.get(key)
+        if n is None:
+            n = self._nodes[key] = runtime.FuseNode('fuse.' + '.'.join(str(k) for k in key))
+        return n
+
+    def _fuse(self, key, terms, relu, training, out=None, out_coff=0):
+        """[relu](sum of terms) - see runtime.FuseNode; terms with a pending BatchNorm are passed with their affine"""
+        return self._node(key).forward(terms, relu, out=out, out_coff=out_coff, training=training)
+
+    def _plain(self, key, s, training):
+        """a conv -> BN -> ReLU output as a stored bf16 tensor (eval: it already is; train: apply the pending BatchNorm + ReLU)"""
+        return s if not training else self._fuse(key, [s], True, True)
 
     @staticmethod
-    def _s2(layer, s, relu):
-        """3x3 stride-2 convolution: the two row-parity views of the (materialised, plain) input"""
+    def _s2(layer, s, relu, training):
+        """3x3 stride-2 convolution: the two row-parity views of the (stored, plain) input"""
         x = s.x
         N, H, W, Cc = x.shape
-        assert H % 2 == 0 and W % 2 == 0, 'stride-2 layers need even sizes (the reference feeds 512x512 / 256x256 tiles)'
+        assert s.scale is None and H % 2 == 0 and W % 2 == 0, 'stride-2 layers need even sizes (the reference feeds 512x512 / 256x256 tiles)'
         views = [Src(x, view=(a * W * Cc, H // 2, W // 2, 2 * Cc, 2 * W * Cc)) for a in (0, 1)]
-        return layer.forward(views, False, relu=relu, H=H // 2, W=W // 2)
+        return layer.forward(views, training, relu=relu and not training, H=H // 2, W=W // 2)
 
-    def _basic(self, pair, x):                            # BasicBlock.forward (:76-92)
+    def _chain(self, key, steps, t, training):
+        """Sequential of (stride-2 conv, BN[, ReLU]); the last element's BatchNorm (+ReLU) is left to the consumer in training"""
+        for k, (layer, relu) in enumerate(steps):
+            t = self._s2(layer, t, relu, training)
+            if training and relu:
+                t = self._fuse(key + ('c', k), [t], True, True)
+        return t
+
+    def _basic(self, key, pair, x, training):             # BasicBlock.forward (:76-92)
         c1, c2 = pair
-        y = c2.forward([c1.forward([x], False, relu=True)], False, relu=False)
-        return self._fuse([y, x], relu=True)
+        y = c2.forward([c1.forward([x], training, relu=True)], training, relu=False)
+        return self._fuse(key, [y, x], True, training)
 
-    def _bottleneck(self, quad, x):                       # Bottleneck.forward (:113-133)
+    def _bottleneck(self, key, quad, x, xres, training):  # Bottleneck.forward (:113-133); x may carry a pending BatchNorm, xres is plain
         c1, c2, c3, ds = quad
-        y = c3.forward([c2.forward([c1.forward([x], False, relu=True)], False, relu=True)], False, relu=False)
-        r = x if ds is None else ds.forward([x], False, relu=False)
-        return self._fuse([y, r], relu=True)
+        y = c3.forward([c2.forward([c1.forward([x], training, relu=True)], training, relu=True)], training, relu=False)
+        r = xres if ds is None else ds.forward([x], training, relu=False)
+        return self._fuse(key, [y, r], True, training)
 
-    def _module(self, mod, xs):                           # HighResolutionModule.forward (:256-283)
+    def _module(self, key, mod, xs, training):            # HighResolutionModule.forward (:256-283)
         br, fu = mod
         xs = list(xs)
         for i, blocks in enumerate(br):
-            for pair in blocks:
-                xs[i] = self._basic(pair, xs[i])
+            for k, pair in enumerate(blocks):
+                xs[i] = self._basic(key + ('b', i, k), pair, xs[i], training)
         outs = []
         for i in range(len(xs)):
             terms = []
@@ -277,29 +349,25 @@ class HighResolutionNet(nn.Module):
                 if f is None:
                     terms.append(xs[j])
                 elif f[0] == 'up':
-                    terms.append(f[1].forward([xs[j]], False, relu=False))      # 1x1 conv + BN at branch j's size; up-sampled in _fuse
+                    terms.append(f[1].forward([xs[j]], training, relu=False))   # 1x1 conv + BN at branch j's size; up-sampled in the sum
                 else:
-                    t = xs[j]
-                    for layer, relu in f[1]:
-                        t = self._s2(layer, t, relu)
-                    terms.append(t)
-            terms.sort(key=lambda t: -t.x.shape[1])       # a full-size term first (any order sums the same set)
-            outs.append(self._fuse(terms, relu=True))
+                    terms.append(self._chain(key + ('d', i, j), f[1], xs[j], training))
+            terms.sort(key=lambda t: -t.Hs)               # a full-size term first (any order sums the same set)
+            outs.append(self._fuse(key + ('f', i), terms, True, training))
         return outs
 
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError('HighResolutionNet: only the inference path is built (DESIGN.md section 8)')
         if not x.is_cuda:
             raise RuntimeError('cdnet_amd HighResolutionNet runs on the MI355X only (no CPU fallback)')
-        if self._rt is None or self._rt_ver != self._param_version():
-            self._build_runtime()
+        training = self.training
+        self._ensure_runtime()
         rt = self._rt
         t = Src(runtime.input_pack(x.float()))
+        t.is_input = True
         for L in rt['stem']:                              # conv1-bn1-relu, conv2-bn2-relu (:495-500)
-            t = L.forward([t], False, relu=True)
-        for quad in rt['layer1']:
-            t = self._bottleneck(quad, t)
+            t = L.forward([t], training, relu=True)
+        for k, quad in enumerate(rt['layer1']):
+            t = self._bottleneck(('l1', k), quad, t, t, training)
         ys = [t]
         for si in range(3):
             tr = rt['transition%d' % (si + 1)]
@@ -308,37 +376,24 @@ class HighResolutionNet(nn.Module):
                 if e is None:
                     xs.append(ys[i])
                 elif e[0] == 's1':
-                    xs.append(e[1].forward([ys[i]], False, relu=True))
+                    xs.append(self._plain(('t', si, i), e[1].forward([ys[i]], training, relu=not training), training))
                 else:                                     # a new, lower-resolution branch from the last one
-                    u = ys[-1]
-                    for layer, relu in e[1]:
-                        u = self._s2(layer, u, relu)
-                    xs.append(u)
-            for mod in rt['stage%d' % (si + 2)]:
-                xs = self._module(mod, xs)
+                    xs.append(self._chain(('t', si, i), e[1], ys[-1], training))
+            for k, mod in enumerate(rt['stage%d' % (si + 2)]):
+                xs = self._module(('s', si, k), mod, xs, training)
             ys = xs
         # F.upsample + torch.cat (:528-533): every branch written (up-sampled) into its slice of one padded buffer
         N, H, W, _ = ys[0].x.shape
         ctot = sum(w for _, w in self._cat_layout)
         cat = torch.empty((N, H, W, ctot), dtype=torch.bfloat16, device=x.device)
-        for y, (p0, _) in zip(ys, self._cat_layout):
-            self._fuse([y], relu=False, out=cat, out_coff=p0) if y.x.shape[1] == H else self._fuse_up(y, cat, p0, H, W)
-        f1 = rt['ru'][0].forward(Src(cat), False)
-        f2 = rt['ru'][1].forward(f1, False)
-        f3 = rt['ru'][2].forward(f2, False)
+        for k, (y, (p0, _)) in enumerate(zip(ys, self._cat_layout)):
+            self._node(('cat', k)).forward([y], False, out=cat, out_coff=p0, training=training)
+        f1 = rt['ru'][0].forward(Src(cat), training)
+        f2 = rt['ru'][1].forward(f1, training)
+        f3 = rt['ru'][2].forward(f2, training)
         return _DamUnet._head(self, (f1, f2, f3))
-
-    def _fuse_up(self, y, cat, p0, H, W):
-        """one lower-resolution branch, bilinearly up-sampled into its channel slice"""
-        x = y.x
-        N, _, _, Cc = x.shape
-        arr = (FuseTerm * 1)()
-        arr[0].x, arr[0].Hs, arr[0].Ws = x.data_ptr(), x.shape[1], x.shape[2]
-        _lib.call('cdnet_fuse_sum', C.byref(arr), 1, N, H, W, Cc, 0, _lib.ptr(cat), cat.shape[3], p0, _lib.stream_ptr())
 
     head_weight_block = _DamUnet.head_weight_block
 
 
-class FuseTerm(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('Hs', C.c_int), ('Ws', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p),
-                ('f16', C.c_int), ('pad_', C.c_int)]
+FuseTerm = runtime.FuseTerm

@@ -112,14 +112,14 @@ class ConvLayer:
                 self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, mode, out=self.wpb)
             else:
                 assert cin_total == self.Cin, 'the RGB stem never needs an input gradient'
-                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, 1, out=self.wpb)
+                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, 7 if self.kind == 'conv3s2' else 1, out=self.wpb)
             self.wpb_version = ver
         return self.wpb, self.cfg_bwd
 
     def eval_fold(self):
         bn = self.bn
         ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-               None if self.bias is None else self.bias._version)
+               None if self.bias is None else self.bias._version, WEIGHTS_EPOCH[0])
         if self.fold is None or self.fold_version != ver:
             if self.fold is None:
                 self.fold = (torch.empty_like(self.scale), torch.empty_like(self.shift))
@@ -165,14 +165,89 @@ class ConvLayer:
         count = float(N * H * W * npar)
         bn = self.bn
         _lib.call('cdnet_bn_finalize_train', _lib.ptr(self.stats), T, self.Cout, count, _lib.ptr(bn.weight.detach()),
-                  _lib.ptr(bn.bias.detach()), None if bias is None else _lib.ptr(bias), BN_EPS, BN_MOMENTUM,
+                  _lib.ptr(bn.bias.detach()), None if bias is None else _lib.ptr(bias), BN_EPS,
+                  BN_MOMENTUM if getattr(bn, 'momentum', None) is None else float(bn.momentum),
                   _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(self.scale), _lib.ptr(self.shift),
                   _lib.ptr(self.save_mean), _lib.ptr(self.save_invstd), _lib.stream_ptr())
         self.saved = (srcs, raw, H, W)
         self.node_relu, self.node_res = relu, None
+        self.fold_version = None               # the running statistics just moved: an eval-mode fold is stale
         if TAPE is not None:
             TAPE.append(self)
         return Src(raw, self.scale, self.shift, relu=relu)
+
+
+class FuseTerm(C.Structure):                   # cdnet_fuse_term (include/cdnet_hip.h)
+    _fields_ = [('x', C.c_void_p), ('Hs', C.c_int), ('Ws', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('f16', C.c_int), ('pad_', C.c_int)]
+
+
+class GradTerm(C.Structure):                   # cdnet_grad_term
+    _fields_ = [('g', C.c_void_p), ('cstride', C.c_int), ('coff', C.c_int)]
+
+
+class FuseNode:
+    """out = [relu](sum of 1..4 terms) through cdnet_fuse_sum: the residual adds and multi-resolution fuse sums of HRNet.
+    Terms are Src objects: plain bf16 tensors or raw (fp16) BatchNorm-pending convolution outputs (their scale / shift is
+    applied on the fly, without ReLU); lower-resolution terms are up-sampled bilinearly.  With `out` the result lands in
+    the channel slice [out_coff, out_coff + C) of a wider tensor (torch.cat of the branches).  In a training forward the
+    node goes onto the tape; backward() routes the output gradient to every term."""
+
+    def __init__(self, name):
+        self.name = name
+        self.saved = None
+
+    def forward(self, terms, relu, out=None, out_coff=0, training=False):
+        """`out` (optional) is the wider [N,H,W,Ctot] tensor whose channel slice receives the sum; it also fixes H, W"""
+        for t in terms:
+            assert t.res is None and not t.pool and not t.relu and t.row_stride == 0 and t.x.is_contiguous()
+        N, Cc = terms[0].N, terms[0].C
+        H, W = (max(t.Hs for t in terms), max(t.Ws for t in terms)) if out is None else (out.shape[1], out.shape[2])
+        arr = (FuseTerm * len(terms))()
+        for k, t in enumerate(terms):
+            assert t.C == Cc
+            arr[k].x, arr[k].Hs, arr[k].Ws = t.x.data_ptr(), t.Hs, t.Ws
+            arr[k].scale, arr[k].shift = (None if t.scale is None else t.scale.data_ptr()), (None if t.shift is None else t.shift.data_ptr())
+            arr[k].f16 = int(t.f16)
+        if out is None:
+            o, cs = torch.empty((N, H, W, Cc), dtype=torch.bfloat16, device=terms[0].x.device), Cc
+        else:
+            o, cs = out, out.shape[3]
+        if DEBUG_NORELU:
+            relu = False
+        _lib.call('cdnet_fuse_sum', C.byref(arr), len(terms), N, H, W, Cc, int(relu), _lib.ptr(o), cs, out_coff, _lib.stream_ptr())
+        if training:
+            self.saved = (list(terms), o, relu, H, W, Cc, out_coff)
+            if TAPE is not None:
+                TAPE.append(self)
+        return Src(o) if out is None else None
+
+    def backward(self, tr, grads, add):
+        """tr: the Trainer (buffer pool).  Gradient of the (slice of the) output -> one contribution per term."""
+        terms, o, relu, H, W, Cc, coff = self.saved
+        sliced = o.shape[3] != Cc
+        if sliced:
+            d, dcs, dco = tr.cat_grad(o, grads), o.shape[3], coff      # the whole concatenation's gradient, summed once
+            if d is None:
+                return
+        else:
+            gl = grads.pop(id(o), None)
+            if gl is None:
+                return
+            if relu or len(gl) > 1 or gl[0].coff or gl[0].cstride not in (0, Cc):
+                d = tr.buf(('dfuse', self.name), o.shape, torch.bfloat16)
+                tr.grad_sum(gl, o if relu else None, o.shape[0] * H * W, Cc, d)
+            else:
+                d = gl[0].t
+            dcs, dco = 0, 0
+        N = o.shape[0]
+        for k, t in enumerate(terms):
+            if t.Hs == H and t.Ws == W:
+                add(t.x, tr.G(d, H, W, coff=dco, cstride=dcs))
+            else:
+                din = tr.buf(('dup', self.name, k), (N, t.Hs, t.Ws, Cc), torch.bfloat16)
+                _lib.call('cdnet_upsample_bilinear_backward', _lib.ptr(d), N, H, W, Cc, dcs, dco, t.Hs, t.Ws, _lib.ptr(din), _lib.stream_ptr())
+                add(t.x, tr.G(din, t.Hs, t.Ws))
 
 
 def input_pack(x):

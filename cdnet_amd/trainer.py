@@ -47,7 +47,8 @@ class FlatState:
     never stepped - torch.optim.Adam skips parameters whose .grad is None)."""
 
     def __init__(self, model):
-        named = dict(model.named_parameters())
+        # a model that computes on zero-padded parameter copies (HRNet) hands those over; its own parameters stay views
+        named = model.trainer_named_parameters() if hasattr(model, 'trainer_named_parameters') else dict(model.named_parameters())
         unused = [n for n in named if n.startswith(tuple(getattr(model, 'UNUSED_PREFIXES', ())))]
         head = [n for n in HEAD_PARAMS if n in named]
         rest = [n for n in named if n not in head and n not in unused]
@@ -69,6 +70,8 @@ class FlatState:
                 p.grad = self.G[off:off + sz].view(p.shape)
                 self.offsets[n] = (off, sz)
                 off += sz
+        if hasattr(model, 'rebind_views'):
+            model.rebind_views()
         self.n_used = sum(named[n].numel() for n in head + rest)
         self.n_head = sum(named[n].numel() for n in head)
         self.step_count = 0
@@ -84,7 +87,12 @@ def _choose_ci_tiles(C_src, Cout):
     return best
 
 
+class GradTerm(C.Structure):
+    _fields_ = [('g', C.c_void_p), ('cstride', C.c_int), ('coff', C.c_int)]
+
+
 class Trainer:
+    G = _G
 
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.99), eps=1e-8, quirk_sample0=True,
                  world_size=1, bucket_mb=25):
@@ -105,6 +113,7 @@ class Trainer:
         self._ws_loss = None
         self.losses = torch.zeros((11,), dtype=torch.float32, device=self.dev)     # 6 loss values + 5 pixel metrics
         self.tape = []
+        self._cat_cache = {}
 
     # ------------------------------------------------------------------------------------------------
     def buf(self, key, shape, dtype):
@@ -119,6 +128,30 @@ class Trainer:
         if self._ws_bn is None or self._ws_bn.numel() < need:
             self._ws_bn = torch.empty((need,), dtype=torch.float32, device=self.dev)
         return self._ws_bn
+
+    def grad_sum(self, gl, mask, npix, Cc, out):
+        """out = [mask > 0] * sum of the gradient contributions `gl` (cdnet_grad_sum)"""
+        assert 1 <= len(gl) <= 6
+        arr = (GradTerm * len(gl))()
+        for k, g in enumerate(gl):
+            assert not g.pooled and g.oy == 0 and g.ox == 0
+            arr[k].g, arr[k].cstride, arr[k].coff = g.t.data_ptr(), g.cstride or Cc, g.coff
+        _lib.call('cdnet_grad_sum', C.byref(arr), len(gl), None if mask is None else _lib.ptr(mask), npix, Cc, _lib.ptr(out), _lib.stream_ptr())
+
+    def cat_grad(self, o, grads):
+        """gradient of a concatenation buffer (several consumers, several writers): summed once per backward"""
+        key = id(o)
+        if key not in self._cat_cache:
+            gl = grads.pop(key, None)
+            if gl is None:
+                d = None
+            elif len(gl) == 1 and not gl[0].coff and gl[0].cstride in (0, o.shape[3]):
+                d = gl[0].t
+            else:
+                d = self.buf(('dcat', key), o.shape, torch.bfloat16)
+                self.grad_sum(gl, None, o.shape[0] * o.shape[1] * o.shape[2], o.shape[3], d)
+            self._cat_cache[key] = d
+        return self._cat_cache[key]
 
     def _slab(self, n):
         if self._ws_slab is None or self._ws_slab.numel() < n:
@@ -183,7 +216,11 @@ class Trainer:
     def _backward_tape(self, grads, add):
         """walk the forward tape backwards: BatchNorm(+ReLU, residual, pool/pad/concat routing) backward, then the
         weight and input gradients of every convolution that received a gradient"""
+        self._cat_cache = {}
         for L in reversed(self.tape):
+            if isinstance(L, runtime.FuseNode):
+                L.backward(self, grads, add)
+                continue
             srcs, out, Hl, Wl = L.saved
             gl = grads.pop(id(out), None)
             if gl is None:
@@ -235,7 +272,7 @@ class Trainer:
         Cout = L.Cout
         cin_total = sum(s.C for s in srcs)
         cin_real = L.Cin
-        mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3}[L.kind]
+        mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3, 'conv3s2': 6}[L.kind]
         taps, npar, ostride = L.taps, (4 if L.transposed else 1), (2 if L.transposed else 1)
         coff = 0
         for s in srcs:
@@ -267,6 +304,15 @@ class Trainer:
             return
         # input gradient: forward convolution with the backward-data pack
         wpb, cfgb = L.backward_pack(cin_total, H, W)
+        if L.kind == 'conv3s2':
+            # stride-2 convolution: gradient in the space-to-depth layout [N,H,W,(a,b,c)], then permuted to [N,2H,2W,C]
+            Cp = cin_total // 4
+            gs2d = self.buf(('ds2d', L.name), (N, H, W, cin_total), torch.bfloat16)
+            engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=9, out=gs2d, H=H, W=W)
+            gin = self.buf(('din', L.name), (N, 2 * H, 2 * W, Cp), torch.bfloat16)
+            _lib.call('cdnet_s2d_to_nhwc', _lib.ptr(gs2d), N, H, W, Cp, _lib.ptr(gin), _lib.stream_ptr())
+            add(srcs[0].x, _G(gin, 2 * H, 2 * W))
+            return
         if not L.transposed:
             gin = self.buf(('din', L.name), (N, H, W, cin_total), torch.bfloat16)
             engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
@@ -296,7 +342,7 @@ class Trainer:
         f = self.flat
         base = f.G.data_ptr()
         pend = {}
-        owners = [p for L in self.tape for p in (L.weight, L.bias, None if L.bn is None else L.bn.weight,
+        owners = [p for L in self.tape if not isinstance(L, runtime.FuseNode) for p in (L.weight, L.bias, None if L.bn is None else L.bn.weight,
                                                  None if L.bn is None else L.bn.bias) if p is not None]
         for p in owners:
             off = (p.grad.data_ptr() - base) // 4
@@ -350,7 +396,7 @@ class Trainer:
                 if L.wp is not None and not L.wp_padded:
                     jobs.append(engine.pack_job(w, L.cfg, L.pack_mode, L.wp)); owners.append((L, 'wp_version'))
                 if L.wpb is not None:
-                    mode = (4 if L.kind == 'convT4' else 5) if L.transposed else 1
+                    mode = (4 if L.kind == 'convT4' else 5) if L.transposed else (7 if L.kind == 'conv3s2' else 1)
                     jobs.append(engine.pack_job(w, L.cfg_bwd, mode, L.wpb)); owners.append((L, 'wpb_version'))
             if not jobs or self.flat.step_count < 1:
                 return

@@ -368,6 +368,15 @@ int cdnet_upsample_bilinear_backward(const uint16_t *dout, int N, int H, int W, 
                                      uint16_t *din, void *stream);
 int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int C, uint16_t *out, void *stream);
 
+/* cdnet_grad_sum: backward of the sums above (autograd's AddBackward + ReluBackward over seg_hrnet_rev1.py:76-92, 256-283 and the
+ * torch.cat of :533): out[npix][C] = [mask > 0] * sum of 1..6 gradient contributions, each a bf16 tensor [npix][cstride] read at
+ * channel slice [coff, coff + C) (cstride 0 = C).  mask = the stored (post-ReLU) forward output, or NULL for a sum without ReLU. */
+typedef struct cdnet_grad_term {
+    const uint16_t *g;
+    int cstride, coff;
+} cdnet_grad_term;
+int cdnet_grad_sum(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Instance metrics (stats_utils.py): one pass over a ground-truth and a predicted label image [N][plane] i32 gives the
  * per-label areas (area_*[N][cap], ids must be < cap <= 65536) and a sparse table of pairwise intersections (open

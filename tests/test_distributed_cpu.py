@@ -110,3 +110,43 @@ def test_overlapped_bucket_schedule_two_ranks():
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
     assert total == -(-sum(sizes) // bucket)               # every bucket reduced exactly once
     assert 0 < early < total                               # most buckets were in flight before the first layer's gradient existed
+
+
+def test_hrnet_parameters_live_in_padded_flat_storage():
+    """HRNet18_rev1 computes on zero-padded parameter copies (18/36/72 -> 32/48/80 channels): the module's own parameters are
+    strided views of that storage, also after the trainer re-homes it into its flat buffers (host logic only, no kernels)"""
+    import torch
+    from cdnet_amd import trainer
+    from cdnet_amd.models.dam.seg_hrnet_rev1 import HighResolutionNet
+    from oracle import hrnet as oh
+
+    class Opt:
+        model = {'out_c': 3}
+    ref = oh.HighResolutionNet()
+    m = HighResolutionNet(Opt())
+    m.load_state_dict(ref.state_dict())
+    fs = trainer.FlatState(m)
+    assert fs.n_head == 855 and fs.P.numel() > sum(p.numel() for p in m.parameters())
+    w = m.stage2[0].branches[0][0].conv1.weight
+    assert tuple(w.shape) == (18, 18, 3, 3) and w.untyped_storage().data_ptr() == fs.P.untyped_storage().data_ptr()
+    assert w.grad is not None and w.grad.untyped_storage().data_ptr() == fs.G.untyped_storage().data_ptr()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.state_dict().keys())
+    assert all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
+    # load_state_dict writes through the views; the two concatenation-reading weights are scattered on the next use
+    ref2 = oh.HighResolutionNet()
+    m.load_state_dict(ref2.state_dict())
+    m._ensure_runtime()
+    named = m.trainer_named_parameters()
+    pp = named['mask_feature.conv1.weight']
+    assert tuple(pp.shape) == (64, 304, 3, 3)
+    assert torch.equal(pp[:, 32:68], ref2.mask_feature.conv1.weight[:, 18:54]) and float(pp[:, 18:32].abs().max()) == 0
+    g = named['stage3.0.branches.2.0.bn1.weight']
+    assert tuple(g.shape) == (80,) and torch.equal(g[:72], ref2.stage3[0].branches[2][0].bn1.weight) and float(g[72:].abs().max()) == 0
+    # values written into the padded storage (what the fused Adam does) show up in the module's state_dict
+    with torch.no_grad():
+        pp[:, 32:68] += 1.0
+        named['conv1.weight'][:, :3] -= 0.5
+    sd = m.state_dict()
+    assert torch.allclose(sd['mask_feature.conv1.weight'][:, 18:54], ref2.mask_feature.conv1.weight[:, 18:54] + 1.0)
+    assert torch.allclose(sd['conv1.weight'], ref2.conv1.weight - 0.5)

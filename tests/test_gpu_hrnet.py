@@ -57,10 +57,3 @@ def test_eval_forward_matches_reference(golden, tag):
         want = z['%s_%s' % (name, tag)].argmax(1)
         got = out[0 if name == 'mask' else 2].float().cpu().numpy().argmax(1)
         assert (want == got).mean() > (0.999 if name == 'mask' else 0.96)      # measured: mask 100 %, direction 97.4-99.1 %
-
-
-def test_training_mode_is_refused():
-    import torch
-    m = _model(0.45).train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros((1, 3, 64, 64), device='cuda'))
