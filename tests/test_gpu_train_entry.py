@@ -43,3 +43,5 @@ def test_entry_point_synthetic_epochs():
     assert len(res) == 11 and np.isfinite(res).all()
     res_u = train.main(['--synthetic', '2', '--epochs', '1', '--batch-size', '2', '--model-name', 'UNet'])
     assert len(res_u) == 3 and np.isfinite(res_u).all()
+    res_h = train.main(['--synthetic', '2', '--epochs', '1', '--batch-size', '2', '--model-name', 'HRNet18_rev1'])
+    assert len(res_h) == 11 and np.isfinite(res_h).all()

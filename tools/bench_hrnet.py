@@ -26,3 +26,19 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 5
 print('HRNet18_rev1 eval forward, %d tiles 512x512: %.2f ms = %.1f tiles/s' % (B, dt * 1e3, B / dt))
+
+# training step (forward with batch-statistics BatchNorm, loss, backward, Adam) at the same shape
+from cdnet_amd import trainer
+m.train()
+tr = trainer.Trainer(m)
+batch = trainer.synthetic_batch(B, torch.device('cuda:0'), seed=5, H=512, W=512)
+for _ in range(3):
+    loss = tr.train_step(*batch)
+torch.cuda.synchronize()
+t = time.perf_counter()
+K = 8
+for _ in range(K):
+    loss = tr.train_step(*batch)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / K
+print('HRNet18_rev1 train step, %d tiles 512x512: %.2f ms = %.1f tiles/s  (loss %.4f)' % (B, dt * 1e3, B / dt, float(loss[0])))
