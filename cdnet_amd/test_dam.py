@@ -8,7 +8,7 @@ import os
 import numpy as np
 import torch
 
-from . import pipeline, postproc, utils
+from . import checkpoint, pipeline, postproc, utils
 from .options import Options
 
 
@@ -40,9 +40,7 @@ def main(argv=None):
     opt = Options(isTrain=False).parse(argv)
     model = utils.chooseModel(opt).cuda()
     if os.path.exists(opt.test['model_path']):
-        ck = torch.load(opt.test['model_path'], map_location='cpu')
-        sd = {k[7:] if k.startswith('module.') else k: v for k, v in ck['state_dict'].items()}   # DataParallel prefix (test_dam.py:158-167)
-        model.load_state_dict(sd, strict=False)
+        checkpoint.load_checkpoint(opt.test['model_path'], model, strict=False)      # DataParallel prefix (test_dam.py:158-167)
     model.eval()
     img_dir = opt.test['img_dir']
     names = sorted(f for f in os.listdir(img_dir) if f.endswith('.png')) if os.path.isdir(img_dir) else []

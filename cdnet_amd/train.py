@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-from . import synth, train_util_dam, utils
+from . import checkpoint, synth, train_util_dam, utils
 from .options import Options
 from .trainer import synthetic_batch, UNetTrainer
 
@@ -62,11 +62,21 @@ def main(argv=None):
         trainer = UNetTrainer(model, lr=opt.train['lr'], weight_decay=opt.train['weight_decay'], world_size=world)
     else:
         trainer, _ = utils.get_optimizer(opt, model, world_size=world)
+    best_iou, best_loss = 0.0, float('inf')
+    if opt.train['checkpoint']:                            # train.py:293-306: resume (weights, Adam moments, epoch, best values)
+        if os.path.isfile(opt.train['checkpoint']):
+            ck = checkpoint.load_checkpoint(opt.train['checkpoint'], model, trainer)
+            opt.train['start_epoch'] = ck.get('epoch', 0)
+            best_iou, best_loss = ck.get('best_iou', best_iou), ck.get('best_loss', best_loss)
+            logger.info("=> loaded checkpoint '{}' (epoch {})".format(opt.train['checkpoint'], opt.train['start_epoch']))
+        else:
+            logger.info("=> no checkpoint found at '{}'".format(opt.train['checkpoint']))
     B = opt.train['batch_size']
     if own.synthetic <= 0:
         raise SystemExit("dataset folders are read by the reference's DataFolder + augmentation pipeline, which is outside the "
                          "accelerated path; run with --synthetic N, or feed train_util_dam.train your own loader")
     loader = _SyntheticLoader(own.synthetic, B, dev, seed=opt.train['seed'] + 1000 * rank)
+    res = None
     for epoch in range(opt.train['start_epoch'], opt.train['num_epochs']):
         t0 = time.time()
         if plain_unet:
@@ -79,10 +89,15 @@ def main(argv=None):
         torch.cuda.synchronize()
         dt = time.time() - t0
         logger.info('epoch {:d}: loss {:.4f}  ({:.1f} tiles/s on {:d} GPU(s))'.format(epoch + 1, float(res[0]), world * B * len(loader) / dt, world))
-    if rank == 0 and opt.train.get('save_dir'):
-        os.makedirs(opt.train['save_dir'], exist_ok=True)
-        torch.save({'epoch': opt.train['num_epochs'], 'state_dict': {'module.' + k: v.detach().cpu() for k, v in model.state_dict().items()}},
-                   os.path.join(opt.train['save_dir'], 'checkpoint_last.pth.tar'))          # DataParallel key prefix (train.py:476-487)
+        if rank == 0 and opt.train.get('save_dir'):
+            # train.py:406-427: checkpoint.pth.tar every epoch, numbered copies at checkpoint_freq, checkpoint_best on a new
+            # best (no validation loop here: the training loss stands in for val_loss)
+            is_best = float(res[0]) < best_loss
+            best_loss = min(best_loss, float(res[0]))
+            cp_flag = int((epoch + 1) % opt.train['checkpoint_freq'] == 0 or epoch + 1 == opt.train['num_epochs'])
+            os.makedirs(opt.train['save_dir'], exist_ok=True)
+            checkpoint.save_checkpoint(checkpoint.make_state(model, trainer, epoch, best_iou, best_loss), epoch, is_best,
+                                       opt.train['save_dir'], 'Main', cp_flag)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -410,6 +410,68 @@ class Trainer:
         for L, attr in owners:
             setattr(L, attr, (L.weight._version, runtime.WEIGHTS_EPOCH[0]))
 
+    # ------------------------------------------------------------------------------------------------
+    # Optimiser state in torch.optim.Adam's state_dict format (what the reference stores under checkpoint['optimizer'],
+    # train.py:421-427, and reads back at :302): parameter indices follow model.parameters(); parameters that never received
+    # a gradient have no entry (Adam creates state lazily).
+    def _real_pieces(self, buf, name, p):
+        """[(index into the real parameter, view of `buf`)] covering parameter `name` (the model's own shape), whether the flat
+        storage holds it as is, zero-padded (leading corner) or scattered over channel segments (HRNet)"""
+        off, sz = self.flat.offsets[name]
+        slots = {id(real): (pp, segs) for real, pp, segs in getattr(self.model, '_slots', [])}
+        if id(p) not in slots:
+            return [(Ellipsis, buf[off:off + sz].view(p.shape))]
+        pp, segs = slots[id(p)]
+        full = buf[off:off + sz].view(pp.shape)
+        if segs is None:
+            return [(Ellipsis, full[tuple(slice(0, n) for n in p.shape)])]
+        return [((slice(None), slice(r0, r0 + n)), full[:, p0:p0 + n]) for r0, n, p0 in segs]
+
+    def refresh_parameters(self):
+        """call after writing parameters behind the trainer's back (load_state_dict does not need it: the module's parameters
+        ARE views of the flat buffer; this only invalidates every packed bf16 weight copy and BatchNorm fold)"""
+        if hasattr(self.model, 'sync_real_parameters') and getattr(self.model, '_rt', None) is not None:
+            self.model._ensure_runtime()
+        runtime.WEIGHTS_EPOCH[0] += 1
+
+    def state_dict(self):
+        f = self.flat
+        params = list(self.model.named_parameters())
+        state = {}
+        if f.step_count > 0:
+            for i, (n, p) in enumerate(params):
+                if f.offsets[n][0] >= f.n_used:
+                    continue                                        # the reference's never-used parameters: no gradient, no state
+                m, v = torch.empty(p.shape, dtype=torch.float32), torch.empty(p.shape, dtype=torch.float32)
+                for idx, piece in self._real_pieces(f.M, n, p):
+                    m[idx] = piece.cpu()
+                for idx, piece in self._real_pieces(f.V, n, p):
+                    v[idx] = piece.cpu()
+                state[i] = {'step': torch.tensor(float(f.step_count)), 'exp_avg': m, 'exp_avg_sq': v}
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.wd, amsgrad=False, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None, params=list(range(len(params))))
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        f = self.flat
+        params = list(self.model.named_parameters())
+        group = sd['param_groups'][0]
+        assert len(sd['param_groups']) == 1 and len(group['params']) == len(params), 'optimizer state of a different model'
+        self.lr, self.betas, self.eps, self.wd = group['lr'], tuple(group['betas']), group['eps'], group['weight_decay']
+        f.M.zero_()
+        f.V.zero_()
+        steps = set()
+        for i, st in sd['state'].items():
+            n, p = params[int(i)]
+            assert f.offsets[n][0] < f.n_used, 'state for a parameter that is never stepped: ' + n
+            for idx, piece in self._real_pieces(f.M, n, p):
+                piece.copy_(st['exp_avg'][idx])
+            for idx, piece in self._real_pieces(f.V, n, p):
+                piece.copy_(st['exp_avg_sq'][idx])
+            steps.add(int(st['step']))
+        assert len(steps) <= 1, 'per-parameter step counts differ: not a state of torch.optim.Adam over the whole model'
+        f.step_count = steps.pop() if steps else 0
+
     def train_step(self, x, label, dirlab, point_t, weight):
         """x f32 [B,3,H,W]; label u8 [B,H,W] in {0,1,2}; dirlab u8 [B,H,W] 0..8; point_t f16 [B,H,W]; weight u8 [B,H,W]
         (the png weight map; /20 on the fly).  Returns the device tensor of 11 values: [total, direction CE, direction dice,

@@ -37,11 +37,27 @@ def test_train_function_matches_oracle_iteration():
     np.testing.assert_allclose(got[6:], L['metrics'], atol=2e-2)
 
 
-def test_entry_point_synthetic_epochs():
+def test_entry_point_synthetic_epochs(tmp_path):
+    import os
+    import torch
     from cdnet_amd import train
-    res = train.main(['--synthetic', '3', '--epochs', '2', '--batch-size', '2'])
+    d = str(tmp_path / 'dam')
+    res = train.main(['--synthetic', '3', '--epochs', '2', '--batch-size', '2', '--save-dir', d])
     assert len(res) == 11 and np.isfinite(res).all()
-    res_u = train.main(['--synthetic', '2', '--epochs', '1', '--batch-size', '2', '--model-name', 'UNet'])
+    # the reference's checkpoint layout (train.py:461-480), resumable: epoch, Adam moments and step count come back
+    for f in ('checkpoint.pth.tar', 'checkpoint_2.pth.tar', 'checkpoint_best.pth.tar'):
+        assert os.path.exists(os.path.join(d, 'checkpoints', f)), f
+    ck = torch.load(os.path.join(d, 'checkpoints', 'checkpoint.pth.tar'), map_location='cpu', weights_only=False)
+    assert ck['epoch'] == 2 and all(k.startswith('module.') for k in ck['state_dict'])
+    assert all(int(s['step']) == 6 for s in ck['optimizer']['state'].values())
+    res2 = train.main(['--synthetic', '3', '--epochs', '3', '--batch-size', '2', '--save-dir', d, '--checkpoint-path',
+                       os.path.join(d, 'checkpoints', 'checkpoint.pth.tar')])
+    assert np.isfinite(res2).all() and res2[0] < res[0] * 1.05           # one more epoch from where it stopped
+    ck2 = torch.load(os.path.join(d, 'checkpoints', 'checkpoint.pth.tar'), map_location='cpu', weights_only=False)
+    assert ck2['epoch'] == 3 and all(int(s['step']) == 9 for s in ck2['optimizer']['state'].values())
+    res_u = train.main(['--synthetic', '2', '--epochs', '1', '--batch-size', '2', '--model-name', 'UNet', '--save-dir', str(tmp_path / 'u')])
     assert len(res_u) == 3 and np.isfinite(res_u).all()
-    res_h = train.main(['--synthetic', '2', '--epochs', '1', '--batch-size', '2', '--model-name', 'HRNet18_rev1'])
+    res_h = train.main(['--synthetic', '2', '--epochs', '1', '--batch-size', '2', '--model-name', 'HRNet18_rev1', '--save-dir', str(tmp_path / 'h')])
     assert len(res_h) == 11 and np.isfinite(res_h).all()
+    ckh = torch.load(str(tmp_path / 'h' / 'checkpoints' / 'checkpoint.pth.tar'), map_location='cpu', weights_only=False)
+    assert tuple(ckh['state_dict']['module.stage2.0.branches.0.0.conv1.weight'].shape) == (18, 18, 3, 3)
