@@ -96,7 +96,8 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
     if ck == 64:
         ck = 32                       # 2 workgroups per CU (LDS) beat one fat one
     bn = 64 if Cout > 32 else 32
-    if ctot <= 128 and bn == 64:
+    import os
+    if (ctot <= 128 and bn == 64) or (os.environ.get('CDNET_CK16', '1') == '1' and ck >= 16):
         ck = 16                       # 34 KB of LDS and <= 168 VGPRs: three workgroups per CU hide the staging latency (measured)
     if ck == 16 and bn > 64:
         bn = 64

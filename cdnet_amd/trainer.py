@@ -114,6 +114,7 @@ class Trainer:
         self.losses = torch.zeros((11,), dtype=torch.float32, device=self.dev)     # 6 loss values + 5 pixel metrics
         self.tape = []
         self._cat_cache = {}
+        self._wstream, self._events = None, {}
 
     # ------------------------------------------------------------------------------------------------
     def buf(self, key, shape, dtype):
@@ -155,6 +156,8 @@ class Trainer:
 
     def _slab(self, n):
         if self._ws_slab is None or self._ws_slab.numel() < n:
+            if self._wstream is not None:
+                self._wstream.synchronize()          # the old workspace may still be in use on the weight-gradient stream
             self._ws_slab = torch.empty((n,), dtype=torch.float32, device=self.dev)
         return self._ws_slab
 
@@ -217,7 +220,8 @@ class Trainer:
         """walk the forward tape backwards: BatchNorm(+ReLU, residual, pool/pad/concat routing) backward, then the
         weight and input gradients of every convolution that received a gradient"""
         self._cat_cache = {}
-        for L in reversed(self.tape):
+        side = self._side_stream()
+        for k, L in enumerate(reversed(self.tape)):
             if isinstance(L, runtime.FuseNode):
                 L.backward(self, grads, add)
                 continue
@@ -230,8 +234,23 @@ class Trainer:
                 g = self._bn_backward(L, out, gl, add)
             else:
                 g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
-            self._conv_backward(L, srcs, g, Hl, Wl, add)
-            self._overlap_done((L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias))
+            params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
+            if side is None:
+                self._weight_backward(L, srcs, g, Hl, Wl)
+                self._overlap_done(params)
+            else:
+                # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient chain
+                ev = self._event(k)
+                ev.record()
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._weight_backward(L, srcs, g, Hl, Wl)
+                    self._overlap_done(params)         # (a bucket released here is ordered after both streams' work so far)
+            self._input_backward(L, srcs, g, Hl, Wl, add)
+        if side is not None:
+            ev = self._event(-1)
+            ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
 
     def _bn_backward(self, L, out, gl, add):
         a = BnBwdArgs()
@@ -266,7 +285,22 @@ class Trainer:
             add(res, _G(dz, Ho, Wo))        # gradient of the residual branch = dz; its producer (conv_1x1) is on the tape
         return draw
 
-    def _conv_backward(self, L, srcs, g, H, W, add):
+    def _side_stream(self):
+        """second HIP stream for the weight-gradient kernels (CDNET_WGRAD_STREAM=0: everything on one stream)"""
+        if os.environ.get('CDNET_WGRAD_STREAM', '1') == '0' or self.dev.type != 'cuda':
+            return None
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(device=self.dev)
+            self._events = {}
+        return self._wstream
+
+    def _event(self, k):
+        e = self._events.get(k)
+        if e is None:
+            e = self._events[k] = torch.cuda.Event()
+        return e
+
+    def _weight_backward(self, L, srcs, g, H, W):
         lib = _lib.load()
         N = g.shape[0]
         Cout = L.Cout
@@ -300,8 +334,13 @@ class Trainer:
                 ws = self._slab(need)
                 _lib.call('cdnet_bias_grad', _lib.ptr(g), g.numel() // Cout, Cout, _lib.ptr(ws), ws.numel(), _lib.ptr(L.bias.grad),
                           _lib.stream_ptr())
+
+    def _input_backward(self, L, srcs, g, H, W, add):
         if not getattr(L, 'needs_input_grad', True):
             return
+        N = g.shape[0]
+        Cout = L.Cout
+        cin_total = sum(s.C for s in srcs)
         # input gradient: forward convolution with the backward-data pack
         wpb, cfgb = L.backward_pack(cin_total, H, W)
         if L.kind == 'conv3s2':
