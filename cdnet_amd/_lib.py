@@ -35,6 +35,7 @@ SIGNATURES = {
     'cdnet_pack_batch_table_bytes': (_sz, [_i]),
     'cdnet_pack_conv_weights_batch': (_i, [_vp, _i, _vp, _sz, _i, _vp]),
     'cdnet_conv_forward': (_i, [_vp, _vp]),
+    'cdnet_src_materialize': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'cdnet_input_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_bn_fold_eval': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'cdnet_bn_finalize_train': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -718,6 +718,59 @@ int dispatch_conv(const ConvArgs &A, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// A source with its pending transform (BatchNorm scale/shift, residual, ReLU, 2x2 max-pool, pad offset) written out as a
+// plain bf16 tensor - exactly the values stage_input would put into LDS.  Used where the on-the-fly transform costs more
+// than a pass over HBM: max-pooled sources (4 loads + 4 transforms per staged element, repeated by every output-channel
+// block and halo; the pooled staging path is not pipelined).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void materialize_kernel(const ConvSrc s, int N, int H, int W, unsigned short *__restrict__ out) {
+    const int VPP = s.C / 8;
+    const size_t total = (size_t)N * H * W * VPP;
+    const bool relu = s.relu != 0, f16 = s.f16 != 0;
+    const int Hl = s.pool ? (s.Hs + (s.pool == 2)) / 2 : s.Hs, Wl = s.pool ? (s.Ws + (s.pool == 2)) / 2 : s.Ws;
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int slot = (int)(i % VPP);
+        const size_t pix = i / VPP;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        ChanXf t;
+        load_chan_xf(t, s, nullptr, 0, slot * 8);
+        const bool plain = !t.on && !relu && s.res == nullptr && !f16;
+        const size_t img = (size_t)n * s.Hs * rs;
+        V16 val;
+        val.u = make_uint4(0, 0, 0, 0);
+        const int ys = y - s.off_y, xs = x - s.off_x;
+        if (ys >= 0 && ys < Hl && xs >= 0 && xs < Wl) {
+            if (!s.pool) {
+                const size_t e = img + (size_t)ys * rs + (size_t)xs * s.C + slot * 8;
+                V16 raw;
+                raw.u = *reinterpret_cast<const uint4 *>(s.x + e);
+                if (plain) val = raw;
+                else if (s.res) { V16 r; r.u = *reinterpret_cast<const uint4 *>(s.res + e); val = xform8(raw, &r, t, relu, f16); }
+                else val = xform8(raw, nullptr, t, relu, f16);
+            } else {
+                V16 raw[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                     // all four loads first (clamped address), then the math
+                    int yy = 2 * ys + (q >> 1), xx = 2 * xs + (q & 1);
+                    ok[q] = q == 0 || (yy < s.Hs && xx < s.Ws);   // ceil-mode partial window
+                    yy = yy < s.Hs ? yy : s.Hs - 1;
+                    xx = xx < s.Ws ? xx : s.Ws - 1;
+                    raw[q].u = *reinterpret_cast<const uint4 *>(s.x + img + (size_t)yy * rs + (size_t)xx * s.C + slot * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const V16 tv = plain ? raw[q] : xform8(raw[q], nullptr, t, relu, f16);
+                    val = q == 0 ? tv : (ok[q] ? max8(val, tv, relu) : val);
+                }
+            }
+        }
+        *reinterpret_cast<uint4 *>(out + pix * s.C + slot * 8) = val.u;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t cdnet_conv_packed_weight_elems(int Cout, int Cin_padded_chunks, int taps, int CK, int BN, int npar) {
@@ -813,4 +866,17 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     if (A.taps == 9) return dispatch_conv<9>(A, st);
     if (A.taps == 4) return dispatch_conv<4>(A, st);
     return dispatch_conv<1>(A, st);
+}
+
+extern "C" int cdnet_src_materialize(const cdnet_conv_src *src, int N, int H, int W, uint16_t *out, void *stream) {
+    CDNET_REQUIRE(src && out && src->x && N > 0 && H > 0 && W > 0, "cdnet_src_materialize: bad args");
+    const ConvSrc &s = *reinterpret_cast<const ConvSrc *>(src);
+    CDNET_REQUIRE(s.C >= 8 && s.C % 8 == 0 && s.Hs > 0 && s.Ws > 0, "cdnet_src_materialize: C=%d must be a multiple of 8", s.C);
+    CDNET_REQUIRE(!(s.pool && s.res), "cdnet_src_materialize: pooled sources carry no residual");
+    CDNET_REQUIRE((s.scale == nullptr) == (s.shift == nullptr), "cdnet_src_materialize: scale and shift come together");
+    const size_t total = (size_t)N * H * W * (s.C / 8);
+    size_t g = (total + 255) / 256;
+    g = g > 8192 ? 8192 : g;
+    materialize_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(s, N, H, W, out);
+    return check_launch("cdnet_src_materialize");
 }

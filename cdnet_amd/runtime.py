@@ -260,10 +260,32 @@ def input_pack(x):
     return out
 
 
-def pooled(s, ceil_mode=False):
-    """The 2x2 max-pooled view of a Src (nn.MaxPool2d(2,2[,ceil_mode]) applied after the Src's own transform)."""
+POOL_MATERIALIZE = _os.environ.get('CDNET_POOL_MATERIALIZE', '1') != '0'
+
+
+def materialize(s, H=None, W=None):
+    """The Src with its pending transform applied, as a stored bf16 tensor (cdnet_src_materialize).  Returns a plain Src."""
+    if H is None:
+        H, W = s.logical_hw()
+    out = torch.empty((s.N, H, W, s.C), dtype=torch.bfloat16, device=s.x.device)
+    cs = engine.ConvSrc()
+    s.fill(cs)
+    _lib.call('cdnet_src_materialize', C.byref(cs), s.N, H, W, _lib.ptr(out), _lib.stream_ptr())
+    return Src(out)
+
+
+def pooled(s, ceil_mode=False, materialized=None):
+    """nn.MaxPool2d(2,2[,ceil_mode]) applied after the Src's own transform.  Either a lazy view (the consumer's staging
+    code takes the max of the four transformed values) or - the default, measured faster - a stored copy; `grad_to` tells
+    backward that the gradient of the copy belongs to the un-pooled producer, routed through the max-pool."""
     assert not s.pool and s.res is None
-    return Src(s.x, s.scale, s.shift, relu=s.relu, pool=2 if ceil_mode else 1)
+    mode = 2 if ceil_mode else 1
+    lazy = Src(s.x, s.scale, s.shift, relu=s.relu, pool=mode)
+    if not (POOL_MATERIALIZE if materialized is None else materialized):
+        return lazy
+    out = materialize(lazy)
+    out.grad_to = (s.x, mode)
+    return out
 
 
 def pad_offsets(small_hw, big_hw):

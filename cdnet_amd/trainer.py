@@ -365,7 +365,8 @@ class Trainer:
             if getattr(s, 'is_input', False):
                 coff += s.C
                 continue
-            add(s.x, _G(gin, H, W, oy=s.off[0], ox=s.off[1], pooled=int(s.pool), coff=coff, cstride=cin_total))
+            tgt, pool = getattr(s, 'grad_to', (s.x, int(s.pool)))          # a materialised max-pool hands its gradient to the producer
+            add(tgt, _G(gin, H, W, oy=s.off[0], ox=s.off[1], pooled=pool, coff=coff, cstride=cin_total))
             coff += s.C
 
     # ------------------------------------------------------------------------------------------------

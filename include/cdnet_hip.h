@@ -237,6 +237,12 @@ size_t cdnet_final_conv1x1_backward_workspace_floats(void);
 int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
                                  uint16_t *df, float *workspace, size_t workspace_floats, float *dw, float *db, void *stream);
 
+/* cdnet_src_materialize: a convolution source with its pending transform - BatchNorm scale / shift, residual add, ReLU,
+ * nn.MaxPool2d(2, 2[, ceil_mode]) (model_unet_rev1.py:268-287 backbone 'M' layers, unet.py:19), F.pad offset - written out
+ * as a plain bf16 NHWC tensor out[N][H][W][C]: bit-identical to what cdnet_conv_forward stages on the fly for the same
+ * source (H, W = the logical size after the pool).  Consumers of a max-pooled training-mode activation read this copy. */
+int cdnet_src_materialize(const cdnet_conv_src *src, int N, int H, int W, uint16_t *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Backward-weight of a convolution (the dW half of loss.backward(), train_util_dam.py:307), one call per input
  * source of the layer.  `src` is the layer's forward source (its lazy transform is re-applied while staging),

@@ -161,3 +161,34 @@ def test_conv_backward_data_pack():
     wp = engine.pack_weights(w.cuda(), cfg, 1)
     out, _ = engine.conv_forward([engine.Src(_nhwc(dy))], wp, Cin, cfg)
     _close(_nchw(out), want, 'bwd-data')
+
+
+@pytest.mark.parametrize('ceil_mode,hw', [(False, (64, 96)), (True, (37, 51))])
+def test_materialized_pool_equals_on_the_fly_pool(ceil_mode, hw):
+    """cdnet_src_materialize writes exactly what the convolution's staging code computes for a BatchNorm + ReLU + 2x2 max-pool
+    source: the convolution over the stored copy is bit-identical to the one over the lazy view (and both match PyTorch)."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine, runtime
+    g = torch.Generator().manual_seed(3)
+    N, Cc, Cout = 2, 64, 32
+    H, W = hw
+    raw = (torch.randn((N, H, W, Cc), generator=g) * 2).half().cuda()
+    sc = (torch.rand((Cc,), generator=g) + 0.5).cuda()
+    sh = (torch.randn((Cc,), generator=g) * 0.3).cuda()
+    w = (torch.randn((Cout, Cc, 3, 3), generator=g) * 0.05).cuda()
+    src = engine.Src(raw, sc, sh, relu=True)
+    lazy = runtime.pooled(src, ceil_mode, materialized=False)
+    stored = runtime.pooled(src, ceil_mode, materialized=True)
+    assert stored.grad_to[0] is raw and stored.x.dtype == torch.bfloat16 and stored.scale is None
+    Hp, Wp = lazy.logical_hw()
+    assert tuple(stored.x.shape) == (N, Hp, Wp, Cc)
+    cfg = engine.choose_cfg([Cc], Cout, Hp, Wp)
+    wp = engine.pack_weights(w, cfg, 0)
+    a, _ = engine.conv_forward([lazy], wp, Cout, cfg)
+    b, _ = engine.conv_forward([stored], wp, Cout, cfg)
+    assert torch.equal(a, b)
+    act = F.relu(raw.float() * sc + sh).permute(0, 3, 1, 2)
+    want = F.max_pool2d(act, 2, 2, ceil_mode=ceil_mode)
+    # (fused multiply-add here vs multiply + add in PyTorch: at most one bf16 ulp)
+    np.testing.assert_allclose(stored.x.float().permute(0, 3, 1, 2).cpu().numpy(), want.cpu().numpy(), rtol=8e-3, atol=1e-6)
