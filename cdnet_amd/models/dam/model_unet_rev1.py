@@ -79,7 +79,7 @@ class _RU:
     def layers(self):
         return [self.c1, self.c2, self.cr]
 
-    def forward(self, x, training):
+    def forward(self, x, training, store=False):
         # the pre-activation pair (bn2 output, residual) is kept in fp16: it is only ever read through the consumer's
         # add+ReLU transform, never as an MFMA operand
         r = self.cr.forward([x], training, out_dtype=torch.float16)               # residual = conv_1x1(x)   (:162)
@@ -87,7 +87,13 @@ class _RU:
         y = self.c2.forward([h], training, relu=False, out_dtype=torch.float16)   # bn2(conv2(.))            (:166-167)
         relu2 = not runtime.DEBUG_NORELU
         self.c2.node_relu, self.c2.node_res = relu2, r.x         # how consumers (and backward) see the unit's output
-        return Src(y.x, y.scale, y.shift, relu=relu2, res=r.x)   # relu2(out + residual)             (:168-169)
+        out = Src(y.x, y.scale, y.shift, relu=relu2, res=r.x)    # relu2(out + residual)             (:168-169)
+        if store and runtime.RU_MATERIALIZE:
+            # three consumers (the next unit's two convolutions and the head) would each redo BatchNorm + add + ReLU over
+            # two fp16 tensors: one stored bf16 copy is cheaper (measured); its gradient belongs to bn2's raw output
+            lazy, out = out, runtime.materialize(out)
+            out.grad_to = (lazy.x, 0)
+        return out
 
 
 class Unet(nn.Module):
@@ -207,8 +213,8 @@ class Unet(nn.Module):
             uh, uw = u.logical_hw()
             u.off = pad_offsets((uh, uw), (sh, sw))                # F.pad (:126-131)
             t = conv2.forward([u, skip], training, H=sh, W=sw)      # cat([x, skip]) -> conv2 -> bn2 -> relu (:133-141)
-        f1 = self._rt['ru'][0].forward(t, training)
-        f2 = self._rt['ru'][1].forward(f1, training)
+        f1 = self._rt['ru'][0].forward(t, training, store=True)
+        f2 = self._rt['ru'][1].forward(f1, training, store=True)
         f3 = self._rt['ru'][2].forward(f2, training)
         return f1, f2, f3
 

@@ -388,8 +388,8 @@ class HighResolutionNet(nn.Module):
         cat = torch.empty((N, H, W, ctot), dtype=torch.bfloat16, device=x.device)
         for k, (y, (p0, _)) in enumerate(zip(ys, self._cat_layout)):
             self._node(('cat', k)).forward([y], False, out=cat, out_coff=p0, training=training)
-        f1 = rt['ru'][0].forward(Src(cat), training)
-        f2 = rt['ru'][1].forward(f1, training)
+        f1 = rt['ru'][0].forward(Src(cat), training, store=True)
+        f2 = rt['ru'][1].forward(f1, training, store=True)
         f3 = rt['ru'][2].forward(f2, training)
         return _DamUnet._head(self, (f1, f2, f3))
 

@@ -261,6 +261,7 @@ def input_pack(x):
 
 
 POOL_MATERIALIZE = _os.environ.get('CDNET_POOL_MATERIALIZE', '1') != '0'
+RU_MATERIALIZE = _os.environ.get('CDNET_RU_MATERIALIZE', '1') != '0'
 
 
 def materialize(s, H=None, W=None):

@@ -211,7 +211,7 @@ class Trainer:
                   _lib.ptr(dmask), _lib.ptr(dpoint), _lib.ptr(ddir), N, H, W, _lib.ptr(df[0]), _lib.ptr(df[1]),
                   _lib.ptr(df[2]), _lib.ptr(self._ws_head), self._ws_head.numel(), _lib.ptr(dhead), _lib.stream_ptr())
         for f, d in zip((f1, f2, f3), df):
-            add(f.x, _G(d, H, W))
+            add(getattr(f, 'grad_to', (f.x,))[0], _G(d, H, W))
         self._overlap_begin()
         self._overlap_done(None)
         self._backward_tape(grads, add)
