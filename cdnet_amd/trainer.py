@@ -115,6 +115,7 @@ class Trainer:
         self.tape = []
         self._cat_cache = {}
         self._wstream, self._events = None, {}
+        self._packb_pending = False
 
     # ------------------------------------------------------------------------------------------------
     def buf(self, key, shape, dtype):
@@ -221,6 +222,9 @@ class Trainer:
         weight and input gradients of every convolution that received a gradient"""
         self._cat_cache = {}
         side = self._side_stream()
+        if self._packb_pending:
+            torch.cuda.current_stream().wait_event(self._event('packb'))      # backward-data packs made beside the forward
+            self._packb_pending = False
         for k, L in enumerate(reversed(self.tape)):
             if isinstance(L, runtime.FuseNode):
                 L.backward(self, grads, add)
@@ -428,27 +432,40 @@ class Trainer:
         f = self.flat
         lo, hi = f.P.data_ptr(), f.P.data_ptr() + f.P.numel() * 4
         if self._pack_jobs is None:
-            jobs, owners = [], []
+            groups = ([], []), ([], [])                      # (jobs, owners) of the forward packs / the backward-data packs
             for L in runtime.LAYERS:
                 if not (lo <= L.weight.data_ptr() < hi):
                     continue
                 w = L.weight.detach()
                 if L.wp is not None and not L.wp_padded:
-                    jobs.append(engine.pack_job(w, L.cfg, L.pack_mode, L.wp)); owners.append((L, 'wp_version'))
+                    groups[0][0].append(engine.pack_job(w, L.cfg, L.pack_mode, L.wp)); groups[0][1].append((L, 'wp_version'))
                 if L.wpb is not None:
                     mode = (4 if L.kind == 'convT4' else 5) if L.transposed else (7 if L.kind == 'conv3s2' else 1)
-                    jobs.append(engine.pack_job(w, L.cfg_bwd, mode, L.wpb)); owners.append((L, 'wpb_version'))
-            if not jobs or self.flat.step_count < 1:
+                    groups[1][0].append(engine.pack_job(w, L.cfg_bwd, mode, L.wpb)); groups[1][1].append((L, 'wpb_version'))
+            if not groups[0][0] or not groups[1][0] or self.flat.step_count < 1:
                 return
-            arr = (engine.PackJob * len(jobs))(*jobs)
-            nbytes = _lib.load().cdnet_pack_batch_table_bytes(len(jobs))
-            table = torch.empty((nbytes,), dtype=torch.uint8, device=f.P.device)
-            self._pack_jobs = (arr, len(jobs), table, owners, [True])
-        arr, n, table, owners, first = self._pack_jobs
-        _lib.call('cdnet_pack_conv_weights_batch', C.byref(arr), n, _lib.ptr(table), table.numel(), int(first[0]), _lib.stream_ptr())
-        first[0] = False
-        for L, attr in owners:
-            setattr(L, attr, (L.weight._version, runtime.WEIGHTS_EPOCH[0]))
+            self._pack_jobs = []
+            for jobs, owners in groups:
+                arr = (engine.PackJob * len(jobs))(*jobs)
+                nbytes = _lib.load().cdnet_pack_batch_table_bytes(len(jobs))
+                table = torch.empty((nbytes,), dtype=torch.uint8, device=f.P.device)
+                self._pack_jobs.append((arr, len(jobs), table, owners, [True]))
+        side = self._side_stream()
+        for k, (arr, n, table, owners, first) in enumerate(self._pack_jobs):
+            if k == 1 and side is not None and os.environ.get('CDNET_PACKB_STREAM', '1') != '0':
+                # the backward-data packs are not needed before the next backward: pack them beside the next forward
+                ev = self._event('adam')
+                ev.record()
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    _lib.call('cdnet_pack_conv_weights_batch', C.byref(arr), n, _lib.ptr(table), table.numel(), int(first[0]), _lib.stream_ptr())
+                    self._event('packb').record()
+                self._packb_pending = True
+            else:
+                _lib.call('cdnet_pack_conv_weights_batch', C.byref(arr), n, _lib.ptr(table), table.numel(), int(first[0]), _lib.stream_ptr())
+            first[0] = False
+            for L, attr in owners:
+                setattr(L, attr, (L.weight._version, runtime.WEIGHTS_EPOCH[0]))
 
     # ------------------------------------------------------------------------------------------------
     # Optimiser state in torch.optim.Adam's state_dict format (what the reference stores under checkpoint['optimizer'],

@@ -11,9 +11,9 @@ dev = torch.device('cuda:0')
 LAYERS = [  # name, Cin, Cout, H, cfgs
     ('enc1_2 64->64@256', 64, 64, 256, [(16, 16, 64)]),
     ('enc2_1 64->128@128', 64, 128, 128, [(16, 16, 64)]),
-    ('enc2_2 128->128@128', 128, 128, 128, [(16, 16, 64)]),
-    ('enc3_2 256->256@64', 256, 256, 64, [(16, 32, 64), (16, 16, 64)]),
-    ('enc4_2 512->512@32', 512, 512, 32, [(16, 32, 64), (16, 16, 64)]),
+    ('enc2_2 128->128@128', 128, 128, 128, [(16, 16, 64), (16, 16, 32), (16, 32, 128)]),
+    ('enc3_2 256->256@64', 256, 256, 64, [(16, 32, 64), (16, 16, 64), (16, 16, 32), (16, 32, 32), (16, 32, 128)]),
+    ('enc4_2 512->512@32', 512, 512, 32, [(16, 32, 64), (16, 16, 64), (16, 16, 32), (16, 32, 32), (8, 32, 64), (8, 64, 64)]),
     ('enc5_2 512->512@16', 512, 512, 16, [(8, 32, 128), (8, 32, 64), (16, 16, 64), (16, 32, 64)]),
     ('dec3 160->32@128', 160, 32, 128, [(16, 32, 32), (16, 16, 32)]),
 ]
