@@ -260,6 +260,9 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
 // and only transformed / written to LDS after it, so their HBM/L2 latency hides under the matrix work (guide T14).
 // Pooled sources (4 loads + max per element) keep the synchronous path.
 // ------------------------------------------------------------------------------------------------------
+#ifndef CDNET_CONV_XCD
+#define CDNET_CONV_XCD 1
+#endif
 #ifndef CDNET_CONV_GLDS
 #define CDNET_CONV_GLDS 1
 #endif
@@ -485,7 +488,19 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
     };
 
     Prefetch<TH, TW, CK, BN, TAPS> P;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); giving XCD k the k-th
+    // contiguous eighth of the tiles keeps neighbouring tiles - which share halo rows / columns - behind one L2
+#if CDNET_CONV_XCD
+    int tile;
+    {
+        const int T = (int)gridDim.x, q = T >> 3, rem = T & 7;
+        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        tile = xcd < rem ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
+        if (A.debug & 16) tile = blockIdx.x;          // ablation (CDNET_CONV_DEBUG=16): dispatch order
+    }
+#else
     const int tile = blockIdx.x;
+#endif
     (void)total_tiles;
     {
         int n, par, y0, x0;
