@@ -73,6 +73,7 @@ struct BnBwdArgs {
     const float *k1, *k2, *k3;   // apply: draw = k1*(dz - k2 - xhat*k3)
     unsigned short *draw;        // bf16 [N][H][W][C]
     unsigned short *dz_out;      // optional bf16 copy of dz (gradient of the residual branch)
+    int rev;                     // apply pass walks the tensor back to front (see cdnet_bn_backward)
 };
 
 // activated value (rounded to bf16 like the forward staging does) of 8 channels at one pixel
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void bn_bwd_window_kernel(BnBwdArgs A, int kp)
         for (int k = 0; k < A.ngin && m < NF; ++k)
             if (k != kp) kf[m++] = k;
     }
-    for (unsigned w = first_pixel(ppb, VPP); w < nwin; w += gridDim.x * ppb) {
+    for (unsigned w0 = first_pixel(ppb, VPP); w0 < nwin; w0 += gridDim.x * ppb) {
+        const unsigned w = (APPLY && A.rev) ? nwin - 1 - w0 : w0;
         const unsigned n = w / (Hp * Wp), r = w - n * Hp * Wp;
         const unsigned py = r / Wp, px = r - py * Wp;
         V16 raw[4], g[4][NF > 0 ? NF : 1], gv;
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
         for (int u = 0; u < BN_U; ++u) {
             unsigned p = p0 + u * step;
             p = p < npix ? p : npix - 1;
+            p = A.rev ? npix - 1 - p : p;
             raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
             if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
 #pragma unroll
@@ -354,8 +357,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
                 z.h[j] = f2bf(dz);
             }
             if (p < npix) {
-                *reinterpret_cast<uint4 *>(A.draw + (size_t)p * A.C + c0) = o.u;
-                if (RES) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)p * A.C + c0) = z.u;
+                const unsigned pw = A.rev ? npix - 1 - p : p;
+                *reinterpret_cast<uint4 *>(A.draw + (size_t)pw * A.C + c0) = o.u;
+                if (RES) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)pw * A.C + c0) = z.u;
             }
         }
     }
@@ -1182,6 +1186,10 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
         if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
     }
     A.draw = draw; A.dz_out = dz_out;
+    // The apply pass re-reads what the reduce pass just streamed (raw + gradients, up to 2 x 134 MB against 256 MB of
+    // Infinity Cache): walking it back to front meets the most recently cached lines first instead of chasing the LRU tail.
+    static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
+    A.rev = rev;
     const bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
     if (A.mean) {
         CDNET_REQUIRE(gamma && A.invstd && workspace, "cdnet_bn_backward: BatchNorm layer needs gamma/invstd/workspace");

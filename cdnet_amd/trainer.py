@@ -305,6 +305,8 @@ class Trainer:
         return e
 
     def _weight_backward(self, L, srcs, g, H, W):
+        if os.environ.get('CDNET_DEBUG_SKIP_WGRAD') == '1':      # timing experiments only (tools/): the input-gradient chain alone
+            return
         lib = _lib.load()
         N = g.shape[0]
         Cout = L.Cout
