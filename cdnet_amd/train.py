@@ -72,10 +72,16 @@ def main(argv=None):
         else:
             logger.info("=> no checkpoint found at '{}'".format(opt.train['checkpoint']))
     B = opt.train['batch_size']
-    if own.synthetic <= 0:
-        raise SystemExit("dataset folders are read by the reference's DataFolder + augmentation pipeline, which is outside the "
-                         "accelerated path; run with --synthetic N, or feed train_util_dam.train your own loader")
-    loader = _SyntheticLoader(own.synthetic, B, dev, seed=opt.train['seed'] + 1000 * rank)
+    if own.synthetic > 0:
+        loader = _SyntheticLoader(own.synthetic, B, dev, seed=opt.train['seed'] + 1000 * rank)
+    else:
+        # train.py:262-290 without validation split: <img_dir>/train, <weight_map_dir>/train, <label_dir>/train
+        from .data_folder import DataFolder, TileBatches
+        sub = 'train'
+        dir_list = ['{:s}/{:s}'.format(opt.train[k], sub) for k in ('img_dir', 'weight_map_dir', 'label_dir')]
+        dset = DataFolder(dir_list, ['weight.png', 'label.png'], [3, 1, 3])
+        loader = TileBatches(dset, opt.transform['train'], B, dev, seed=opt.train['seed'] + 1000 * rank, logger=logger)
+        logger.info('{:d} training images in {:s}'.format(len(dset), dir_list[0]))
     res = None
     for epoch in range(opt.train['start_epoch'], opt.train['num_epochs']):
         t0 = time.time()

@@ -1,6 +1,11 @@
 """train_util_dam.train (reference signature -> ndarray[11]) and the train.py entry point on synthetic data."""
 import numpy as np
+import os
+import sys
+
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -61,3 +66,34 @@ def test_entry_point_synthetic_epochs(tmp_path):
     assert len(res_h) == 11 and np.isfinite(res_h).all()
     ckh = torch.load(str(tmp_path / 'h' / 'checkpoints' / 'checkpoint.pth.tar'), map_location='cpu', weights_only=False)
     assert tuple(ckh['state_dict']['module.stage2.0.branches.0.0.conv1.weight'].shape) == (18, 18, 3, 3)
+
+
+def test_entry_point_reads_dataset_folders(tmp_path, monkeypatch):
+    """python -m cdnet_amd.train without --synthetic: ./data/<dataset>/{images,weight_maps,labels}/train through DataFolder and the
+    device-side batch pipeline (crop / flips on the host, one cdnet_label_encoding launch per batch)"""
+    import torch
+    from test_data_folder import make_dataset
+    from cdnet_amd import train
+    from cdnet_amd.data_folder import DataFolder, TileBatches
+    from cdnet_amd.my_transforms_direction import label_encoding_batch
+    from cdnet_amd.options import Options
+    root = tmp_path / 'data' / Options(isTrain=True).dataset
+    dirs = make_dataset(root, n=5, size=(150, 170), seed=3)
+    monkeypatch.chdir(tmp_path)
+    # the batches carry exactly what the label-encoding kernel makes of the cropped label
+    ds = DataFolder(dirs, ['weight.png', 'label.png'], [3, 1, 3])
+    tb = TileBatches(ds, {'horizontal_flip': True, 'vertical_flip': True, 'random_crop': 64, 'label_encoding': [3, 2, 1], 'to_tensor': 1},
+                     2, torch.device('cuda:0'), seed=1)
+    assert len(tb) == 3
+    seen = 0
+    for img, weight, label, point, direction in tb:
+        B = img.shape[0]
+        seen += B
+        assert img.shape == (B, 3, 64, 64) and img.dtype == torch.float32 and 0 <= float(img.min()) and float(img.max()) <= 1
+        assert weight.shape == (B, 1, 64, 64) and weight.dtype == torch.uint8 and int(weight.max()) == 20
+        assert label.shape == (B, 1, 64, 64) and set(np.unique(label.cpu().numpy())) <= {0, 127, 255} and len(torch.unique(label)) > 1
+        assert point.shape == (B, 64, 64) and point.dtype == torch.float16 and direction.dtype == torch.uint8 and int(direction.max()) <= 8
+        assert bool(((direction > 0) <= (label[:, 0] != 0)).all())              # direction classes only on the nuclei
+    assert seen == 5
+    res = train.main(['--epochs', '2', '--batch-size', '2', '--input-size', '64', '--save-dir', str(tmp_path / 'exp')])
+    assert len(res) == 11 and np.isfinite(res).all()
