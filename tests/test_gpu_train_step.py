@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B=2, S=64, seed=0):
+def _setup(B=2, S=64, seed=0, W=None):
     import torch
     from cdnet_amd import synth
     from cdnet_amd.models.dam.model_unet_rev1 import Unet
@@ -27,8 +27,9 @@ def _setup(B=2, S=64, seed=0):
             torch.nn.init.normal_(mod.bias, 0, 0.2)
     m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3)
     m.load_state_dict(ref.state_dict())
-    lab, dirn, point, weight = synth.train_targets(B, S, S, 21)
-    x = torch.from_numpy(synth.det_input((B, 3, S, S), 9))
+    W = W or S
+    lab, dirn, point, weight = synth.train_targets(B, S, W, 21)
+    x = torch.from_numpy(synth.det_input((B, 3, S, W), 9))
     t = [torch.from_numpy(a) for a in (lab, dirn, point, weight)]
     return m.cuda(), ref, x, t
 
@@ -86,6 +87,25 @@ def test_linearised_network_gradients_tight():
     for n in ('point_conv.weight', 'mask_conv.weight', 'direction_conv.weight', 'mask_feature.conv2.weight',
               'upsample_blocks.4.conv2.weight', 'upsample_blocks.4.up.weight'):
         assert rel[n] <= 1e-2, (n, rel[n])
+
+
+def test_ragged_tile_gradients():
+    """72 x 88 tiles: the pooled pyramid is 36x44, 18x22, 9x11, 4x5, 2x2, so the decoder pads (model_unet_rev1.py:126-131) and the
+    max-pool windows / BatchNorm-backward routing see odd sizes - linearised network, same bound as the square case"""
+    from cdnet_amd import runtime
+    from oracle import emulate
+    runtime.DEBUG_NORELU = emulate.NORELU = True
+    try:
+        m, ref, x, t = _setup(S=72, W=88)
+        tr, g = _hip_grads(m, x, t)
+        L, rg = _oracle_grads(ref, x, t, emulated=True)
+    finally:
+        runtime.DEBUG_NORELU = emulate.NORELU = False
+    rel = {n: float((g[n] - want).norm() / want.norm()) for n, want in rg.items() if want.norm() >= 1e-6}
+    worst = max(rel, key=rel.get)
+    assert rel[worst] <= 8e-2, (worst, rel[worst])
+    assert np.median(list(rel.values())) <= 2e-2
+    np.testing.assert_allclose(tr.losses.cpu().numpy()[:5], [L[k] for k in ('total', 'dce', 'wdice', 'mse', 'ce')], rtol=5e-3)
 
 
 def test_real_network_gradient_direction():
