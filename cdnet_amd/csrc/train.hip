@@ -881,8 +881,16 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
     const int tid = threadIdx.x;
     for (int idx = tid; idx < B * K_SUMS; idx += 256) {
         const int b = idx / K_SUMS, k = idx % K_SUMS;
-        float s = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) s += partial[((size_t)b * nchunk + ch) * K_SUMS + k];
+        // four independent chains of loads (a single dependent chain of nchunk L2 round trips dominated this kernel)
+        const float *pp = partial + (size_t)b * nchunk * K_SUMS + k;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int ch = 0;
+        for (; ch + 3 < nchunk; ch += 4) {
+            s0 += pp[(size_t)ch * K_SUMS]; s1 += pp[(size_t)(ch + 1) * K_SUMS];
+            s2 += pp[(size_t)(ch + 2) * K_SUMS]; s3 += pp[(size_t)(ch + 3) * K_SUMS];
+        }
+        for (; ch < nchunk; ++ch) s0 += pp[(size_t)ch * K_SUMS];
+        const float s = (s0 + s1) + (s2 + s3);
         s_sum[idx] = s;
         if (sums) sums[idx] = s;
     }
@@ -917,6 +925,19 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
         }
         for (int i = 0; i < 9; ++i) cf[6 + i] = bsum[i];
     }
+    // the 28 batch-mean dice ratios, one thread each (they were ~450 serial divisions on thread 0):
+    // [0,3) mask dice c; [3,12) wdice(i,i); [12,20) wdice(i,prev(i)), i=1..8; [20,28) wdice(i,next(i)), i=1..8
+    __shared__ float s_term[28];
+    if (tid < 28) {
+        int num, da, db;                      // mean_b 2 (S[num] + 1) / (S[da] + S[db] + 1)
+        if (tid < 3) { num = tid; da = 3 + tid; db = 6 + tid; }
+        else if (tid < 12) { const int i = tid - 3; num = 27 + i; da = 9 + i; db = 18 + i; }
+        else if (tid < 20) { const int i = tid - 12 + 1, j = dprev(i); num = 36 + j; da = 9 + i; db = 18 + j; }
+        else { const int i = tid - 20 + 1, j = dnext(i); num = 45 + j; da = 9 + i; db = 18 + j; }
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) { const float *S = s_sum + b * K_SUMS; acc += 2.f * (S[num] + 1.f) / (S[da] + S[db] + 1.f); }
+        s_term[tid] = 1.f - acc / fB;
+    }
     __syncthreads();
     if (tid == 0) {
         const float n = (float)B * (float)P;
@@ -924,24 +945,11 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
         for (int b = 0; b < B; ++b) { ce += s_sum[b * K_SUMS + 54]; dce += s_sum[b * K_SUMS + 55]; mse += s_sum[b * K_SUMS + 56]; }
         ce /= n; dce /= n; mse /= n;
         float dice = 0.f;
-        for (int c = 0; c < 3; ++c) {
-            float s = 0.f;
-            for (int b = 0; b < B; ++b) { const float *S = s_sum + b * K_SUMS; s += 2.f * (S[c] + 1.f) / (S[3 + c] + S[6 + c] + 1.f); }
-            dice += 1.f - s / fB;
-        }
+        for (int c = 0; c < 3; ++c) dice += s_term[c];
         float wd = 0.f;
         for (int i = 0; i < 9; ++i) {
-            // wdice(i,j) = 1 - mean_b 2 (S_ij + 1) / (Pw_i + Tw_j + 1)
-            auto wdice = [&](int ii, int jj, int off) {
-                float s = 0.f;
-                for (int b = 0; b < B; ++b) { const float *S = s_sum + b * K_SUMS; s += 2.f * (S[off + jj] + 1.f) / (S[9 + ii] + S[18 + jj] + 1.f); }
-                return 1.f - s / fB;
-            };
-            if (i == 0) wd += 2.f * wdice(0, 0, 27);
-            else {
-                // S[i][prev(i)]: column j=prev(i), row next(j)=i -> offset 36;  S[i][next(i)]: column j=next(i), row prev(j)=i -> 45
-                wd += wdice(i, i, 27) - (1.f - wdice(i, dprev(i), 36)) - (1.f - wdice(i, dnext(i), 45));
-            }
+            if (i == 0) wd += 2.f * s_term[3];
+            else wd += s_term[3 + i] - (1.f - s_term[12 + i - 1]) - (1.f - s_term[20 + i - 1]);
         }
         wd /= 9.f;
         losses[0] = ce + dice + dce + wd + mse;
