@@ -359,10 +359,17 @@ class HighResolutionNet(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError('cdnet_amd HighResolutionNet runs on the MI355X only (no CPU fallback)')
+        return self.forward_packed(runtime.input_pack(x.float()))
+
+    def forward_packed(self, x16):
+        """forward on packed bf16 NHWC input [N,H,W,16] (3 real channels): what cdnet_input_pack / cdnet_window_pack produce
+        (sliding-window / TTA inference, cdnet_amd.utils.split_forward_views)"""
         training = self.training
         self._ensure_runtime()
         rt = self._rt
-        t = Src(runtime.input_pack(x.float()))
+        x = x16
+        assert x.shape[1] % 8 == 0 and x.shape[2] % 8 == 0, 'HRNet18_rev1 needs tile sizes divisible by 8 (three stride-2 stages)'
+        t = Src(x16)
         t.is_input = True
         for L in rt['stem']:                              # conv1-bn1-relu, conv2-bn2-relu (:495-500)
             t = L.forward([t], training, relu=True)

@@ -57,3 +57,22 @@ def test_eval_forward_matches_reference(golden, tag):
         want = z['%s_%s' % (name, tag)].argmax(1)
         got = out[0 if name == 'mask' else 2].float().cpu().numpy().argmax(1)
         assert (want == got).mean() > (0.999 if name == 'mask' else 0.96)      # measured: mask 100 %, direction 97.4-99.1 %
+
+
+def test_sliding_window_inference_runs_through_the_pipeline():
+    """test_dam.py's per-image path (8 TTA views x sliding windows, probmaps, DDM, CC chain) with HRNet18_rev1 as the model:
+    utils.split_forward_views feeds packed bf16 windows through forward_packed; the stitched logits agree with the
+    whole-image forward away from the window seams' zero padding"""
+    import torch
+    from cdnet_amd import pipeline, synth, utils
+    m = _model(0.45)
+    img = torch.from_numpy(synth.det_input((1, 3, 208, 176), 8, bf16_exact=True))[0].cuda()
+    with torch.no_grad():
+        r = pipeline.infer_image(m, img, tta=True, all_img_test=0, patch_size=128, overlap=40)
+        assert tuple(r['final'].shape) == (208, 176) and r['final'].dtype == torch.int32 and int(r['final'].max()) == r['count']
+        (mw, pw, dw), = utils.split_forward_views(m, img, 128, 40, (0,))
+        mf, pf, df = m(img[None])
+    assert tuple(mw.shape) == (3, 208, 176) and tuple(pw.shape) == (1, 208, 176) and tuple(dw.shape) == (9, 208, 176)
+    # the first window's kept region [0:108, 0:108] minus HRNet's receptive-field margin sees exactly the whole image's context
+    a, b = mw[:, :40, :40].float().cpu(), mf[0, :, :40, :40].float().cpu()
+    assert float((a - b).abs().max()) <= 0.1 * float(b.abs().max())
