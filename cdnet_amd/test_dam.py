@@ -8,7 +8,7 @@ import os
 import numpy as np
 import torch
 
-from . import checkpoint, pipeline, postproc, utils
+from . import checkpoint, pipeline, postproc, stats_utils, utils
 from .options import Options
 
 
@@ -36,16 +36,54 @@ def process_image(model, image, opt):
     return dict(final=r['final'].cpu().numpy(), count=r['count'], pred=r['pred'].cpu().numpy())
 
 
+def ground_truth_instances(label_dir, name):
+    """instance map of the ground truth as test_dam.py builds it: `<label_dir>_ins/<name>.npy` when present (:237-238), else
+    the 8-connected components of channel 0 of `<name>_label.png` grown by disk(1) (:242-246)"""
+    from PIL import Image
+    from scipy import ndimage as ndi
+    ins = '{:s}_ins/{:s}.npy'.format(label_dir.rstrip('/'), name)
+    if os.path.exists(ins):
+        a = np.load(ins)
+        return (a[:, :, 0] if a.ndim == 3 else a).astype(np.int32)
+    path = '{:s}/{:s}_label.png'.format(label_dir, name)
+    if not os.path.exists(path):
+        return None
+    lab = np.asarray(Image.open(path))
+    inside = (lab if lab.ndim == 2 else lab[:, :, 0]) > 127
+    cc, _ = ndi.label(inside, structure=np.ones((3, 3), int))
+    disk1 = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+    return ndi.grey_dilation(cc, footprint=disk1).astype(np.int32)
+
+
+def evaluate_labels(pred_labeled, gt_labeled):
+    """the per-image numbers of test_dam.py:591-660: pixel-level accuracy / IoU / recall / precision / F1 of foreground vs
+    foreground (utils.compute_pixel_level_metrics) and AJI, Dice, DQ / SQ / PQ of the instance maps (stats_utils, on the GPU)"""
+    p, t = (np.asarray(pred_labeled) > 0).astype(np.float64), (np.asarray(gt_labeled) > 0).astype(np.float64)
+    tp, tn = float((p * t).sum()), float(((1 - p) * (1 - t)).sum())
+    fp, fn = float((p * (1 - t)).sum()), float(((1 - p) * t).sum())
+    precision, recall = tp / (tp + fp + 1e-10), tp / (tp + fn + 1e-10)
+    out = {'pixel_accu': (tp + tn) / (tp + fp + tn + fn + 1e-10), 'pixel_iou': tp / (tp + fp + fn + 1e-10), 'pixel_recall': recall,
+           'pixel_precision': precision, 'pixel_F1': 2 * precision * recall / (precision + recall + 1e-10)}
+    gt, pr = stats_utils.remap_label(np.asarray(gt_labeled).astype(np.int32)), stats_utils.remap_label(np.asarray(pred_labeled).astype(np.int32))
+    if gt.max() == 0 or pr.max() == 0:
+        out.update(AJI=0.0, Dice=0.0, DQ=0.0, SQ=0.0, PQ=0.0)
+        return out
+    (dq, sq, pq), _ = stats_utils.get_fast_pq(gt, pr, match_iou=0.5)
+    out.update(AJI=float(stats_utils.get_fast_aji(gt, pr)[0]), Dice=float(stats_utils.get_dice_1(gt, pr)), DQ=float(dq), SQ=float(sq), PQ=float(pq))
+    return out
+
+
 def main(argv=None):
     opt = Options(isTrain=False).parse(argv)
     model = utils.chooseModel(opt).cuda()
     if os.path.exists(opt.test['model_path']):
         checkpoint.load_checkpoint(opt.test['model_path'], model, strict=False)      # DataParallel prefix (test_dam.py:158-167)
     model.eval()
-    img_dir = opt.test['img_dir']
+    img_dir, label_dir = opt.test['img_dir'], opt.test['label_dir']
     names = sorted(f for f in os.listdir(img_dir) if f.endswith('.png')) if os.path.isdir(img_dir) else []
     os.makedirs(opt.test['save_dir'], exist_ok=True)
     from PIL import Image
+    all_results = {}
     for f in names:
         img = np.asarray(Image.open(os.path.join(img_dir, f)).convert('RGB'), dtype=np.float32) / 255.0
         x = torch.from_numpy(img).permute(2, 0, 1).contiguous()
@@ -55,6 +93,22 @@ def main(argv=None):
         r = process_image(model, x, opt)
         Image.fromarray(r['final'].astype(np.uint16)).save(os.path.join(opt.test['save_dir'], f[:-4] + '_seg.tiff'))
         print('{:s}: {:d} nuclei'.format(f, r['count']))
+        gt = ground_truth_instances(label_dir, f[:-4]) if label_dir and os.path.isdir(label_dir) else None
+        if gt is not None and gt.shape == r['final'].shape:                # eval_flag (test_dam.py:132, 591-660)
+            res = evaluate_labels(r['final'], gt)
+            all_results[f[:-4]] = res
+            print('\tpixel_iou = {pixel_iou:.4f}, pixel_F1 = {pixel_F1:.4f}, AJI = {AJI:.4f}, Dice = {Dice:.4f}, DQ = {DQ:.4f}, '
+                  'SQ = {SQ:.4f}, PQ = {PQ:.4f}'.format(**res))
+    if all_results:
+        keys = list(next(iter(all_results.values())).keys())
+        avg = {k: float(np.mean([v[k] for v in all_results.values()])) for k in keys}
+        print('Average of {:d} images: '.format(len(all_results)) + ', '.join('{:s} = {:.4f}'.format(k, avg[k]) for k in keys))
+        with open(os.path.join(opt.test['save_dir'], 'test_results.txt'), 'w') as fh:          # test_dam.py:714-760
+            fh.write('Average:\t' + '\t'.join('{:.4f}'.format(avg[k]) for k in keys) + '\n')
+            for n, v in sorted(all_results.items()):
+                fh.write(n + '\t' + '\t'.join('{:.4f}'.format(v[k]) for k in keys) + '\n')
+        return avg
+    return None
 
 
 if __name__ == '__main__':

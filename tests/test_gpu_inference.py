@@ -104,3 +104,37 @@ def test_infer_image_pipeline_tta_windows_vs_whole_and_oracle():
     assert np.array_equal(r['pred'].cpu().numpy(), want['pred'])
     assert np.array_equal(r['final'].cpu().numpy(), want['final'])
     assert r['count'] == want['count']
+
+
+def test_test_dam_entry_point_with_ground_truth(tmp_path):
+    """python -m cdnet_amd.test_dam on a folder of images + labels: train a few steps, save a reference-format checkpoint, run the
+    entry point (TTA, whole-image forward, post-processing, instance metrics against the ground truth); identical instance maps
+    score 1"""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_data_folder import make_dataset
+    from cdnet_amd import checkpoint, test_dam, trainer
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    make_dataset(tmp_path, n=2, size=(96, 112), seed=5, sub='test1')
+    torch.manual_seed(0)
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda()
+    tr = trainer.Trainer(m)
+    batch = trainer.synthetic_batch(2, torch.device('cuda:0'), seed=1, H=64, W=64)
+    for _ in range(3):
+        tr.train_step(*batch)
+    ck = checkpoint.save_checkpoint(checkpoint.make_state(m, tr, 0), 0, True, str(tmp_path), 'Main', 0)
+    out = str(tmp_path / 'out')
+    avg = test_dam.main(['--img-dir', str(tmp_path / 'images' / 'test1'), '--label-dir', str(tmp_path / 'labels' / 'test1'),
+                         '--save-dir', out, '--model-path', ck])
+    assert os.path.exists(os.path.join(out, 'im0_seg.tiff')) and os.path.exists(os.path.join(out, 'test_results.txt'))
+    assert avg is not None and all(np.isfinite(v) and 0.0 <= v <= 1.0 + 1e-9 for v in avg.values()), avg
+    gt = test_dam.ground_truth_instances(str(tmp_path / 'labels' / 'test1'), 'im0')
+    assert gt is not None and gt.shape == (96, 112) and gt.max() >= 2
+    same = test_dam.evaluate_labels(gt, gt)
+    for k in ('pixel_iou', 'pixel_F1', 'AJI', 'Dice', 'DQ'):
+        assert abs(same[k] - 1.0) < 1e-6, (k, same[k])
+    assert abs(same['PQ'] - same['SQ']) < 1e-9 and same['SQ'] > 0.999
+    none = test_dam.evaluate_labels(np.zeros_like(gt), gt)
+    assert none['AJI'] == 0.0 and none['pixel_recall'] == 0.0
