@@ -20,6 +20,7 @@ def model_state(model):
 
 def make_state(model, trainer, epoch, best_iou=0.0, best_loss=float('inf')):
     """the dict train.py:421-427 hands to save_checkpoint"""
+    trainer.write_bn_counters()
     return {'epoch': epoch + 1, 'state_dict': model_state(model), 'best_iou': best_iou, 'best_loss': best_loss,
             'optimizer': trainer.state_dict()}
 
@@ -48,6 +49,8 @@ def load_checkpoint(path, model, trainer=None, strict=True):
     if trainer is not None:
         # the fused optimiser keeps its own fp32 master copy of the parameters: refresh it from the module
         trainer.refresh_parameters()
+        nbt = [v for k, v in sd.items() if k.endswith('num_batches_tracked')]
+        trainer._bn_base, trainer._forwards = (int(max(int(v) for v in nbt)) if nbt else 0), 0
         if ck.get('optimizer') is not None:
             trainer.load_state_dict(ck['optimizer'])
     return ck

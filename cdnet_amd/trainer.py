@@ -116,6 +116,7 @@ class Trainer:
         self._cat_cache = {}
         self._wstream, self._events = None, {}
         self._packb_pending = False
+        self._forwards, self._bn_base = 0, 0                 # training forwards run here / counted in a loaded checkpoint
 
     # ------------------------------------------------------------------------------------------------
     def buf(self, key, shape, dtype):
@@ -166,6 +167,7 @@ class Trainer:
     def forward(self, x):
         m = self.model
         m.train()
+        self._forwards += 1
         runtime.TAPE = self.tape
         del self.tape[:]
         try:
@@ -485,6 +487,15 @@ class Trainer:
         if segs is None:
             return [(Ellipsis, full[tuple(slice(0, n) for n in p.shape)])]
         return [((slice(None), slice(r0, r0 + n)), full[:, p0:p0 + n]) for r0, n, p0 in segs]
+
+    def write_bn_counters(self):
+        """nn.BatchNorm2d.num_batches_tracked of every BatchNorm that ran = the number of training forwards (PyTorch adds one per
+        forward, `nn.BatchNorm2d.forward`); kept as a host counter during training and written out for checkpoints"""
+        with torch.no_grad():
+            unused = tuple(getattr(self.model, 'UNUSED_PREFIXES', ()))
+            for name, mod in self.model.named_modules():
+                if isinstance(mod, torch.nn.BatchNorm2d) and mod.num_batches_tracked is not None and not (name + '.').startswith(unused or ('\0',)):
+                    mod.num_batches_tracked.fill_(self._bn_base + self._forwards)
 
     def refresh_parameters(self):
         """call after writing parameters behind the trainer's back (load_state_dict does not need it: the module's parameters

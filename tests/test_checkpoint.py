@@ -44,12 +44,19 @@ def test_checkpoint_written_here_loads_in_pytorch_and_back(kind, tmp_path):
             f.M[off:off + sz] *= keep.reshape(-1)
             f.V[off:off + sz] *= keep.reshape(-1)
     f.step_count = 7
+    tr._forwards = 7                                       # seven training forwards: BatchNorm's num_batches_tracked
     path = checkpoint.save_checkpoint(checkpoint.make_state(m, tr, epoch=4, best_iou=0.5, best_loss=1.25), 4, True, str(tmp_path), 'Main', 1)
     for name in ('checkpoint.pth.tar', 'checkpoint_5.pth.tar', 'checkpoint_best.pth.tar'):       # train.py:461-480
         assert (tmp_path / 'checkpoints' / name).exists()
     # --- the reference's side: DataParallel(model).load_state_dict + Adam.load_state_dict (train.py:297-302)
     ck = torch.load(path, map_location='cpu', weights_only=False)
     assert ck['epoch'] == 5 and ck['best_iou'] == 0.5 and all(k.startswith('module.') for k in ck['state_dict'])
+    nbt = [int(v) for k, v in ck['state_dict'].items() if k.endswith('num_batches_tracked')]
+    unused_p = tuple('module.' + u for u in getattr(m, 'UNUSED_PREFIXES', ()))
+    for k, v in ck['state_dict'].items():
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == (0 if unused_p and k.startswith(unused_p) else 7), k          # never-run BatchNorms keep 0, as in PyTorch
+    assert nbt
     dp = torch.nn.DataParallel(ref)
     dp.load_state_dict(ck['state_dict'])
     for (n, p), (n2, p2) in zip(ref.named_parameters(), m.named_parameters()):
@@ -76,7 +83,7 @@ def test_checkpoint_written_here_loads_in_pytorch_and_back(kind, tmp_path):
     m2, _ = _pair(kind)
     tr2 = trainer.Trainer(m2)
     got = checkpoint.load_checkpoint(str(tmp_path / 'ref.pth.tar'), m2, tr2)
-    assert got['epoch'] == 9 and tr2.flat.step_count == 7 and tr2.lr == 2e-3
+    assert got['epoch'] == 9 and tr2.flat.step_count == 7 and tr2.lr == 2e-3 and tr2._bn_base == 7
     for (n, p), (_, p2) in zip(ref.named_parameters(), m2.named_parameters()):
         assert torch.equal(p.detach(), p2.detach()), n
     if hasattr(m2, '_slots'):
