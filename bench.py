@@ -25,7 +25,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'auto'), choices=['auto', 'train', 'infer'])
+    ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'auto'), choices=['auto', 'train', 'infer', 'roofline'],
+                    help="'roofline': only the dominant-kernel measurement of the roofline object (the command profiles/<round>/dominant_conv_* are taken with)")
     ap.add_argument('--batch', type=int, default=None, help='tiles per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer-extra', action='store_true', help='train mode: skip the additional inference timing')
@@ -141,6 +142,11 @@ def main():
     from cdnet_amd.models.dam.model_unet_rev1 import Unet
 
     mode = a.mode
+    if mode == 'roofline':
+        # exactly the measurement that fills the `roofline` object of the normal run, alone in the process, so that
+        # `rocprofv3 --kernel-trace --stats -- python3 bench.py --mode roofline` averages this kernel and nothing else
+        print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps)}))
+        return
     if mode == 'auto':
         try:
             from cdnet_amd import trainer  # noqa: F401

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o t -- python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/train_b16_bench_line.json 2> $OUT/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/infer -o t -- python3 $ROOT/bench.py --mode infer --steps 5 --warmup 2 > $OUT/infer_b64_bench_line.json 2> $OUT/infer.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dom -o t -- python3 $ROOT/tools/profile_dominant.py > $OUT/dom.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- python3 $ROOT/tools/profile_dominant.py > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- python3 $ROOT/tools/profile_dominant.py > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dom -o t -- python3 $ROOT/bench.py --mode roofline > $OUT/dom.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- python3 $ROOT/bench.py --mode roofline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- python3 $ROOT/bench.py --mode roofline > $OUT/pmc_write.log 2>&1
 ls -R $OUT | head -60
