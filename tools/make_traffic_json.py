@@ -1,4 +1,4 @@
-"""Turn the two rocprofv3 PMC passes over tools/profile_dominant.py (FETCH_SIZE, WRITE_SIZE - separate runs, as
+"""Turn the two rocprofv3 PMC passes over `bench.py --mode roofline` (FETCH_SIZE, WRITE_SIZE - separate runs, as
 MI355X_MICROARCH.md prescribes) into profiles/<round>/dominant_conv_traffic.json.
 usage: python tools/make_traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import csv
