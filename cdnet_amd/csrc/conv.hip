@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                 }
             }
         };
-        if (A.out_f16) write_tile(std::true_type{});
+        if (A.out_f16 || A.eres) write_tile(std::true_type{});        // the fused residual epilogue stages r in fp16
         else write_tile(std::false_type{});
         if (A.stats) {
 #pragma unroll
@@ -678,14 +678,31 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
             constexpr int VO = BN / 8;
             const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
             const int pa = par >> 1, pb = par & 1;
+            ChanXf et;                                       // fused residual epilogue: the other branch's per-channel affine
+            et.on = false;
+            if (A.eres && A.eres_scale) {
+                const int c8 = cout0 + (tid % VO) * 8;          // 256 % VO == 0: a thread always stores the same 8 channels
+                et.on = true;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { et.sc[j] = c8 + j < A.Cout ? A.eres_scale[c8 + j] : 1.f; et.sh[j] = c8 + j < A.Cout ? A.eres_shift[c8 + j] : 0.f; }
+            }
             for (int v = tid; v < TH * TW * VO; v += 256) {
                 const int m = v / VO, q = v % VO;
                 const int y = y0 + m / TW, x = x0 + m % TW;
                 const int co = cout0 + q * 8;
                 if (y < A.H && x < A.W && co < A.Cout) {
                     const int oy = y * A.ostride + pa, ox = x * A.ostride + pb;
-                    const uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
-                    unsigned short *dst = A.out + (((size_t)n * Ho + oy) * Wo + ox) * A.out_cstride + A.out_coff + co;
+                    uint4 val = *reinterpret_cast<const uint4 *>(s_out + m * OSTR + q * 16);
+                    const size_t opix = ((size_t)n * Ho + oy) * Wo + ox;
+                    if (A.eres) {
+                        // out = bf16([relu]((eres * scale + shift) + r)), r = this convolution's fp16-rounded result: the same
+                        // arithmetic as the staging transform of a (raw, residual) source pair (xform8)
+                        V16 e, r;
+                        e.u = *reinterpret_cast<const uint4 *>(A.eres + opix * A.Cout + co);
+                        r.u = val;
+                        val = xform8(e, &r, et, A.eres_relu != 0, A.eres_f16 != 0).u;
+                    }
+                    unsigned short *dst = A.out + opix * A.out_cstride + A.out_coff + co;
                     *reinterpret_cast<uint4 *>(dst) = val;               // Cout % 8 == 0 (checked by the ABI entry)
                 }
             }
@@ -863,6 +880,11 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         CDNET_REQUIRE(ctot_xf <= XF_MAX, "cdnet_conv_forward: %d source channels exceed the %d-entry scale/shift table", ctot_xf, XF_MAX);
     }
     CDNET_REQUIRE(A.ws == 0, "cdnet_conv_forward: ws must be 0 (reserved)");
+    if (A.eres) {
+        CDNET_REQUIRE(A.ostride == 1 && A.npar == 1 && A.out_coff == 0 && A.out_cstride == A.Cout && !A.stats && !A.oscale && !A.oshift && !A.orelu &&
+                      !A.out_f16 && A.eres_f16 == 1 && ((A.eres_scale == nullptr) == (A.eres_shift == nullptr)),
+                      "cdnet_conv_forward: fused residual epilogue needs a dense bf16 output, an fp16 eres, no statistics / output affine");
+    }
     int nchunk = 0;
     for (int i = 0; i < A.nsrc; ++i) {
         CDNET_REQUIRE(A.src[i].x && A.src[i].C % A.CK == 0, "cdnet_conv_forward: source %d channels %d not a multiple of CK=%d",

@@ -29,6 +29,9 @@ struct ConvArgs {
     int debug;
     int ws;
     int pad2_;
+    const unsigned short *eres;
+    const float *eres_scale, *eres_shift;
+    int eres_f16, eres_relu;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");

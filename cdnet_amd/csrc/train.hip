@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(BnBwdArgs A) {
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     const unsigned npix = (unsigned)(A.N * A.H * A.W);
     const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
-    const bool f16 = A.f16 != 0, relu = A.relu != 0;
+    const bool f16 = A.f16 != 0, relu = A.relu != 0, outmask = A.relu == 2;
     for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
         V16 raw[BN_U], res[BN_U], g[BN_U][NG];
 #pragma unroll
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(BnBwdArgs A) {
             for (int j = 0; j < 8; ++j) {
                 const float x = ld16(raw[u].h[j], f16);
                 float v = fmaf(x, sc[j], sh[j]);
-                if (RES) v += ld16(res[u].h[j], f16);
+                if (RES) v = outmask ? bf2f(res[u].h[j]) : v + ld16(res[u].h[j], f16);     // outmask: res IS the stored output
                 float gs = bf2f(g[u][0].h[j]);
 #pragma unroll
                 for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
     load8(A.k1, c0, k1, 1.f); load8(A.k2, c0, k2, 0.f); load8(A.k3, c0, k3, 0.f);
     const unsigned npix = (unsigned)(A.N * A.H * A.W);
     const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
-    const bool f16 = A.f16 != 0, relu = A.relu != 0;
+    const bool f16 = A.f16 != 0, relu = A.relu != 0, outmask = A.relu == 2;
     for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
         V16 raw[BN_U], res[BN_U], g[BN_U][NG];
 #pragma unroll
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
             for (int j = 0; j < 8; ++j) {
                 const float x = ld16(raw[u].h[j], f16);
                 float v = fmaf(x, sc[j], sh[j]);
-                if (RES) v += ld16(res[u].h[j], f16);
+                if (RES) v = outmask ? bf2f(res[u].h[j]) : v + ld16(res[u].h[j], f16);
                 float gs = bf2f(g[u][0].h[j]);
 #pragma unroll
                 for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
@@ -1199,6 +1199,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
     A.rev = rev;
     const bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
+    CDNET_REQUIRE(A.relu != 2 || (flat && A.res), "cdnet_bn_backward: relu = 2 (mask from the stored output) needs same-size gradient sources and res");
     if (A.mean) {
         CDNET_REQUIRE(gamma && A.invstd && workspace, "cdnet_bn_backward: BatchNorm layer needs gamma/invstd/workspace");
         const size_t need = (size_t)nb * 2 * A.C + 3 * (size_t)A.C;

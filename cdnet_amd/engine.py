@@ -20,7 +20,8 @@ class ConvArgs(C.Structure):
                 ('Cout', C.c_int), ('out_cstride', C.c_int), ('out_coff', C.c_int), ('stats', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
-                ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('pad2_', C.c_int)]
+                ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('pad2_', C.c_int),
+                ('eres', C.c_void_p), ('eres_scale', C.c_void_p), ('eres_shift', C.c_void_p), ('eres_f16', C.c_int), ('eres_relu', C.c_int)]
 
 
 def _dp(t):
@@ -165,7 +166,7 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
     tile, CK, BN = cfg[:3]
     s0 = srcs[0]
@@ -196,5 +197,9 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
     a.ws = 0
+    if eres is not None:                 # fused residual epilogue: eres = Src(other branch[, scale, shift], relu=...)
+        assert not transposed and stats is None and oscale is None and out.dtype == torch.bfloat16 and tuple(eres.x.shape) == tuple(out.shape)
+        a.eres, a.eres_scale, a.eres_shift = eres.x.data_ptr(), _dp(eres.scale), _dp(eres.shift)
+        a.eres_f16, a.eres_relu = int(eres.f16), int(eres.relu)
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

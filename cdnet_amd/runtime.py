@@ -131,7 +131,7 @@ class ConvLayer:
         return self.fold
 
     # -- forward ------------------------------------------------------------------------------------
-    def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=torch.bfloat16):
+    def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=torch.bfloat16, eres=None):
         """Returns the output as a Src (lazy transform attached in train mode).  Raw (pre-BatchNorm) outputs of the
         training path are stored as fp16: the consumer's affine needs more than bf16's 8 significant bits."""
         if H is None:
@@ -141,8 +141,9 @@ class ConvLayer:
         self.prepare([s.C for s in srcs], H, W, srcs[0].N)
         bias = None if self.bias is None else self.bias.detach()
         if self.bn is None:
+            # eres: fused residual epilogue (the other branch of a ResidualUnit as a Src): out = bf16([relu](eres' + this conv))
             out, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, bias=bias, H=H, W=W,
-                                         out_dtype=out_dtype)
+                                         out_dtype=out_dtype, eres=eres)
             if training:
                 self.saved = (srcs, out, H, W)
                 self.node_relu, self.node_res = False, None
@@ -262,6 +263,7 @@ def input_pack(x):
 
 POOL_MATERIALIZE = _os.environ.get('CDNET_POOL_MATERIALIZE', '1') != '0'
 RU_MATERIALIZE = _os.environ.get('CDNET_RU_MATERIALIZE', '1') != '0'
+RU_FUSE = _os.environ.get('CDNET_RU_FUSE', '1') != '0'       # ResidualUnit: add + ReLU in the epilogue of its conv_1x1
 
 
 def materialize(s, H=None, W=None):

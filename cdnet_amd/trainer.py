@@ -231,32 +231,47 @@ class Trainer:
             if isinstance(L, runtime.FuseNode):
                 L.backward(self, grads, add)
                 continue
-            srcs, out, Hl, Wl = L.saved
-            gl = grads.pop(id(out), None)
+            gl = grads.pop(id(L.saved[1]), None)
             if gl is None:
                 continue
-            No, Ho, Wo, Co = out.shape
-            if L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
-                g = self._bn_backward(L, out, gl, add)
-            else:
-                g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
-            params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
-            if side is None:
-                self._weight_backward(L, srcs, g, Hl, Wl)
-                self._overlap_done(params)
-            else:
-                # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient chain
-                ev = self._event(k)
-                ev.record()
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    self._weight_backward(L, srcs, g, Hl, Wl)
-                    self._overlap_done(params)         # (a bucket released here is ordered after both streams' work so far)
-            self._input_backward(L, srcs, g, Hl, Wl, add)
+            owner = getattr(L, 'fused_res_of', None)
+            if owner is not None:
+                # ResidualUnit.conv_1x1 with the fused residual epilogue: its stored output is the unit's output f.  The consumers'
+                # gradients of f first pass bn2 + ReLU of the other branch (mask read from f); that dz is this layer's gradient.
+                grads.setdefault(id(owner.saved[1]), []).extend(gl)
+                owner.deferred_layer = L
+                continue
+            self._layer_backward(k, L, gl, grads, add, side)
+            d = getattr(L, 'deferred_layer', None)
+            if d is not None:
+                L.deferred_layer = None
+                self._layer_backward(('deferred', k), d, grads.pop(id(d.saved[1])), grads, add, side)
         if side is not None:
             ev = self._event(-1)
             ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
+
+    def _layer_backward(self, k, L, gl, grads, add, side):
+        """one convolution layer: BatchNorm / residual / ReLU backward of its output, weight gradient (side stream), input gradient"""
+        srcs, out, Hl, Wl = L.saved
+        No, Ho, Wo, Co = out.shape
+        if L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
+            g = self._bn_backward(L, out, gl, add)
+        else:
+            g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
+        params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
+        if side is None:
+            self._weight_backward(L, srcs, g, Hl, Wl)
+            self._overlap_done(params)
+        else:
+            # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient chain
+            ev = self._event(k)
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self._weight_backward(L, srcs, g, Hl, Wl)
+                self._overlap_done(params)         # (a bucket released here is ordered after both streams' work so far)
+        self._input_backward(L, srcs, g, Hl, Wl, add)
 
     def _bn_backward(self, L, out, gl, add):
         a = BnBwdArgs()

@@ -157,6 +157,14 @@ typedef struct cdnet_conv_args {
     int debug;              /* must be 0 (kernel ablation switches used by tools/bench_conv.py) */
     int ws;                 /* reserved, must be 0 */
     int pad2_;
+    /* Optional fused residual epilogue (ResidualUnit, model_unet_rev1.py:161-170: relu2(bn2(conv2(.)) + conv_1x1(x))): the
+     * convolution result (bias added, rounded to fp16) is the residual r; eres = the other branch, a dense fp16 (eres_f16 = 1)
+     * or bf16 tensor [N][H][W][Cout] with an optional per-channel affine (training: raw conv2 output x BatchNorm scale /
+     * shift).  out = bf16( [relu]( (eres * eres_scale + eres_shift) + r ) ), bit-identical to cdnet_src_materialize over the
+     * same pair.  NULL = off.  Needs ostride 1, out_coff 0, out_cstride = Cout, no stats / oscale / orelu. */
+    const uint16_t *eres;
+    const float *eres_scale, *eres_shift;
+    int eres_f16, eres_relu;
 } cdnet_conv_args;
 
 /* packed element count for a weight tensor; nchunk = Cin/CK over all sources */
@@ -275,12 +283,13 @@ typedef struct cdnet_grad_in {     /* gradient w.r.t. a tensor as delivered by O
 
 typedef struct cdnet_bn_bwd_args {
     const uint16_t *raw;           /* the layer's stored forward output [N][H][W][C] (fp16 when f16 = 1, else bf16) */
-    const uint16_t *res;           /* residual that was added before the ReLU (same format) or NULL */
+    const uint16_t *res;           /* residual that was added before the ReLU (same format) or NULL; with relu = 2: the stored
+                                      post-ReLU OUTPUT of the unit (bf16) - the ReLU mask is read from it instead of being recomputed */
     const float *scale, *shift;    /* forward per-channel affine (BatchNorm as applied), NULL = identity */
     const float *mean, *invstd;    /* saved batch statistics; NULL = no BatchNorm (gradient passes through) */
     cdnet_grad_in gin[3];
     int ngin;
-    int f16, relu;
+    int f16, relu;                 /* relu: 0 none, 1 relu(affine [+ res]), 2 mask = res > 0 (fused residual epilogue of cdnet_conv_forward) */
     int N, H, W, C;
 } cdnet_bn_bwd_args;
 
