@@ -192,3 +192,27 @@ def test_materialized_pool_equals_on_the_fly_pool(ceil_mode, hw):
     want = F.max_pool2d(act, 2, 2, ceil_mode=ceil_mode)
     # (fused multiply-add here vs multiply + add in PyTorch: at most one bf16 ulp)
     np.testing.assert_allclose(stored.x.float().permute(0, 3, 1, 2).cpu().numpy(), want.cpu().numpy(), rtol=8e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('affine', [True, False])
+def test_fused_residual_epilogue_equals_conv_plus_materialize(affine):
+    """cdnet_conv_args.eres (ResidualUnit: relu2(bn2(raw2) + conv_1x1(x)) in the epilogue of conv_1x1) is bit-identical to the
+    separate path: conv_1x1 -> fp16 residual tensor, then cdnet_src_materialize over the (raw2, residual) pair"""
+    import torch
+    from cdnet_amd import engine, runtime
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cin, Cout = 2, 37, 53, 16, 64
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).cuda()
+    raw2 = (torch.randn((N, H, W, Cout), generator=g) * 2).half().cuda()
+    sc = (torch.rand((Cout,), generator=g) + 0.5).cuda() if affine else None
+    sh = (torch.randn((Cout,), generator=g) * 0.3).cuda() if affine else None
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) * 0.2).cuda()
+    b = torch.randn((Cout,), generator=g).cuda()
+    cfg = engine.choose_cfg([Cin], Cout, H, W, taps=1)
+    wp = engine.pack_weights(w, cfg, 0)
+    r, _ = engine.conv_forward([engine.Src(x)], wp, Cout, cfg, taps=1, bias=b, out_dtype=torch.float16)
+    want = runtime.materialize(engine.Src(raw2, sc, sh, relu=True, res=r))
+    got, _ = engine.conv_forward([engine.Src(x)], wp, Cout, cfg, taps=1, bias=b, eres=engine.Src(raw2, sc, sh, relu=True))
+    assert got.dtype == torch.bfloat16 and torch.equal(got, want.x)
+    ref = torch.relu((raw2.float() * sc + sh if affine else raw2.float()) + r.float())
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.cpu().numpy(), rtol=8e-3, atol=1e-6)
