@@ -700,7 +700,18 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                         V16 e, r;
                         e.u = *reinterpret_cast<const uint4 *>(A.eres + opix * A.Cout + co);
                         r.u = val;
-                        val = xform8(e, &r, et, A.eres_relu != 0, A.eres_f16 != 0).u;
+                        if (A.eres_f16) val = xform8(e, &r, et, A.eres_relu != 0, true).u;
+                        else {                                   // bf16 other branch (identity shortcut of an HRNet block)
+                            V16 o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                float t = bf2f(e.h[j]);
+                                if (et.on) t = fmaf(t, et.sc[j], et.sh[j]);
+                                t += ld16(r.h[j], true);
+                                o.h[j] = f2bf(A.eres_relu ? fmaxf(t, 0.f) : t);
+                            }
+                            val = o.u;
+                        }
                     }
                     unsigned short *dst = A.out + opix * A.out_cstride + A.out_coff + co;
                     *reinterpret_cast<uint4 *>(dst) = val;               // Cout % 8 == 0 (checked by the ABI entry)
@@ -881,9 +892,9 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     }
     CDNET_REQUIRE(A.ws == 0, "cdnet_conv_forward: ws must be 0 (reserved)");
     if (A.eres) {
-        CDNET_REQUIRE(A.ostride == 1 && A.npar == 1 && A.out_coff == 0 && A.out_cstride == A.Cout && !A.stats && !A.oscale && !A.oshift && !A.orelu &&
-                      !A.out_f16 && A.eres_f16 == 1 && ((A.eres_scale == nullptr) == (A.eres_shift == nullptr)),
-                      "cdnet_conv_forward: fused residual epilogue needs a dense bf16 output, an fp16 eres, no statistics / output affine");
+        CDNET_REQUIRE(A.ostride == 1 && A.npar == 1 && A.out_coff == 0 && A.out_cstride == A.Cout && !A.stats && !A.orelu &&
+                      !A.out_f16 && ((A.eres_scale == nullptr) == (A.eres_shift == nullptr)),
+                      "cdnet_conv_forward: fused residual epilogue needs a dense bf16 output, no statistics and no ReLU before the add");
     }
     int nchunk = 0;
     for (int i = 0; i < A.nsrc; ++i) {

@@ -198,7 +198,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.out_f16 = int(out.dtype == torch.float16)
     a.ws = 0
     if eres is not None:                 # fused residual epilogue: eres = Src(other branch[, scale, shift], relu=...)
-        assert not transposed and stats is None and oscale is None and out.dtype == torch.bfloat16 and tuple(eres.x.shape) == tuple(out.shape)
+        assert not transposed and stats is None and not orelu and out.dtype == torch.bfloat16 and tuple(eres.x.shape) == tuple(out.shape)
         a.eres, a.eres_scale, a.eres_shift = eres.x.data_ptr(), _dp(eres.scale), _dp(eres.shift)
         a.eres_f16, a.eres_relu = int(eres.f16), int(eres.relu)
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())

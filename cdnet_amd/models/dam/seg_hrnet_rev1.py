@@ -326,11 +326,17 @@ class HighResolutionNet(nn.Module):
 
     def _basic(self, key, pair, x, training):             # BasicBlock.forward (:76-92)
         c1, c2 = pair
+        if not training and runtime.RU_FUSE and x.scale is None:
+            # eval: BatchNorm is folded, so the shortcut add + ReLU ride in conv2's epilogue (cdnet_conv_args.eres)
+            return c2.forward([c1.forward([x], False, relu=True)], False, relu=False, eres=Src(x.x, relu=True))
         y = c2.forward([c1.forward([x], training, relu=True)], training, relu=False)
         return self._fuse(key, [y, x], True, training)
 
     def _bottleneck(self, key, quad, x, xres, training):  # Bottleneck.forward (:113-133); x may carry a pending BatchNorm, xres is plain
         c1, c2, c3, ds = quad
+        if not training and runtime.RU_FUSE:
+            r = xres if ds is None else ds.forward([x], False, relu=False)
+            return c3.forward([c2.forward([c1.forward([x], False, relu=True)], False, relu=True)], False, relu=False, eres=Src(r.x, relu=True))
         y = c3.forward([c2.forward([c1.forward([x], training, relu=True)], training, relu=True)], training, relu=False)
         r = xres if ds is None else ds.forward([x], training, relu=False)
         return self._fuse(key, [y, r], True, training)

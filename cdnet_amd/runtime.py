@@ -153,7 +153,7 @@ class ConvLayer:
         if not training:
             sc, sh = self.eval_fold()
             out, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, oscale=sc,
-                                         oshift=sh, orelu=relu, H=H, W=W, out_dtype=out_dtype)
+                                         oshift=sh, orelu=relu and eres is None, H=H, W=W, out_dtype=out_dtype, eres=eres)
             return Src(out)
         tile = self.cfg[0]
         N = srcs[0].N

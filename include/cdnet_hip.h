@@ -161,7 +161,9 @@ typedef struct cdnet_conv_args {
      * convolution result (bias added, rounded to fp16) is the residual r; eres = the other branch, a dense fp16 (eres_f16 = 1)
      * or bf16 tensor [N][H][W][Cout] with an optional per-channel affine (training: raw conv2 output x BatchNorm scale /
      * shift).  out = bf16( [relu]( (eres * eres_scale + eres_shift) + r ) ), bit-identical to cdnet_src_materialize over the
-     * same pair.  NULL = off.  Needs ostride 1, out_coff 0, out_cstride = Cout, no stats / oscale / orelu. */
+     * same pair.  The convolution's own epilogue affine (oscale / oshift: eval-mode BatchNorm fold) applies before the add, so
+     * the identity-shortcut blocks of HRNet in eval mode (seg_hrnet_rev1.py:76-92, 113-133: relu(bn(conv(.)) + x), eres = x in
+     * bf16) use it too.  NULL = off.  Needs ostride 1, out_coff 0, out_cstride = Cout, no stats, orelu = 0. */
     const uint16_t *eres;
     const float *eres_scale, *eres_shift;
     int eres_f16, eres_relu;
