@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { et.sc[j] = c8 + j < A.Cout ? A.eres_scale[c8 + j] : 1.f; et.sh[j] = c8 + j < A.Cout ? A.eres_shift[c8 + j] : 0.f; }
             }
-            for (int v = tid; v < TH * TW * VO; v += 256) {
+            // one 16-byte vector of the tile: optional fused residual epilogue, then the store
+            auto store_vec = [&](int v, const uint4 *pre) {
                 const int m = v / VO, q = v % VO;
                 const int y = y0 + m / TW, x = x0 + m % TW;
                 const int co = cout0 + q * 8;
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                         // out = bf16([relu]((eres * scale + shift) + r)), r = this convolution's fp16-rounded result: the same
                         // arithmetic as the staging transform of a (raw, residual) source pair (xform8)
                         V16 e, r;
-                        e.u = *reinterpret_cast<const uint4 *>(A.eres + opix * A.Cout + co);
+                        e.u = pre ? *pre : *reinterpret_cast<const uint4 *>(A.eres + opix * A.Cout + co);
                         r.u = val;
                         if (A.eres_f16) val = xform8(e, &r, et, A.eres_relu != 0, true).u;
                         else {                                   // bf16 other branch (identity shortcut of an HRNet block)
@@ -716,6 +717,28 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                     unsigned short *dst = A.out + opix * A.out_cstride + A.out_coff + co;
                     *reinterpret_cast<uint4 *>(dst) = val;               // Cout % 8 == 0 (checked by the ABI entry)
                 }
+            };
+            constexpr bool PRE = (BN == 64 && TH == 16 && CK == 16);      // the configuration the residual units run
+            if constexpr (PRE) {
+                if (A.eres) {
+                    // the other branch's vectors are requested up front (clamped address): their latency overlaps instead of
+                    // sitting in front of every store
+                    constexpr int NV = TH * TW * VO / 256;
+                    uint4 ev[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const int v = tid + i * 256, m = v / VO, q = v % VO;
+                        int y = y0 + m / TW, x = x0 + m % TW, co = cout0 + q * 8;
+                        y = y < A.H ? y : A.H - 1; x = x < A.W ? x : A.W - 1; co = co < A.Cout ? co : 0;
+                        ev[i] = *reinterpret_cast<const uint4 *>(A.eres + (((size_t)n * A.H + y) * A.W + x) * A.Cout + co);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) store_vec(tid + i * 256, &ev[i]);
+                } else {
+                    for (int v = tid; v < TH * TW * VO; v += 256) store_vec(v, nullptr);
+                }
+            } else {
+                for (int v = tid; v < TH * TW * VO; v += 256) store_vec(v, nullptr);
             }
         }
     }
