@@ -5,3 +5,16 @@ the path runs in hand-written HIP kernels behind the C ABI declared in include/c
 (cdnet_amd/csrc -> cdnet_amd/libcdnet_hip.so, loaded by cdnet_amd._lib).
 """
 __version__ = '0.1.0'
+
+
+def set_precision(p):
+    """Arithmetic of the convolution stack: 'bf16' (16-bit NHWC activations, bf16 MFMA operands, fp32 accumulation) or
+    'fp32' (fp32 activations and gradients in HBM, every product as three split-bf16 MFMAs with fp32 accumulation - the
+    reference's precision).  Applies to models / trainers used afterwards; packed weights are rebuilt lazily."""
+    from . import runtime
+    runtime.set_precision(p)
+
+
+def get_precision():
+    from . import runtime
+    return runtime.PRECISION

@@ -64,6 +64,7 @@ struct PackDesc {            // one (layer, sub-pixel parity) packing job
     unsigned short *out;
     int Cout, Cin, KH, KW, CK, BN, nchunk, ntile, TAPS, mode, parity;
     unsigned block0, nblocks; // its slice of the batched launch
+    int split;                // 1: fp32-precision pack - per chunk the bf16(w) image followed by the bf16(w - bf16(w)) image
 };
 
 __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size_t stride) {
@@ -71,7 +72,7 @@ __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size
     unsigned short *__restrict__ out = d.out;
     const int Cout = d.Cout, Cin = d.Cin, KH = d.KH, KW = d.KW, CK = d.CK, BN = d.BN, nchunk = d.nchunk, TAPS = d.TAPS, mode = d.mode,
               parity = d.parity;
-    const size_t total = (size_t)d.ntile * nchunk * TAPS * (CK / 16) * 2 * BN * 8;
+    const size_t total = (size_t)d.ntile * nchunk * TAPS * (CK / 16) * 2 * BN * 8 * (d.split ? 2 : 1);
     for (size_t i = first; i < total; i += stride) {
         size_t r = i;
         int j = r % 8; r /= 8;
@@ -79,6 +80,8 @@ __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size
         int half = r % 2; r /= 2;
         int kc = r % (CK / 16); r /= (CK / 16);
         int tap = r % TAPS; r /= TAPS;
+        int hl = 0;
+        if (d.split) { hl = r % 2; r /= 2; }
         int chunk = r % nchunk; r /= nchunk;
         int tile = (int)r;
         int co = tile * BN + col;
@@ -127,7 +130,8 @@ __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size
                 }
             }
         }
-        out[i] = f2bf(v);
+        const unsigned short hi = f2bf(v);
+        out[i] = hl ? f2bf(v - bf2f(hi)) : hi;
     }
 }
 
@@ -845,11 +849,14 @@ extern "C" size_t cdnet_conv_packed_weight_elems(int Cout, int Cin_padded_chunks
 
 static int fill_pack_desc(PackDesc &d, const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode, int p,
                           const char *who) {
+    const int split = (mode & 16) ? 1 : 0;            // CDNET_PACK_SPLIT: hi | lo images (fp32-precision convolutions)
+    mode &= 15;
     CDNET_REQUIRE(w && packed, "%s: null pointer", who);
     CDNET_REQUIRE(CK % 16 == 0 && BN % 32 == 0 && Cin % CK == 0 && mode >= 0 && mode <= 7, "%s: Cin=%d CK=%d BN=%d mode=%d", who, Cin, CK, BN, mode);
     const int taps = mode == 2 ? 4 : (mode == 3 ? 1 : ((mode == 4 || mode == 6 || mode == 7) ? 9 : (mode == 5 ? 1 : KH * KW)));
     const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
-    const size_t per = (size_t)ntile * nchunk * taps * CK * BN;
+    const size_t per = (size_t)ntile * nchunk * taps * CK * BN * (split ? 2 : 1);
+    d.split = split;
     d.w = w; d.out = (unsigned short *)packed + (size_t)p * per;
     d.Cout = Cout; d.Cin = Cin; d.KH = KH; d.KW = KW; d.CK = CK; d.BN = BN; d.nchunk = nchunk; d.ntile = ntile; d.TAPS = taps; d.mode = mode;
     d.parity = p;
@@ -861,7 +868,7 @@ static int fill_pack_desc(PackDesc &d, const float *w, void *packed, int Cout, i
 
 extern "C" int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN,
                                        int mode, void *stream) {
-    const int npar = (mode == 2 || mode == 3) ? 4 : 1;
+    const int npar = ((mode & 15) == 2 || (mode & 15) == 3) ? 4 : 1;
     for (int p = 0; p < npar; ++p) {
         PackDesc d;
         int rc = fill_pack_desc(d, w, packed, Cout, Cin, KH, KW, CK, BN, mode, p, "cdnet_pack_conv_weights");
@@ -882,7 +889,7 @@ extern "C" int cdnet_pack_conv_weights_batch(const cdnet_pack_job *jobs, int n_j
     unsigned blocks = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const cdnet_pack_job &J = jobs[j];
-        const int npar = (J.mode == 2 || J.mode == 3) ? 4 : 1;
+        const int npar = ((J.mode & 15) == 2 || (J.mode & 15) == 3) ? 4 : 1;
         for (int p = 0; p < npar; ++p) {
             PackDesc d;
             int rc = fill_pack_desc(d, J.w, J.packed, J.Cout, J.Cin, J.KH, J.KW, J.CK, J.BN, J.mode, p, "cdnet_pack_conv_weights_batch");
@@ -914,6 +921,14 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         CDNET_REQUIRE(ctot_xf <= XF_MAX, "cdnet_conv_forward: %d source channels exceed the %d-entry scale/shift table", ctot_xf, XF_MAX);
     }
     CDNET_REQUIRE(A.ws == 0, "cdnet_conv_forward: ws must be 0 (reserved)");
+    if (A.f32) {
+        CDNET_REQUIRE(A.f32 == 1, "cdnet_conv_forward: f32 must be 0 or 1");
+        for (int i = 0; i < A.nsrc; ++i)
+            CDNET_REQUIRE(A.src[i].f16 == 2, "cdnet_conv_forward(f32): every source must be fp32 (f16 = 2)");
+    } else {
+        for (int i = 0; i < A.nsrc; ++i)
+            CDNET_REQUIRE(A.src[i].f16 == 0 || A.src[i].f16 == 1, "cdnet_conv_forward: fp32 sources need args.f32 = 1");
+    }
     if (A.eres) {
         CDNET_REQUIRE(A.ostride == 1 && A.npar == 1 && A.out_coff == 0 && A.out_cstride == A.Cout && !A.stats && !A.orelu &&
                       !A.out_f16 && ((A.eres_scale == nullptr) == (A.eres_shift == nullptr)),
@@ -932,6 +947,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
                   "cdnet_conv_forward: taps=%d npar=%d ostride=%d", A.taps, A.npar, A.ostride);
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (A.f32) return conv_forward_f32(A, st);
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }
     if (A.taps == 9) return dispatch_conv<9>(A, st);
@@ -945,6 +961,7 @@ extern "C" int cdnet_src_materialize(const cdnet_conv_src *src, int N, int H, in
     CDNET_REQUIRE(s.C >= 8 && s.C % 8 == 0 && s.Hs > 0 && s.Ws > 0, "cdnet_src_materialize: C=%d must be a multiple of 8", s.C);
     CDNET_REQUIRE(!(s.pool && s.res), "cdnet_src_materialize: pooled sources carry no residual");
     CDNET_REQUIRE((s.scale == nullptr) == (s.shift == nullptr), "cdnet_src_materialize: scale and shift come together");
+    if (s.f16 == 2) return materialize_f32(s, N, H, W, out, (hipStream_t)stream);
     const size_t total = (size_t)N * H * W * (s.C / 8);
     size_t g = (total + 255) / 256;
     g = g > 8192 ? 8192 : g;

@@ -28,7 +28,7 @@ struct ConvArgs {
     int out_f16;
     int debug;
     int ws;
-    int pad2_;
+    int f32;
     const unsigned short *eres;
     const float *eres_scale, *eres_shift;
     int eres_f16, eres_relu;
@@ -36,3 +36,9 @@ struct ConvArgs {
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");
 static_assert(sizeof(ConvArgs) == sizeof(cdnet_conv_args), "ConvArgs layout");
+
+namespace cdnet {
+// conv32.hip: the fp32-storage / split-bf16x3 variant
+int conv_forward_f32(const ConvArgs &A, hipStream_t st);
+int materialize_f32(const ConvSrc &s, int N, int H, int W, void *out, hipStream_t st);
+}

@@ -21,6 +21,31 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 import os as _os
+
+# 'bf16': NHWC bf16 activations (fp16 for raw pre-BatchNorm outputs), bf16 MFMA operands, fp32 accumulation
+# 'fp32': NHWC fp32 activations / gradients, split-bf16 (hi, lo) operands, three MFMAs per product, fp32 accumulation
+PRECISION = _os.environ.get('CDNET_PRECISION', 'bf16')
+assert PRECISION in ('bf16', 'fp32'), PRECISION
+
+
+def set_precision(p):
+    global PRECISION
+    assert p in ('bf16', 'fp32'), p
+    if p != PRECISION:
+        PRECISION = p
+        WEIGHTS_EPOCH[0] += 1            # every packed weight copy is stale (hi-only vs hi|lo packs)
+
+
+def act_dtype():
+    """stored activations / gradients that are MFMA operands"""
+    return torch.float32 if PRECISION == 'fp32' else torch.bfloat16
+
+
+def raw_dtype():
+    """raw pre-BatchNorm convolution outputs and residual branches"""
+    return torch.float32 if PRECISION == 'fp32' else torch.float16
+
+
 DEBUG_NORELU = bool(int(_os.environ.get('CDNET_DEBUG_NORELU', '0')))   # debug aid (tools/debug_train.py): linearised network
 TAPE = None              # set by cdnet_amd.trainer around a training forward: layers append themselves in execution order
 WEIGHTS_EPOCH = [0]      # bumped by the fused Adam step (it updates parameters behind torch's version counters)

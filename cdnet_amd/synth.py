@@ -213,3 +213,49 @@ def crc(*arrays):
     for a in arrays:
         c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
     return np.uint32(c & 0xffffffff)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# learnable synthetic histology: the image actually shows its nuclei, so a network trained on it produces
+# nucleus-like outputs (used by the label-level parity gate, tests/test_gpu_label_gate.py)
+# ---------------------------------------------------------------------------------------------------------
+def render_nuclei(inst, rs):
+    """RGB float32 [3,H,W] in [0,1]: pink background, darker violet nuclei with per-instance shade, blurred edges, noise."""
+    H, W = inst.shape
+    inside = (inst > 0).astype(np.float64)
+    shade = np.concatenate([[0.0], 0.75 + 0.5 * rs.rand(int(inst.max()))])[inst]          # per-instance stain strength
+    a = gaussian_blur(inside * shade, 1.0)
+    bg = np.array([0.86, 0.70, 0.82])[:, None, None]
+    fg = np.array([0.38, 0.24, 0.55])[:, None, None]
+    img = bg + (fg - bg) * np.clip(a, 0, 1.2)[None]
+    img += gaussian_blur(rs.randn(H, W), 3.0)[None] * 0.15                                   # slow stain variation
+    img += rs.randn(3, H, W) * 0.03
+    return np.clip(img, 0.0, 1.0).astype(np.float32)
+
+
+def nuclei_batch(B, H, W, seed, n=60, rmin=5, rmax=12):
+    """B rendered tiles with their training targets: x f32 [B,3,H,W], label u8 {0,1,2}, direction u8 0..8, point f16,
+    weight u8 (constant 20), instance maps i32."""
+    rs = np.random.RandomState(seed)
+    x = np.zeros((B, 3, H, W), np.float32)
+    lab = np.zeros((B, H, W), np.uint8)
+    dirn = np.zeros((B, H, W), np.uint8)
+    point = np.zeros((B, H, W), np.float16)
+    insts = np.zeros((B, H, W), np.int32)
+    for b in range(B):
+        inst = ellipse_instances(H, W, n, rs, rmin, rmax, 10)
+        insts[b] = inst
+        x[b] = render_nuclei(inst, rs)
+        inside = inst > 0
+        ero = erode8(inside)
+        lab[b][ero] = 1
+        lab[b][inside & ~ero] = 2
+        d, cents = centroid_direction(inst)
+        d[~ero] = 0
+        dirn[b] = d
+        pt = np.zeros((H, W), np.float64)
+        for cy, cx in cents:
+            pt[cy, cx] = 255.0
+        point[b] = gaussian_blur(pt, 2.0).astype(np.float16)
+    weight = np.full((B, H, W), 20, np.uint8)
+    return x, lab, dirn, point, weight, insts

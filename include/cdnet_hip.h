@@ -130,7 +130,8 @@ typedef struct cdnet_conv_src {
     int pool;               /* 1: logical input = maxpool2x2(transformed source), size Hs/2 x Ws/2 */
     int relu;
     int off_y, off_x;       /* F.pad: logical (y,x) reads source (y-off_y, x-off_x); outside -> 0 */
-    int f16;                /* storage of x / res: 0 = bf16, 1 = fp16 (raw pre-BatchNorm outputs, residual branches) */
+    int f16;                /* storage of x / res: 0 = bf16, 1 = fp16 (raw pre-BatchNorm outputs, residual branches),
+                               2 = fp32 (the pointers then address float tensors; fp32-precision path, cdnet_conv_args.f32) */
     int row_stride;         /* elements between rows (0 = dense: Ws*C); images are Hs*row_stride apart.  Lets the
                                space-to-depth view of a 2x-upsampled gradient be read without a copy. */
 } cdnet_conv_src;
@@ -156,7 +157,9 @@ typedef struct cdnet_conv_args {
     int out_f16;            /* 1: store the output as fp16 instead of bf16 */
     int debug;              /* must be 0 (kernel ablation switches used by tools/bench_conv.py) */
     int ws;                 /* reserved, must be 0 */
-    int pad2_;
+    int f32;                /* 1: fp32 precision - x / res / eres / out are fp32 tensors (every source has f16 = 2), `w` is the split
+                               pack (mode | CDNET_PACK_SPLIT), each product runs as three bf16 MFMAs over (hi, lo) operand pairs with
+                               fp32 accumulation; CK = 16, no pooled sources (materialise them).  0: the 16-bit path. */
     /* Optional fused residual epilogue (ResidualUnit, model_unet_rev1.py:161-170: relu2(bn2(conv2(.)) + conv_1x1(x))): the
      * convolution result (bias added, rounded to fp16) is the residual r; eres = the other branch, a dense fp16 (eres_f16 = 1)
      * or bf16 tensor [N][H][W][Cout] with an optional per-channel affine (training: raw conv2 output x BatchNorm scale /
@@ -180,6 +183,8 @@ size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, in
  * with 2*Cout_t channels ordered (column parity, channel)); Cout := transposed-conv in_channels, Cin := 4*out_channels.
  * mode 6: forward Conv2d [Cout][C][3][3] stride 2 pad 1 (HRNet transition / fuse layers, seg_hrnet_rev1.py:228-247,
  * 436-443) as a 3x3 convolution over the same space-to-depth view of its INPUT; Cin := 4*C. */
+#define CDNET_PACK_SPLIT 16   /* OR into `mode`: fp32-precision pack = per Cin chunk the bf16(w) image followed by the
+                                bf16(w - bf16(w)) image; twice cdnet_conv_packed_weight_elems elements */
 int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode,
                             void *stream);
 /* The same packing for many tensors in one launch (the training step re-packs every layer's forward and backward-data

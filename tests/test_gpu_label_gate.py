@@ -1,0 +1,119 @@
+"""Label-level parity gate of the inference path (north_star: "AJI/Dice within +-0.002 of the reference"; SURVEY 8c-1:
+>= 99.9 % argmax agreement on mask and direction classes).
+
+MoNuSeg images and trained weights cannot be here (no network), so the gate is built from what can: a network is trained
+for a few hundred steps on rendered synthetic nuclei (cdnet_amd.synth.nuclei_batch) with the HIP trainer so that it
+actually segments nuclei; the SAME weights then run (a) through the product path - HIP kernels, pipeline.infer_tiles /
+infer_image incl. TTA + sliding windows + device post-processing - and (b) through the fp32 CPU oracle
+(oracle.models.Unet + oracle.infer + oracle.postproc, each pinned to the reference).  The two instance-label maps are scored
+against each other with the reference's own metrics (stats_utils.get_fast_aji / get_dice_1, test_dam.py:591-669): AJI and
+Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.002.
+
+CDNET_PRECISION selects the arithmetic of the product path: 'fp32' (fp32 activations, split-bf16 x3 MFMA) or 'bf16'."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+AJI_MIN = 0.998
+DICE_MIN = 0.998
+ARGMAX_MIN = 0.999
+
+
+def _train(precision, steps=300, B=8, seed=0):
+    import torch
+    import cdnet_amd
+    from cdnet_amd import synth, trainer
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    cdnet_amd.set_precision(precision)
+    torch.manual_seed(seed)
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda()
+    tr = trainer.Trainer(m)
+    dev = torch.device('cuda:0')
+    batches = []
+    for k in range(4):
+        x, lab, dirn, point, weight, _ = synth.nuclei_batch(B, 128, 128, 100 + k, n=22)
+        batches.append([torch.from_numpy(a).to(dev) for a in (x, lab, dirn, point, weight)])
+    first = last = None
+    for s in range(steps):
+        loss = tr.train_step(*batches[s % len(batches)])
+        if s == 0:
+            first = float(loss[0])
+    last = float(loss[0])
+    assert last < 0.5 * first, 'training did not converge: %g -> %g' % (first, last)
+    return m
+
+
+def _oracle_of(m):
+    from oracle import models as om
+    ref = om.Unet()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    return ref.eval()
+
+
+def _score(name, got, want, min_instances):
+    """reference metrics between the two label maps (test_dam.py:613-617: both are re-labelled first)"""
+    from cdnet_amd import stats_utils
+    assert want.max() >= min_instances, '%s: the oracle found only %d instances - not a meaningful gate' % (name, want.max())
+    if np.array_equal(got, want):
+        return 1.0, 1.0
+    # contiguous ids first, as the reference does (measure.label on the label image, test_dam.py:613-614)
+    t, p = stats_utils.remap_label(want), stats_utils.remap_label(got)
+    aji = float(stats_utils.get_fast_aji(t, p)[0])
+    dice = float(stats_utils.get_dice_1(t, p))
+    return aji, dice
+
+
+@pytest.fixture(scope='module')
+def trained():
+    import cdnet_amd
+    prec = os.environ.get('CDNET_PRECISION', cdnet_amd.get_precision())
+    m = _train(prec)
+    m.eval()
+    return m, _oracle_of(m), prec
+
+
+def test_tiles_label_parity(trained):
+    """three 256x256 tiles, single view (pipeline.infer_tiles): argmax agreement and instance-label parity"""
+    import torch
+    from cdnet_amd import pipeline, synth
+    from oracle import infer as oinf
+    m, ref, prec = trained
+    x, lab, dirn, point, weight, inst = synth.nuclei_batch(3, 256, 256, 777, n=60)
+    with torch.no_grad():
+        r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda())
+        want_logits = ref(torch.from_numpy(x))
+    got_mask, got_dir = r['prob'].argmax(1).cpu().numpy(), r['dcm'].cpu().numpy().reshape(3, 256, 256)
+    report = []
+    for b in range(3):
+        w = oinf.infer_image(ref, x[b], tta=False, all_img_test=1)
+        agree_m = (got_mask[b] == w['probs'][0].argmax(0)).mean()
+        agree_d = (got_dir[b] == w['dcms'][0, 0]).mean()
+        aji, dice = _score('tile %d' % b, r['final'][b].cpu().numpy(), w['final'], 20)
+        report.append((b, agree_m, agree_d, aji, dice, int(w['count']), int(r['counts'][b])))
+    print('label gate [%s] tiles: ' % prec + '; '.join('tile %d mask %.5f dir %.5f AJI %.5f Dice %.5f n=%d/%d' % t for t in report))
+    for b, am, ad, aji, dice, n_w, n_g in report:
+        assert am >= ARGMAX_MIN and ad >= ARGMAX_MIN, (prec, b, am, ad)
+        assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, b, aji, dice)
+
+
+def test_full_image_tta_label_parity(trained):
+    """BASELINE config 3 shape: one 1000x1000 image, 8 TTA views x 25 sliding windows (256/40), per-view DDM, boost, CC chain"""
+    import torch
+    from cdnet_amd import pipeline, synth
+    from oracle import infer as oinf
+    m, ref, prec = trained
+    rs = np.random.RandomState(4242)
+    inst = synth.ellipse_instances(1000, 1000, 700, rs, 5, 14, 10)
+    img = synth.render_nuclei(inst, rs)
+    with torch.no_grad():
+        r = pipeline.infer_image(m, torch.from_numpy(img).cuda(), tta=True, all_img_test=0, patch_size=256, overlap=40)
+    w = oinf.infer_image(ref, img, tta=True, all_img_test=0, patch_size=256, overlap=40)
+    got = r['final'].cpu().numpy()
+    aji, dice = _score('1000x1000', got, w['final'], 200)
+    agree = (r['pred'].cpu().numpy() == w['pred']).mean()
+    print('label gate [%s] 1000x1000 TTA: pred agreement %.6f AJI %.5f Dice %.5f instances %d/%d' % (prec, agree, aji, dice, w['count'], r['count']))
+    assert agree >= ARGMAX_MIN, (prec, agree)
+    assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, aji, dice)
