@@ -37,12 +37,14 @@ SIGNATURES = {
     'cdnet_conv_forward': (_i, [_vp, _vp]),
     'cdnet_src_materialize': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'cdnet_input_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_input_pack_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_bn_fold_eval': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'cdnet_bn_finalize_train': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_dam_head_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_final_conv1x1': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_bias_grad_workspace_floats': (_sz, [_i]),
     'cdnet_bias_grad': (_i, [_vp, _sz, _i, _vp, _sz, _vp, _vp]),
+    'cdnet_bias_grad_f32': (_i, [_vp, _sz, _i, _vp, _sz, _vp, _vp]),
     'cdnet_final_conv1x1_backward_workspace_floats': (_sz, []),
     'cdnet_final_conv1x1_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     'cdnet_conv_wgrad_slab_floats': (_sz, [_i] * 6),
@@ -55,6 +57,7 @@ SIGNATURES = {
     'cdnet_dam_loss': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'cdnet_window_pack': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
+    'cdnet_window_pack_f32': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
     'cdnet_window_stitch': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
     'cdnet_label_encoding_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'cdnet_label_encoding': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),

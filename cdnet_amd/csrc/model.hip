@@ -34,6 +34,20 @@ __global__ __launch_bounds__(256) void input_pack_kernel(const float *__restrict
     }
 }
 
+// x f32 [N][C][H][W] -> out f32 [N][H][W][16]  (fp32-precision path)
+__global__ __launch_bounds__(256) void input_pack_f32_kernel(const float *__restrict__ x, int N, int C, int plane, float *__restrict__ out) {
+    const size_t total = (size_t)N * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, p = i - n * plane;
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = c < C ? x[(n * C + c) * plane + p] : 0.f;
+        float4 *dst = reinterpret_cast<float4 *>(out + i * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+}
+
 // eval-mode fold: scale = g / sqrt(rv + eps); shift = b + (bias - rm) * scale
 __global__ void bn_fold_eval_kernel(const float *g, const float *b, const float *rm, const float *rv, const float *bias,
                                     float eps, int C, float *scale, float *shift) {
@@ -109,7 +123,30 @@ struct HeadW {            // 64-channel 1x1 heads, fp32
     float a2[9];          // maskAtt.Conv1x1 (9->1, no bias)
 };
 
+// fp32-stored feature (f16 == 2): NC channels starting at c0, plain fp32 arithmetic (no 16-bit rounding anywhere)
+template <int NC>
+__device__ __forceinline__ void load_feat_f32(const HeadFeat &f, size_t pix, int c0, const float *s_sc, const float *s_sh, float *v) {
+    const float4 *pr = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(f.raw) + pix * 64 + c0);
+    const float4 *ps = f.res ? reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(f.res) + pix * 64 + c0) : nullptr;
+#pragma unroll
+    for (int q = 0; q < NC / 4; ++q) {
+        const float4 r = pr[q];
+        float x[4] = {r.x, r.y, r.z, r.w};
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ps) { const float4 t = ps[q]; rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = x[j];
+            if (f.scale) t = fmaf(t, s_sc[c0 + q * 4 + j], s_sh[c0 + q * 4 + j]);
+            if (ps) t += rr[j];
+            if (f.relu) t = fmaxf(t, 0.f);
+            v[q * 4 + j] = t;
+        }
+    }
+}
+
 __device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const float *s_sc, const float *s_sh, float *v) {
+    if (f.f16 == 2) { load_feat_f32<64>(f, pix, 0, s_sc, s_sh, v); return; }
     const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64);
     const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64) : nullptr;
 #pragma unroll
@@ -135,6 +172,7 @@ __device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const
 
 // 16 channels [16q, 16q+16) of the feature at one pixel (q = lane & 3): four lanes share a pixel
 __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q, const float *s_sc, const float *s_sh, float *v) {
+    if (f.f16 == 2) { load_feat_f32<16>(f, pix, q * 16, s_sc, s_sh, v); return; }
     const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64 + q * 16);
     const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64 + q * 16) : nullptr;
     const bool fast = f.f16 && f.scale && f.relu;        // training-mode feature: packed math (xform.h)
@@ -270,6 +308,32 @@ __device__ __forceinline__ void view_to_image(int xf, int vy, int vx, int H, int
 
 // img f32 [C][H][W] (one image) -> tiles bf16 NHWC [ny*nx][th][tw][16]; window (ky,kx) starts at (ky*stride, kx*stride)
 // of the (zero-padded) view
+__global__ __launch_bounds__(256) void window_pack_f32_kernel(const float *__restrict__ img, int C, int H, int W, int xf, int th,
+                                                              int tw, int stride, int ny, int nx, float *__restrict__ out) {
+    const int hv = (xf & 4) ? W : H, wv = (xf & 4) ? H : W;
+    const size_t total = (size_t)ny * nx * th * tw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int tx = r % tw; r /= tw;
+        const int ty = r % th; r /= th;
+        const int kx = r % nx; const int ky = (int)(r / nx);
+        const int vy = ky * stride + ty, vx = kx * stride + tx;
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = 0.f;
+        if (vy < hv && vx < wv) {
+            int iy, ix;
+            view_to_image(xf, vy, vx, H, W, iy, ix);
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < C) v[c] = img[((size_t)c * H + iy) * W + ix];
+        }
+        float4 *dst = reinterpret_cast<float4 *>(out + i * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void window_pack_kernel(const float *__restrict__ img, int C, int H, int W, int xf, int th,
                                                           int tw, int stride, int ny, int nx, unsigned short *__restrict__ out) {
     const int hv = (xf & 4) ? W : H, wv = (xf & 4) ? H : W;
@@ -506,6 +570,13 @@ extern "C" int cdnet_input_pack(const float *x, int N, int C, int H, int W, void
     return check_launch("cdnet_input_pack");
 }
 
+extern "C" int cdnet_input_pack_f32(const float *x, int N, int C, int H, int W, float *out, void *stream) {
+    CDNET_REQUIRE(x && out, "cdnet_input_pack_f32: null pointer");
+    CDNET_REQUIRE(N > 0 && C > 0 && C <= 16 && H > 0 && W > 0, "cdnet_input_pack_f32: bad size (C=%d must be <= 16)", C);
+    input_pack_f32_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(x, N, C, H * W, out);
+    return check_launch("cdnet_input_pack_f32");
+}
+
 extern "C" int cdnet_bn_fold_eval(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
                                   const float *conv_bias, float eps, int C, float *scale, float *shift, void *stream) {
     CDNET_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "cdnet_bn_fold_eval: bad args");
@@ -558,6 +629,16 @@ extern "C" int cdnet_window_pack(const float *img, int C, int H, int W, int view
     window_pack_kernel<<<lin_grid((size_t)ny * nx * tile_h * tile_w), 256, 0, (hipStream_t)stream>>>(
         img, C, H, W, view_xform, tile_h, tile_w, stride, ny, nx, (unsigned short *)out_bf16_nhwc16);
     return check_launch("cdnet_window_pack");
+}
+
+extern "C" int cdnet_window_pack_f32(const float *img, int C, int H, int W, int view_xform, int tile_h, int tile_w, int stride, int ny,
+                                     int nx, float *out_f32_nhwc16, void *stream) {
+    CDNET_REQUIRE(img && out_f32_nhwc16, "cdnet_window_pack_f32: null pointer");
+    CDNET_REQUIRE(C > 0 && C <= 16 && H > 0 && W > 0 && tile_h > 0 && tile_w > 0 && stride > 0 && ny > 0 && nx > 0 &&
+                  view_xform >= 0 && view_xform < 8, "cdnet_window_pack_f32: bad arguments");
+    window_pack_f32_kernel<<<lin_grid((size_t)ny * nx * tile_h * tile_w), 256, 0, (hipStream_t)stream>>>(
+        img, C, H, W, view_xform, tile_h, tile_w, stride, ny, nx, out_f32_nhwc16);
+    return check_launch("cdnet_window_pack_f32");
 }
 
 extern "C" int cdnet_window_stitch(const float *tiles, int K, int tile_h, int tile_w, int stride, int overlap, int ny, int nx, int Hv,

@@ -76,8 +76,40 @@ struct BnBwdArgs {
     int rev;                     // apply pass walks the tensor back to front (see cdnet_bn_backward)
 };
 
+__device__ __forceinline__ void ldf8(const void *base, size_t e, float *v) {
+    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + e);
+    const float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void stf8(void *base, size_t e, const float *v) {
+    float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(base) + e);
+    p[0] = make_float4(v[0], v[1], v[2], v[3]);
+    p[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// fp32 tensors (f16 == 2): the activated value in plain fp32 arithmetic; relu == 2: `res` is the stored post-ReLU output of the
+// unit (fused residual epilogue) and the mask is read from it
+__device__ __forceinline__ void act8_f32(const BnBwdArgs &A, size_t e, const float *sc, const float *sh, float *a, float *rawf) {
+    float x[8], r[8];
+    ldf8(A.raw, e, x);
+    if (A.res) ldf8(A.res, e, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (rawf) rawf[j] = x[j];
+        float v = A.scale ? fmaf(x[j], sc[j], sh[j]) : x[j];
+        if (A.relu == 2) v = r[j];
+        else {
+            if (A.res) v += r[j];
+            if (A.relu) v = fmaxf(v, 0.f);
+        }
+        a[j] = v;
+    }
+}
+
 // activated value (rounded to bf16 like the forward staging does) of 8 channels at one pixel
+template <bool F32 = false>
 __device__ __forceinline__ void act8(const BnBwdArgs &A, size_t e, const float *sc, const float *sh, float *a, float *rawf) {
+    if (F32) { act8_f32(A, e, sc, sh, a, rawf); return; }
     V16 r, rr;
     r.u = *reinterpret_cast<const uint4 *>(A.raw + e);
     rr.u = make_uint4(0, 0, 0, 0);
@@ -95,12 +127,12 @@ __device__ __forceinline__ void act8(const BnBwdArgs &A, size_t e, const float *
 }
 
 // dz for 8 channels of pixel (n,y,x); also returns xhat
-template <bool WANT_XHAT>
+template <bool WANT_XHAT, bool F32 = false>
 __device__ __forceinline__ void dz8(const BnBwdArgs &A, int n, int y, int x, int c0, const float *sc, const float *sh,
                                     const float *mu, const float *is, float *dz, float *xhat) {
     const size_t e = (((size_t)n * A.H + y) * A.W + x) * A.C + c0;
     float a[8], rawf[8];
-    act8(A, e, sc, sh, a, rawf);
+    act8<F32>(A, e, sc, sh, a, rawf);
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = 0.f;
@@ -109,10 +141,18 @@ __device__ __forceinline__ void dz8(const BnBwdArgs &A, int n, int y, int x, int
         if (!gi.pooled) {
             const int yy = y + gi.oy, xx = x + gi.ox;
             if (yy >= 0 && yy < gi.Hg && xx >= 0 && xx < gi.Wg) {
-                V16 v;
-                v.u = *reinterpret_cast<const uint4 *>(gi.g + (((size_t)n * gi.Hg + yy) * gi.Wg + xx) * gi.cstride + gi.coff + c0);
+                const size_t ge = (((size_t)n * gi.Hg + yy) * gi.Wg + xx) * gi.cstride + gi.coff + c0;
+                if (F32) {
+                    float t[8];
+                    ldf8(gi.g, ge, t);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] += bf2f(v.h[j]);
+                    for (int j = 0; j < 8; ++j) g[j] += t[j];
+                } else {
+                    V16 v;
+                    v.u = *reinterpret_cast<const uint4 *>(gi.g + ge);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += bf2f(v.h[j]);
+                }
             }
         } else {
             const int py = y >> 1, px = x >> 1;
@@ -128,14 +168,22 @@ __device__ __forceinline__ void dz8(const BnBwdArgs &A, int n, int y, int x, int
                     const int yy = (y & ~1) + (q >> 1), xx = (x & ~1) + (q & 1);
                     if (yy >= A.H || xx >= A.W) continue;
                     float b[8];
-                    act8(A, (((size_t)n * A.H + yy) * A.W + xx) * A.C + c0, sc, sh, b, nullptr);
+                    act8<F32>(A, (((size_t)n * A.H + yy) * A.W + xx) * A.C + c0, sc, sh, b, nullptr);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) sel[j] = sel[j] && (q < q0 ? a[j] > b[j] : a[j] >= b[j]);
                 }
-                V16 v;
-                v.u = *reinterpret_cast<const uint4 *>(gi.g + (((size_t)n * gi.Hg + py) * gi.Wg + px) * gi.cstride + gi.coff + c0);
+                const size_t ge = (((size_t)n * gi.Hg + py) * gi.Wg + px) * gi.cstride + gi.coff + c0;
+                if (F32) {
+                    float t[8];
+                    ldf8(gi.g, ge, t);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] += sel[j] ? bf2f(v.h[j]) : 0.f;
+                    for (int j = 0; j < 8; ++j) g[j] += sel[j] ? t[j] : 0.f;
+                } else {
+                    V16 v;
+                    v.u = *reinterpret_cast<const uint4 *>(gi.g + ge);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += sel[j] ? bf2f(v.h[j]) : 0.f;
+                }
             }
         }
     }
@@ -155,11 +203,12 @@ __device__ __forceinline__ void load8(const float *p, int c0, float *o, float df
 constexpr int BN_U = 4;
 constexpr int BN_MAX_BLOCKS = 2048;
 
+template <bool F32 = false>
 __device__ __forceinline__ void dz8_at(const BnBwdArgs &A, unsigned p, unsigned HW, int c0, const float *sc, const float *sh, const float *mu,
                                        const float *is, float *dz, float *xh) {
     const unsigned n = p / HW, r = p - n * HW;
     const unsigned y = r / (unsigned)A.W, x = r - y * (unsigned)A.W;
-    dz8<true>(A, (int)n, (int)y, (int)x, c0, sc, sh, mu, is, dz, xh);
+    dz8<true, F32>(A, (int)n, (int)y, (int)x, c0, sc, sh, mu, is, dz, xh);
 }
 
 // Window kernels: the layer's consumers are one 2x2 max-pool plus NF same-size un-shifted tensors (the skip connection).
@@ -365,6 +414,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
     }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     __shared__ float s_red[256][17];
     const int VPP = A.C / 8;
@@ -383,7 +433,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
             const unsigned p = p0 + u * step;
-            if (p < npix) dz8_at(A, p, HW, c0, sc, sh, mu, is, dz[u], xh[u]);
+            if (p < npix) dz8_at<F32>(A, p, HW, c0, sc, sh, mu, is, dz[u], xh[u]);
             else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { dz[u][j] = 0.f; xh[u][j] = 0.f; }
@@ -433,6 +483,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs A) {
     const int VPP = A.C / 8;
     const int tid = threadIdx.x;
@@ -448,12 +499,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs A) {
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
             const unsigned p = p0 + u * step;
-            if (p < npix) dz8_at(A, p, HW, c0, sc, sh, mu, is, dz[u], xh[u]);
+            if (p < npix) dz8_at<F32>(A, p, HW, c0, sc, sh, mu, is, dz[u], xh[u]);
         }
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
             const unsigned p = p0 + u * step;
             if (p >= npix) continue;
+            if (F32) {
+                float o32[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o32[j] = k1[j] * (dz[u][j] - k2[j] - xh[u][j] * k3[j]);
+                if (A.draw) stf8(A.draw, (size_t)p * A.C + c0, o32);
+                if (A.dz_out) stf8(A.dz_out, (size_t)p * A.C + c0, dz[u]);
+                continue;
+            }
             V16 o, z;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -486,6 +545,21 @@ struct HeadW {
 };
 constexpr int HEADW_FLOATS = sizeof(HeadW) / 4;      // 855; the gradient block has the same layout
 
+// fp32-stored feature (f16 == 2): 8 channels, plain fp32 arithmetic
+__device__ __forceinline__ void feat8_f32(const HeadFeat &f, size_t pix, int c0, const float *s_sc, const float *s_sh, float *v) {
+    float x[8], r[8];
+    ldf8(f.raw, pix * 64 + c0, x);
+    if (f.res) ldf8(f.res, pix * 64 + c0, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = x[j];
+        if (f.scale) t = fmaf(t, s_sc[c0 + j], s_sh[c0 + j]);
+        if (f.res) t += r[j];
+        if (f.relu) t = fmaxf(t, 0.f);
+        v[j] = t;
+    }
+}
+
 __device__ __forceinline__ float feat1(const HeadFeat &f, size_t pix, int c, const float *s_sc, const float *s_sh) {
     float x = f.f16 ? h2f(f.raw[pix * 64 + c]) : bf2f(f.raw[pix * 64 + c]);
     if (f.scale || f.res || f.relu) {
@@ -499,6 +573,7 @@ __device__ __forceinline__ float feat1(const HeadFeat &f, size_t pix, int c, con
 
 // 8 channels [c0, c0+8) of the feature at one pixel
 __device__ __forceinline__ void feat8(const HeadFeat &f, size_t pix, int c0, const float *s_sc, const float *s_sh, float *v) {
+    if (f.f16 == 2) { feat8_f32(f, pix, c0, s_sc, s_sh, v); return; }
     V16 r, rr;
     r.u = *reinterpret_cast<const uint4 *>(f.raw + pix * 64 + c0);
     rr.u = make_uint4(0, 0, 0, 0);
@@ -523,6 +598,11 @@ __device__ __forceinline__ void feat8(const HeadFeat &f, size_t pix, int c0, con
 }
 
 __device__ __forceinline__ void feat64(const HeadFeat &f, size_t pix, const float *s_sc, const float *s_sh, float *v) {
+    if (f.f16 == 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) feat8_f32(f, pix, q * 8, s_sc, s_sh, v + q * 8);
+        return;
+    }
     const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64);
     const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64) : nullptr;
 #pragma unroll
@@ -560,6 +640,8 @@ __device__ __forceinline__ void feat16(const HeadFeat &f, size_t pix, int q, con
     feat8(f, pix, q * 16 + 8, s_sc, s_sh, v + 8);
 }
 __device__ __forceinline__ float quad_sum(float v) { return xf_quad_sum(v); }
+// 16 gradient values of one lane: element offset e of a bf16 (f32 = false) or fp32 tensor
+__device__ __forceinline__ void store16_grad(unsigned short *base, size_t e, const float *v, bool f32);
 __device__ __forceinline__ void store16_bf16(unsigned short *dst, const float *v) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -568,6 +650,11 @@ __device__ __forceinline__ void store16_bf16(unsigned short *dst, const float *v
         for (int j = 0; j < 8; ++j) o.h[j] = f2bf(v[h2 * 8 + j]);
         reinterpret_cast<uint4 *>(dst)[h2] = o.u;
     }
+}
+
+__device__ __forceinline__ void store16_grad(unsigned short *base, size_t e, const float *v, bool f32) {
+    if (f32) { stf8(base, e, v); stf8(base, e + 8, v + 8); }
+    else store16_bf16(base + e, v);
 }
 
 // Kernel 1: four lanes per pixel (16 channels each).  Recomputes the head, writes the three feature gradients, the 13
@@ -599,6 +686,7 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
     __syncthreads();
     const size_t total = (size_t)N * plane;
     const int q = tid & 3;
+    const bool f32 = f1.f16 == 2;                // fp32 features -> fp32 feature gradients
     // scalar gradients accumulated by the q == 0 lane of each pixel: dbm[3] | dbd[9] | dbp | da1 | da2[9]
     float sg[23];
 #pragma unroll
@@ -637,7 +725,7 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         xf_axpy16(dm[0], w.wm[0] + q * 16, v, false);
         xf_axpy16(dm[1], w.wm[1] + q * 16, v, true);
         xf_axpy16(dm[2], w.wm[2] + q * 16, v, true);
-        if (ok) store16_bf16(df1 + ii * 64 + q * 16, v);
+        if (ok) store16_grad(df1, ii * 64 + q * 16, v, f32);
         const float dq2 = dg2 * sg2 * (1.f - sg2);
         float du[9], dg1 = 0.f;
 #pragma unroll
@@ -650,14 +738,14 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) xf_axpy16(du[k], w.wd[k] + q * 16, v, k != 0);
-        if (ok) store16_bf16(df2 + ii * 64 + q * 16, v);
+        if (ok) store16_grad(df2, ii * 64 + q * 16, v, f32);
         const float dsg1 = dg1 * sg1 * (1.f - sg1);
         const float dpt = (ok ? dpoint[n * plane + p] : 0.f) + dsg1 * w.a1;
         sg[12] += dpt;
         sg[13] = fmaf(dsg1, pt, sg[13]);
         xf_axpy16(dpt, w.wp + q * 16, v, false);
         if (ok) {
-            store16_bf16(df3 + ii * 64 + q * 16, v);
+            store16_grad(df3, ii * 64 + q * 16, v, f32);
             // coefficient row [dpt | du[9] | dm[3] | 0 0 0]: lane q writes floats 4q..4q+3
             float4 cf;
             if (q == 0) cf = make_float4(dpt, du[0], du[1], du[2]);
@@ -1086,7 +1174,7 @@ __global__ __launch_bounds__(256) void final_conv_bwd_kernel(HeadFeat f, const f
         }
 #pragma unroll
         for (int k = 0; k < FC_KMAX; ++k) gb[k] += d[k];
-        if (ok) store16_bf16(df + ii * 64 + q * 16, o);
+        if (ok) store16_grad(df, ii * 64 + q * 16, o, f.f16 == 2);
     }
     // lanes with the same q own the same channels: butterfly over the 16 pixel slots of the wave, then one row per wave
 #pragma unroll
@@ -1117,6 +1205,7 @@ __global__ void final_conv_scatter_kernel(const float *__restrict__ sums, int K,
 
 // bias gradient of a BatchNorm-less convolution (the plain UNet's ConvTranspose2d, models/unet.py:30):
 // db[c] = sum over pixels of the bf16 NHWC output gradient.  thread = (8 channels, pixel group); per-block partials.
+template <bool F32>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short *__restrict__ g, unsigned npix, int C,
                                                         float *__restrict__ partial) {
     __shared__ float s_red[256][9];
@@ -1127,10 +1216,17 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const unsigned short *__
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const unsigned ppb = 256 / VPP;
     for (unsigned p = first_pixel(ppb, VPP); p < npix; p += gridDim.x * ppb) {
-        V16 v;
-        v.u = *reinterpret_cast<const uint4 *>(g + (size_t)p * C + slot * 8);
+        if (F32) {
+            float t[8];
+            ldf8(g, (size_t)p * C + slot * 8, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v.h[j]);
+            for (int j = 0; j < 8; ++j) acc[j] += t[j];
+        } else {
+            V16 v;
+            v.u = *reinterpret_cast<const uint4 *>(g + (size_t)p * C + slot * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v.h[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) s_red[tid][j] = acc[j];
@@ -1177,7 +1273,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
     if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
     if (nb < 1) nb = 1;
-    bool simple = true, window = false;              // every gradient source a same-size, un-shifted tensor?
+    bool simple = true, window = false;               // every gradient source a same-size, un-shifted tensor?
     int npool = 0, kp = 0, nflat = 0;
     for (int k = 0; k < A.ngin; ++k) {
         const GradIn &g = A.gin[k];
@@ -1198,8 +1294,10 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     // Infinity Cache): walking it back to front meets the most recently cached lines first instead of chasing the LRU tail.
     static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
     A.rev = rev;
-    const bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
+    bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
     CDNET_REQUIRE(A.relu != 2 || (flat && A.res), "cdnet_bn_backward: relu = 2 (mask from the stored output) needs same-size gradient sources and res");
+    const bool f32 = A.f16 == 2;                      // fp32 tensors: the generic kernels (every routing case, plain fp32 arithmetic)
+    if (f32) { window = false; flat = false; }
     if (A.mean) {
         CDNET_REQUIRE(gamma && A.invstd && workspace, "cdnet_bn_backward: BatchNorm layer needs gamma/invstd/workspace");
         const size_t need = (size_t)nb * 2 * A.C + 3 * (size_t)A.C;
@@ -1219,7 +1317,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
                 case 6: bn_bwd_reduce_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
                 default: bn_bwd_reduce_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
             }
-        } else bn_bwd_reduce_kernel<<<nb, 256, 0, st>>>(A);
+        } else if (f32) bn_bwd_reduce_kernel<true><<<nb, 256, 0, st>>>(A);
+        else bn_bwd_reduce_kernel<false><<<nb, 256, 0, st>>>(A);
         bn_bwd_finalize_kernel<<<A.C, 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
                                                               k + A.C, k + 2 * A.C);
         A.k1 = k; A.k2 = k + A.C; A.k3 = k + 2 * A.C;
@@ -1237,7 +1336,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
             case 6: bn_bwd_apply_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
             default: bn_bwd_apply_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
         }
-    } else bn_bwd_apply_kernel<<<nb, 256, 0, st>>>(A);
+    } else if (f32) bn_bwd_apply_kernel<true><<<nb, 256, 0, st>>>(A);
+    else bn_bwd_apply_kernel<false><<<nb, 256, 0, st>>>(A);
     return check_launch("cdnet_bn_backward");
 }
 
@@ -1340,8 +1440,16 @@ extern "C" int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const floa
 
 extern "C" size_t cdnet_bias_grad_workspace_floats(int C) { return (size_t)512 * C; }
 
+static int bias_grad_impl(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream, bool f32);
 extern "C" int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db,
                                void *stream) {
+    return bias_grad_impl(grad_out, npix, C, workspace, workspace_floats, db, stream, false);
+}
+extern "C" int cdnet_bias_grad_f32(const float *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db,
+                                   void *stream) {
+    return bias_grad_impl(reinterpret_cast<const uint16_t *>(grad_out), npix, C, workspace, workspace_floats, db, stream, true);
+}
+static int bias_grad_impl(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream, bool f32) {
     CDNET_REQUIRE(grad_out && workspace && db, "cdnet_bias_grad: null pointer");
     CDNET_REQUIRE(C >= 8 && C % 8 == 0 && C <= 2048 && npix > 0 && npix < ((size_t)1 << 31), "cdnet_bias_grad: C=%d unsupported", C);
     if (workspace_floats < cdnet_bias_grad_workspace_floats(C)) { set_error("cdnet_bias_grad: workspace too small"); return CDNET_E_WORKSPACE; }
@@ -1350,7 +1458,8 @@ extern "C" int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, flo
     int nb = (int)((npix + ppb * 8 - 1) / (ppb * 8));
     if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
-    bias_grad_kernel<<<nb, 256, 0, st>>>(grad_out, (unsigned)npix, C, workspace);
+    if (f32) bias_grad_kernel<true><<<nb, 256, 0, st>>>(grad_out, (unsigned)npix, C, workspace);
+    else bias_grad_kernel<false><<<nb, 256, 0, st>>>(grad_out, (unsigned)npix, C, workspace);
     reduce_partials_kernel<<<cdiv(C, 4), 256, 0, st>>>(workspace, nb, C, db);
     return check_launch("cdnet_bias_grad");
 }

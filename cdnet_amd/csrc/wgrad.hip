@@ -517,6 +517,214 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fp32-precision variant (src.f16 == 2: input, residual and output gradient are fp32 tensors).  Both MFMA operands are
+// split into (hi, lo) bf16 planes while they are staged - [pixel][channel] LDS tiles A_hi | A_lo | G_hi | G_lo, read with
+// the same transposing loads - and every k-step runs three MFMAs per tap: a_lo*g_hi + a_hi*g_lo + a_hi*g_hi, fp32
+// accumulation (see conv32.hip for the error bound).  8 waves = 4 dW quadrants x 2 halves of the tile's k-steps; one LDS
+// stage, the next tile's global loads in flight in registers during the MFMA phase.  Pooled sources are materialised first.
+// ------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float wg_f32x2;
+
+__device__ __forceinline__ void wg_split8(const float *v, u32x4 &hi, u32x4 &lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const wg_f32x2 x = {v[2 * k], v[2 * k + 1]};
+        const wg_bf16x2 h = __builtin_convertvector(x, wg_bf16x2);
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        const wg_f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        hi[k] = hb;
+        lo[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, wg_bf16x2));
+    }
+}
+
+constexpr int NT32 = 256;      // 4 waves, one per SIMD (512 registers each): one dW quadrant x all k-steps of a tile per wave
+
+template <int CI_T, int CO_T, int TAPS>
+__global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
+    constexpr int CI = CI_T * 32, CO = CO_T * 32;
+    constexpr int PA = pstride(CI), PG = pstride(CO);
+    constexpr int A_BYTES = NPIX_A * PA, G_BYTES = NPIX_G * PG;
+    constexpr int VA = CI / 8, VG = CO / 8;
+    constexpr int NA = (NPIX_A * VA + NT32 - 1) / NT32, NG = NPIX_G * VG / NT32;
+    static_assert(CI_T * CO_T == 4 && NPIX_G * VG % NT32 == 0, "one 32x32 quadrant per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [A_hi][A_lo][G_hi][G_lo]
+    typedef s16x4 __attribute__((address_space(3))) * lptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int quad = wave;
+    const int wci = quad / CO_T, wco = quad % CO_T;
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int co_blocks = (A.Cout + CO - 1) / CO;
+    const int ci_blocks = (A.src.C + CI - 1) / CI;
+    const int cb = blockIdx.x % co_blocks, ib = blockIdx.x / co_blocks;
+    const int par = blockIdx.y;
+    const int ks = blockIdx.z;
+    const int pa = par >> 1, pb = par & 1;
+    auto tap_off = [&](int t) -> int {
+        if (TAPS == 9) return ((t / 3) * HALO_W + t % 3) * PA;
+        if (TAPS == 4) {
+            const int ty = t >> 1, tx = t & 1;
+            const int r = pa == 0 ? (ty == 0 ? 1 : 0) : (ty == 0 ? 2 : 1);
+            const int c = pb == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
+            return (r * HALO_W + c) * PA;
+        }
+        return (HALO_W + 1) * PA;
+    };
+    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    const int g_lane = 2 * A_BYTES + (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_img = tiles_y * tiles_x;
+    const int ntiles = A.N * tiles_img;
+    const int ntl = ks < ntiles ? (ntiles - ks + A.ksplit - 1) / A.ksplit : 0;
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
+    fill_xf<CI>(s_xf, A.src, ib * CI, tid);
+
+    const ConvSrc &s = A.src;
+    const float *sx = reinterpret_cast<const float *>(s.x), *sr = reinterpret_cast<const float *>(s.res);
+    const float *gx = reinterpret_cast<const float *>(A.g);
+    const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
+    const int slot_a = tid % VA, cbase = ib * CI + slot_a * 8;
+    const bool cok_a = cbase < s.C;
+    const int slot_g = tid % VG, co = cb * CO + slot_g * 8;
+    const bool cok_g = co < A.Cout;
+    const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
+    const bool on = s.scale != nullptr, relu = s.relu != 0;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_xf[slot_a * 8 + j]; sh[j] = s_xf[CI + slot_a * 8 + j]; }
+
+    float4 pa_[NA][2], pg_[NG][2];
+    int ea[NA];                          // element offset of the thread's i-th input vector, -1 = zero fill (tensors < 2^31 elements)
+    unsigned gvalid = 0;
+    auto issue = [&](int j) {
+        const int tile = ks + j * A.ksplit;
+        const int n = tile / tiles_img, rem = tile - n * tiles_img;
+        const int ty = rem / tiles_x;
+        const int y0 = ty * TH, x0 = (rem - ty * tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * NT32, pix = v / VA;
+            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const int ys = y - s.off_y, xs = x - s.off_x;
+            const bool ok = v < NPIX_A * VA && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
+                            (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
+            ea[i] = ok ? (int)((size_t)n * s.Hs * rs + (size_t)ys * rs + (size_t)xs * s.C + cbase) : -1;
+            const float4 *pp = reinterpret_cast<const float4 *>(sx + (ok ? ea[i] : 0));
+            pa_[i][0] = pp[0];
+            pa_[i][1] = pp[1];
+        }
+        gvalid = 0;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int pix = tid / VG + i * (NT32 / VG);
+            const int y = y0 + pix / TW, x = x0 + pix % TW;
+            const bool ok = cok_g && y < A.H && x < A.W;
+            const size_t e = ok ? (((size_t)n * Ho + (y * A.ostride + pa)) * Wo + (x * A.ostride + pb)) * A.Cout + co : 0;
+            const float4 *pp = reinterpret_cast<const float4 *>(gx + e);
+            pg_[i][0] = pp[0];
+            pg_[i][1] = pp[1];
+            gvalid |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto commit = [&]() {
+        float4 rr[NA][2];
+        if (sr) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const float4 *pp = reinterpret_cast<const float4 *>(sr + (ea[i] >= 0 ? ea[i] : 0));
+                rr[i][0] = pp[0];
+                rr[i][1] = pp[1];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + i * NT32;
+            if (v >= NPIX_A * VA) continue;
+            u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+            if (ea[i] >= 0) {
+                float x[8] = {pa_[i][0].x, pa_[i][0].y, pa_[i][0].z, pa_[i][0].w, pa_[i][1].x, pa_[i][1].y, pa_[i][1].z, pa_[i][1].w};
+                if (on) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], sc[j], sh[j]);
+                }
+                if (sr) {
+                    const float r[8] = {rr[i][0].x, rr[i][0].y, rr[i][0].z, rr[i][0].w, rr[i][1].x, rr[i][1].y, rr[i][1].z, rr[i][1].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += r[j];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                }
+                wg_split8(x, hi, lo);
+            }
+            unsigned char *d = smem + (v / VA) * PA + slot_a * 16;
+            *reinterpret_cast<u32x4 *>(d) = hi;
+            *reinterpret_cast<u32x4 *>(d + A_BYTES) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int pix = tid / VG + i * (NT32 / VG);
+            u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+            if (gvalid & (1u << i)) {
+                const float x[8] = {pg_[i][0].x, pg_[i][0].y, pg_[i][0].z, pg_[i][0].w, pg_[i][1].x, pg_[i][1].y, pg_[i][1].z, pg_[i][1].w};
+                wg_split8(x, hi, lo);
+            }
+            unsigned char *d = smem + 2 * A_BYTES + pix * PG + slot_g * 16;
+            *reinterpret_cast<u32x4 *>(d) = hi;
+            *reinterpret_cast<u32x4 *>(d + G_BYTES) = lo;
+        }
+    };
+    auto frag2 = [&](int off, int pstr) -> bf16x8 {
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(smem + off));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(smem + off + 4 * pstr));
+        s16x8 av;
+        av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
+        av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
+        return __builtin_bit_cast(bf16x8, av);
+    };
+
+    if (ntl > 0) issue(0);
+    for (int j = 0; j < ntl; ++j) {
+        __syncthreads();                              // the previous tile's fragment reads are done
+        commit();
+        __syncthreads();
+        if (j + 1 < ntl) issue(j + 1);
+#pragma unroll 2
+        for (int ky = 0; ky < TH; ++ky) {
+            const int gaddr = g_lane + ky * TW * PG;
+            const bf16x8 gh = frag2(gaddr, PG), gl = frag2(gaddr + G_BYTES, PG);
+            const int abase = a_lane + ky * HALO_W * PA;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const bf16x8 ah = frag2(abase + tap_off(t), PA), al = frag2(abase + tap_off(t) + A_BYTES, PA);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
+        }
+}
+
 // sum the split-K slabs in a fixed order and scatter into the PyTorch parameter-gradient layout
 //   mode 0: Conv2d  dW[Cout][Cin][KH][KW]  (taps = KH*KW)
 //   mode 2: ConvTranspose2d k4 s2 p1  dW[Cin][Cout][4][4]   (npar 4 x taps 4)
@@ -611,11 +819,28 @@ int launch_wgrad_gen(const WgradArgs &A, hipStream_t st) {
     return check_launch("wgrad_kernel");
 }
 
+template <int CI_T, int CO_T, int TAPS>
+int launch_wgrad_f32(const WgradArgs &A, hipStream_t st) {
+    constexpr int CI = CI_T * 32, CO = CO_T * 32;
+    constexpr int smem = 2 * (NPIX_A * pstride(CI) + NPIX_G * pstride(CO));
+    auto kern = wgrad_f32_kernel<CI_T, CO_T, TAPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(wgrad_f32)");
+        attr_done = true;
+    }
+    dim3 grid(cdiv(A.src.C, CI) * cdiv(A.Cout, CO), A.npar, A.ksplit);
+    kern<<<grid, NT32, smem, st>>>(A);
+    return check_launch("wgrad_f32_kernel");
+}
+
 // kernel choice: un-pooled sources with CI <= 64 take the specialised-wave kernel with a compile-time transform
 // (plain / training-mode fast path / generic); pooled sources, CI = 128 blocks and generic-with-residual the 8-wave one
 template <int CI_T, int CO_T, int TAPS>
 int launch_wgrad(const WgradArgs &A, hipStream_t st) {
     const ConvSrc &s = A.src;
+    if (s.f16 == 2) return launch_wgrad_f32<CI_T, CO_T, TAPS>(A, st);
     const bool res = s.res != nullptr;
     if (CI_T != 4 && !s.pool && !(A.debug & 8)) {
         const bool plain = !s.scale && !s.relu && !s.f16 && !res;
@@ -649,6 +874,8 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     CDNET_REQUIRE(ci_tiles == 1 || ci_tiles == 2 || ci_tiles == 4, "cdnet_conv_backward_weight: ci_tiles=%d", ci_tiles);
     CDNET_REQUIRE(src->C % 8 == 0, "cdnet_conv_backward_weight: source channels %d not a multiple of 8", src->C);
     CDNET_REQUIRE(!(src->res && src->pool), "cdnet_conv_backward_weight: a pooled source with a residual branch is not supported");
+    CDNET_REQUIRE(!(src->f16 == 2 && src->pool), "cdnet_conv_backward_weight: fp32 pooled sources must be materialised");
+    CDNET_REQUIRE(!(src->f16 == 2 && mode == 6), "cdnet_conv_backward_weight: stride-2 convolutions have no fp32 path");
     CDNET_REQUIRE(ksplit >= 1 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "cdnet_conv_backward_weight: bad size (Cout %% 8)");
     CDNET_REQUIRE((taps == 9 && npar == 1 && ostride == 1 && mode == 0) || (taps == 1 && npar == 1 && ostride == 1 && mode == 0) ||
                   (taps == 9 && npar == 1 && ostride == 1 && mode == 6) ||

@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
                 ('Cout', C.c_int), ('out_cstride', C.c_int), ('out_coff', C.c_int), ('stats', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
-                ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('pad2_', C.c_int),
+                ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('f32', C.c_int),
                 ('eres', C.c_void_p), ('eres_scale', C.c_void_p), ('eres_shift', C.c_void_p), ('eres_f16', C.c_int), ('eres_relu', C.c_int)]
 
 
@@ -34,7 +34,7 @@ class Src:
     `x` instead of the dense tensor (space-to-depth view of an upsampled gradient)."""
 
     def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0), view=None):
-        assert x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+        assert x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.is_contiguous()
         assert res is None or res.dtype == x.dtype
         self.x, self.scale, self.shift, self.relu, self.pool, self.res, self.off = x, scale, shift, relu, pool, res, off
         if view is None:
@@ -47,14 +47,19 @@ class Src:
 
     @property
     def f16(self):
-        return self.x.dtype == torch.float16
+        """storage code of the ABI: 0 bf16, 1 fp16, 2 fp32"""
+        return {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[self.x.dtype]
+
+    @property
+    def f32(self):
+        return self.x.dtype == torch.float32
 
     @property
     def C(self):
         return self.Cc
 
     def ptr(self):
-        return self.x.data_ptr() + 2 * self.ptr_off
+        return self.x.data_ptr() + self.x.element_size() * self.ptr_off
 
     def logical_hw(self):
         h, w = self.Hs, self.Ws
@@ -79,8 +84,15 @@ _SUPPORTED = {(16, 16, 32), (16, 16, 64), (16, 32, 32), (16, 32, 64), (16, 32, 1
               (8, 32, 64), (8, 32, 128), (8, 64, 64)}
 
 
-def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False, N=16):
+def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False, N=16, f32=False):
     """(tile, CK, BN) for a layer.  CK must divide every source's channel count.  N = images per launch."""
+    if f32:
+        # fp32-precision kernels (csrc/conv32.hip): 16-channel chunks, 16x16 tiles (8x8 for the few-pixel layers)
+        assert all(c % 16 == 0 for c in src_channels), src_channels
+        small = min(H, W) <= 8 or (min(H, W) <= 16 and N <= 32)
+        if small and Cout > 32:
+            return (8, 16, 64)
+        return (16, 16, 64 if Cout > 32 else 32)
     if override is not None:
         assert tuple(override) in _SUPPORTED, override
         return tuple(override)
@@ -134,16 +146,20 @@ class PackJob(C.Structure):
                 ('CK', C.c_int), ('BN', C.c_int), ('mode', C.c_int), ('pad_', C.c_int)]
 
 
-def pack_job(w, cfg, mode, out):
+def pack_job(w, cfg, mode, out, split=False):
     """descriptor of one re-pack of `w` into the existing packed buffer `out` (cdnet_pack_conv_weights_batch)"""
     Cout, Cin, KH, KW, CK, BN, taps, npar = _pack_dims(w, cfg, mode)
-    assert out.numel() == packed_elems(Cout, Cin // CK, taps, CK, BN, npar)
+    assert out.numel() == packed_elems(Cout, Cin // CK, taps, CK, BN, npar) * (2 if split else 1)
     j = PackJob()
-    j.w, j.packed, j.Cout, j.Cin, j.KH, j.KW, j.CK, j.BN, j.mode = w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, CK, BN, mode
+    j.w, j.packed, j.Cout, j.Cin, j.KH, j.KW, j.CK, j.BN = w.data_ptr(), out.data_ptr(), Cout, Cin, KH, KW, CK, BN
+    j.mode = mode | (PACK_SPLIT if split else 0)
     return j
 
 
-def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
+PACK_SPLIT = 16       # CDNET_PACK_SPLIT
+
+
+def pack_weights(w, cfg, mode, Cin_pad=None, out=None, split=False):
     """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
     Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
     assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
@@ -157,19 +173,24 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None):
         else:
             raise NotImplementedError
         w, Cin = wp.contiguous(), Cin_p
-    n = packed_elems(Cout, Cin // CK, taps, CK, BN, npar)
-    if out is None:
+    n = packed_elems(Cout, Cin // CK, taps, CK, BN, npar) * (2 if split else 1)
+    if out is None or out.numel() != n:
         out = torch.empty((n,), dtype=torch.int16, device=w.device)
-    assert out.numel() == n
-    _lib.call('cdnet_pack_conv_weights', _lib.ptr(w), _lib.ptr(out), Cout, Cin, KH, KW, CK, BN, mode, _lib.stream_ptr())
+    _lib.call('cdnet_pack_conv_weights', _lib.ptr(w), _lib.ptr(out), Cout, Cin, KH, KW, CK, BN, mode | (PACK_SPLIT if split else 0),
+              _lib.stream_ptr())
     return out
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
                  orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None):
-    """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats)."""
+    """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
+    kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
     s0 = srcs[0]
+    f32 = s0.f32
+    assert all(s.f32 == f32 for s in srcs)
+    if f32:
+        out_dtype = torch.float32
     N = s0.N
     if H is None:
         H, W = s0.logical_hw()
@@ -197,8 +218,11 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
     a.ws = 0
+    a.f32 = int(f32)
+    assert (out.dtype == torch.float32) == f32
     if eres is not None:                 # fused residual epilogue: eres = Src(other branch[, scale, shift], relu=...)
-        assert not transposed and stats is None and not orelu and out.dtype == torch.bfloat16 and tuple(eres.x.shape) == tuple(out.shape)
+        assert not transposed and stats is None and not orelu and out.dtype == (torch.float32 if f32 else torch.bfloat16) and tuple(eres.x.shape) == tuple(out.shape)
+        assert eres.f32 == f32
         a.eres, a.eres_scale, a.eres_shift = eres.x.data_ptr(), _dp(eres.scale), _dp(eres.shift)
         a.eres_f16, a.eres_relu = int(eres.f16), int(eres.relu)
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())

@@ -86,7 +86,7 @@ class _RU:
             # branch in its epilogue (cdnet_conv_args.eres): the unit's output leaves as one stored bf16 tensor - no separate
             # residual tensor, no add+ReLU pass, and every consumer (next unit, head) reads a plain source
             h = self.c1.forward([x], training, relu=True)
-            y = self.c2.forward([h], training, relu=False, out_dtype=torch.float16)       # raw fp16; BatchNorm pending in training
+            y = self.c2.forward([h], training, relu=False, out_dtype=runtime.raw_dtype())       # raw fp16; BatchNorm pending in training
             f = self.cr.forward([x], training, eres=Src(y.x, y.scale, y.shift, relu=relu2))
             # backward: the consumers' gradients of f go through bn2 first (ReLU mask read from f), its dz is conv_1x1's gradient
             self.c2.node_relu, self.c2.node_res = (2 if relu2 else 0), f.x
@@ -95,9 +95,9 @@ class _RU:
         self.cr.fused_res_of = None
         # the pre-activation pair (bn2 output, residual) is kept in fp16: it is only ever read through the consumer's
         # add+ReLU transform, never as an MFMA operand
-        r = self.cr.forward([x], training, out_dtype=torch.float16)               # residual = conv_1x1(x)   (:162)
+        r = self.cr.forward([x], training, out_dtype=runtime.raw_dtype())               # residual = conv_1x1(x)   (:162)
         h = self.c1.forward([x], training, relu=True)                             # relu1(bn1(conv1(x)))     (:163-165)
-        y = self.c2.forward([h], training, relu=False, out_dtype=torch.float16)   # bn2(conv2(.))            (:166-167)
+        y = self.c2.forward([h], training, relu=False, out_dtype=runtime.raw_dtype())   # bn2(conv2(.))            (:166-167)
         self.c2.node_relu, self.c2.node_res = relu2, r.x         # how consumers (and backward) see the unit's output
         out = Src(y.x, y.scale, y.shift, relu=relu2, res=r.x)    # relu2(out + residual)             (:168-169)
         if store and runtime.RU_MATERIALIZE:

@@ -85,6 +85,7 @@ class ConvLayer:
         self.transposed = kind in ('convT4', 'convT2')
         self.pack_mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3, 'conv3s2': 6}[kind]
         self.cfg = None
+        self.cfg_f32 = False                   # the precision self.cfg / self.wp / self.wpb were made for
         self.wp = None
         self.wp_version = None
         self.fold = None                       # eval-mode (scale, shift)
@@ -113,31 +114,35 @@ class ConvLayer:
 
     def prepare(self, src_channels, H, W, N=16):
         cin_total = sum(src_channels)
-        if self.cfg is None:
-            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override, taps=self.taps, transposed=self.transposed, N=N)
+        f32 = PRECISION == 'fp32'
+        if self.cfg is None or self.cfg_f32 != f32:
+            self.cfg = engine.choose_cfg(src_channels, self.Cout, H, W, self.cfg_override, taps=self.taps, transposed=self.transposed, N=N,
+                                         f32=f32)
+            self.cfg_f32, self.wp, self.cfg_bwd, self.wpb = f32, None, None, None
         ver = (self.weight._version, WEIGHTS_EPOCH[0])
         if self.wp is None or self.wp_version != ver:
             pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16
             self.wp_padded = pad is not None
-            self.wp = engine.pack_weights(self.weight.detach(), self.cfg, self.pack_mode, Cin_pad=pad, out=self.wp)
+            self.wp = engine.pack_weights(self.weight.detach(), self.cfg, self.pack_mode, Cin_pad=pad, out=self.wp, split=f32)
             self.wp_version = ver
 
     def backward_pack(self, cin_total, H, W):
         """(packed weights, cfg) of the backward-data convolution: a forward convolution with flipped / transposed
         weights (Conv2d), or a 3x3 / 1x1 convolution over the space-to-depth view of the gradient (ConvTranspose2d)."""
         ver = (self.weight._version, WEIGHTS_EPOCH[0])
+        f32 = self.cfg_f32
         if self.cfg_bwd is None:
             if self.transposed:
-                self.cfg_bwd = engine.choose_cfg([2 * self.Cout, 2 * self.Cout], self.Cin, H, W, taps=(9 if self.kind == 'convT4' else 1))
+                self.cfg_bwd = engine.choose_cfg([2 * self.Cout, 2 * self.Cout], self.Cin, H, W, taps=(9 if self.kind == 'convT4' else 1), f32=f32)
             else:
-                self.cfg_bwd = engine.choose_cfg([self.Cout], cin_total, H, W, taps=self.taps)
+                self.cfg_bwd = engine.choose_cfg([self.Cout], cin_total, H, W, taps=self.taps, f32=f32)
         if self.wpb is None or self.wpb_version != ver:
             if self.transposed:
                 mode = 4 if self.kind == 'convT4' else 5
-                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, mode, out=self.wpb)
+                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, mode, out=self.wpb, split=f32)
             else:
                 assert cin_total == self.Cin, 'the RGB stem never needs an input gradient'
-                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, 7 if self.kind == 'conv3s2' else 1, out=self.wpb)
+                self.wpb = engine.pack_weights(self.weight.detach(), self.cfg_bwd, 7 if self.kind == 'conv3s2' else 1, out=self.wpb, split=f32)
             self.wpb_version = ver
         return self.wpb, self.cfg_bwd
 
@@ -156,9 +161,14 @@ class ConvLayer:
         return self.fold
 
     # -- forward ------------------------------------------------------------------------------------
-    def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=torch.bfloat16, eres=None):
+    def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=None, eres=None):
         """Returns the output as a Src (lazy transform attached in train mode).  Raw (pre-BatchNorm) outputs of the
-        training path are stored as fp16: the consumer's affine needs more than bf16's 8 significant bits."""
+        training path are stored as fp16: the consumer's affine needs more than bf16's 8 significant bits.  In the fp32
+        precision mode every stored tensor is fp32 (out_dtype is ignored)."""
+        if PRECISION == 'fp32':
+            out_dtype = torch.float32
+        elif out_dtype is None:
+            out_dtype = torch.bfloat16
         if H is None:
             H, W = srcs[0].logical_hw()
         if DEBUG_NORELU:
@@ -187,7 +197,7 @@ class ConvLayer:
         if self.stats is None or self.stats.shape[0] != T:
             self.stats = torch.empty((T, 2, self.Cout), dtype=torch.float32, device=self.weight.device)
         raw, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, stats=self.stats,
-                                     H=H, W=W, out_dtype=torch.float16)
+                                     H=H, W=W, out_dtype=raw_dtype())
         count = float(N * H * W * npar)
         bn = self.bn
         _lib.call('cdnet_bn_finalize_train', _lib.ptr(self.stats), T, self.Cout, count, _lib.ptr(bn.weight.detach()),
@@ -277,12 +287,13 @@ class FuseNode:
 
 
 def input_pack(x):
-    """f32 NCHW [N,C<=16,H,W] cuda -> bf16 NHWC [N,H,W,16]"""
+    """f32 NCHW [N,C<=16,H,W] cuda -> NHWC [N,H,W,16] in the activation dtype of the current precision (bf16 / fp32)"""
     assert x.dtype == torch.float32 and x.is_cuda and x.dim() == 4
     x = x.contiguous()
     N, Cc, H, W = x.shape
-    out = torch.empty((N, H, W, 16), dtype=torch.bfloat16, device=x.device)
-    _lib.call('cdnet_input_pack', _lib.ptr(x), N, Cc, H, W, _lib.ptr(out), _lib.stream_ptr())
+    out = torch.empty((N, H, W, 16), dtype=act_dtype(), device=x.device)
+    _lib.call('cdnet_input_pack_f32' if PRECISION == 'fp32' else 'cdnet_input_pack', _lib.ptr(x), N, Cc, H, W, _lib.ptr(out),
+              _lib.stream_ptr())
     return out
 
 
@@ -295,7 +306,7 @@ def materialize(s, H=None, W=None):
     """The Src with its pending transform applied, as a stored bf16 tensor (cdnet_src_materialize).  Returns a plain Src."""
     if H is None:
         H, W = s.logical_hw()
-    out = torch.empty((s.N, H, W, s.C), dtype=torch.bfloat16, device=s.x.device)
+    out = torch.empty((s.N, H, W, s.C), dtype=(torch.float32 if s.f32 else torch.bfloat16), device=s.x.device)
     cs = engine.ConvSrc()
     s.fill(cs)
     _lib.call('cdnet_src_materialize', C.byref(cs), s.N, H, W, _lib.ptr(out), _lib.stream_ptr())
@@ -309,7 +320,7 @@ def pooled(s, ceil_mode=False, materialized=None):
     assert not s.pool and s.res is None
     mode = 2 if ceil_mode else 1
     lazy = Src(s.x, s.scale, s.shift, relu=s.relu, pool=mode)
-    if not (POOL_MATERIALIZE if materialized is None else materialized):
+    if not (POOL_MATERIALIZE if materialized is None else materialized) and not s.f32:      # (the fp32 kernels read stored pools only)
         return lazy
     out = materialize(lazy)
     out.grad_to = (s.x, mode)

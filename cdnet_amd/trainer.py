@@ -151,7 +151,7 @@ class Trainer:
             elif len(gl) == 1 and not gl[0].coff and gl[0].cstride in (0, o.shape[3]):
                 d = gl[0].t
             else:
-                d = self.buf(('dcat', key), o.shape, torch.bfloat16)
+                d = self.buf(('dcat', key), o.shape, runtime.act_dtype())
                 self.grad_sum(gl, None, o.shape[0] * o.shape[1] * o.shape[2], o.shape[3], d)
             self._cat_cache[key] = d
         return self._cat_cache[key]
@@ -204,7 +204,7 @@ class Trainer:
             grads.setdefault(id(t), []).append(g)
 
         # head
-        df = [self.buf('dF%d' % k, (N, H, W, 64), torch.bfloat16) for k in range(3)]
+        df = [self.buf('dF%d' % k, (N, H, W, 64), runtime.act_dtype()) for k in range(3)]
         hf = [runtime.head_feat(f) for f in (f1, f2, f3)]
         dhead = self.flat.G[:self.flat.n_head]
         need = _lib.load().cdnet_dam_head_backward_workspace_floats(N, H, W)
@@ -290,13 +290,13 @@ class Trainer:
             a.gin[k].g = g.t.data_ptr()
             a.gin[k].Hg, a.gin[k].Wg, a.gin[k].oy, a.gin[k].ox = g.Hg, g.Wg, g.oy, g.ox
             a.gin[k].pooled, a.gin[k].coff, a.gin[k].cstride = int(g.pooled), g.coff, g.cstride or Co
-        a.f16 = int(out.dtype == torch.float16)
+        a.f16 = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[out.dtype]
         a.relu = int(getattr(L, 'node_relu', True))
         a.N, a.H, a.W, a.C = No, Ho, Wo, Co
-        draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), torch.bfloat16)
+        draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
         dz = None
         if res is not None:
-            dz = self.buf(('dz', L.name), (No, Ho, Wo, Co), torch.bfloat16)
+            dz = self.buf(('dz', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
         ws = self._bn_ws(Co)
         bn = L.bn
         _lib.call('cdnet_bn_backward', C.byref(a), _lib.ptr(bn.weight.detach()) if has_bn else None,
@@ -355,8 +355,8 @@ class Trainer:
                 # stand-alone biased convolution (plain UNet's ConvTranspose2d): db = sum of the output gradient
                 need = lib.cdnet_bias_grad_workspace_floats(Cout)
                 ws = self._slab(need)
-                _lib.call('cdnet_bias_grad', _lib.ptr(g), g.numel() // Cout, Cout, _lib.ptr(ws), ws.numel(), _lib.ptr(L.bias.grad),
-                          _lib.stream_ptr())
+                _lib.call('cdnet_bias_grad_f32' if g.dtype == torch.float32 else 'cdnet_bias_grad', _lib.ptr(g), g.numel() // Cout, Cout,
+                          _lib.ptr(ws), ws.numel(), _lib.ptr(L.bias.grad), _lib.stream_ptr())
 
     def _input_backward(self, L, srcs, g, H, W, add):
         if not getattr(L, 'needs_input_grad', True):
@@ -369,18 +369,18 @@ class Trainer:
         if L.kind == 'conv3s2':
             # stride-2 convolution: gradient in the space-to-depth layout [N,H,W,(a,b,c)], then permuted to [N,2H,2W,C]
             Cp = cin_total // 4
-            gs2d = self.buf(('ds2d', L.name), (N, H, W, cin_total), torch.bfloat16)
+            gs2d = self.buf(('ds2d', L.name), (N, H, W, cin_total), runtime.act_dtype())
             engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=9, out=gs2d, H=H, W=W)
-            gin = self.buf(('din', L.name), (N, 2 * H, 2 * W, Cp), torch.bfloat16)
+            gin = self.buf(('din', L.name), (N, 2 * H, 2 * W, Cp), runtime.act_dtype())
             _lib.call('cdnet_s2d_to_nhwc', _lib.ptr(gs2d), N, H, W, Cp, _lib.ptr(gin), _lib.stream_ptr())
             add(srcs[0].x, _G(gin, 2 * H, 2 * W))
             return
         if not L.transposed:
-            gin = self.buf(('din', L.name), (N, H, W, cin_total), torch.bfloat16)
+            gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())
             engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
         else:
             # space-to-depth view of g [N,2H,2W,Cout]: two row-parity sources of 2*Cout channels each
-            gin = self.buf(('din', L.name), (N, H, W, cin_total), torch.bfloat16)
+            gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())
             views = [Src(g, view=(a * 2 * W * Cout, H, W, 2 * Cout, 4 * W * Cout)) for a in (0, 1)]
             engine.conv_forward(views, wpb, cin_total, cfgb, taps=(9 if L.kind == 'convT4' else 1), out=gin, H=H, W=W)
         coff = 0
@@ -450,6 +450,8 @@ class Trainer:
         has its packed buffers."""
         f = self.flat
         lo, hi = f.P.data_ptr(), f.P.data_ptr() + f.P.numel() * 4
+        if self._pack_jobs is not None and getattr(self, '_pack_prec', None) != runtime.PRECISION:
+            self._pack_jobs = None                           # the layers re-made their packs for the other precision
         if self._pack_jobs is None:
             groups = ([], []), ([], [])                      # (jobs, owners) of the forward packs / the backward-data packs
             for L in runtime.LAYERS:
@@ -457,13 +459,14 @@ class Trainer:
                     continue
                 w = L.weight.detach()
                 if L.wp is not None and not L.wp_padded:
-                    groups[0][0].append(engine.pack_job(w, L.cfg, L.pack_mode, L.wp)); groups[0][1].append((L, 'wp_version'))
+                    groups[0][0].append(engine.pack_job(w, L.cfg, L.pack_mode, L.wp, split=L.cfg_f32)); groups[0][1].append((L, 'wp_version'))
                 if L.wpb is not None:
                     mode = (4 if L.kind == 'convT4' else 5) if L.transposed else (7 if L.kind == 'conv3s2' else 1)
-                    groups[1][0].append(engine.pack_job(w, L.cfg_bwd, mode, L.wpb)); groups[1][1].append((L, 'wpb_version'))
+                    groups[1][0].append(engine.pack_job(w, L.cfg_bwd, mode, L.wpb, split=L.cfg_f32)); groups[1][1].append((L, 'wpb_version'))
             if not groups[0][0] or not groups[1][0] or self.flat.step_count < 1:
                 return
             self._pack_jobs = []
+            self._pack_prec = runtime.PRECISION
             for jobs, owners in groups:
                 arr = (engine.PackJob * len(jobs))(*jobs)
                 nbytes = _lib.load().cdnet_pack_batch_table_bytes(len(jobs))
@@ -601,7 +604,7 @@ class UNetTrainer(Trainer):
         def add(t, g):
             grads.setdefault(id(t), []).append(g)
         K = m.num_classes
-        df = self.buf('dF', (N, H, W, 64), torch.bfloat16)
+        df = self.buf('dF', (N, H, W, 64), runtime.act_dtype())
         lib = _lib.load()
         ws = self._slab(lib.cdnet_final_conv1x1_backward_workspace_floats())
         hf = runtime.head_feat(feat)

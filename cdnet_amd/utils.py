@@ -46,8 +46,11 @@ def split_forward_views(model, image, size, overlap, xforms=(0,), direction_clas
     for xf in xforms:
         hv, wv = (W0, H0) if xf & 4 else (H0, W0)
         stride, th, tw, ny, nx = window_grid(hv, wv, size, overlap)
-        t = torch.empty((ny * nx, th, tw, 16), dtype=torch.bfloat16, device=image.device)
-        _lib.call('cdnet_window_pack', _lib.ptr(image), Cc, H0, W0, int(xf), th, tw, stride, ny, nx, _lib.ptr(t), _lib.stream_ptr())
+        from . import runtime
+        f32 = runtime.PRECISION == 'fp32'
+        t = torch.empty((ny * nx, th, tw, 16), dtype=runtime.act_dtype(), device=image.device)
+        _lib.call('cdnet_window_pack_f32' if f32 else 'cdnet_window_pack', _lib.ptr(image), Cc, H0, W0, int(xf), th, tw, stride, ny, nx,
+                  _lib.ptr(t), _lib.stream_ptr())
         packs.append(t)
         geo.append((hv, wv, stride, th, tw, ny, nx))
     # batch windows of equal shape through the network

@@ -212,6 +212,8 @@ int cdnet_conv_forward(const cdnet_conv_args *args, void *stream);
  *   deterministic (fixed tree, fp64).
  * ---------------------------------------------------------------------------------------------------- */
 int cdnet_input_pack(const float *x, int N, int C, int H, int W, void *out_bf16_nhwc16, void *stream);
+/* the same layout change for the fp32-precision path: out f32 NHWC [N][H][W][16] */
+int cdnet_input_pack_f32(const float *x, int N, int C, int H, int W, float *out_f32_nhwc16, void *stream);
 int cdnet_bn_fold_eval(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
                        const float *conv_bias, float eps, int C, float *scale, float *shift, void *stream);
 int cdnet_bn_finalize_train(const float *stats, int T, int C, float count, const float *gamma, const float *beta,
@@ -226,7 +228,7 @@ typedef struct cdnet_head_feat {
     const float *scale;     /* optional per-channel affine */
     const float *shift;
     int relu;
-    int f16;                /* 0: raw/res are bf16, 1: fp16 */
+    int f16;                /* 0: raw/res are bf16, 1: fp16, 2: fp32 (pointers address float tensors; nothing is rounded to 16 bits) */
 } cdnet_head_feat;
 
 /* Direction-aware-mask head: replaces models/dam/model_unet_rev1.py:258-263 (point_conv, directionAtt,
@@ -245,6 +247,7 @@ int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, const float *b
  * db[c] = sum over the npix pixels of grad_out (bf16 NHWC [npix][C]).  workspace: cdnet_bias_grad_workspace_floats(C). */
 size_t cdnet_bias_grad_workspace_floats(int C);
 int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);
+int cdnet_bias_grad_f32(const float *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);   /* fp32-precision path */
 /* backward of that classifier (plain-UNet training, train_util.py:126-200 loss.backward()): dlogits f32 [N][K][H][W] ->
  * df bf16 NHWC [N][H][W][64] (gradient of the activated feature), dw f32 [K][64], db f32 [K].  K <= 4.
  * workspace: cdnet_final_conv1x1_backward_workspace_floats() floats. */
@@ -344,6 +347,9 @@ int cdnet_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
  * ---------------------------------------------------------------------------------------------------- */
 int cdnet_window_pack(const float *img, int C, int H, int W, int view_xform, int tile_h, int tile_w, int stride, int ny,
                       int nx, void *out_bf16_nhwc16, void *stream);
+/* fp32-precision path: the same windows as f32 NHWC [ny*nx][tile_h][tile_w][16] */
+int cdnet_window_pack_f32(const float *img, int C, int H, int W, int view_xform, int tile_h, int tile_w, int stride, int ny,
+                          int nx, float *out_f32_nhwc16, void *stream);
 int cdnet_window_stitch(const float *tiles, int K, int tile_h, int tile_w, int stride, int overlap, int ny, int nx, int Hv,
                         int Wv, float *out, void *stream);
 

@@ -12,11 +12,18 @@ import torch.nn.functional as F
 NORELU = bool(int(os.environ.get('CDNET_DEBUG_NORELU', '0')))      # debug aid: linearised network (tools/debug_train.py)
 
 
+QUANT = True       # False: no rounding points at all (the fp32-precision path's counterpart; NORELU still applies)
+
+
 def q_bf(x):
+    if not QUANT:
+        return x
     return x + (x.detach().to(torch.bfloat16).float() - x.detach())
 
 
 def q_h(x):
+    if not QUANT:
+        return x
     return x + (x.detach().to(torch.float16).float() - x.detach())
 
 

@@ -1,0 +1,240 @@
+"""fp32-precision training kernels (fp32 tensors, split-bf16 x3 MFMA products) against plain PyTorch fp32 / fp64 (CPU autograd)
+references of the same ops.  Tolerances: MFMA kernels 5e-5 relative (2^-16 per product), streaming kernels 1e-5."""
+import ctypes as C
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().float().cuda()
+
+
+def _nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _wgrad(srcs, g, weight_shape, kind, H, W, cin_real=None, ksplit=7):
+    import torch
+    from cdnet_amd import _lib, engine, trainer
+    lib = _lib.load()
+    dw = torch.zeros(weight_shape, dtype=torch.float32, device='cuda')
+    mode = {'conv3': 0, 'conv1': 0, 'convT4': 2, 'convT2': 3}[kind]
+    taps = {'conv3': 9, 'conv1': 1, 'convT4': 4, 'convT2': 1}[kind]
+    tr = kind.startswith('convT')
+    npar, ostride = (4, 2) if tr else (1, 1)
+    Cout = weight_shape[1] if tr else weight_shape[0]
+    cin_real = cin_real or (weight_shape[0] if tr else weight_shape[1])
+    N = g.shape[0]
+    coff = 0
+    for s in srcs:
+        ci_t = trainer._choose_ci_tiles(s.C, Cout)
+        slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit),), dtype=torch.float32, device='cuda')
+        cs = engine.ConvSrc()
+        s.fill(cs)
+        assert cs.f16 == 2
+        _lib.call('cdnet_conv_backward_weight', C.byref(cs), coff, min(s.C, cin_real - coff), cin_real, _lib.ptr(g), Cout, N, H, W,
+                  taps, npar, ostride, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(dw), mode, _lib.stream_ptr())
+        coff += s.C
+    return dw.cpu()
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 24, 40), (1, 32, 128, 16, 16), (2, 128, 32, 9, 21), (1, 16, 64, 32, 32),
+                                  (2, 64, 16, 16, 48), (1, 256, 64, 8, 8)])
+def test_wgrad_fp32_conv3x3(case):
+    import torch
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    dy = torch.randn((N, Cout, H, W), generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+    got = _wgrad([engine.Src(_nhwc(x))], _nhwc(dy), (Cout, Cin, 3, 3), 'conv3', H, W)
+    assert _rel(got, want) < 5e-5, _rel(got, want)
+
+
+def test_wgrad_fp32_transformed_sources_1x1_and_transposed():
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(5)
+    # two concat sources: affine+relu, and padded affine+residual+relu
+    N, Ca, Cb, Cout, H, W = 2, 32, 64, 64, 20, 28
+    a = torch.randn((N, Ca, H, W), generator=g)
+    b = torch.randn((N, Cb, H - 1, W - 3), generator=g)
+    res = torch.randn((N, Cb, H - 1, W - 3), generator=g)
+    sa, ha = torch.rand((Ca,), generator=g) + 0.5, torch.randn((Ca,), generator=g) * 0.3
+    sb, hb = torch.rand((Cb,), generator=g) + 0.5, torch.randn((Cb,), generator=g) * 0.3
+    dy = torch.randn((N, Cout, H, W), generator=g)
+    ta = F.relu(a * sa.view(1, -1, 1, 1) + ha.view(1, -1, 1, 1))
+    tb = F.pad(F.relu(b * sb.view(1, -1, 1, 1) + hb.view(1, -1, 1, 1) + res), (1, 2, 0, 1))
+    want = torch.nn.grad.conv2d_weight(torch.cat([ta, tb], 1).double(), (Cout, Ca + Cb, 3, 3), dy.double(), padding=1)
+    srcs = [engine.Src(_nhwc(a), sa.cuda(), ha.cuda(), relu=True),
+            engine.Src(_nhwc(b), sb.cuda(), hb.cuda(), relu=True, res=_nhwc(res), off=(0, 1))]
+    got = _wgrad(srcs, _nhwc(dy), (Cout, Ca + Cb, 3, 3), 'conv3', H, W)
+    assert _rel(got, want) < 5e-5, _rel(got, want)
+    # stem: 3 real channels stored as 16
+    x = torch.rand((2, 3, 32, 32), generator=g)
+    dy = torch.randn((2, 64, 32, 32), generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 3, 3), dy.double(), padding=1)
+    x16 = torch.zeros((2, 16, 32, 32)); x16[:, :3] = x
+    got = _wgrad([engine.Src(_nhwc(x16))], _nhwc(dy), (64, 3, 3, 3), 'conv3', 32, 32, cin_real=3)
+    assert _rel(got, want) < 5e-5
+    # 1x1
+    x = torch.randn((2, 64, 24, 16), generator=g)
+    dy = torch.randn((2, 64, 24, 16), generator=g)
+    want = torch.nn.grad.conv2d_weight(x.double(), (64, 64, 1, 1), dy.double())
+    got = _wgrad([engine.Src(_nhwc(x))], _nhwc(dy), (64, 64, 1, 1), 'conv1', 24, 16)
+    assert _rel(got, want) < 5e-5
+    # transposed k4 s2 p1 and k2 s2
+    for (N, Cin, Cout, H, W, k) in [(2, 64, 32, 8, 8, 4), (1, 32, 16, 24, 40, 4), (2, 64, 32, 12, 20, 2)]:
+        x = torch.randn((N, Cin, H, W), generator=g).double()
+        w = torch.zeros((Cin, Cout, k, k), dtype=torch.float64, requires_grad=True)
+        dy = torch.randn((N, Cout, 2 * H, 2 * W), generator=g)
+        F.conv_transpose2d(x, w, None, stride=2, padding=1 if k == 4 else 0).backward(dy.double())
+        got = _wgrad([engine.Src(_nhwc(x))], _nhwc(dy), (Cin, Cout, k, k), 'convT4' if k == 4 else 'convT2', H, W)
+        assert _rel(got, w.grad) < 5e-5, (k, _rel(got, w.grad))
+
+
+def test_backward_data_fp32():
+    """input gradients: 3x3 / 1x1 with the flipped pack (mode 1), transposed convolutions through the space-to-depth view"""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(9)
+    for (N, Cin, Cout, H, W, k) in [(2, 64, 64, 24, 20, 3), (1, 128, 32, 16, 16, 3), (2, 64, 64, 12, 12, 1)]:
+        x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64).requires_grad_(True)
+        w = torch.randn((Cout, Cin, k, k), generator=g) * 0.1
+        dy = torch.randn((N, Cout, H, W), generator=g)
+        F.conv2d(x, w.double(), padding=k // 2).backward(dy.double())
+        cfg = engine.choose_cfg([Cout], Cin, H, W, taps=k * k, N=N, f32=True)
+        wp = engine.pack_weights(w.cuda(), cfg, 1, split=True)
+        out, _ = engine.conv_forward([engine.Src(_nhwc(dy))], wp, Cin, cfg, taps=k * k, H=H, W=W)
+        assert _rel(_nchw(out), x.grad) < 5e-5, (k, _rel(_nchw(out), x.grad))
+    for (N, Cin, Cout, H, W, k) in [(2, 64, 32, 8, 8, 4), (1, 32, 16, 24, 40, 4), (2, 64, 32, 12, 20, 2)]:
+        x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64).requires_grad_(True)
+        w = torch.randn((Cin, Cout, k, k), generator=g) * 0.1
+        dy = torch.randn((N, Cout, 2 * H, 2 * W), generator=g)
+        F.conv_transpose2d(x, w.double(), None, stride=2, padding=1 if k == 4 else 0).backward(dy.double())
+        cfg = engine.choose_cfg([2 * Cout, 2 * Cout], Cin, H, W, taps=9 if k == 4 else 1, N=N, f32=True)
+        wp = engine.pack_weights(w.cuda(), cfg, 4 if k == 4 else 5, split=True)
+        gy = _nhwc(dy)
+        views = [engine.Src(gy, view=(a * 2 * W * Cout, H, W, 2 * Cout, 4 * W * Cout)) for a in (0, 1)]
+        out, _ = engine.conv_forward(views, wp, Cin, cfg, taps=9 if k == 4 else 1, H=H, W=W)
+        assert _rel(_nchw(out), x.grad) < 5e-5, (k, _rel(_nchw(out), x.grad))
+
+
+def _bn_case(pooled, with_res, two_grads, seed, outmask=False):
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import _lib, trainer
+    g = torch.Generator().manual_seed(seed)
+    N, Cc, H, W = 2, 32, 12, 20
+    raw = torch.randn((N, Cc, H, W), generator=g).requires_grad_(True)
+    res = torch.randn((N, Cc, H, W), generator=g).requires_grad_(True) if with_res else None
+    gamma = (torch.rand((Cc,), generator=g) + 0.5).requires_grad_(True)
+    gamma.data[::4] *= -1
+    beta = (torch.randn((Cc,), generator=g) * 0.2).requires_grad_(True)
+    mean = raw.detach().mean((0, 2, 3))
+    var = raw.detach().var((0, 2, 3), unbiased=False)
+    y = F.batch_norm(raw, None, None, gamma, beta, training=True, eps=1e-5)
+    if with_res:
+        y = y + res
+    a = F.relu(y)
+    total = 0
+    gins = []
+    if pooled:
+        p = F.max_pool2d(a, 2)
+        gp = torch.randn(p.shape, generator=g)
+        total = total + (p * gp).sum()
+        gins.append(trainer._G(_nhwc(gp), p.shape[2], p.shape[3], pooled=1))
+    if two_grads or not pooled:
+        if outmask:
+            gfull = torch.randn((N, Cc, H, W), generator=g)
+            total = total + (a * gfull).sum()
+            gins.append(trainer._G(_nhwc(gfull), H, W))
+        else:
+            ap = F.pad(a, (2, 1, 1, 0))
+            gfull = torch.randn((N, Cc + 16, H + 1, W + 3), generator=g)
+            total = total + (ap * gfull[:, 8:8 + Cc]).sum()
+            gins.append(trainer._G(_nhwc(gfull), H + 1, W + 3, oy=1, ox=2, coff=8, cstride=Cc + 16))
+    total.backward()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = (gamma.detach() * invstd)
+    shift = beta.detach() - mean * scale
+    A = trainer.BnBwdArgs()
+    raw_d = _nhwc(raw.detach())
+    # relu = 2: `res` is the stored post-ReLU output of the unit (the fused residual epilogue), the mask is read from it
+    res_d = (_nhwc(a.detach()) if outmask else _nhwc(res.detach())) if with_res else None
+    A.raw, A.res = raw_d.data_ptr(), (res_d.data_ptr() if with_res else None)
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    sc, sh, mu, iv, gm = dev(scale), dev(shift), dev(mean), dev(invstd), dev(gamma)
+    A.scale, A.shift, A.mean, A.invstd = sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), iv.data_ptr()
+    A.ngin = len(gins)
+    for k, gi in enumerate(gins):
+        A.gin[k].g = gi.t.data_ptr()
+        A.gin[k].Hg, A.gin[k].Wg, A.gin[k].oy, A.gin[k].ox = gi.Hg, gi.Wg, gi.oy, gi.ox
+        A.gin[k].pooled, A.gin[k].coff, A.gin[k].cstride = gi.pooled, gi.coff, gi.cstride or Cc
+    A.f16, A.relu, A.N, A.H, A.W, A.C = 2, (2 if outmask else 1), N, H, W, Cc
+    ws = torch.empty((_lib.load().cdnet_bn_backward_workspace_floats(Cc),), dtype=torch.float32, device='cuda')
+    dgamma, dbeta = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
+    draw = torch.empty((N, H, W, Cc), dtype=torch.float32, device='cuda')
+    dz = torch.empty((N, H, W, Cc), dtype=torch.float32, device='cuda')
+    _lib.call('cdnet_bn_backward', C.byref(A), _lib.ptr(gm), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel(),
+              _lib.ptr(draw), _lib.ptr(dz) if with_res else None, _lib.stream_ptr())
+    assert _rel(_nchw(draw), raw.grad) < 1e-5, ('draw', _rel(_nchw(draw), raw.grad))
+    assert _rel(dgamma.cpu(), gamma.grad) < 1e-5 and _rel(dbeta.cpu(), beta.grad) < 1e-5
+    if with_res:
+        assert _rel(_nchw(dz), res.grad) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(False, False, False), (True, False, False), (True, False, True), (False, True, False),
+                                 (True, True, True)])
+def test_bn_backward_fp32(cfg):
+    _bn_case(*cfg, seed=11)
+
+
+def test_bn_backward_fp32_mask_from_stored_output():
+    _bn_case(False, True, False, seed=12, outmask=True)
+
+
+def test_head_forward_backward_fp32():
+    """DAM head on fp32 features vs PyTorch autograd (float64)"""
+    import torch
+    from cdnet_amd import _lib, runtime, engine
+    from oracle import models as om
+    torch.manual_seed(3)
+    ref = om.Unet().double()
+    N, H, W = 2, 24, 20
+    f = [torch.randn((N, 64, H, W), dtype=torch.float64).requires_grad_(True) for _ in range(3)]
+    # model_unet_rev1.py:258-263
+    x_point = ref.point_conv(f[2])
+    x_dir = ref.direction_conv(ref.directionAtt(f[1], x_point))
+    x_mask = ref.mask_conv(ref.maskAtt(f[0], x_dir))
+    gm, gp, gd = torch.randn(x_mask.shape, dtype=torch.float64), torch.randn(x_point.shape, dtype=torch.float64), torch.randn(x_dir.shape, dtype=torch.float64)
+    ((x_mask * gm).sum() + (x_point * gp).sum() + (x_dir * gd).sum()).backward()
+    ps = [ref.point_conv.weight, ref.direction_conv.weight, ref.mask_conv.weight, ref.point_conv.bias, ref.direction_conv.bias,
+          ref.mask_conv.bias, ref.directionAtt.Conv1x1.weight, ref.maskAtt.Conv1x1.weight]
+    hw = torch.cat([p.detach().reshape(-1).float() for p in ps]).cuda().contiguous()
+    feats = [engine.Src(_nhwc(t.detach())) for t in f]
+    hf = [runtime.head_feat(s) for s in feats]
+    mask = torch.empty((N, 3, H, W), device='cuda'); point = torch.empty((N, 1, H, W), device='cuda'); dirn = torch.empty((N, 9, H, W), device='cuda')
+    _lib.call('cdnet_dam_head_forward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(hw), N, H, W, _lib.ptr(mask), _lib.ptr(point),
+              _lib.ptr(dirn), _lib.stream_ptr())
+    assert _rel(mask.cpu(), x_mask.detach()) < 1e-5 and _rel(point.cpu(), x_point.detach()) < 1e-5 and _rel(dirn.cpu(), x_dir.detach()) < 1e-5
+    df = [torch.empty((N, H, W, 64), dtype=torch.float32, device='cuda') for _ in range(3)]
+    need = _lib.load().cdnet_dam_head_backward_workspace_floats(N, H, W)
+    ws = torch.empty((need,), device='cuda')
+    dhw = torch.zeros((855,), device='cuda')
+    dm, dp, dd = [t.float().cuda().contiguous() for t in (gm, gp, gd)]
+    _lib.call('cdnet_dam_head_backward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(hw), _lib.ptr(dm), _lib.ptr(dp), _lib.ptr(dd),
+              N, H, W, _lib.ptr(df[0]), _lib.ptr(df[1]), _lib.ptr(df[2]), _lib.ptr(ws), ws.numel(), _lib.ptr(dhw), _lib.stream_ptr())
+    for k in range(3):
+        assert _rel(_nchw(df[k]), f[k].grad) < 1e-5, (k, _rel(_nchw(df[k]), f[k].grad))
+    want = torch.cat([p.grad.reshape(-1) for p in ps])
+    assert _rel(dhw.cpu(), want) < 1e-5
