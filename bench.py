@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the CDNet hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--mode train|infer] [--batch B]
+  python bench.py --gpus N --steps K --warmup W [--mode train|infer|image|roofline] [--dtype bf16|fp32] [--batch B]
 
 One rank per GPU (the driver launches N>1 through torch.distributed.run); RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* come
 from the environment.  W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; the step time
 is the max over ranks; rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+
+The line's `value` is the training rate of BASELINE config 2 in the arithmetic named by `dtype`.  Beside it (same protocol,
+fewer steps): `inference` (tiles/s incl. post-processing), `fp32` = the same two rates at the reference's precision (fp32
+activations, split-bf16 x3 MFMA products), `image` = BASELINE config 3 (one 1000x1000 image, 8 TTA views x 25 windows),
+`roofline` (dominant kernel), `roofline_path` (whole-step fractions in SURVEY 8d's units) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -17,7 +22,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DENSE_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16/f16 MFMA
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # ibid.: v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate (no TF32/xf32 on gfx950)
 HBM_PEAK_GBS = 8000.0                # ibid.: 8 TB/s spec (6.3 TB/s measured float4 copy)
+
+# SURVEY.md 8d / BASELINE.md section 3 (forward hooks on the reference modules), per 256x256 tile
+INFER_GFLOP_PER_TILE = 75.06
+TRAIN_GFLOP_PER_TILE = 225.2
+INFER_MB_PER_TILE = {'bf16': 256.2, 'fp32': 512.4}          # activations r+w, conv+BN+ReLU fused per layer
+TRAIN_MB_PER_TILE = {'bf16': 770.0, 'fp32': 1540.0}         # ~3x forward (fwd write, bwd re-read, grad r/w)
+WEIGHT_MB = {'bf16': 41.0, 'fp32': 81.9}                    # read once per batch (inference)
+OPT_MB_PER_STEP = 4 * 81.9                                  # parameter / gradient / Adam-moment traffic per step (fp32 masters in both modes)
+POSTPROC_MB_PER_TILE = 1.835                                # 28 B/pixel
 
 
 def parse():
@@ -25,15 +40,65 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'auto'), choices=['auto', 'train', 'infer', 'roofline'],
+    ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'train'), choices=['auto', 'train', 'infer', 'image', 'roofline'],
                     help="'roofline': only the dominant-kernel measurement of the roofline object (the command profiles/<round>/dominant_conv_* are taken with)")
+    ap.add_argument('--dtype', default=os.environ.get('CDNET_BENCH_DTYPE', 'bf16'), choices=['bf16', 'fp32'],
+                    help='arithmetic of the headline value; the other precision is reported beside it')
     ap.add_argument('--batch', type=int, default=None, help='tiles per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-infer-extra', action='store_true', help='train mode: skip the additional inference timing')
+    ap.add_argument('--no-extras', action='store_true', help='only the headline measurement (+ roofline)')
+    ap.add_argument('--no-infer-extra', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline_infer(n_tiles=2):
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _median_time(fn, warm=2, reps=5, budget_s=60.0):
+    """BASELINE.md section 4 protocol: `warm` warm-ups, then >= `reps` timed repetitions (fewer only if the time budget is
+    exhausted - reported), median wall-clock"""
+    for _ in range(warm):
+        fn()
+    ts, t_all = [], time.time()
+    for _ in range(reps):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+        if time.time() - t_all > budget_s and len(ts) >= 3:
+            break
+    ts.sort()
+    return ts[len(ts) // 2], len(ts)
+
+
+def cpu_baseline_train(n_tiles=4):
+    """The fp32 PyTorch-CPU oracle train iteration (oracle/train.py, pinned to the reference's train_util_dam.train) on a
+    bounded sample of the same synthetic workload."""
+    import torch
+    from cdnet_amd.trainer import synthetic_batch
+    from oracle import models as om
+    from oracle import train as ot
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = om.Unet()
+    opt = ot.make_adam(net)
+    x, lab, dirn, point, weight = [t.cpu() for t in synthetic_batch(n_tiles, torch.device('cpu'))]
+    med, reps = _median_time(lambda: ot.train_iteration(net, opt, x, lab, dirn, point, weight), 2, 5, 75.0)
+    return dict(value=n_tiles / med, unit='tiles/s', cores=cores, kind='port', cpu=cpu_model(), seconds_per_iteration=med,
+                sample='%d synthetic 256x256 tiles per iteration (the workload of the GPU run at batch %d): oracle fp32 PyTorch-CPU train '
+                       'iteration (forward, 5 losses, autograd backward, Adam; %d threads), median of %d repetitions after 2 warm-ups'
+                       % (n_tiles, n_tiles, cores, reps))
+
+
+def cpu_baseline_infer(n_tiles=4):
     """The oracle (PyTorch fp32 CPU network + plain-C post-processing) timed on the host: a bounded sample."""
     import numpy as np
     import torch
@@ -55,27 +120,23 @@ def cpu_baseline_infer(n_tiles=2):
             with np.errstate(all='ignore'):
                 r = orc.fuse_boost_argmax(prob[None], point[i].numpy()[None], ddm[None])
             orc.cc_chain(r['pred'] == 1, 20, 2)
-    run()
-    t0 = time.time()
-    reps = 2
-    for _ in range(reps):
-        run()
-    dt = (time.time() - t0) / reps
-    return dict(value=n_tiles / dt, unit='tiles/s', cores=cores, kind='port',
-                sample='%d synthetic 256x256 tiles: oracle fp32 PyTorch-CPU UNet2RevA1_vgg16 forward (%d threads) + '
-                       'plain-C probmaps/DDM/boost/CC chain (1 thread), %d repetitions' % (n_tiles, cores, reps))
+    med, reps = _median_time(run, 2, 5, 45.0)
+    return dict(value=n_tiles / med, unit='tiles/s', cores=cores, kind='port', cpu=cpu_model(), seconds_per_iteration=med,
+                sample='%d synthetic 256x256 tiles: oracle fp32 PyTorch-CPU UNet2RevA1_vgg16 forward (%d threads) + plain-C '
+                       'probmaps/DDM/boost/CC chain (1 thread), median of %d repetitions after 2 warm-ups' % (n_tiles, cores, reps))
 
 
-def time_dominant_conv(torch, B, steps=20):
+def time_dominant_conv(torch, B, steps=20, precision='bf16'):
     """Average launch duration of the dominant kernel (3x3 conv 64->64 @256x256, the head/stem shape), measured live
     with HIP events on the stream the kernel is launched on (torch's current stream == the ABI stream argument)."""
     from cdnet_amd import engine
+    f32 = precision == 'fp32'
     dev = torch.device('cuda', torch.cuda.current_device())
-    x = (torch.rand((B, 256, 256, 64), device=dev) - 0.3).to(torch.bfloat16)
+    x = (torch.rand((B, 256, 256, 64), device=dev) - 0.3).to(torch.float32 if f32 else torch.bfloat16)
     w = torch.randn((64, 64, 3, 3), device=dev) * 0.06
-    cfg = engine.choose_cfg([64], 64, 256, 256)
-    wp = engine.pack_weights(w, cfg, 0)
-    out = torch.empty((B, 256, 256, 64), dtype=torch.bfloat16, device=dev)
+    cfg = engine.choose_cfg([64], 64, 256, 256, f32=f32)
+    wp = engine.pack_weights(w, cfg, 0, split=f32)
+    out = torch.empty((B, 256, 256, 64), dtype=x.dtype, device=dev)
     for _ in range(3):
         engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -85,44 +146,47 @@ def time_dominant_conv(torch, B, steps=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    esz = 4 if f32 else 2
     flops = 2.0 * B * 256 * 256 * 64 * 64 * 9             # algorithmic: 2*MACs of this layer (forward hooks)
-    alg_bytes = B * 256 * 256 * (64 + 64) * 2             # algorithmic: input read once + output written once, bf16
-    # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 -> the HBM term bounds this layer
-    traffic = None
-    tj = os.path.join(ROOT, 'profiles', 'r01', 'dominant_conv_traffic.json')
-    if os.path.exists(tj) and B == 16:
-        with open(tj) as f:
-            traffic = json.load(f).get('hbm_bytes_per_launch')       # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes
+    alg_bytes = B * 256 * 256 * (64 + 64) * esz           # algorithmic: input read once + output written once
+    # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 bf16 -> the HBM term bounds this layer
+    traffic, traffic_src = None, None
+    for rnd in ('r02', 'r01'):
+        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_traffic.json')
+        if os.path.exists(tj) and B == 16 and not f32:
+            with open(tj) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')   # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes
+            traffic_src = 'profiles/%s/dominant_conv_traffic.json (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % rnd
+            break
     gbs = alg_bytes / ms / 1e6
-    return dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, traffic=traffic,
-                kernel='conv_fwd_kernel<%s> 3x3 64->64 @256x256 x%d tiles' % (','.join(str(c) for c in cfg), B),
+    name = 'conv_f32_kernel' if f32 else 'conv_fwd_kernel'
+    mfma_peak = DENSE_BF16_PEAK_TFLOPS / 3 if f32 else DENSE_BF16_PEAK_TFLOPS
+    return dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, ','.join(str(c) for c in cfg), B), dtype=precision,
                 ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
-                mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / DENSE_BF16_PEAK_TFLOPS)
+                mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / mfma_peak)
 
 
-def cpu_baseline_train(n_tiles=2):
-    """The fp32 PyTorch-CPU oracle train iteration (oracle/train.py, pinned to the reference) on a bounded sample."""
-    import numpy as np
-    import torch
-    from cdnet_amd import synth
-    from cdnet_amd.trainer import synthetic_batch
-    from oracle import models as om
-    from oracle import train as ot
-    cores = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    net = om.Unet()
-    opt = ot.make_adam(net)
-    x, lab, dirn, point, weight = [t.cpu() for t in synthetic_batch(n_tiles, torch.device('cpu'))]
-    ot.train_iteration(net, opt, x, lab, dirn, point, weight)
-    t0 = time.time()
-    reps = 2
-    for _ in range(reps):
-        ot.train_iteration(net, opt, x, lab, dirn, point, weight)
-    dt = (time.time() - t0) / reps
-    return dict(value=n_tiles / dt, unit='tiles/s', cores=cores, kind='port',
-                sample='%d synthetic 256x256 tiles per iteration: oracle fp32 PyTorch-CPU train iteration (forward, 5 losses, '
-                       'autograd backward, Adam; %d threads), %d repetitions after 1 warm-up' % (n_tiles, cores, reps))
+def path_roofline(kind, precision, tiles_per_step, ms_per_step):
+    """Whole-step fraction of roofline in SURVEY 8d's units: roofline_time = max(FLOPs / peak_MFMA(dtype), bytes / peak_HBM) with
+    the algorithmic per-tile figures (every convolution reads its input once and writes its output once)."""
+    if kind == 'train':
+        gflop = TRAIN_GFLOP_PER_TILE * tiles_per_step
+        mb = TRAIN_MB_PER_TILE[precision] * tiles_per_step + OPT_MB_PER_STEP
+    else:
+        gflop = INFER_GFLOP_PER_TILE * tiles_per_step
+        mb = (INFER_MB_PER_TILE[precision] + POSTPROC_MB_PER_TILE) * tiles_per_step + WEIGHT_MB[precision]
+    # fp32 mode: one product = three bf16 MFMAs, so its matrix roof is a third of the bf16 peak (5.3x gfx950's fp32 MFMA peak)
+    peak_tf = DENSE_BF16_PEAK_TFLOPS / 3 if precision == 'fp32' else DENSE_BF16_PEAK_TFLOPS
+    t_flop = gflop / peak_tf                      # ms  (GFLOP / (TFLOP/s) = ms)
+    t_hbm = mb / HBM_PEAK_GBS                     # ms  (MB / (GB/s) = ms)
+    t_roof = max(t_flop, t_hbm)
+    out = dict(frac=t_roof / ms_per_step, bound='mfma' if t_flop > t_hbm else 'hbm', roofline_ms=t_roof, hbm_ms=t_hbm, mfma_ms=t_flop,
+               hbm_frac=t_hbm / ms_per_step, mfma_frac=t_flop / ms_per_step, achieved_GBs=mb / ms_per_step, achieved_TFLOPs=gflop / ms_per_step,
+               algorithmic_MB_per_step=mb, algorithmic_GFLOP_per_step=gflop, peak_GBs=HBM_PEAK_GBS, peak_TFLOPs=peak_tf)
+    if precision == 'fp32':
+        out['vs_fp32_mfma_peak'] = gflop / ms_per_step / FP32_MATRIX_PEAK_TFLOPS
+    return out
 
 
 def main():
@@ -138,101 +202,123 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
-    from cdnet_amd import synth, pipeline
+    import cdnet_amd
+    from cdnet_amd import synth, pipeline, trainer
     from cdnet_amd.models.dam.model_unet_rev1 import Unet
 
-    mode = a.mode
+    mode = 'train' if a.mode == 'auto' else a.mode
     if mode == 'roofline':
         # exactly the measurement that fills the `roofline` object of the normal run, alone in the process, so that
         # `rocprofv3 --kernel-trace --stats -- python3 bench.py --mode roofline` averages this kernel and nothing else
-        print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps)}))
+        print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps, precision=a.dtype)}))
         return
-    if mode == 'auto':
-        try:
-            from cdnet_amd import trainer  # noqa: F401
-            mode = 'train'
-        except ImportError:
-            mode = 'infer'
-    torch.manual_seed(2022)
-    model = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).to(dev)
 
-    if mode == 'infer':
-        B = a.batch or 64
-        model.eval()
-        x = torch.from_numpy(synth.tiles_u8(B, seed=2022 + rank).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
-
-        def step():
-            return pipeline.infer_tiles(model, x)
-        metric = 'tiles/sec inference incl. post-proc, 256x256'
-        workload = 'CDNet UNet2RevA1_vgg16 (UNet+DAM) inference + direction-diff/CC post-processing, 256x256x3 synthetic tiles'
-    else:
-        from cdnet_amd import trainer
-        B = a.batch or 16
-        step, metric, workload = trainer.make_bench_step(model, B, dev, rank, world)
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # the metric names both rates: in the default (train) run also time the inference + post-processing path, same
-    # protocol (warm-up, barrier + synchronize on both sides, max over ranks); reported beside the headline value
-    infer_extra = None
-    if mode == 'train' and not a.no_infer_extra:
-        model.eval()
-        Bi = 64
-        xi = torch.from_numpy(synth.tiles_u8(Bi, seed=4044 + rank).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
-        for _ in range(2):
-            pipeline.infer_tiles(model, xi)
+    def timed(step, steps, warmup):
+        """W warm-ups, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+        for _ in range(warmup):
+            step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ti = time.perf_counter()
-        ni = 5
-        for _ in range(ni):
-            pipeline.infer_tiles(model, xi)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        dti = time.perf_counter() - ti
+        dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dti], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dti = float(t.item())
-        infer_extra = {'metric': 'tiles/sec inference incl. post-proc, 256x256', 'value': world * Bi * ni / dti, 'unit': 'tiles/s',
-                       'ms_per_step': dti / ni * 1e3, 'tiles_per_gpu_per_step': Bi, 'steps': ni}
+            dt = float(t.item())
+        return dt
+
+    def new_model():
+        torch.manual_seed(2022)
+        return Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).to(dev)
+
+    def run_train(precision, B, steps, warmup):
+        cdnet_amd.set_precision(precision)
+        step, metric, workload = trainer.make_bench_step(new_model(), B, dev, rank, world)
+        dt = timed(step, steps, warmup)
+        return dict(metric=metric, workload=workload, value=world * B * steps / dt, ms_per_step=dt / steps * 1e3, tiles=B, steps=steps)
+
+    def run_infer(precision, B, steps, warmup):
+        cdnet_amd.set_precision(precision)
+        model = new_model().eval()
+        x = torch.from_numpy(synth.tiles_u8(B, seed=2022 + rank).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
+        dt = timed(lambda: pipeline.infer_tiles(model, x), steps, warmup)
+        return dict(metric='tiles/sec inference incl. post-proc, 256x256',
+                    workload='CDNet UNet2RevA1_vgg16 (UNet+DAM) inference + direction-diff/CC post-processing, 256x256x3 synthetic tiles',
+                    value=world * B * steps / dt, ms_per_step=dt / steps * 1e3, tiles=B, steps=steps)
+
+    def run_image(precision, steps, warmup):
+        """BASELINE config 3: one 1000x1000 image per rank and step, 8 TTA views x 25 sliding windows (256/40), per-view DDM, CC chain"""
+        cdnet_amd.set_precision(precision)
+        model = new_model().eval()
+        img = torch.from_numpy(np.random.RandomState(2022 + rank).randint(0, 256, size=(3, 1000, 1000)).astype(np.float32) / 255.0).to(dev)
+        dt = timed(lambda: pipeline.infer_image(model, img, tta=True, all_img_test=0, patch_size=256, overlap=40), steps, warmup)
+        return dict(metric='images/sec, 1000x1000 image, 8-view TTA x 25 sliding windows + post-proc',
+                    workload='CDNet inference of 1000x1000 images (BASELINE config 3): 8 TTA views x 25 windows of 256/40, per-view '
+                             'direction-difference maps, boost, CC chain',
+                    value=world * steps / dt, ms_per_step=dt / steps * 1e3, window_evaluations_per_s=world * 200 * steps / dt, steps=steps)
+
+    other = 'fp32' if a.dtype == 'bf16' else 'bf16'
+    extras = not a.no_extras
+    if mode == 'train':
+        B = a.batch or 16
+        head = run_train(a.dtype, B, a.steps, a.warmup)
+    elif mode == 'infer':
+        B = a.batch or 64
+        head = run_infer(a.dtype, B, a.steps, a.warmup)
+    else:
+        B = 1
+        head = run_image(a.dtype, a.steps, a.warmup)
+    kind = 'train' if mode == 'train' else 'infer'
+    line = {
+        'metric': head['metric'], 'value': head['value'], 'unit': 'images/s' if mode == 'image' else 'tiles/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': head['workload'], 'mode': mode, 'tiles_per_gpu_per_step': B, 'global_batch': world * B,
+                   'tile': '1000x1000x3' if mode == 'image' else '256x256x3', 'parallelism': 'dp%d' % world,
+                   'precision': ('bf16/fp16 NHWC activations, bf16 MFMA operands, fp32 accumulation; label-level parity gate vs the fp32 oracle: '
+                                 'tests/test_gpu_label_gate.py' if a.dtype == 'bf16' else
+                                 'fp32 NHWC activations and gradients, each product as three split-bf16 MFMAs, fp32 accumulation')},
+    }
+    rp = {}
+    if mode != 'image':
+        rp[kind + '_' + a.dtype] = path_roofline(kind, a.dtype, B, head['ms_per_step'])
+    if extras and mode == 'train' and not a.no_infer_extra:
+        inf = run_infer(a.dtype, 64, 5, 2)
+        line['inference'] = {'metric': inf['metric'], 'value': inf['value'], 'unit': 'tiles/s', 'ms_per_step': inf['ms_per_step'],
+                             'tiles_per_gpu_per_step': 64, 'steps': 5, 'dtype': a.dtype}
+        rp['infer_' + a.dtype] = path_roofline('infer', a.dtype, 64, inf['ms_per_step'])
+    if extras and mode == 'train' and world == 1:
+        # the same two rates in the other arithmetic, and BASELINE config 3, same protocol with fewer steps
+        ksteps = max(5, a.steps // 2)
+        t2 = run_train(other, B, ksteps, 2)
+        i2 = run_infer(other, 64, 5, 2)
+        line[other] = {'value': t2['value'], 'unit': 'tiles/s', 'ms_per_step': t2['ms_per_step'], 'steps': ksteps, 'warmup': 2,
+                       'tiles_per_gpu_per_step': B, 'dtype': other,
+                       'inference': {'value': i2['value'], 'unit': 'tiles/s', 'ms_per_step': i2['ms_per_step'], 'tiles_per_gpu_per_step': 64, 'steps': 5}}
+        rp['train_' + other] = path_roofline('train', other, B, t2['ms_per_step'])
+        rp['infer_' + other] = path_roofline('infer', other, 64, i2['ms_per_step'])
+        im = run_image(a.dtype, 3, 1)
+        im2 = run_image(other, 3, 1)
+        line['image'] = {'metric': im['metric'], 'value': im['value'], 'unit': 'images/s', 'ms_per_image': im['ms_per_step'],
+                         'window_evaluations_per_s': im['window_evaluations_per_s'], 'steps': 3, 'warmup': 1, 'dtype': a.dtype,
+                         other: {'value': im2['value'], 'ms_per_image': im2['ms_per_step']}}
+    if rp:
+        line['roofline_path'] = rp
     if rank == 0:
-        roof = time_dominant_conv(torch, 16)
-        line = {
-            'metric': metric, 'value': world * B * a.steps / dt, 'unit': 'tiles/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': workload, 'mode': mode, 'tiles_per_gpu_per_step': B, 'global_batch': world * B,
-                       'tile': '256x256x3', 'parallelism': 'dp%d' % world},
-            'roofline': roof,
-        }
-        if infer_extra is not None:
-            line['inference'] = infer_extra
+        cdnet_amd.set_precision(a.dtype)
+        line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype)
+        if extras and world == 1:
+            line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)
         if not a.no_cpu_baseline and world == 1:
-            if mode == 'infer':
-                line['cpu_baseline'] = cpu_baseline_infer()
-            else:
-                line['cpu_baseline'] = cpu_baseline_train()
+            line['cpu_baseline'] = cpu_baseline_infer() if mode == 'infer' else cpu_baseline_train()
         print(json.dumps(line))
     if world > 1:
         dist.barrier()                    # rank 0 times the roofline kernel after the timed region: leave together

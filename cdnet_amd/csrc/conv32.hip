@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // register staging types (HIP's float4 / uint4 structs defeat SROA)
 
 namespace {
 
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs A) {
     const unsigned short *wbase = A.w + ((size_t)(par * gridDim.y + cout_tile) * A.nchunk) * (size_t)(L::B_PLANE);      // u16 elements: 2 planes x B_PLANE/2
 
     // register prefetch of one chunk: halo vectors (two float4 each) and the weight image
-    float4 pa[NA][2];
-    uint4 pb[NB];
+    f32x4 pa[NA][2];
+    u32x4 pb[NB];
     auto issue = [&](int chunk) {
         int si, cc0;
         chunk_src(chunk, si, cc0);
@@ -139,11 +140,11 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs A) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = si ? eoff[1][i] : eoff[0][i];
-            const float4 *p = reinterpret_cast<const float4 *>(base + (e >= 0 ? e : 0));
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(base + (e >= 0 ? e : 0));
             pa[i][0] = p[0];
             pa[i][1] = p[1];
         }
-        const uint4 *wsrc = reinterpret_cast<const uint4 *>(wbase + (size_t)chunk * L::B_PLANE);
+        const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(wbase + (size_t)chunk * L::B_PLANE);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int v = tid + i * 256;
@@ -161,14 +162,14 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs A) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
         }
-        float4 rr[NA][2];
+        f32x4 rr[NA][2];
         if (s.res) {
             const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
             const float *rbase = reinterpret_cast<const float *>(s.res) + (size_t)n * s.Hs * rs + cc0;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int e = si ? eoff[1][i] : eoff[0][i];
-                const float4 *p = reinterpret_cast<const float4 *>(rbase + (e >= 0 ? e : 0));
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(rbase + (e >= 0 ? e : 0));
                 rr[i][0] = p[0];
                 rr[i][1] = p[1];
             }
@@ -180,13 +181,13 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs A) {
             const int e = si ? eoff[1][i] : eoff[0][i];
             u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
             if (e >= 0) {
-                float v[8] = {pa[i][0].x, pa[i][0].y, pa[i][0].z, pa[i][0].w, pa[i][1].x, pa[i][1].y, pa[i][1].z, pa[i][1].w};
+                float v[8] = {pa[i][0][0], pa[i][0][1], pa[i][0][2], pa[i][0][3], pa[i][1][0], pa[i][1][1], pa[i][1][2], pa[i][1][3]};
                 if (on) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
                 }
                 if (s.res) {
-                    const float r[8] = {rr[i][0].x, rr[i][0].y, rr[i][0].z, rr[i][0].w, rr[i][1].x, rr[i][1].y, rr[i][1].z, rr[i][1].w};
+                    const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += r[j];
                 }
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs A) {
             *reinterpret_cast<u32x4 *>(d) = hi;
             *reinterpret_cast<u32x4 *>(d + L::A_PLANE) = lo;
         }
-        uint4 *bdst = reinterpret_cast<uint4 *>(lds_b);
+        u32x4 *bdst = reinterpret_cast<u32x4 *>(lds_b);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int v = tid + i * 256;

@@ -526,6 +526,7 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
 // ------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float wg_f32x2;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
 
 __device__ __forceinline__ void wg_split8(const float *v, u32x4 &hi, u32x4 &lo) {
 #pragma unroll
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = s_xf[slot_a * 8 + j]; sh[j] = s_xf[CI + slot_a * 8 + j]; }
 
-    float4 pa_[NA][2], pg_[NG][2];
+    wg_f32x4 pa_[NA][2], pg_[NG][2];
     int ea[NA];                          // element offset of the thread's i-th input vector, -1 = zero fill (tensors < 2^31 elements)
     unsigned gvalid = 0;
     auto issue = [&](int j) {
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
             const bool ok = v < NPIX_A * VA && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
                             (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
             ea[i] = ok ? (int)((size_t)n * s.Hs * rs + (size_t)ys * rs + (size_t)xs * s.C + cbase) : -1;
-            const float4 *pp = reinterpret_cast<const float4 *>(sx + (ok ? ea[i] : 0));
+            const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sx + (ok ? ea[i] : 0));
             pa_[i][0] = pp[0];
             pa_[i][1] = pp[1];
         }
@@ -630,18 +631,18 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
             const int y = y0 + pix / TW, x = x0 + pix % TW;
             const bool ok = cok_g && y < A.H && x < A.W;
             const size_t e = ok ? (((size_t)n * Ho + (y * A.ostride + pa)) * Wo + (x * A.ostride + pb)) * A.Cout + co : 0;
-            const float4 *pp = reinterpret_cast<const float4 *>(gx + e);
+            const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(gx + e);
             pg_[i][0] = pp[0];
             pg_[i][1] = pp[1];
             gvalid |= (ok ? 1u : 0u) << i;
         }
     };
     auto commit = [&]() {
-        float4 rr[NA][2];
+        wg_f32x4 rr[NA][2];
         if (sr) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const float4 *pp = reinterpret_cast<const float4 *>(sr + (ea[i] >= 0 ? ea[i] : 0));
+                const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sr + (ea[i] >= 0 ? ea[i] : 0));
                 rr[i][0] = pp[0];
                 rr[i][1] = pp[1];
             }
@@ -652,13 +653,13 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
             if (v >= NPIX_A * VA) continue;
             u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
             if (ea[i] >= 0) {
-                float x[8] = {pa_[i][0].x, pa_[i][0].y, pa_[i][0].z, pa_[i][0].w, pa_[i][1].x, pa_[i][1].y, pa_[i][1].z, pa_[i][1].w};
+                float x[8] = {pa_[i][0][0], pa_[i][0][1], pa_[i][0][2], pa_[i][0][3], pa_[i][1][0], pa_[i][1][1], pa_[i][1][2], pa_[i][1][3]};
                 if (on) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], sc[j], sh[j]);
                 }
                 if (sr) {
-                    const float r[8] = {rr[i][0].x, rr[i][0].y, rr[i][0].z, rr[i][0].w, rr[i][1].x, rr[i][1].y, rr[i][1].z, rr[i][1].w};
+                    const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] += r[j];
                 }
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
             const int pix = tid / VG + i * (NT32 / VG);
             u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
             if (gvalid & (1u << i)) {
-                const float x[8] = {pg_[i][0].x, pg_[i][0].y, pg_[i][0].z, pg_[i][0].w, pg_[i][1].x, pg_[i][1].y, pg_[i][1].z, pg_[i][1].w};
+                const float x[8] = {pg_[i][0][0], pg_[i][0][1], pg_[i][0][2], pg_[i][0][3], pg_[i][1][0], pg_[i][1][1], pg_[i][1][2], pg_[i][1][3]};
                 wg_split8(x, hi, lo);
             }
             unsigned char *d = smem + 2 * A_BYTES + pix * PG + slot_g * 16;
