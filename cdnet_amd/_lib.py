@@ -28,6 +28,7 @@ SIGNATURES = {
     'cdnet_remap_label': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_watershed_workspace_bytes': (_sz, [_i, _i, _i]),
     'cdnet_watershed_process': (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'cdnet_fill_label_process': (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     'cdnet_cc_workspace_bytes': (_sz, [_i, _i, _i]),
     'cdnet_cc_chain': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_conv_packed_weight_elems': (_sz, [_i] * 6),

@@ -39,10 +39,12 @@ def save_checkpoint(state, epoch, is_best, save_dir, branch_value, cp_flag):
     return filename
 
 
-def load_checkpoint(path, model, trainer=None, strict=True):
+def load_checkpoint(path, model, trainer=None, strict=True, trusted_pickle=False):
     """Load a checkpoint written by the reference or by save_checkpoint.  Returns the checkpoint dict (epoch, best_iou, ...).
-    Keys with or without the DataParallel prefix are accepted (test_dam.py:163-165 loads with strict=False)."""
-    ck = torch.load(path, map_location='cpu', weights_only=False)
+    Keys with or without the DataParallel prefix are accepted (test_dam.py:163-165 loads with strict=False).
+    The interchange format holds only tensors, numbers, strings and containers of them, so the file is read with
+    `weights_only=True`; `trusted_pickle=True` opts into full unpickling for legacy files from a trusted source."""
+    ck = torch.load(path, map_location='cpu', weights_only=not trusted_pickle)
     sd = ck['state_dict'] if 'state_dict' in ck else ck
     sd = {(k[len(PREFIX):] if k.startswith(PREFIX) else k): v for k, v in sd.items()}
     model.load_state_dict(sd, strict=strict)

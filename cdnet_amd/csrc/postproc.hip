@@ -923,6 +923,11 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int *__restrict__ L,
     }
 }
 
+__global__ __launch_bounds__(256) void ws_binarize_kernel(const uint8_t *__restrict__ in, int plane, uint8_t *__restrict__ out) {
+    const size_t base = (size_t)blockIdx.y * plane;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256) out[base + i] = in[base + i] ? 1 : 0;
+}
+
 size_t ws_layout(int N, int H, int W, size_t o[10]) {
     const size_t P = (size_t)N * H * W;
     size_t off = 0;
@@ -996,4 +1001,41 @@ extern "C" int cdnet_watershed_process(const uint8_t *pred, int N, int H, int W,
     ws_hist_kernel<<<gl, 256, 0, st>>>(labels, plane, hb);
     ws_drop_small_kernel<<<gl, 256, 0, st>>>(labels, hb, plane, min_size);
     return check_launch("cdnet_watershed_process");
+}
+
+// postproc_other.process, ws = False branch (postproc_other.py:49-52; forced for model_mode 'unet' / 'micronet', :35):
+//   scipy.ndimage.binary_fill_holes -> measurements.label (4-connected, ids in raster order of each component's first pixel)
+//   -> skimage remove_small_objects on the LABEL image (labels with fewer than min_size pixels become 0, ids are kept).
+// Same workspace as the watershed variant.
+extern "C" int cdnet_fill_label_process(const uint8_t *pred, int N, int H, int W, int min_size, void *workspace, size_t workspace_bytes,
+                                        int32_t *labels, void *stream) {
+    CDNET_REQUIRE(pred && labels && workspace, "cdnet_fill_label_process: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0 && (size_t)H * W < (1u << 30), "cdnet_fill_label_process: bad size");
+    size_t o[10];
+    const size_t need = ws_layout(N, H, W, o);
+    if (workspace_bytes < need) { set_error("cdnet_fill_label_process: workspace %zu < %zu bytes", workspace_bytes, need); return CDNET_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int *L2 = (int *)(ws + o[1]), *aux = (int *)(ws + o[2]), *hb = (int *)(ws + o[3]), *chunk = (int *)(ws + o[9]);
+    uint8_t *m = (uint8_t *)(ws + o[7]), *m2 = (uint8_t *)(ws + o[8]);
+    const int plane = H * W, nchunk = cdiv(plane, CHUNK);
+    const size_t P = (size_t)N * plane;
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    const dim3 gl(grid_lin(plane), N);
+    ws_binarize_kernel<<<gl, 256, 0, st>>>(pred, plane, m);                           // non-zero -> 1
+    // fill holes: 4-connected components of the background, those touching the border stay background
+    cc_init_kernel<0><<<gr, br, 0, st>>>(m, 1, H, W, L2);
+    cc_merge_kernel<0, 4><<<gr, br, 0, st>>>(m, 1, H, W, L2);
+    cc_flatten_kernel<false><<<gr, br, 0, st>>>(H, W, L2, nullptr);
+    fill_mark_border_kernel<<<dim3(cdiv(2 * (H + W), 256), N), 256, 0, st>>>(H, W, L2);
+    fill_output_kernel<<<gl, 256, 0, st>>>(m, 1, plane, L2, m2);
+    label4_roots(m2, N, H, W, L2, st);
+    cc_count_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L2, plane, nchunk, chunk);
+    cc_scan_chunks_kernel<<<N, 256, 0, st>>>(nchunk, chunk, nullptr);
+    cc_rank_roots_kernel<<<dim3(nchunk, N), 256, 0, st>>>(L2, plane, nchunk, chunk, aux);
+    cc_relabel_kernel<<<gl, 256, 0, st>>>(L2, aux, plane, labels);
+    if (hipMemsetAsync(hb, 0, P * 4, st) != hipSuccess) return check_launch("memset");
+    ws_hist_kernel<<<gl, 256, 0, st>>>(labels, plane, hb);
+    ws_drop_small_kernel<<<gl, 256, 0, st>>>(labels, hb, plane, min_size);
+    return check_launch("cdnet_fill_label_process");
 }

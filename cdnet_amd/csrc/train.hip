@@ -414,6 +414,94 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
     }
 }
 
+// fp32 variants of the flat kernels: 4 channels per thread (one float4 per tensor and pixel), BN_U pixels in flight, plain
+// fp32 arithmetic (no 16-bit rounding of the activation); relu == 2 reads the mask from the stored output in `res`.
+typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load4(const float *p, int c0, float *o, float dflt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = p ? p[c0 + j] : dflt;
+}
+
+template <int NG, bool RES, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_flat32_kernel(BnBwdArgs A) {
+    __shared__ float s_red[APPLY ? 1 : 256][9];
+    const int VPP = A.C / 4;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 4;
+    float sc[4], sh[4], mu[4], is[4], k1[4], k2[4], k3[4], s1[4], s2[4];
+    load4(A.scale, c0, sc, 1.f); load4(A.shift, c0, sh, 0.f); load4(A.mean, c0, mu, 0.f); load4(A.invstd, c0, is, 1.f);
+    if (APPLY) { load4(A.k1, c0, k1, 1.f); load4(A.k2, c0, k2, 0.f); load4(A.k3, c0, k3, 0.f); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const unsigned npix = (unsigned)(A.N * A.H * A.W);
+    const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
+    const bool relu = A.relu != 0, outmask = A.relu == 2;
+    const float *raw = reinterpret_cast<const float *>(A.raw), *resp = reinterpret_cast<const float *>(A.res);
+    float *draw = reinterpret_cast<float *>(A.draw), *dzo = reinterpret_cast<float *>(A.dz_out);
+    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
+        bn_f32x4 x[BN_U], r[BN_U], g[BN_U][NG];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            unsigned p = p0 + u * step;
+            p = p < npix ? p : npix - 1;
+            if (APPLY && A.rev) p = npix - 1 - p;
+            x[u] = *reinterpret_cast<const bn_f32x4 *>(raw + (size_t)p * A.C + c0);
+            if (RES) r[u] = *reinterpret_cast<const bn_f32x4 *>(resp + (size_t)p * A.C + c0);
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+                g[u][k] = *reinterpret_cast<const bn_f32x4 *>(reinterpret_cast<const float *>(A.gin[k].g) + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const unsigned p = p0 + u * step;
+            const bool valid = p < npix;
+            bn_f32x4 o, z;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = fmaf(x[u][j], sc[j], sh[j]);
+                if (RES) v = outmask ? r[u][j] : v + r[u][j];
+                float gs = g[u][0][j];
+#pragma unroll
+                for (int k = 1; k < NG; ++k) gs += g[u][k][j];
+                const float dz = (!valid || (relu && !(v > 0.f))) ? 0.f : gs;
+                const float xh = (x[u][j] - mu[j]) * is[j];
+                if (APPLY) { o[j] = k1[j] * (dz - k2[j] - xh * k3[j]); z[j] = dz; }
+                else { s1[j] += dz; s2[j] = fmaf(dz, xh, s2[j]); }
+            }
+            if (APPLY && valid) {
+                const unsigned pw = A.rev ? npix - 1 - p : p;
+                *reinterpret_cast<bn_f32x4 *>(draw + (size_t)pw * A.C + c0) = o;
+                if (RES) *reinterpret_cast<bn_f32x4 *>(dzo + (size_t)pw * A.C + c0) = z;
+            }
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_red[tid][j] = s1[j]; s_red[tid][4 + j] = s2[j]; }
+        __syncthreads();
+        for (int q = tid; q < 8 * VPP; q += 256) {
+            const int sl = q % VPP, j = q / VPP;
+            float t = 0.f;
+            for (int k = sl; k < 256; k += VPP) t += s_red[k][j];
+            float *op = A.partial + (size_t)blockIdx.x * 2 * A.C;
+            op[(j >> 2) * A.C + sl * 4 + (j & 3)] = t;
+        }
+    }
+}
+
+template <bool APPLY>
+static void launch_flat32(const BnBwdArgs &A, int nb, hipStream_t st) {
+    switch (A.ngin * 2 + (A.res ? 1 : 0)) {
+        case 2: bn_bwd_flat32_kernel<1, false, APPLY><<<nb, 256, 0, st>>>(A); break;
+        case 3: bn_bwd_flat32_kernel<1, true, APPLY><<<nb, 256, 0, st>>>(A); break;
+        case 4: bn_bwd_flat32_kernel<2, false, APPLY><<<nb, 256, 0, st>>>(A); break;
+        case 5: bn_bwd_flat32_kernel<2, true, APPLY><<<nb, 256, 0, st>>>(A); break;
+        case 6: bn_bwd_flat32_kernel<3, false, APPLY><<<nb, 256, 0, st>>>(A); break;
+        default: bn_bwd_flat32_kernel<3, true, APPLY><<<nb, 256, 0, st>>>(A); break;
+    }
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     __shared__ float s_red[256][17];
@@ -861,16 +949,27 @@ struct LossIn {
     int quirk0;                              // mask the direction one-hot with SAMPLE 0's foreground (:139)
 };
 
-__global__ void loss_single_kernel(const unsigned char *dirlab, int P, int *single) {
-    __shared__ int s_min[256], s_max[256];
+// per sample: is the direction label constant (the one-hot of a single class, train_util_dam.py:131-137)?  The same scan
+// validates the label content: a mask class > 2 or a direction class > 8 would index past the per-class accumulators, so
+// it raises *err (the finalize kernel then poisons every loss with NaN - the reference's NLLLoss fails loudly on such targets)
+// and the accumulation kernels clamp their indices.
+__global__ void loss_single_kernel(const unsigned char *dirlab, const unsigned char *label, int P, int *single, int *err) {
+    __shared__ int s_min[256], s_max[256], s_lmax[256];
     const unsigned char *d = dirlab + (size_t)blockIdx.x * P;
-    int mn = 255, mx = 0;
-    for (int i = threadIdx.x; i < P; i += 256) { int v = d[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-    s_min[threadIdx.x] = mn; s_max[threadIdx.x] = mx;
+    const unsigned char *l = label + (size_t)blockIdx.x * P;
+    int mn = 255, mx = 0, lm = 0;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        int v = d[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+        v = l[i]; lm = v > lm ? v : lm;
+    }
+    s_min[threadIdx.x] = mn; s_max[threadIdx.x] = mx; s_lmax[threadIdx.x] = lm;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 256; ++i) { mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; }
+        for (int i = 1; i < 256; ++i) {
+            mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; lm = s_lmax[i] > lm ? s_lmax[i] : lm;
+        }
         single[blockIdx.x] = (mn == mx) ? 1 : 0;
+        if (mx > 8 || lm > 2) atomicOr(err, 1);
     }
 }
 
@@ -898,7 +997,8 @@ __device__ __forceinline__ void softmax9(const float *l, float *p, float *logp) 
 // target class of the weighted dice for pixel i of sample b: -1 = all nine one-hot channels are zero
 __device__ __forceinline__ int dice_target(const LossIn &L, int b, int i) {
     if (L.single[b]) return 0;
-    const int t = L.dirlab[(size_t)b * L.P + i];
+    int t = L.dirlab[(size_t)b * L.P + i];
+    t = t > 8 ? 8 : t;
     if (L.quirk0) return L.label[i] != 0 ? t : -1;               // sample 0's label
     return L.label[(size_t)b * L.P + i] != 0 ? t : -1;
 }
@@ -919,7 +1019,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossIn L, float *__res
         softmax3(l3, p3, lp3);
         softmax9(l9, p9, lp9);
         const float w = (float)L.weight[ob + i] / 20.f;
-        const int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        lab = lab > 2 ? 2 : lab; dl = dl > 8 ? 8 : dl;           // (out-of-range content is reported through *err, see loss_single_kernel)
         acc[lab][tid] += p3[lab];
         acc[6 + lab][tid] += 1.f;
 #pragma unroll
@@ -964,7 +1065,7 @@ constexpr int K_COEF = 6 + 36;
 // single block: per-sample sums -> loss terms (5 + total) and the pass-2 coefficients
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int nchunk, int B, int P,
                                                             float *__restrict__ sums, float *__restrict__ coef,
-                                                            float *__restrict__ losses) {
+                                                            float *__restrict__ losses, const int *__restrict__ err) {
     __shared__ float s_sum[64 * K_SUMS];      // B <= 64
     const int tid = threadIdx.x;
     for (int idx = tid; idx < B * K_SUMS; idx += 256) {
@@ -1055,6 +1156,9 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
             m[4] += 2 * precision * recall / (precision + recall + 1e-10);
         }
         for (int k = 0; k < 5; ++k) losses[6 + k] = (float)(m[k] / B);
+        if (*err) {                          // label content out of range: no silent garbage
+            for (int k = 0; k < 11; ++k) losses[k] = __builtin_nanf("");
+        }
     }
 }
 
@@ -1074,7 +1178,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossIn L, const float *_
         softmax3(l3, p3, lp3);
         softmax9(l9, p9, lp9);
         const float w = (float)L.weight[ob + i] / 20.f;
-        const int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        lab = lab > 2 ? 2 : lab; dl = dl > 8 ? 8 : dl;           // (out-of-range content is reported through *err, see loss_single_kernel)
         // mask: dice gradient w.r.t. probabilities, through the softmax, plus the weighted CE
         float gp[3], dot = 0.f;
 #pragma unroll
@@ -1296,8 +1401,15 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     A.rev = rev;
     bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
     CDNET_REQUIRE(A.relu != 2 || (flat && A.res), "cdnet_bn_backward: relu = 2 (mask from the stored output) needs same-size gradient sources and res");
-    const bool f32 = A.f16 == 2;                      // fp32 tensors: the generic kernels (every routing case, plain fp32 arithmetic)
+    const bool f32 = A.f16 == 2;                      // fp32 tensors: flat32 kernels (same-size sources) or the generic ones (pool / pad routing)
+    const bool flat32 = f32 && flat && A.C <= 1024;
     if (f32) { window = false; flat = false; }
+    if (flat32) {
+        const int ppb4 = 256 / (A.C / 4);
+        nb = (int)((npix + (size_t)ppb4 * BN_U - 1) / ((size_t)ppb4 * BN_U));
+        if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+        if (nb < 1) nb = 1;
+    }
     if (A.mean) {
         CDNET_REQUIRE(gamma && A.invstd && workspace, "cdnet_bn_backward: BatchNorm layer needs gamma/invstd/workspace");
         const size_t need = (size_t)nb * 2 * A.C + 3 * (size_t)A.C;
@@ -1317,7 +1429,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
                 case 6: bn_bwd_reduce_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
                 default: bn_bwd_reduce_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
             }
-        } else if (f32) bn_bwd_reduce_kernel<true><<<nb, 256, 0, st>>>(A);
+        } else if (flat32) launch_flat32<false>(A, nb, st);
+        else if (f32) bn_bwd_reduce_kernel<true><<<nb, 256, 0, st>>>(A);
         else bn_bwd_reduce_kernel<false><<<nb, 256, 0, st>>>(A);
         bn_bwd_finalize_kernel<<<A.C, 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
                                                               k + A.C, k + 2 * A.C);
@@ -1336,7 +1449,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
             case 6: bn_bwd_apply_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
             default: bn_bwd_apply_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
         }
-    } else if (f32) bn_bwd_apply_kernel<true><<<nb, 256, 0, st>>>(A);
+    } else if (flat32) launch_flat32<true>(A, nb, st);
+    else if (f32) bn_bwd_apply_kernel<true><<<nb, 256, 0, st>>>(A);
     else bn_bwd_apply_kernel<false><<<nb, 256, 0, st>>>(A);
     return check_launch("cdnet_bn_backward");
 }
@@ -1393,14 +1507,16 @@ extern "C" int cdnet_dam_loss(const float *mask, const float *point, const float
     float *partial = workspace;
     float *coef = partial + (size_t)B * nchunk * K_SUMS;
     float *sums = coef + (size_t)B * K_COEF;
+    int *err = reinterpret_cast<int *>(sums + (size_t)B * K_SUMS);          // first word of the 16-float pad
     int *single = reinterpret_cast<int *>(sums + (size_t)B * K_SUMS + 16);
     hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return check_launch("cdnet_dam_loss(memset)");
     LossIn L;
     L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.point_t = point_target_f16;
     L.weight = weight_u8; L.single = single; L.B = B; L.P = P; L.quirk0 = quirk_sample0;
-    loss_single_kernel<<<B, 256, 0, st>>>(dirlab, P, single);
+    loss_single_kernel<<<B, 256, 0, st>>>(dirlab, label, P, single, err);
     loss_reduce_kernel<<<dim3(nchunk, B), 256, 0, st>>>(L, partial);
-    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, nchunk, B, P, sums, coef, losses);
+    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, nchunk, B, P, sums, coef, losses, err);
     if (dmask) {
         CDNET_REQUIRE(dpoint && ddir, "cdnet_dam_loss: all three gradient outputs or none");
         loss_grad_kernel<<<dim3(lin_grid((size_t)P, 256), B), 256, 0, st>>>(L, coef, dmask, dpoint, ddir);

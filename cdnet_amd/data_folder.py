@@ -112,6 +112,15 @@ class TileBatches:
         if unknown:
             raise NotImplementedError('transforms {} are outside the accelerated input pipeline'.format(unknown))
         self.items = [[np.asarray(im) for im in dataset.load(i)] for i in range(len(dataset))]      # decoded once, kept on the host
+        for k, it in enumerate(self.items):
+            lab = it[2] if it[2].ndim == 2 else it[2][:, :, 0]
+            if len(np.unique(lab)) > 2:
+                # LabelEncoding's `label_level_len > 2` branch (my_transforms_direction.py:752-760: instance-level labels, boundary from
+                # per-instance dilation / erosion, instances through postproc_other.process) is not on the device path: cast to
+                # uint8 and thresholded, such a label would silently give wrong targets
+                raise NotImplementedError('label image %d holds %d distinct values: instance-level labels (the reference\'s <label_dir>/train_ins '
+                                          'layout) are not supported by the device input pipeline - supply the 3-class label PNGs'
+                                          % (k, len(np.unique(lab))))
 
     def __len__(self):
         n = len(self.items)

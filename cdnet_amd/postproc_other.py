@@ -2,9 +2,10 @@
 
 Same signature as the reference: `process(pred, model_mode, min_size=10, ws=True) -> labels`.  `pred` is a numpy HW
 probability / binary map (or a torch CUDA tensor [H,W] / [N,H,W]); the result has the input's container type.  Modes:
-every non-'dcan' mode of the reference; 'unet' / 'micronet' force ws=False exactly like postproc_other.py:35 (that
-branch is fill holes -> 4-connected label -> remove small, served by the same kernels).  The 'dcan' contour branch and
-micronet's per-instance re-dilation are outside the hot path and raise NotImplementedError.
+every non-'dcan' mode of the reference; 'unet' forces ws=False exactly like postproc_other.py:35 - that branch (fill holes ->
+4-connected label -> remove small labels, :49-52) is `cdnet_fill_label_process`, built from the kernels of the watershed
+entry's marker stage.  The 'dcan' contour branch and micronet's per-instance re-dilation are outside the hot path (SURVEY 8a
+row 16) and raise NotImplementedError.
 All compute runs in csrc/postproc.hip; there is no CPU fallback."""
 import numpy as np
 import torch
@@ -28,6 +29,18 @@ def watershed_process(pred_u8, min_size=10, stages=False):
     return (labels, dist, marker) if stages else labels
 
 
+def fill_label_process(pred_u8, min_size=10):
+    """ws=False branch on the device: pred_u8 torch.uint8 CUDA [N,H,W], non-zero = foreground -> labels int32 [N,H,W]"""
+    assert pred_u8.is_cuda and pred_u8.dtype == torch.uint8 and pred_u8.dim() == 3
+    pred_u8 = pred_u8.contiguous()
+    N, H, W = pred_u8.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.cdnet_watershed_workspace_bytes(N, H, W),), dtype=torch.uint8, device=pred_u8.device)
+    labels = torch.empty((N, H, W), dtype=torch.int32, device=pred_u8.device)
+    _lib.call('cdnet_fill_label_process', _lib.ptr(pred_u8), N, H, W, int(min_size), _lib.ptr(ws), ws.numel(), _lib.ptr(labels), _lib.stream_ptr())
+    return labels
+
+
 def process(pred, model_mode, min_size=10, ws=True):
     if model_mode == 'dcan':
         raise NotImplementedError("postproc_other.process: the 'dcan' contour branch is outside the accelerated path")
@@ -45,10 +58,7 @@ def process(pred, model_mode, min_size=10, ws=True):
     if ws:
         out = watershed_process(binary, min_size)
     else:
-        # :50-53  binary_fill_holes -> measurements.label (4-connected) -> remove_small_objects: the marker stage of the
-        # watershed entry point is exactly this chain applied to its thresholded distance map, so feed the mask through a
-        # dedicated call of the same kernels
-        raise NotImplementedError('ws=False branch: use cdnet_amd.postproc.cc_chain (test_dam.py path)')
+        out = fill_label_process(binary, min_size)                     # :49-52
     if squeeze:
         out = out[0]
     return out.cpu().numpy() if is_np else out

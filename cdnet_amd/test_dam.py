@@ -78,6 +78,12 @@ def main(argv=None):
     model = utils.chooseModel(opt).cuda()
     if os.path.exists(opt.test['model_path']):
         checkpoint.load_checkpoint(opt.test['model_path'], model, strict=False)      # DataParallel prefix (test_dam.py:158-167)
+    elif os.environ.get('CDNET_ALLOW_RANDOM_WEIGHTS') == '1':
+        print("=> no checkpoint at '{}': evaluating RANDOM weights (CDNET_ALLOW_RANDOM_WEIGHTS=1)".format(opt.test['model_path']))
+    else:
+        # the reference's torch.load raises here (test_dam.py:158); a mistyped path must not produce plausible-looking metrics
+        raise FileNotFoundError("checkpoint '{}' not found (set CDNET_ALLOW_RANDOM_WEIGHTS=1 to evaluate an untrained model)"
+                                .format(opt.test['model_path']))
     model.eval()
     img_dir, label_dir = opt.test['img_dir'], opt.test['label_dir']
     names = sorted(f for f in os.listdir(img_dir) if f.endswith('.png')) if os.path.isdir(img_dir) else []

@@ -69,6 +69,7 @@ def main(argv=None):
             opt.train['start_epoch'] = ck.get('epoch', 0)
             best_iou, best_loss = ck.get('best_iou', best_iou), ck.get('best_loss', best_loss)
             logger.info("=> loaded checkpoint '{}' (epoch {})".format(opt.train['checkpoint'], opt.train['start_epoch']))
+            trainer.sync_from_rank0()                      # every replica continues from rank 0's file
         else:
             logger.info("=> no checkpoint found at '{}'".format(opt.train['checkpoint']))
     B = opt.train['batch_size']
@@ -89,7 +90,7 @@ def main(argv=None):
             tot = np.zeros(3)
             for x, w, target0, _, _ in loader:
                 tot += trainer.train_step(x, train_util_dam._label3(target0), w[:, 0].contiguous()).cpu().numpy()
-            res = tot / len(loader)
+            res = trainer.reduce_scalars(tot / len(loader))
         else:
             res = train_util_dam.train(loader, model, trainer, None, epoch, opt, logger)
         torch.cuda.synchronize()

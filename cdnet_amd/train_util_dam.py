@@ -24,8 +24,14 @@ def _label3(target0, boundary=2):
         lab[t[:, 2] == mx] = boundary
         return lab
     t = t[:, 0] if t.dim() == 4 else t
-    if int(t.max()) == 255:
+    mx = int(t.max())
+    if mx == 255:
         t = t // int(255 / 2)                             # :107-108
+    elif mx > 2:
+        # e.g. a {0, 127} batch: the reference divides only when the batch maximum is 255 (:107) and its NLLLoss then raises on
+        # class 127 ("Target 127 is out of bounds"); fail as loudly here instead of handing the value to the loss kernel
+        raise ValueError('label values %s are neither {0,1,2} nor the {0,127/128,255} encoding (batch maximum %d)'
+                         % (torch.unique(t).tolist()[:8], mx))
     return t.to(torch.uint8)
 
 
@@ -50,6 +56,8 @@ def train(train_loader, model, optimizer, criterion, epoch, opt, logger, get_pro
             logger.info('\tIteration: [{:d}/{:d}]\tLoss {r[0]:.4f}\tloss_direction_CE {r[1]:.4f}\tloss_direction_dice {r[2]:.4f}'
                         '\tloss_mse {r[3]:.4f}\tLoss_CE {r[4]:.4f}\tPixel_Accu {r[6]:.4f}\tpixel_IoU {r[7]:.4f}'
                         .format(i, len(train_loader), r=results.avg))
+    if getattr(trainer, 'world', 1) > 1:
+        results.avg = trainer.reduce_scalars(results.avg)         # global-batch means, as DataParallel's gathered loss gives
     if logger is not None:
         logger.info('\t=> Train Avg: Loss {r[0]:.4f}\tloss_CE {r[4]:.4f}\tPixel_Accu {r[6]:.4f}\tIoU {r[7]:.4f}'.format(r=results.avg))
     return results.avg

@@ -117,6 +117,46 @@ class Trainer:
         self._wstream, self._events = None, {}
         self._packb_pending = False
         self._forwards, self._bn_base = 0, 0                 # training forwards run here / counted in a loaded checkpoint
+        if world_size > 1:
+            self.sync_from_rank0()                           # replicas start identical whatever each rank's RNG / checkpoint did
+
+    # ------------------------------------------------------------------------------------------------
+    def sync_from_rank0(self, src=0):
+        """Broadcast rank `src`'s parameters (the whole flat buffer incl. the never-used ones), Adam moments, step counter and
+        every module buffer (BatchNorm running statistics) to all ranks - what nn.DataParallel's per-iteration replicate
+        (train.py:185) guarantees in the reference.  Called at construction and after a checkpoint load; without it a rank whose
+        RNG drifted or that loaded a different file would silently train a different replica."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        f = self.flat
+        works = [dist.broadcast(t, src=src, async_op=True) for t in (f.P, f.M, f.V)]
+        meta = torch.tensor([float(f.step_count), float(self._bn_base + self._forwards)], dtype=torch.float64, device=self.dev)
+        works.append(dist.broadcast(meta, src=src, async_op=True))
+        bufs = [b for b in self.model.buffers() if b.is_floating_point()]
+        if bufs:
+            flatb = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+            dist.broadcast(flatb, src=src)
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    b.copy_(flatb[off:off + b.numel()].view(b.shape))
+                    off += b.numel()
+        for w in works:
+            w.wait()
+        f.step_count = int(meta[0].item())
+        self._bn_base, self._forwards = int(meta[1].item()), 0
+        self.refresh_parameters()
+
+    def reduce_scalars(self, values):
+        """mean over ranks of a small vector of logging scalars (the 11 values of train_util_dam.train): with nn.DataParallel the
+        reference computes them on the gathered global batch; here every rank holds its shard's means"""
+        import torch.distributed as dist
+        if self.world <= 1 or not (dist.is_available() and dist.is_initialized()):
+            return values
+        t = torch.as_tensor(values, dtype=torch.float64).to(self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return (t / dist.get_world_size()).cpu().numpy()
 
     # ------------------------------------------------------------------------------------------------
     def buf(self, key, shape, dtype):

@@ -94,6 +94,12 @@ int cdnet_tta_boost_argmax(const float *probs, const float *points, const uint8_
 size_t cdnet_watershed_workspace_bytes(int N, int H, int W);
 int cdnet_watershed_process(const uint8_t *pred, int N, int H, int W, int min_size, void *workspace, size_t workspace_bytes,
                             uint8_t *dist, int32_t *marker, int32_t *labels, void *stream);
+/* The ws = False branch of the same function (postproc_other.py:49-52; forced for model_mode 'unet' / 'micronet', :35):
+ *   scipy.ndimage.binary_fill_holes -> measurements.label (4-connected, ids in raster order) -> remove_small_objects on the label
+ *   image (labels with fewer than min_size pixels become 0; the other ids are kept).  pred u8 [N][H][W] non-zero = foreground;
+ *   labels i32 [N][H][W]; workspace: cdnet_watershed_workspace_bytes(N, H, W) bytes. */
+int cdnet_fill_label_process(const uint8_t *pred, int N, int H, int W, int min_size, void *workspace, size_t workspace_bytes,
+                             int32_t *labels, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Connected-component chain.   Replaces test_dam.py:546-563:
@@ -324,7 +330,9 @@ int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_head_feat *f2
  * quirk_sample0 = 1 reproduces train_util_dam.py:139 (direction one-hot masked by sample 0's foreground).
  * losses[11] = {total, direction CE, direction weighted dice, MSE, CE, dice, then the pixel-level metrics of
  * train_util_dam.py:279-293 (argmax direction class == 1 vs direction label == 1, utils.py:67-110), averaged over the batch:
- * accuracy, IoU, recall, precision, F1}.  dmask/dpoint/ddir may all be NULL. */
+ * accuracy, IoU, recall, precision, F1}.  dmask/dpoint/ddir may all be NULL.  * Label content is validated on the device: a mask class > 2 or a direction class > 8 makes every entry of `losses` NaN
+ * (indices are clamped, nothing is read or written out of bounds) - the reference's nn.NLLLoss raises on such targets.
+ */
 size_t cdnet_dam_loss_workspace_floats(int B, int P);
 int cdnet_dam_loss(const float *mask, const float *point, const float *direction, const uint8_t *label,
                    const uint8_t *dirlab, const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W,

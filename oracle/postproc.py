@@ -203,3 +203,16 @@ def watershed_process(pred, min_size=10, use_scipy=True):
     out = watershed((-canvas.astype(np.int32) & 255).astype(np.uint8), marker, pred)   # -dist on uint8 wraps (:47)
     out = remove_small_labels(out, min_size)                                      # (:48)
     return dict(dist=canvas, marker=marker, labels=out)
+
+
+def fill_label_process(pred, min_size=10):
+    """postproc_other.process with ws = False (postproc_other.py:33-34, 49-52), by the very scipy calls the reference makes;
+    skimage.morphology.remove_small_objects on an integer label image = zero every label whose pixel count is below min_size."""
+    from scipy import ndimage as ndi
+    b = np.asarray(pred) > 0.5
+    lab = ndi.label(ndi.binary_fill_holes(b))[0].astype(np.int32)          # default structure: 4-connected
+    sizes = np.bincount(lab.ravel())
+    small = sizes < min_size
+    small[0] = False
+    lab[small[lab]] = 0
+    return lab

@@ -150,3 +150,66 @@ def test_hrnet_parameters_live_in_padded_flat_storage():
     sd = m.state_dict()
     assert torch.allclose(sd['mask_feature.conv1.weight'][:, 18:54], ref2.mask_feature.conv1.weight[:, 18:54] + 1.0)
     assert torch.allclose(sd['conv1.weight'], ref2.conv1.weight - 0.5)
+
+
+class _TinyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(3, 8, 3)
+        self.bn = torch.nn.BatchNorm2d(8)
+        self.unused = torch.nn.Conv2d(1, 2, 1)
+    UNUSED_PREFIXES = ('unused.',)
+
+
+def _sync_worker(rank, world, port, out):
+    """replicas built from DIFFERENT seeds (and different BatchNorm statistics / Adam state) are identical after the trainer's
+    start-up broadcast; the 11 logging scalars come back as the mean over ranks"""
+    import torch.distributed as dist
+    from cdnet_amd import trainer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)
+    m = _TinyNet()
+    with torch.no_grad():
+        m.bn.running_mean.add_(float(rank + 1))
+        m.bn.running_var.mul_(2.0 + rank)
+    tr = trainer.Trainer(m, world_size=world)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    # a later divergence (e.g. one rank loads a checkpoint) is repaired by an explicit sync
+    with torch.no_grad():
+        tr.flat.P.add_(float(rank))
+        tr.flat.M.add_(float(rank) * 0.5)
+    tr.flat.step_count = 7 + rank
+    tr.sync_from_rank0()
+    means = tr.reduce_scalars(np.arange(11, dtype=np.float64) * (rank + 1))
+    out.put((rank, sd, tr.flat.P.clone(), tr.flat.M.clone(), tr.flat.step_count, np.asarray(means)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_broadcast_and_scalar_mean_two_ranks():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r = q.get(timeout=120)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sd0, P0, M0, step0, mean0 = got[0]
+    sd1, P1, M1, step1, mean1 = got[1]
+    torch.manual_seed(1000)
+    want = _TinyNet().state_dict()                         # rank 0's initialisation
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert torch.equal(sd0['conv.weight'], want['conv.weight']) and torch.equal(sd0['unused.weight'], want['unused.weight'])
+    assert float(sd1['bn.running_mean'][0]) == 1.0 and float(sd1['bn.running_var'][0]) == 2.0       # rank 0's buffers
+    assert torch.equal(P0, P1) and torch.equal(M0, M1) and step0 == step1 == 7
+    np.testing.assert_allclose(mean0, np.arange(11) * 1.5)
+    np.testing.assert_allclose(mean1, mean0)

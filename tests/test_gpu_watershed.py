@@ -56,3 +56,39 @@ def test_touching_border_and_full_mask():
         want = op.watershed_process(preds[i], 10)
         np.testing.assert_array_equal(dist[i].cpu().numpy(), want['dist'])
         np.testing.assert_array_equal(lab[i].cpu().numpy(), want['labels'])
+
+
+def _holes(H, W, n, seed):
+    """blobs with punched holes (some touching the border) and specks below the size threshold"""
+    rs = np.random.RandomState(seed)
+    m = _blobs(H, W, n, seed, 5, 14)
+    yy, xx = np.mgrid[:H, :W]
+    for _ in range(n):
+        cy, cx, r = rs.randint(0, H), rs.randint(0, W), rs.randint(1, 4)
+        m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0
+    for _ in range(n):
+        m[rs.randint(0, H), rs.randint(0, W)] = 1
+    return m
+
+
+@pytest.mark.parametrize('case', [(64, 64, 10, 1), (96, 80, 24, 2), (50, 120, 20, 3), (256, 256, 150, 4), (33, 65, 6, 5), (1000, 1000, 900, 6)])
+def test_ws_false_branch_bit_exact(case):
+    """postproc_other.process(pred, 'unet') / ws=False (postproc_other.py:35, 49-52): fill holes -> 4-connected label -> remove
+    small labels, against the same scipy calls the reference makes"""
+    import torch
+    from cdnet_amd import postproc_other
+    from oracle import postproc as op
+    H, W, n, seed = case
+    pred = _holes(H, W, n, seed)
+    for min_size in (10, 5):
+        want = op.fill_label_process(pred, min_size)
+        got = postproc_other.process(pred.astype(np.float32) * 0.8, 'unet', min_size=min_size)
+        assert isinstance(got, np.ndarray) and got.dtype == np.int32
+        np.testing.assert_array_equal(got, want)
+    got = postproc_other.process(torch.from_numpy(pred).cuda(), 'UNet2RevA1_vgg16', min_size=10, ws=False)
+    np.testing.assert_array_equal(got.cpu().numpy(), op.fill_label_process(pred, 10))
+    # batch form + empty / full masks
+    batch = np.stack([pred, np.zeros_like(pred), np.ones_like(pred)])
+    got = postproc_other.fill_label_process(torch.from_numpy(batch).cuda(), 10).cpu().numpy()
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], op.fill_label_process(batch[i], 10))

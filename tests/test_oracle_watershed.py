@@ -59,3 +59,18 @@ def test_more_than_one_basin_per_component():
     comp = ndi.label(pred)[0]
     split = sum(1 for c in range(1, comp.max() + 1) if len(set(np.unique(r['labels'][comp == c])) - {0}) > 1)
     assert split >= 3                                              # the case actually exercises the splitting
+
+
+def test_fill_label_process_oracle_semantics():
+    """ws = False branch: ids are scipy's raster-order 4-connected labels; small labels vanish, the others keep their ids"""
+    import numpy as np
+    from oracle import postproc as op
+    m = np.zeros((12, 14), np.uint8)
+    m[1:4, 1:4] = 1; m[2, 2] = 0                 # ring with a hole: filled -> 9 px
+    m[6, 6] = 1                                   # speck (1 px)
+    m[8:11, 8:12] = 1                             # 12 px
+    m[7, 7] = 1                                   # diagonal neighbour of the speck: 4-connectivity keeps them apart
+    lab = op.fill_label_process(m, 5)
+    assert lab[2, 2] == 1 and (lab[1:4, 1:4] == 1).all()
+    assert lab[6, 6] == 0 and lab[7, 7] == 0
+    assert set(np.unique(lab)) == {0, 1, 4} and (lab[8:11, 8:12] == 4).all()
