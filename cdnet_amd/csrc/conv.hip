@@ -768,6 +768,601 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
     return check_launch("conv_fwd_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Wave-specialised, weight-stationary, persistent variant for the layers whose whole weight tile fits the LDS
+// (taps * Cin * BN * 2 bytes <= ~92 KB: the 64-channel full-resolution layers of the encoder stem, the decoder's last block
+// and the three residual units - forward, backward-data and the space-to-depth backward of the last transposed conv).
+//
+//   * one 8-wave workgroup per CU, persistent over a contiguous run of tiles (XCD-contiguous, like conv_fwd_kernel);
+//   * the weights of the workgroup's cout tile are loaded ONCE and stay in LDS;
+//   * waves 4..7 (producers) only move data: four 16-channel halo chunks in flight in registers (>= 2 us of HBM latency
+//     covered), transform (BatchNorm scale/shift, residual, ReLU) and write them into a two-slot LDS ring;
+//   * waves 0..3 (consumers) only read fragments, issue MFMAs and run the epilogue: a consumer wave owns 64 pixels x BN
+//     couts of the tile and its own out-tile region, so the epilogue needs no workgroup-wide synchronisation and the
+//     producers run on into the next tile meanwhile;
+//   * one barrier per 16-channel chunk step.
+// Accumulation order, MFMA shapes and epilogue arithmetic are those of conv_fwd_kernel<16,16,16,BN,4,1,TAPS>: the results are
+// bit-identical (tests/test_gpu_conv.py compares the two).
+// ------------------------------------------------------------------------------------------------------
+// Measured in round 2 (tools/bench_conv_ws.py, bench.py): bit-identical, at parity on the isolated layer, but the whole
+// inference / training step is 3-7 % SLOWER with it than with conv_fwd_kernel (one consumer group per CU serialises MFMA phase and
+// epilogue; three co-resident conv_fwd_kernel workgroups overlap them).  Kept as a tested experiment: off unless CDNET_CONV_WS=1.
+#ifndef CDNET_CONV_WS
+#define CDNET_CONV_WS 0
+#endif
+
+template <int BN, int TAPS>
+struct WsLds {
+    static constexpr int TH = 16, TW = 16, CK = 16;
+    static constexpr int PSTR = CK * 2 + 16;
+    static constexpr int NPIX = (TH + 2) * (TW + 2);
+    static constexpr int A_BYTES = NPIX * PSTR;                   // one ring slot: the halo tile of a 16-channel chunk
+    static constexpr int B_CHUNK = TAPS * CK * BN * 2;            // packed weights of one chunk
+    static constexpr int OSTR = BN * 2 + 8;
+    static constexpr int OUT_WAVE = 64 * OSTR;                    // a consumer wave's 64 pixels
+    static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum|sumsq][BN]
+    static int bytes(int nchunk, int ctot) {
+        return nchunk * B_CHUNK + 2 * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4;
+    }
+};
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));      // register staging type (HIP's uint4 struct copies defeat SROA)
+
+// XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
+// BatchNorm source, packed math), 2 anything (run-time flags)
+template <int BN, int TAPS, int XF, bool DEFER>
+__global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
+    using L = WsLds<BN, TAPS>;
+    constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
+    constexpr int NT = BN / 32, NPW = NT, MPW = 2;               // consumer wave wm: M tiles 2wm, 2wm+1 (64 pixels), all N tiles
+    constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
+    constexpr int OSTR = L::OSTR;
+    constexpr int PF = 4;                                         // halo chunks in flight per producer thread
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nchunk = A.nchunk;
+    unsigned char *lds_w = smem;
+    unsigned char *lds_a = smem + nchunk * L::B_CHUNK;
+    unsigned char *lds_o = lds_a + 2 * L::A_BYTES;
+    float *s_stats = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE);          // [2][4][2][BN]
+    float *s_xf = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE + L::STATS_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
+    const int xfs = (ctot + 7) / 8 * 8;
+    const int cout_tile = blockIdx.y;
+
+    // this workgroup's contiguous run of tiles; XCD k (workgroups k, k+8, ...) serves the k-th eighth of the tiles
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int T = A.N * tiles_img;
+    int t_lo, t_hi;
+    {
+        const int G = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((G & 7) == 0) {
+            const int xcd = b & 7, idx = b >> 3, nw = G >> 3;
+            const long long x0 = (long long)T * xcd / 8, x1 = (long long)T * (xcd + 1) / 8;
+            t_lo = (int)(x0 + (x1 - x0) * idx / nw);
+            t_hi = (int)(x0 + (x1 - x0) * (idx + 1) / nw);
+        } else {
+            t_lo = (int)((long long)T * b / G);
+            t_hi = (int)((long long)T * (b + 1) / G);
+        }
+    }
+    const int ntl = t_hi - t_lo;
+    const int S = ntl * nchunk;                                   // chunk steps of this workgroup
+    const int S4 = (S + 3) & ~3;                                  // barriers executed by both roles
+
+    // resident weights + scale/shift table
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * nchunk * (L::B_CHUNK / 2));
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
+        const int nv = nchunk * (L::B_CHUNK / 16);
+        for (int v = tid; v < nv; v += 512) dst[v] = src[v];
+        for (int c = tid; c < ctot; c += 512) {
+            const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
+            const int cc = c < c0n ? c : c - c0n;
+            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (S == 0) return;
+
+    auto chunk_src = [&](int k, int &si, int &cc0) {
+        const int n0 = A.src[0].C / CK;
+        if (k < n0) { si = 0; cc0 = k * CK; } else { si = 1; cc0 = (k - n0) * CK; }
+    };
+
+    if (wave >= 4) {
+        // ================================ producers ================================
+        // Straight-line code only: every load is issued unconditionally (clamped address, clamped chunk index past the end of
+        // the run) and out-of-range vectors are zeroed by a mask, so that the compiler can count the loads in flight
+        // (s_waitcnt vmcnt(N)) instead of draining them at a join.
+        const int ptid = tid - 256;
+        const int slot = ptid % VPP;
+        // the producers' vector instructions must slip in between the consumers' MFMAs on the same SIMD: raise their priority
+        u32x4v pa[PF][NA];
+        unsigned vm[PF];                         // bit i: vector i of the chunk is inside the image / source
+        int eo[PF][NA];                          // element offsets (only read for sources with a residual operand)
+        // per-thread constants: halo coordinates of its NA vectors
+        int hyx[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pix = (ptid + i * 256) / VPP;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 16) | hx) : -1;
+        }
+        // cursors (no integer division per chunk): the issue cursor walks chunks 0, 1, 2, ... of the run and stops on the last
+        // one; the commit cursor only needs the chunk-in-tile index
+        int ik = 0, ic = 0, in_, iy0, ix0;
+        {
+            in_ = t_lo / tiles_img;
+            const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
+            iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
+        }
+        int ck = 0;
+        // staging geometry of the current tile and source (the chunks of one source share it): element offset of each vector
+        // without the chunk's channel offset, validity mask
+        int ge[NA];
+        unsigned gm = 0;
+        const int n0 = A.src[0].C / CK;
+        auto issue = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            int si, cc0;
+            chunk_src(ik, si, cc0);
+            const ConvSrc &s = A.src[si];
+            if (ik == 0 || ik == n0) {
+                const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
+                const int img = in_ * s.Hs * rs + slot * 8;
+                gm = 0;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int y = iy0 - 1 + (hyx[i] >> 16), x = ix0 - 1 + (hyx[i] & 0xffff);
+                    const int ys = y - s.off_y, xs = x - s.off_x;
+                    const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
+                                    (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
+                    ge[i] = ok ? img + ys * rs + xs * s.C : -1;
+                    gm |= (ok ? 1u : 0u) << i;
+                }
+            }
+            const unsigned short *base = s.x + cc0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = ge[i] >= 0 ? ge[i] : 0;
+                eo[R][i] = e + cc0;
+                if (!(A.debug & 128)) pa[R][i] = *reinterpret_cast<const u32x4v *>(base + e);
+            }
+            vm[R] = gm;
+            // advance (saturating at the last chunk of the run)
+            if (ic + 1 < S) {
+                ++ic;
+                if (++ik == nchunk) {
+                    ik = 0;
+                    ix0 += TW;
+                    if (ix0 >= A.W) { ix0 = 0; iy0 += TH; if (iy0 >= A.H) { iy0 = 0; ++in_; } }
+                }
+            }
+        };
+        auto commit = [&](auto rc, int c_) {
+            constexpr int R = decltype(rc)::value;
+            int si, cc0;
+            chunk_src(ck, si, cc0);
+            if (c_ + 1 < S) { if (++ck == nchunk) ck = 0; }
+            const ConvSrc &s = A.src[si];
+            const float *xf = s_xf + (si ? c0n : 0) + cc0 + slot * 8;
+            float sc[8], sh[8];
+            if (XF != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
+            }
+            unsigned char *dst0 = lds_a + (c_ & 1) * L::A_BYTES + (ptid / VPP) * PSTR + slot * 16;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                u32x4v val;
+                if (XF == 0) val = pa[R][i];
+                else if (XF == 1) val = xf_bnrelu_f16<false>(pa[R][i], pa[R][i], sc, sh);
+                else {
+                    ChanXf t;
+                    t.on = s.scale != nullptr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { t.sc[j] = sc[j]; t.sh[j] = sh[j]; }
+                    V16 raw, rr;
+                    raw.u = __builtin_bit_cast(uint4, pa[R][i]);
+                    const bool relu = s.relu != 0, f16 = s.f16 != 0;
+                    if (s.res) {
+                        rr.u = *reinterpret_cast<const uint4 *>(s.res + eo[R][i]);
+                        val = __builtin_bit_cast(u32x4v, xform8(raw, &rr, t, relu, f16).u);
+                    } else if (!t.on && !relu && !f16) val = pa[R][i];
+                    else val = __builtin_bit_cast(u32x4v, xform8(raw, nullptr, t, relu, f16).u);
+                }
+                const unsigned keep = (vm[R] >> i) & 1u ? 0xffffffffu : 0u;
+                val &= keep;
+                if (i < NA - 1 || ptid + i * 256 < NPIX * VPP)
+                    *reinterpret_cast<u32x4v *>(dst0 + i * (256 / VPP) * PSTR) = val;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        issue(I0{});
+        issue(I1{});
+        issue(I2{});
+        issue(I3{});
+        commit(I0{}, 0);
+        issue(I0{});
+        __syncthreads();
+        // step q: the consumers work on chunk q; chunk q+1 goes into the other slot, its register set takes chunk q+5
+        // (the step count is padded to a multiple of four - the consumers idle through the padding steps - so that the loop body
+        //  has no conditional part and the number of loads in flight is the same on every path to its head)
+        for (int q0 = 0; q0 < S4; q0 += 4) {
+            commit(I1{}, q0 + 1); issue(I1{}); __syncthreads();
+            commit(I2{}, q0 + 2); issue(I2{}); __syncthreads();
+            commit(I3{}, q0 + 3); issue(I3{}); __syncthreads();
+            commit(I0{}, q0 + 4); issue(I0{}); __syncthreads();
+        }
+        if (DEFER) __syncthreads();                              // the consumers' last (serial) epilogue parks its statistics
+        return;
+    }
+
+    // ================================ consumers ================================
+    const int wm = wave;
+    const int half = lane >> 5, l31 = lane & 31;
+    int abase[MPW];
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int m = (wm * MPW + mi) * 32 + l31;
+        abase[mi] = ((m / TW) * HW_ + m % TW) * PSTR + half * 16;
+    }
+    const int bbase = half * BN * 16 + l31 * 16;
+    auto toff = [](int t) { return ((TAPS == 9 ? t / 3 : 1) * HW_ + (TAPS == 9 ? t % 3 : 1)) * PSTR; };      // folds to immediates
+    f32x16 acc[MPW][NPW];            // the tile being accumulated
+    f32x16 accB[MPW][NPW];           // DEFER: the finished tile whose epilogue rides under the next tile's MFMAs
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; accB[mi][ni][r] = 0.f; }
+    unsigned char *s_out = lds_o + wave * L::OUT_WAVE;          // this wave's 64 pixels x BN couts
+    const int cout0 = cout_tile * BN;
+    // epilogue constants of this lane (the same for every tile of the run): one consumer group per CU means nothing else would
+    // hide the latency of these loads if they sat inside the epilogue
+    float e_osc[NPW], e_osh[NPW];
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) {
+        const int co = cout0 + ni * 32 + l31;
+        const bool cok = co < A.Cout;
+        e_osc[ni] = (A.oscale && cok) ? A.oscale[co] : 1.f;
+        e_osh[ni] = fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
+    }
+    constexpr int VO = BN / 8, NV = VO, PPI = 64 / VO;           // a lane's NV out vectors: pixel lane / VO + i * PPI, channels (lane % VO) * 8 ..
+    const int qv = lane % VO, ml0 = lane / VO;
+    const bool f16out = A.out_f16 != 0;
+    const bool odd = (l31 & 1) != 0;
+    const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
+
+    // ---- epilogue micro-operations on an accumulator set (full tiles only in the deferred form) ----
+    // one (row pair rp, N tile ni) of M tile mi: bias/scale/shift, pair swap through DPP, 16-bit conversion, ReLU, LDS
+    auto epi_write1 = [&](float a0, float a1, int mi, int ni, int rp) {
+        const int col = ni * 32 + l31;
+        const float osc = e_osc[ni], osh = e_osh[ni];
+        unsigned char *dst = s_out + (col & ~1) * 2 + (odd ? OSTR : 0);
+        const int r = 2 * rp;
+        const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the wave's 64 pixels
+        const float v0 = fmaf(a0, osc, osh), v1 = fmaf(a1, osc, osh);
+        const float send = odd ? v0 : v1;
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+        const xf_f32x2 pr = {odd ? got : v0, odd ? v1 : got};
+        const xf_s16x2 ph = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(pr, xf_h16x2));
+        const xf_s16x2 pb = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(pr, xf_bf16x2));
+        xf_s16x2 pk = f16out ? ph : pb;
+        pk = __builtin_elementwise_max(pk, lo_clamp);
+        *reinterpret_cast<unsigned *>(dst + ml * OSTR) = __builtin_bit_cast(unsigned, pk);
+    };
+    float st_sum[NPW], st_sq[NPW];
+    // statistics of one accumulator register group (full tile: no masks)
+    auto epi_stat1 = [&](float a0, float a1, float a2, float a3, int ni) {
+        st_sum[ni] += a0; st_sq[ni] = fmaf(a0, a0, st_sq[ni]);
+        st_sum[ni] += a1; st_sq[ni] = fmaf(a1, a1, st_sq[ni]);
+        st_sum[ni] += a2; st_sq[ni] = fmaf(a2, a2, st_sq[ni]);
+        st_sum[ni] += a3; st_sq[ni] = fmaf(a3, a3, st_sq[ni]);
+    };
+    auto epi_stat_flush = [&](int par) {
+        float *sp = s_stats + par * (4 * 2 * BN);
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) {
+            const float a = st_sum[ni] + __shfl_xor(st_sum[ni], 32), b2 = st_sq[ni] + __shfl_xor(st_sq[ni], 32);
+            if (half == 0) {
+                sp[(wave * 2 + 0) * BN + ni * 32 + l31] = a;
+                sp[(wave * 2 + 1) * BN + ni * 32 + l31] = b2;
+            }
+        }
+    };
+
+    int k = 0, tl = 0;                                           // chunk inside the tile, tile inside the run
+    int stats_tile = -1, stats_par = 0;                         // statistics parked in LDS by a finished epilogue
+    int pend_tile = -1;                                          // DEFER: tile whose accumulators wait in accB
+    unsigned short *pend_out = nullptr;                          // its output origin for this lane (row 0 of the wave, lane's channels)
+    uint4 vv[NV / 2];
+
+    // one chunk step: TAPS x (MPW x NPW) MFMAs with the fragments of the next tap requested ahead; PART > 0 interleaves a quarter
+    // of the pending tile's epilogue (program order = issue order: the vector / LDS / store instructions ride in the MFMA shadow)
+    auto mfma_step = [&](auto part_c, const unsigned char *la, const unsigned char *lw) {
+        constexpr int PART = decltype(part_c)::value;
+        bf16x8 af[2][MPW], bfr[2][NPW];
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi] + toff(0));
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) bfr[0][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ni * 512);
+        if (PART == 1) {
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) { st_sum[ni] = 0.f; st_sq[ni] = 0.f; }
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            if (t + 1 < TAPS) {
+#pragma unroll
+                for (int mi = 0; mi < MPW; ++mi) af[(t + 1) & 1][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi] + toff(t + 1));
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni) bfr[(t + 1) & 1][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ((t + 1) * 2) * BN * 16 + ni * 512);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][mi], bfr[t & 1][ni], acc[mi][ni], 0, 0, 0);
+                    // ---- a slice of the pending tile's epilogue after every MFMA (slot sl of TAPS * MPW * NPW): straight-line
+                    // ---- vector / LDS / store instructions that issue in the shadow of the matrix pipe
+                    constexpr int SLOTS = TAPS * MPW * NPW;
+                    constexpr int NW = 8 * NPW, NS = 4 * MPW * NPW, NH = NV / 2;
+                    static_assert(NW + NS <= SLOTS && SLOTS / 2 + NH <= SLOTS, "epilogue slices fit the MFMA slots of a chunk step");
+                    const int sl = (t * MPW + mi) * NPW + ni;
+                    if ((PART == 1 || PART == 2) && sl < NW) {
+                        constexpr int EMI = PART == 2 ? 1 : 0;
+                        const int eni = sl / 8, erp = sl % 8;
+                        epi_write1(accB[EMI][eni][2 * erp], accB[EMI][eni][2 * erp + 1], EMI, eni, erp);
+                    }
+                    if (PART == 1 && sl >= NW && sl < NW + NS) {
+                        const int g = sl - NW;
+                        const int smi = (g / 4) / NPW, sni = (g / 4) % NPW, r0 = (g % 4) * 4;
+                        epi_stat1(accB[smi][sni][r0], accB[smi][sni][r0 + 1], accB[smi][sni][r0 + 2], accB[smi][sni][r0 + 3], sni);
+                    }
+                    if (PART == 3 || PART == 4) {
+                        // half of the lane's out vectors: LDS reads in the first slots, stores in the later ones
+                        constexpr int I0 = (PART - 3) * NH;
+                        if (sl < NH) vv[sl] = *reinterpret_cast<const uint4 *>(s_out + (ml0 + (I0 + sl) * PPI) * OSTR + qv * 16);
+                        if (sl >= SLOTS / 2 && sl < SLOTS / 2 + NH) {
+                            const int ml = ml0 + (I0 + (sl - SLOTS / 2)) * PPI;          // pixel inside the wave's four tile rows
+                            *reinterpret_cast<uint4 *>(pend_out + ((size_t)(ml / TW) * A.W + ml % TW) * A.out_cstride) = vv[sl - SLOTS / 2];
+                        }
+                    }
+                }
+        }
+        if (PART == 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    using P3 = std::integral_constant<int, 3>;
+    using P4 = std::integral_constant<int, 4>;
+
+    // serial epilogue of the accumulators in `acc` (partial tiles, layers with fewer than four chunks, the last tile of the run)
+    auto serial_epilogue = [&](int tile) {
+        const int n = tile / tiles_img, rr_ = tile - n * tiles_img;
+        const int ty = rr_ / tiles_x;
+        const int y0 = ty * TH, x0 = (rr_ - ty * tiles_x) * TW;
+        const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
+        if (A.stats) {
+            const int par = (tl & 1);
+            float *sp = s_stats + par * (4 * 2 * BN);
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) {
+                float ssum = 0.f, ssq = 0.f;
+                if (full) {
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; ssum += v; ssq = fmaf(v, v, ssq); }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const float v = ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W) ? acc[mi][ni][r] : 0.f;
+                            ssum += v;
+                            ssq = fmaf(v, v, ssq);
+                        }
+                }
+                ssum += __shfl_xor(ssum, 32);
+                ssq += __shfl_xor(ssq, 32);
+                if (half == 0) {
+                    sp[(wave * 2 + 0) * BN + ni * 32 + l31] = ssum;
+                    sp[(wave * 2 + 1) * BN + ni * 32 + l31] = ssq;
+                }
+            }
+            stats_tile = tile;
+            stats_par = par;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) epi_write1(acc[mi][ni][2 * rp], acc[mi][ni][2 * rp + 1], mi, ni, rp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int co = cout0 + qv * 8;
+        unsigned short *obase = A.out + (((size_t)n * A.H + y0) * A.W + x0) * A.out_cstride + A.out_coff + co;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i) vv[i] = *reinterpret_cast<const uint4 *>(s_out + (ml0 + (h2 * (NV / 2) + i) * PPI) * OSTR + qv * 16);
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i) {
+                const int m = wm * 64 + ml0 + (h2 * (NV / 2) + i) * PPI;
+                const int yl = m / TW, xl = m % TW;
+                if ((full || (y0 + yl < A.H && x0 + xl < A.W)) && co < A.Cout)
+                    *reinterpret_cast<uint4 *>(obase + ((size_t)yl * A.W + xl) * A.out_cstride) = vv[i];
+            }
+        }
+    };
+    auto flush_stats = [&]() {
+        if (stats_tile >= 0 && tid < 2 * BN) {
+            // per-tile channel sums: the four waves' partials in a fixed order (deterministic)
+            const int which = tid / BN, col = tid % BN;
+            const float *sp = s_stats + stats_par * (4 * 2 * BN);
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += sp[(w4 * 2 + which) * BN + col];
+            const int co = cout0 + col;
+            if (co < A.Cout) A.stats[((size_t)stats_tile * 2 + which) * A.Cout + co] = v;
+        }
+        stats_tile = -1;
+    };
+
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    };
+    __syncthreads();                                             // chunk 0 is staged
+    if (DEFER) {
+        // Every tile is full, nchunk >= 4, Cout a multiple of BN (checked by the launcher).  Straight-line tile body: the first four
+        // chunk steps of a tile carry the four quarters of the previous tile's epilogue; the first tile of the run carries none
+        // (peeled), the last tile's epilogue runs after the loop.
+        int q = 0;
+        auto la_of = [&](int qq) { return lds_a + (qq & 1) * L::A_BYTES; };
+        for (int j = 0; j < ntl; ++j) {
+            const int tile = t_lo + j;
+            if (j == 0) {
+                for (int kk = 0; kk < nchunk; ++kk) { mfma_step(P0{}, la_of(q), lds_w + kk * L::B_CHUNK); ++q; __syncthreads(); }
+            } else {
+                flush_stats();
+                mfma_step(P1{}, la_of(q), lds_w); ++q; __syncthreads();
+                mfma_step(P2{}, la_of(q), lds_w + L::B_CHUNK); ++q;
+                if (A.stats) { epi_stat_flush(j & 1); stats_tile = pend_tile; stats_par = j & 1; }
+                __syncthreads();
+                flush_stats();
+                mfma_step(P3{}, la_of(q), lds_w + 2 * L::B_CHUNK); ++q; __syncthreads();
+                mfma_step(P4{}, la_of(q), lds_w + 3 * L::B_CHUNK); ++q; __syncthreads();
+                for (int kk = 4; kk < nchunk; ++kk) { mfma_step(P0{}, la_of(q), lds_w + kk * L::B_CHUNK); ++q; __syncthreads(); }
+            }
+            // park the finished tile
+            const int n = tile / tiles_img, rr_ = tile - n * tiles_img;
+            const int ty = rr_ / tiles_x;
+            const int y0 = ty * TH, x0 = (rr_ - ty * tiles_x) * TW;
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni) accB[mi][ni] = acc[mi][ni];
+            pend_tile = tile;
+            pend_out = A.out + (((size_t)n * A.H + y0 + wm * 4) * A.W + x0) * A.out_cstride + A.out_coff + cout0 + qv * 8;
+            zero_acc();
+        }
+        for (; q < S4; ++q) __syncthreads();
+        // the last tile of the run: serial epilogue (serial_epilogue reads `acc`)
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) acc[mi][ni] = accB[mi][ni];
+        tl = ntl;
+        flush_stats();
+        serial_epilogue(pend_tile);
+        __syncthreads();                                         // (the producers wait here too) the last tile's statistics are parked
+        flush_stats();
+        return;
+    }
+    for (int q = 0; q < S4; ++q) {
+        if (q >= S) { __syncthreads(); continue; }
+        flush_stats();
+        mfma_step(P0{}, lds_a + (q & 1) * L::A_BYTES, lds_w + k * L::B_CHUNK);
+        if (++k == nchunk) {
+            k = 0;
+            const int tile = t_lo + tl;
+            ++tl;
+            serial_epilogue(tile);
+            zero_acc();
+        }
+        __syncthreads();
+    }
+    flush_stats();
+}
+
+// eligibility + launch of the wave-specialised kernel; returns -1 when the layer must take conv_fwd_kernel
+template <int BN, int TAPS>
+int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
+    using L = WsLds<BN, TAPS>;
+    int ctot = 0;
+    if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
+    for (int i = 0; i < A.nsrc; ++i) {
+        if (A.src[i].pool) return -1;
+        ctot += A.src[i].C;
+    }
+    const int smem = L::bytes(A.nchunk, ctot);
+    if (smem > 160 * 1024) return -1;
+    const int T = cdiv(A.W, 16) * cdiv(A.H, 16) * A.N;
+    bool any_xf = false;
+    for (int i = 0; i < A.nsrc; ++i) any_xf = any_xf || A.src[i].scale || A.src[i].relu || A.src[i].f16;
+    // measured on 3x3 64->64 @256x256 (tools/bench_conv_ws.py): plain sources 0.105-0.120 vs 0.108 ms at 16 tiles (parity), 0.41 vs
+    // 0.49 ms at 64 tiles; lazily transformed (training-mode) sources 0.122-0.130 vs 0.139 ms at 16 tiles
+    if (!(A.debug & 64) && (T < 512 || (!any_xf && T < 8192))) return -1;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return check_launch("hipGetDeviceProperties");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    bool all_plain = true, all_fast = true;
+    for (int i = 0; i < A.nsrc; ++i) {
+        const ConvSrc &s = A.src[i];
+        all_plain = all_plain && !s.scale && !s.relu && !s.res && !s.f16;
+        all_fast = all_fast && s.scale && s.relu && !s.res && s.f16 == 1;
+    }
+    const int ctiles = cdiv(A.Cout, BN);
+    int G = n_cu / ctiles;
+    G = G > T ? T : G;
+    if (G >= 8) G &= ~7;
+    if (G < 1) G = 1;
+    dim3 grid(G, ctiles, 1);
+    auto launch = [&](auto xf_c, auto defer_c) -> int {
+        constexpr int XF = decltype(xf_c)::value;
+        constexpr bool DF = decltype(defer_c)::value;
+        auto kern = conv_ws_kernel<BN, TAPS, XF, DF>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(conv_ws)");
+            attr_done = true;
+        }
+        kern<<<grid, 512, smem, st>>>(A);
+        return CDNET_OK;
+    };
+    // DEFER (the finished tile's epilogue interleaved with the next tile's MFMAs) is bit-identical but measured slower
+    // (0.132 vs 0.105-0.120 ms on 64->64 @256x256 x16: the fillers cost the MFMA stream more than the serial epilogue): off unless asked for
+    static const int want_defer = getenv("CDNET_CONV_WS_DEFER") ? atoi(getenv("CDNET_CONV_WS_DEFER")) : 0;
+    const bool defer = want_defer && A.nchunk >= 4 && A.H % 16 == 0 && A.W % 16 == 0 && A.Cout % BN == 0;
+    const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
+    int rc;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (defer) rc = xf == 0 ? launch(std::integral_constant<int, 0>{}, T_{}) : (xf == 1 ? launch(std::integral_constant<int, 1>{}, T_{}) : launch(std::integral_constant<int, 2>{}, T_{}));
+    else rc = xf == 0 ? launch(std::integral_constant<int, 0>{}, F_{}) : (xf == 1 ? launch(std::integral_constant<int, 1>{}, F_{}) : launch(std::integral_constant<int, 2>{}, F_{}));
+    if (rc != CDNET_OK) return rc;
+    return check_launch("conv_ws_kernel");
+}
+
 template <int TAPS>
 int dispatch_conv(const ConvArgs &A, hipStream_t st) {
     // configuration key: (tile, CK, BN); chosen by the host (cdnet_amd/engine.py) per layer
@@ -949,7 +1544,13 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (A.f32) return conv_forward_f32(A, st);
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
+    static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
+    if (use_ws && (!dbg || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
+        const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, st) : try_launch_conv_ws<32, 9>(A, st);
+        if (rc >= 0) return rc;
+    }
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }
+    if (A.debug & 32) { ConvArgs B = A; B.debug = 0; if (B.taps == 9) return dispatch_conv<9>(B, st); if (B.taps == 4) return dispatch_conv<4>(B, st); return dispatch_conv<1>(B, st); }
     if (A.taps == 9) return dispatch_conv<9>(A, st);
     if (A.taps == 4) return dispatch_conv<4>(A, st);
     return dispatch_conv<1>(A, st);

@@ -181,6 +181,9 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None, split=False):
     return out
 
 
+CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_fwd_kernel only, 64 = force conv_ws_kernel)
+
+
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
                  orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
@@ -218,6 +221,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
     a.ws = 0
+    a.debug = CONV_DEBUG
     a.f32 = int(f32)
     assert (out.dtype == torch.float32) == f32
     if eres is not None:                 # fused residual epilogue: eres = Src(other branch[, scale, shift], relu=...)

@@ -216,3 +216,99 @@ def test_fused_residual_epilogue_equals_conv_plus_materialize(affine):
     assert got.dtype == torch.bfloat16 and torch.equal(got, want.x)
     ref = torch.relu((raw2.float() * sc + sh if affine else raw2.float()) + r.float())
     np.testing.assert_allclose(got.float().cpu().numpy(), ref.cpu().numpy(), rtol=8e-3, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# conv_ws_kernel (wave-specialised, weight-stationary, persistent) == conv_fwd_kernel, bit for bit
+# ---------------------------------------------------------------------------------------------------------
+def _run_both(fn):
+    """fn() launches convolutions through engine.conv_forward; returns its outputs once per kernel choice"""
+    import torch
+    from cdnet_amd import engine
+    outs = []
+    for dbg in (32, 64):                      # 32: conv_fwd_kernel only; 64: conv_ws_kernel even for small launches
+        engine.CONV_DEBUG = dbg
+        try:
+            outs.append(fn())
+            torch.cuda.synchronize()
+        finally:
+            engine.CONV_DEBUG = 0
+    return outs
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 64, 64), (1, 64, 64, 40, 56), (3, 16, 64, 33, 17), (2, 32, 32, 48, 32), (2, 64, 16, 32, 48),
+                                  (16, 64, 64, 256, 256)])
+def test_ws_kernel_bit_identical_plain_stats_and_folded(case):
+    import torch
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(N + Cin + H)
+    x = _nhwc(torch.randn((N, Cin, H, W), generator=g))
+    raw = _nhwc(torch.randn((N, Cin, H, W), generator=g), torch.float16)
+    sc, sh = (torch.rand((Cin,), generator=g) + 0.5).cuda(), (torch.randn((Cin,), generator=g) * 0.3).cuda()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    b = torch.randn((Cout,), generator=g).cuda()
+    osc, osh = (torch.rand((Cout,), generator=g) + 0.5).cuda(), (torch.randn((Cout,), generator=g) * 0.2).cuda()
+    cfg = (16, 16, 64 if Cout > 32 else 32)
+    wp = engine.pack_weights(w, cfg, 0)
+
+    def run():
+        o1, st = engine.conv_forward([engine.Src(x)], wp, Cout, cfg, bias=b, stats=True, out_dtype=torch.float16)          # training-mode raw + stats
+        o2, _ = engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, Cout, cfg, oscale=osc, oshift=osh, orelu=True)   # lazily transformed source, folded epilogue
+        return o1.clone(), st.clone(), o2.clone()
+    a, bb = _run_both(run)
+    for u, v in zip(a, bb):
+        assert torch.equal(u, v)
+    if case[0] == 16:
+        return
+    # and it is right: against PyTorch fp32
+    import torch.nn.functional as F
+    want = F.conv2d(_nchw(x), _bf(w.cpu()), b.cpu(), padding=1)
+    _close(_nchw(bb[0]), want, 'ws plain')
+
+
+def test_ws_kernel_bit_identical_two_sources_residual_and_fused_epilogue():
+    import torch
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 2, 44, 52
+    a = _nhwc(torch.randn((N, 16, H - 1, W - 2), generator=g), torch.float16)          # padded small source (decoder up branch)
+    sa, ha = (torch.rand((16,), generator=g) + 0.5).cuda(), (torch.randn((16,), generator=g) * 0.3).cuda()
+    bsrc = _nhwc(torch.randn((N, 48, H, W), generator=g), torch.float16)
+    res = _nhwc(torch.randn((N, 48, H, W), generator=g), torch.float16)
+    sb, hb = (torch.rand((48,), generator=g) + 0.5).cuda(), (torch.randn((48,), generator=g) * 0.3).cuda()
+    w = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).cuda()
+    cfg = (16, 16, 64)
+    wp = engine.pack_weights(w, cfg, 0)
+    e = _nhwc(torch.randn((N, 64, H, W), generator=g), torch.float16)
+    esc, esh = (torch.rand((64,), generator=g) + 0.5).cuda(), (torch.randn((64,), generator=g) * 0.1).cuda()
+    bias = torch.randn((64,), generator=g).cuda()
+
+    def run():
+        srcs = [engine.Src(a, sa, ha, relu=True, off=(1, 1)), engine.Src(bsrc, sb, hb, relu=True, res=res)]
+        o1, st = engine.conv_forward(srcs, wp, 64, cfg, stats=True, H=H, W=W, out_dtype=torch.float16)
+        o2, _ = engine.conv_forward(srcs, wp, 64, cfg, bias=bias, H=H, W=W, eres=engine.Src(e, esc, esh, relu=True))       # fused residual epilogue
+        return o1.clone(), st.clone(), o2.clone()
+    x, y = _run_both(run)
+    for u, v in zip(x, y):
+        assert torch.equal(u, v)
+
+
+def test_ws_kernel_backward_data_view_sources():
+    """backward-data of ConvTranspose2d(32 -> 16, k4 s2 p1) = 3x3 convolution over the two row-parity views of the gradient
+    (row_stride sources): both kernels, bit for bit"""
+    import torch
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(4)
+    N, Cin, Cout, H, W = 2, 32, 16, 24, 40
+    w = (torch.randn((Cin, Cout, 4, 4), generator=g) * 0.1).cuda()
+    dy = _nhwc(torch.randn((N, Cout, 2 * H, 2 * W), generator=g))
+    cfg = (16, 16, 32)
+    wp = engine.pack_weights(w, cfg, 4)
+
+    def run():
+        views = [engine.Src(dy, view=(a * 2 * W * Cout, H, W, 2 * Cout, 4 * W * Cout)) for a in (0, 1)]
+        out, _ = engine.conv_forward(views, wp, Cin, cfg, taps=9, H=H, W=W)
+        return (out.clone(),)
+    x, y = _run_both(run)
+    assert torch.equal(x[0], y[0])
