@@ -1545,7 +1545,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     if (A.f32) return conv_forward_f32(A, st);
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
-    if (use_ws && (!dbg || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
+    if ((use_ws || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
         const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, st) : try_launch_conv_ws<32, 9>(A, st);
         if (rc >= 0) return rc;
     }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat
 // final 1x1 classifier of the plain UNet (models/unet.py:75,104): logits f32 NCHW from a 64-channel feature
 __global__ __launch_bounds__(256) void final_conv1x1_kernel(HeadFeat f, const float *__restrict__ w, const float *__restrict__ b,
                                                             int K, int N, int plane, float *__restrict__ out) {
-    __shared__ float s_w[16 * 64], s_b[16], s_sc[64], s_sh[64];
+    __shared__ float s_w[32 * 64], s_b[32], s_sc[64], s_sh[64];
     for (int i = threadIdx.x; i < K * 64; i += 256) s_w[i] = w[i];
     if (threadIdx.x < K) s_b[threadIdx.x] = b[threadIdx.x];
     if (threadIdx.x < 64) {
@@ -616,7 +616,7 @@ extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_hea
 extern "C" int cdnet_final_conv1x1(const cdnet_head_feat *f, const float *w, const float *b, int K, int N, int H, int W,
                                    float *out, void *stream) {
     CDNET_REQUIRE(f && f->raw && w && b && out, "cdnet_final_conv1x1: null pointer");
-    CDNET_REQUIRE(K >= 1 && K <= 16 && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1: K=%d must be in [1,16]", K);
+    CDNET_REQUIRE(K >= 1 && K <= 32 && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1: K=%d must be in [1,32]", K);
     final_conv1x1_kernel<<<lin_grid((size_t)N * H * W), 256, 0, (hipStream_t)stream>>>(mk_feat(*f), w, b, K, N, H * W, out);
     return check_launch("cdnet_final_conv1x1");
 }

@@ -1233,6 +1233,84 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 
 
 // ======================================================================================================
+// validate() loss mix (train_util_dam.py:499-580) - per-sample sums, one pass over the logits.  The host combines them:
+//   0..2 I_c = sum p_c [label==c]   3..5 P_c = sum p_c   6..8 T_c = sum [label==c]   9 sum -log p_label (UNweighted, :499-505)
+//   10..18 Iq_i = sum q'_i t_i   19..27 Pq_i = sum q'_i   28..36 Tq_i = sum t_i   with q' = softmax(direction), q'_0 *= p_0 (:564-566)
+//            and t = one-hot of the direction class RANK (lut) masked by SAMPLE 0's foreground (:463-470)
+//   37 sum w * -log q_dir (:553-559)   38 sum (point - target / 255)^2 (:575-580)
+//   39 tp  40 fp  41 fn  of (argmax mask == 1) vs (label == 1)  (utils.accuracy_pixel_level, :585-590)
+// ======================================================================================================
+constexpr int V_SUMS = 42;
+
+struct ValIn {
+    const float *mask, *point, *dirn;
+    const unsigned char *label, *dirlab, *weight;
+    const unsigned short *point_t;
+    int lut[9];                              // direction class value -> channel (rank among the batch's unique values), -1 = absent
+    int B, P;
+};
+
+__global__ __launch_bounds__(256) void val_sums_kernel(ValIn L, float *__restrict__ partial) {
+    __shared__ float acc[V_SUMS][256];
+    const int tid = threadIdx.x, b = blockIdx.y;
+#pragma unroll
+    for (int k = 0; k < V_SUMS; ++k) acc[k][tid] = 0.f;
+    const size_t ob = (size_t)b * L.P;
+    for (int i = blockIdx.x * 256 + tid; i < L.P; i += gridDim.x * 256) {
+        float l3[3], p3[3], lp3[3], l9[9], p9[9], lp9[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l3[c] = L.mask[((size_t)b * 3 + c) * L.P + i];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) l9[c] = L.dirn[((size_t)b * 9 + c) * L.P + i];
+        softmax3(l3, p3, lp3);
+        softmax9(l9, p9, lp9);
+        int lab = L.label[ob + i], dl = L.dirlab[ob + i];
+        lab = lab > 2 ? 2 : lab; dl = dl > 8 ? 8 : dl;
+        const float w = (float)L.weight[ob + i] / 20.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[3 + c][tid] += p3[c];
+            if (c == lab) { acc[c][tid] += p3[c]; acc[6 + c][tid] += 1.f; }
+        }
+        acc[9][tid] -= lp3[lab];
+        p9[0] *= p3[0];
+        const bool fg0 = L.label[i] != 0;                     // sample 0's foreground (the reference indexes target[0])
+        const int tch = (fg0 && L.lut[dl] >= 0) ? L.lut[dl] : -1;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            acc[19 + c][tid] += p9[c];
+            if (c == tch) { acc[10 + c][tid] += p9[c]; acc[28 + c][tid] += 1.f; }
+        }
+        acc[37][tid] -= w * lp9[dl];
+        const float dpt = L.point[ob + i] - h2f(L.point_t[ob + i]) / 255.f;
+        acc[38][tid] = fmaf(dpt, dpt, acc[38][tid]);
+        int am = 0;                                            // np.argmax: first maximum
+        if (l3[1] > l3[am]) am = 1;
+        if (l3[2] > l3[am]) am = 2;
+        const bool pi = am == 1, ti = lab == 1;
+        if (pi && ti) acc[39][tid] += 1.f;
+        if (pi && !ti) acc[40][tid] += 1.f;
+        if (!pi && ti) acc[41][tid] += 1.f;
+    }
+    __syncthreads();
+    if (tid < V_SUMS) {
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s += acc[tid][k];
+        partial[((size_t)b * gridDim.x + blockIdx.x) * V_SUMS + tid] = s;
+    }
+}
+
+// sums[b][k] = sum over chunks, fixed order
+__global__ void val_sums_reduce_kernel(const float *__restrict__ partial, int nchunk, int B, float *__restrict__ sums) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * V_SUMS) return;
+    const int b = idx / V_SUMS, k = idx % V_SUMS;
+    double s = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) s += (double)partial[((size_t)b * nchunk + ch) * V_SUMS + k];
+    sums[idx] = (float)s;
+}
+
+// ======================================================================================================
 // Backward of the plain UNet's 64 -> K classifier (models/unet.py:75,104).  Four lanes per pixel (16 channels each):
 //   dF[c] = sum_k dlogit_k * w[k][c];  dW[k][c] = sum_px dlogit_k * F[c];  db[k] = sum_px dlogit_k.
 // Per-block partial sums [K*64 | K], reduced in a fixed order by reduce_partials_kernel (deterministic).
@@ -1522,6 +1600,32 @@ extern "C" int cdnet_dam_loss(const float *mask, const float *point, const float
         loss_grad_kernel<<<dim3(lin_grid((size_t)P, 256), B), 256, 0, st>>>(L, coef, dmask, dpoint, ddir);
     }
     return check_launch("cdnet_dam_loss");
+}
+
+extern "C" size_t cdnet_dam_val_sums_workspace_floats(int B, int P) {
+    int nchunk = cdiv(P, 256 * 8);
+    if (nchunk > 64) nchunk = 64;
+    return (size_t)B * nchunk * V_SUMS;
+}
+
+extern "C" int cdnet_dam_val_sums(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
+                                  const uint16_t *point_target_f16, const uint8_t *weight_u8, const int *dir_rank_host, int B, int H, int W,
+                                  float *workspace, size_t workspace_floats, float *sums, void *stream) {
+    CDNET_REQUIRE(mask && point && dirn && label && dirlab && point_target_f16 && weight_u8 && dir_rank_host && workspace && sums,
+                  "cdnet_dam_val_sums: null pointer");
+    CDNET_REQUIRE(B >= 1 && B <= 64 && H > 0 && W > 0, "cdnet_dam_val_sums: batch %d not in [1,64]", B);
+    const int P = H * W;
+    if (workspace_floats < cdnet_dam_val_sums_workspace_floats(B, P)) { set_error("cdnet_dam_val_sums: workspace too small"); return CDNET_E_WORKSPACE; }
+    int nchunk = cdiv(P, 256 * 8);
+    if (nchunk > 64) nchunk = 64;
+    ValIn L;
+    L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.weight = weight_u8; L.point_t = point_target_f16;
+    for (int k = 0; k < 9; ++k) L.lut[k] = dir_rank_host[k];
+    L.B = B; L.P = P;
+    hipStream_t st = (hipStream_t)stream;
+    val_sums_kernel<<<dim3(nchunk, B), 256, 0, st>>>(L, workspace);
+    val_sums_reduce_kernel<<<cdiv(B * V_SUMS, 256), 256, 0, st>>>(workspace, nchunk, B, sums);
+    return check_launch("cdnet_dam_val_sums");
 }
 
 extern "C" int cdnet_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,

@@ -1,0 +1,9 @@
+"""`Unet` of the reference's models/dam/model_unet_MandD16.py (ablation of the direction-aware-mask head: mask + 16+1-class direction;
+forward :246-268).  Same constructor, state_dict keys and return tuple; encoder, decoder and residual units are the kernels of
+model_unet_rev1, the heads are plain 1x1 classifiers (cdnet_final_conv1x1).  Inference only on the accelerated path."""
+from .model_unet_rev1 import Unet as _Rev1
+
+
+class Unet(_Rev1):
+    VARIANT = 'MandD'
+    DIRECTION_OUT = 17

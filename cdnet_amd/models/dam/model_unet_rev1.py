@@ -109,6 +109,10 @@ class _RU:
 
 
 class Unet(nn.Module):
+    # head wiring: 'rev1' = the direction-aware-mask head of CDNet; the ablation models of models/dam/model_unet_MandD*.py reuse
+    # this class with VARIANT 'MandD' (mask + direction, no gates, no point branch) / 'MandDandP' (plus the point branch)
+    VARIANT = 'rev1'
+    DIRECTION_OUT = 9
 
     def __init__(self, backbone_name='vgg16_bn', pretrained=True, encoder_freeze=False, classes=21,
                  decoder_filters=(256, 128, 64, 32, 16), parametric_upsampling=True, shortcut_features='default',
@@ -133,9 +137,11 @@ class Unet(nn.Module):
         self.point_feature = ResidualUnit(64, 64)
         self.point_conv = nn.Conv2d(64, 1, kernel_size=1)
         self.directionAtt = revAttention(1)
-        self.direction_conv = nn.Conv2d(64, 9, kernel_size=1)
-        self.maskAtt = revAttention(9)
+        self.direction_conv = nn.Conv2d(64, self.DIRECTION_OUT, kernel_size=1)
+        self.maskAtt = revAttention(self.DIRECTION_OUT)
         self.mask_conv = nn.Conv2d(64, 3, kernel_size=1)
+        if self.VARIANT != 'rev1':
+            self.residual = ResidualUnit(64, 64)            # model_unet_MandD.py:234
         if encoder_freeze:
             self.freeze_encoder()
         self._rt = None
@@ -167,6 +173,8 @@ class Unet(nn.Module):
         self._rt = dict(enc=enc, dec=dec, ru=[_RU('mask_feature', self.mask_feature),
                                                _RU('direction_feature', self.direction_feature),
                                                _RU('point_feature', self.point_feature)])
+        if self.VARIANT != 'rev1':
+            self._rt['ru_res'] = _RU('residual', self.residual)
 
     def conv_layers(self):
         if self._rt is None:
@@ -227,8 +235,13 @@ class Unet(nn.Module):
             t = conv2.forward([u, skip], training, H=sh, W=sw)      # cat([x, skip]) -> conv2 -> bn2 -> relu (:133-141)
         f1 = self._rt['ru'][0].forward(t, training, store=True)
         f2 = self._rt['ru'][1].forward(f1, training, store=True)
-        f3 = self._rt['ru'][2].forward(f2, training)
-        return f1, f2, f3
+        if self.VARIANT == 'rev1':
+            f3 = self._rt['ru'][2].forward(f2, training)
+            return f1, f2, f3
+        # ablation heads (model_unet_MandD.py:254-266, model_unet_MandDandP.py:254-268)
+        f3 = self._rt['ru'][2].forward(f2, training) if self.VARIANT == 'MandDandP' else None
+        f1m = self._rt['ru_res'].forward(f1, training)
+        return f1m, f2, f3
 
     def forward(self, *input):
         x = input[0]
@@ -238,7 +251,30 @@ class Unet(nn.Module):
         """forward on already packed bf16 NHWC windows (sliding-window / TTA inference)"""
         return self._head(self.forward_features_packed(x16, self.training))
 
+    def _plain_head(self, feats):
+        """ablation heads: plain 1x1 classifiers on the features, no attention gates (cdnet_final_conv1x1)"""
+        import ctypes as C
+        f1m, f2, f3 = feats
+        if self.training:
+            raise NotImplementedError('the ablation heads (model_unet_MandD*) run inference only on the accelerated path')
+        N, H, W, _ = f1m.x.shape
+        dev = f1m.x.device
+
+        def cls(f, conv):
+            K = conv.out_channels
+            out = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+            hf = runtime.head_feat(f)
+            w = conv.weight.detach().reshape(K, 64).contiguous()
+            _lib.call('cdnet_final_conv1x1', C.byref(hf), _lib.ptr(w), _lib.ptr(conv.bias.detach()), K, N, H, W, _lib.ptr(out), _lib.stream_ptr())
+            return out
+        mask, direction = cls(f1m, self.mask_conv), cls(f2, self.direction_conv)
+        if self.VARIANT == 'MandDandP':
+            return mask, cls(f3, self.point_conv), direction
+        return mask, direction
+
     def _head(self, feats):
+        if getattr(self, 'VARIANT', 'rev1') != 'rev1':
+            return self._plain_head(feats)
         f1, f2, f3 = feats
         N, H, W, _ = f1.x.shape
         dev = f1.x.device

@@ -41,6 +41,7 @@ class _SyntheticLoader:
 def main(argv=None):
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--synthetic', type=int, default=0, help='number of synthetic batches per epoch (0 = read the dataset folders)')
+    ap.add_argument('--synthetic-val', type=int, default=0, help='synthetic validation batches per epoch (with --synthetic and --validation 1)')
     own, rest = ap.parse_known_args(argv)
     opt = Options(isTrain=True).parse(rest)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -83,6 +84,21 @@ def main(argv=None):
         dset = DataFolder(dir_list, ['weight.png', 'label.png'], [3, 1, 3])
         loader = TileBatches(dset, opt.transform['train'], B, dev, seed=opt.train['seed'] + 1000 * rank, logger=logger)
         logger.info('{:d} training images in {:s}'.format(len(dset), dir_list[0]))
+    # validation set (train.py:262-290: <img_dir>/val etc.) for the best-checkpoint / early-stopping logic of train.py:348-447
+    val_loader = None
+    if opt.train['validation'] == 1 and not plain_unet:
+        if own.synthetic > 0:
+            val_loader = _SyntheticLoader(max(1, own.synthetic_val), B, dev, seed=opt.train['seed'] + 777 + 1000 * rank)
+        else:
+            from .data_folder import DataFolder, TileBatches
+            vdirs = ['{:s}/val'.format(opt.train[k]) for k in ('img_dir', 'weight_map_dir', 'label_dir')]
+            if all(os.path.isdir(d) for d in vdirs):
+                vset = DataFolder(vdirs, ['weight.png', 'label.png'], [3, 1, 3])
+                vt = {k: v for k, v in opt.transform['train'].items() if k in ('random_crop', 'label_encoding', 'to_tensor', 'normalize')}
+                val_loader = TileBatches(vset, vt, 1, dev, seed=opt.train['seed'], shuffle=False, logger=logger)
+            else:
+                logger.info('validation = 1 but {} is missing: the training results stand in for the validation results'.format(vdirs[0]))
+    early_stopping = utils.EarlyStopping(patience=opt.train['early_stop']) if opt.train['early_stop'] > 0 else None
     res = None
     for epoch in range(opt.train['start_epoch'], opt.train['num_epochs']):
         t0 = time.time()
@@ -96,15 +112,31 @@ def main(argv=None):
         torch.cuda.synchronize()
         dt = time.time() - t0
         logger.info('epoch {:d}: loss {:.4f}  ({:.1f} tiles/s on {:d} GPU(s))'.format(epoch + 1, float(res[0]), world * B * len(loader) / dt, world))
+        # train.py:348-387: validation results (or the training results standing in for them), best model by val_iou
+        if val_loader is not None:
+            val = trainer.reduce_scalars(train_util_dam.validate(val_loader, model, None, opt, logger, all_img_test=opt.all_img_test))
+            val_loss, val_iou, val_F1 = float(val[0]), float(val[5]), float(val[8])
+        elif plain_unet:
+            val_loss, val_iou, val_F1 = float(res[0]), 0.0, 0.0
+        else:
+            val_loss, val_iou, val_F1 = float(res[0]), float(res[7]), float(res[10])
+        is_best = val_iou > best_iou                       # train.py:385
+        best_iou, new_best_loss = max(val_iou, best_iou), min(val_loss, best_loss)
         if rank == 0 and opt.train.get('save_dir'):
-            # train.py:406-427: checkpoint.pth.tar every epoch, numbered copies at checkpoint_freq, checkpoint_best on a new
-            # best (no validation loop here: the training loss stands in for val_loss)
-            is_best = float(res[0]) < best_loss
-            best_loss = min(best_loss, float(res[0]))
+            # train.py:406-427: checkpoint.pth.tar every epoch, numbered copies at checkpoint_freq, checkpoint_best on a new best
+            if val_loader is None and plain_unet:
+                is_best = val_loss < best_loss
+            best_loss = new_best_loss
             cp_flag = int((epoch + 1) % opt.train['checkpoint_freq'] == 0 or epoch + 1 == opt.train['num_epochs'])
             os.makedirs(opt.train['save_dir'], exist_ok=True)
             checkpoint.save_checkpoint(checkpoint.make_state(model, trainer, epoch, best_iou, best_loss), epoch, is_best,
                                        opt.train['save_dir'], 'Main', cp_flag)
+        best_loss = new_best_loss
+        if early_stopping is not None:                     # train.py:442-447: monitored value -F1 - IoU, never before epoch 100
+            early_stopping(-val_F1 - val_iou, epoch)
+            if early_stopping.early_stop:
+                logger.info('epoch = {} Early stopping...'.format(epoch))
+                break
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -61,3 +61,70 @@ def train(train_loader, model, optimizer, criterion, epoch, opt, logger, get_pro
     if logger is not None:
         logger.info('\t=> Train Avg: Loss {r[0]:.4f}\tloss_CE {r[4]:.4f}\tPixel_Accu {r[6]:.4f}\tIoU {r[7]:.4f}'.format(r=results.avg))
     return results.avg
+
+
+def validate(val_loader, model, criterion, opt, logger, get_process_worktime=1, get_process_detail=1, all_img_test=1, accuracy_tensor=0,
+             do_object_metric=0):
+    """train_util_dam.validate (train_util_dam.py:367-636) -> ndarray[16]: [loss, loss_direction_CE, loss_direction_dice, loss_mse,
+    pixel_accu, pixel_iou, pixel_recall, pixel_precision, pixel_F1, obj_recall, obj_precision, obj_F1, obj_dice, obj_iou, obj_haus,
+    obj_AJI].  Eval-mode forward of the whole tile (all_img_test == 1) or through `utils.split_forward_dam` with
+    opt.train['input_size'] / opt.train['val_overlap'] (:474); validate's OWN loss mix - unweighted mask CE + multi-class dice +
+    weighted direction CE + plain dice on the background-gated direction probabilities + MSE against point / 255 - from one pass of
+    `cdnet_dam_val_sums` over the logits, combined here in float64; the pixel metrics of the mask arg-max (:585-590).  With
+    do_object_metric = 0 (the reference's call, train.py:348) the object slots are 0 and obj_iou = pixel_iou (:617-619)."""
+    import ctypes as C
+    from . import _lib
+    assert opt.model['direction'] == 1 and opt.model['mseloss'] == 1 and opt.train['alpha'] == 0 and opt.model['dice'] == 1, \
+        'validate implements the default configuration (direction + point branches, dice = 1, no variance term)'
+    if do_object_metric:
+        raise NotImplementedError('do_object_metric = 1 (Hausdorff-based object metrics) is outside the accelerated path')
+    results = utils.AverageMeter(16)
+    model.eval()
+    dev = next(model.parameters()).device
+    lib = _lib.load()
+    ws = None
+    for i, sample in enumerate(val_loader):
+        input, weight_map, target0, target_point0, target_direction0 = sample
+        label = _label3(target0.to(dev), 2 if opt.model['multi_class'] else 1).contiguous()
+        w = weight_map.to(dev)
+        w = (w[:, 0] if w.dim() == 4 else w).to(torch.uint8).contiguous()
+        dirlab = target_direction0.to(dev).to(torch.uint8).contiguous()
+        point_t = target_point0.to(dev).to(torch.float16).contiguous()
+        x = input.to(dev).float()
+        with torch.no_grad():
+            if all_img_test == 1:
+                mask, point, direction = model(x)
+            else:
+                outs = [utils.split_forward_dam(model, x[b:b + 1], opt.train['input_size'], opt.train['val_overlap'], opt) for b in range(x.shape[0])]
+                mask, point, direction = [torch.cat([o[k] for o in outs], 0).contiguous() for k in range(3)]
+        B, _, H, W = mask.shape
+        # channel of a direction class = its rank among the batch's unique values (:462-468); a class the batch lacks has none
+        uniq = torch.unique(dirlab).cpu().tolist()
+        if len(uniq) < opt.direction_classes:
+            raise IndexError('validate: the batch holds %d of the %d direction classes (the reference indexes unique_number[k] for '
+                             'every k, train_util_dam.py:467)' % (len(uniq), opt.direction_classes))
+        rank = (C.c_int * 9)(*[(uniq.index(v) if v in uniq else -1) for v in range(9)])
+        need = lib.cdnet_dam_val_sums_workspace_floats(B, H * W)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty((need,), dtype=torch.float32, device=dev)
+        sums = torch.empty((B, 42), dtype=torch.float32, device=dev)
+        _lib.call('cdnet_dam_val_sums', _lib.ptr(mask.contiguous()), _lib.ptr(point.contiguous()), _lib.ptr(direction.contiguous()), _lib.ptr(label),
+                  _lib.ptr(dirlab), _lib.ptr(point_t), _lib.ptr(w), C.cast(rank, C.c_void_p), B, H, W, _lib.ptr(ws), ws.numel(), _lib.ptr(sums),
+                  _lib.stream_ptr())
+        S = sums.cpu().numpy().astype(np.float64)
+        n = float(B * H * W)
+        ce, dce, mse = S[:, 9].sum() / n, S[:, 37].sum() / n, S[:, 38].sum() / n
+        dice = sum(1.0 - np.mean(2.0 * (S[:, c] + 1.0) / (S[:, 3 + c] + S[:, 6 + c] + 1.0)) for c in range(3))          # loss.py:135-176
+        ddice = sum(1.0 - np.mean(2.0 * (S[:, 10 + c] + 1.0) / (S[:, 19 + c] + S[:, 28 + c] + 1.0)) for c in range(9))
+        loss = ce + dice + dce + ddice + mse
+        tp, fp, fn = S[:, 39], S[:, 40], S[:, 41]
+        tn = H * W - tp - fp - fn
+        precision, recall = tp / (tp + fp + 1e-10), tp / (tp + fn + 1e-10)
+        m = [np.mean((tp + tn) / (tp + fp + tn + fn + 1e-10)), np.mean(tp / (tp + fp + fn + 1e-10)), np.mean(recall), np.mean(precision),
+             np.mean(2 * precision * recall / (precision + recall + 1e-10))]
+        results.update([loss, dce, ddice, mse, m[0], m[1], m[2], m[3], m[4], 0, 0, 0, 0, m[1], 0, 0])
+    if logger is not None:
+        logger.info('\t=> Val Avg:   \tLoss {r[0]:.4f}\tloss_direction_CE {r[1]:.4f}\tloss_direction_dice {r[2]:.4f}\tloss_mse {r[3]:.4f}'
+                    '\tPixel_Acc {r[4]:.4f}\tPixel_IoU {r[5]:.4f}\tpixel_Recall {r[6]:.4f}\tpixel_Precision {r[7]:.4f}\tpixel_F1 {r[8]:.4f}'
+                    .format(r=results.avg))
+    return results.avg

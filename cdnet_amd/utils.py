@@ -21,10 +21,14 @@ def chooseModel(opt):
         from .models.dam.model_unet_rev1 import Unet
         # the reference hard-codes pretrained=True (ImageNet download); weights are supplied via load_state_dict here
         return Unet(backbone_name='vgg16_bn', pretrained=False, encoder_freeze=False, classes=opt.model['out_c'])
+    if name in ('model_unet_MandD', 'model_unet_MandD4', 'model_unet_MandD16', 'model_unet_MandDandP'):      # utils.py:857-874
+        import importlib
+        mod = importlib.import_module('.models.dam.' + name, __package__)
+        return mod.Unet(backbone_name='vgg16_bn', pretrained=False, encoder_freeze=False, classes=opt.model['out_c'])
     if name == 'HRNet18_rev1':                       # utils.py:880-882
         from .models.dam.seg_hrnet_rev1 import HighResolutionNet
         return HighResolutionNet(opt)
-    raise NotImplementedError('model {} is outside the CDNet hot path (SURVEY.md section 8: UNet, UNet2RevA1_vgg16, HRNet18_rev1)'.format(name))
+    raise NotImplementedError('model {} is outside the CDNet hot path (SURVEY.md section 8: UNet, UNet2RevA1_vgg16, model_unet_MandD*, HRNet18_rev1)'.format(name))
 
 
 def window_grid(h0, w0, size, overlap):
@@ -124,3 +128,28 @@ def get_optimizer(args, model, world_size=1):
 def adjust_learning_rate(args, trainer, epoch):
     """utils.py:965-977: scheduler 'None' keeps the learning rate constant"""
     return trainer.lr
+
+
+class EarlyStopping:
+    """Early stops the training if the monitored value does not improve after `patience` epochs - and, as in the reference, never
+    before epoch 100 (utils.py:992-1034)."""
+
+    def __init__(self, patience=7, verbose=False, delta=0):
+        self.patience, self.verbose, self.delta = patience, verbose, delta
+        self.counter, self.best_score, self.early_stop = 0, None, False
+        self.val_loss_min = np.inf
+
+    def __call__(self, val_loss, epoch):
+        score = -val_loss
+        if self.best_score is None:
+            self.best_score = score
+            self.val_loss_min = val_loss
+        elif score < self.best_score + self.delta:
+            self.counter += 1
+            print('===================== EarlyStopping counter: {} out of {} ====================='.format(self.counter, self.patience))
+            if self.counter >= self.patience and epoch >= 100:
+                self.early_stop = True
+        else:
+            self.best_score = score
+            self.val_loss_min = val_loss
+            self.counter = 0

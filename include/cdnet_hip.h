@@ -332,7 +332,8 @@ int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_head_feat *f2
  * quirk_sample0 = 1 reproduces train_util_dam.py:139 (direction one-hot masked by sample 0's foreground).
  * losses[11] = {total, direction CE, direction weighted dice, MSE, CE, dice, then the pixel-level metrics of
  * train_util_dam.py:279-293 (argmax direction class == 1 vs direction label == 1, utils.py:67-110), averaged over the batch:
- * accuracy, IoU, recall, precision, F1}.  dmask/dpoint/ddir may all be NULL.  * Label content is validated on the device: a mask class > 2 or a direction class > 8 makes every entry of `losses` NaN
+ * accuracy, IoU, recall, precision, F1}.  dmask/dpoint/ddir may all be NULL.
+ * Label content is validated on the device: a mask class > 2 or a direction class > 8 makes every entry of `losses` NaN
  * (indices are clamped, nothing is read or written out of bounds) - the reference's nn.NLLLoss raises on such targets.
  */
 size_t cdnet_dam_loss_workspace_floats(int B, int P);
@@ -340,6 +341,20 @@ int cdnet_dam_loss(const float *mask, const float *point, const float *direction
                    const uint8_t *dirlab, const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W,
                    int quirk_sample0, float *workspace, size_t workspace_floats, float *losses, float *dmask,
                    float *dpoint, float *ddir, void *stream);
+
+/* validate() loss mix of train_util_dam.py:367-636 (default options): per-sample sums of ONE pass over the logits, combined on the
+ * host by cdnet_amd.train_util_dam.validate.  sums f32 [B][CDNET_VAL_SUMS]:
+ *   0..2 sum p_c [label==c], 3..5 sum p_c, 6..8 sum [label==c], 9 sum -log p_label (unweighted mask CE, :499-505);
+ *   10..18 / 19..27 / 28..36 the same three sums for the direction probabilities with channel 0 multiplied by P(background)
+ *   (:564-566) against the one-hot direction target - channel = dir_rank_host[class value] (the rank among the batch's unique
+ *   values, :462-468; -1 = absent), zeroed off SAMPLE 0's foreground (:469); 37 sum w * -log q_dir (:553-559);
+ *   38 sum (point - target / 255)^2 (:575-580); 39..41 tp, fp, fn of (argmax mask == 1) vs (label == 1) (:585-590).
+ * workspace: cdnet_dam_val_sums_workspace_floats(B, H * W) floats. */
+#define CDNET_VAL_SUMS 42
+size_t cdnet_dam_val_sums_workspace_floats(int B, int P);
+int cdnet_dam_val_sums(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
+                       const uint16_t *point_target_f16, const uint8_t *weight_u8, const int *dir_rank_host, int B, int H, int W,
+                       float *workspace, size_t workspace_floats, float *sums, void *stream);
 
 /* torch.optim.Adam step (utils.py:915-918: betas (0.9, 0.99), L2 weight decay added to the gradient) on flat fp32
  * buffers; `step` is 1-based; grad_scale multiplies the gradient first (1/world_size after an all-reduce). */

@@ -138,3 +138,59 @@ def unet_train_iteration(model, optimizer, x, label, weight_png):
     L['total'].backward()
     optimizer.step()
     return {k: float(v) for k, v in L.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# validate (train_util_dam.py:367-636, default options; do_object_metric = 0)
+# ---------------------------------------------------------------------------------------------------------
+def validate_losses(mask_logits, point_out, dir_logits, label, direction, point_target, weight_png):
+    """The loss mix of validate(): unweighted mask CE (:499-505, the weight-map multiply is commented out), multi-class dice on
+    softmax(mask) (:540-543), weighted direction CE (:553-559), PLAIN multi-class dice on the direction probabilities whose
+    channel 0 is multiplied by P(background) (:564-568) against the one-hot direction target masked by SAMPLE 0's foreground
+    (:463-470, `target[0]`), MSE against point_target / 255 (:575-580)."""
+    w = weight_png.float().div(20)
+    if w.dim() == 4:
+        w = w.squeeze(1)
+    label = label.long()
+    direction = direction.long()
+    ce = F.nll_loss(F.log_softmax(mask_logits, 1), label, reduction='none').mean()
+    prob = F.softmax(mask_logits, 1)
+    dice = multiclass_dice(prob, F.one_hot(label, 3).permute(0, 3, 1, 2).float())
+    dce = (F.nll_loss(F.log_softmax(dir_logits, 1), direction, reduction='none') * w).mean()
+    # one-hot: channel k <-> k-th value of torch.unique over the batch (:462-468), zeroed off sample 0's foreground
+    uniq = torch.unique(direction)
+    C = dir_logits.shape[1]
+    oh = torch.zeros((direction.shape[0], C) + tuple(direction.shape[1:]))
+    fg0 = (label[0] == 1) | (label[0] == 2)
+    for k in range(C):
+        oh[:, k] = (direction == uniq[k]).float() * fg0.float()          # IndexError like the reference when a class is absent
+    q = F.softmax(dir_logits, 1).clone()
+    q[:, 0] = q[:, 0] * prob[:, 0]
+    ddice = multiclass_dice(q, oh)
+    pt = point_target.float()
+    if pt.dim() == 3:
+        pt = pt.unsqueeze(1)
+    mse = F.mse_loss(point_out, pt / 255)
+    return dict(ce=ce, dice=dice, dce=dce, ddice=ddice, mse=mse, total=ce + dice + dce + ddice + mse)
+
+
+def validate_iteration(model, x, label, direction, point_target, weight_png, split=None):
+    """One validate() sample -> the 16-value row [loss, direction CE, direction dice, MSE, pixel accuracy, IoU, recall, precision,
+    F1, 0, 0, 0, 0, IoU, 0, 0] (:620-623 with do_object_metric = 0: `iou = pixel_iou`).  split = (size, overlap) evaluates through
+    the sliding windows of utils.split_forward_dam (all_img_test = 0)."""
+    import numpy as np
+    model.eval()
+    with torch.no_grad():
+        if split is None:
+            mask, point, dirn = model(x)
+        else:
+            from . import infer
+            mask, point, dirn = infer.split_forward(model, x, split[0], split[1], dirn_classes(model))
+        L = validate_losses(mask, point, dirn, label, direction, point_target, weight_png)
+    m = pixel_metrics(mask.argmax(1).numpy(), label.numpy())
+    return np.array([float(L['total']), float(L['dce']), float(L['ddice']), float(L['mse']), m[0], m[1], m[2], m[3], m[4],
+                     0, 0, 0, 0, m[1], 0, 0], dtype=np.float64)
+
+
+def dirn_classes(model):
+    return model.direction_conv.out_channels

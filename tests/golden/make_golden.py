@@ -14,6 +14,8 @@ Fixtures:
   dam_fwd.npz      models/dam/model_unet_rev1.py Unet forward (train-mode BN and eval-mode BN) + grads
   losses.npz       loss.py dice / weighted-dice, log-softmax NLL, MSE on fixed logits
   train_iter.npz   train_util_dam.train: two iterations on a 1-batch loader (losses + params after Adam)
+  ablation.npz     models/dam/model_unet_MandD{,4,16,andP}.py eval forward (heads without attention gates)
+  validate.npz     train_util_dam.validate: the 16-value result vector, whole-tile and sliding-window forward
   cdm.npz          my_transforms_direction.LabelEncoding (direction branch) on synthetic ellipse labels
                    [skimage-semantics restated: scipy stand-ins for dilation/erosion/label]
   split_fwd.npz    utils.split_forward_dam stitching with a position-coding toy model
@@ -280,6 +282,50 @@ def gen_train_iter():
     out['rm_backbone.1.running_mean'] = m.state_dict()['backbone.1.running_mean'].numpy().copy()
     out['rm_backbone.1.running_var'] = m.state_dict()['backbone.1.running_var'].numpy().copy()
     save('train_iter', **out)
+
+
+def gen_ablation():
+    """eval forward of the four ablation models of utils.py:857-874 (models/dam/model_unet_MandD*.py), closed-form weights; outputs
+    stored as float16 slices (the networks share encoder / decoder with model_unet_rev1: the heads are what is pinned)"""
+    import importlib, io, contextlib
+    out = {}
+    x = det_input((1, 3, 48, 64), 12)
+    for name in ('model_unet_MandD', 'model_unet_MandD4', 'model_unet_MandD16', 'model_unet_MandDandP'):
+        mod = importlib.import_module('models.dam.' + name)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = mod.Unet(backbone_name='vgg16_bn', pretrained=False, encoder_freeze=False, classes=3)
+        m = det_fill(m).eval()
+        with torch.no_grad():
+            res = m(x)
+        out['n_' + name] = np.int64(len(res))
+        out['keys_' + name] = np.array(list(m.state_dict().keys()))
+        for k, o in enumerate(res):
+            out['%s_%d' % (name, k)] = o.numpy().astype(np.float16)
+    out['x_cfg'] = np.array([1, 3, 48, 64, 12])
+    save('ablation', **out)
+
+
+def gen_validate():
+    """train_util_dam.validate (train_util_dam.py:367-636) on a 1-batch loader, default options: eval-mode forward of the whole
+    tile (all_img_test = 1) and through utils.split_forward_dam (all_img_test = 0, 64 / 16 windows), its own loss mix (unweighted
+    mask CE + multi-class dice + weighted direction CE + plain dice on the background-gated direction probabilities + MSE against
+    point / 255) and the pixel metrics of the mask arg-max -> the 16-value result vector"""
+    import train_util_dam
+    B, H, W = 2, 96, 96
+    lab, dirn, point, weight = _synthetic_targets(B, H, W, 23)
+    x = det_input((B, 3, H, W), 10)
+    target0 = torch.from_numpy(lab * 127 + (lab == 2)).long().unsqueeze(1)
+    sample = (x, torch.from_numpy(weight), target0, torch.from_numpy(point), torch.from_numpy(dirn))
+    m = det_fill(_dam_model())
+    opt = _Opt()
+    opt.train.update(input_size=64, val_overlap=16)
+    opt.post = dict(min_area=20, radius=2)
+    crit = torch.nn.NLLLoss(reduction='none')
+    whole = train_util_dam.validate([sample], m, crit, opt, _Logger(), all_img_test=1)
+    one = (x[:1], torch.from_numpy(weight[:1]), target0[:1], torch.from_numpy(point[:1]), torch.from_numpy(dirn[:1]))
+    split = train_util_dam.validate([one], m, crit, opt, _Logger(), all_img_test=0)
+    save('validate', x_cfg=np.array([B, 3, H, W, 10]), tgt_cfg=np.array([B, H, W, 23]), win_cfg=np.array([64, 16]),
+         whole=np.array(whole, dtype=np.float64), split=np.array(split, dtype=np.float64))
 
 
 def gen_hrnet():
@@ -569,7 +615,7 @@ def gen_aji():
     save('aji', **out)
 
 
-ALL = {'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
+ALL = {'validate': gen_validate, 'ablation': gen_ablation, 'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
        'cdm': gen_cdm, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':

@@ -139,3 +139,30 @@ def test_plain_unet_forward_vs_oracle_and_golden(golden):
     scale = want.abs().max()
     err = (got - want).abs()
     assert err.max() <= 8e-2 * scale and err.mean() <= 1e-2 * scale, (float(err.max()), float(err.mean()), float(scale))
+
+
+@pytest.mark.parametrize('name', ['model_unet_MandD', 'model_unet_MandD4', 'model_unet_MandD16', 'model_unet_MandDandP'])
+def test_ablation_heads_vs_reference_golden(golden, name):
+    """the four ablation models of utils.py:857-874 (heads without attention gates): same state_dict keys as the reference, eval
+    forward vs the reference's outputs (tests/golden/ablation.npz); bf16 path tolerance as for the rev1 model"""
+    import torch
+    from cdnet_amd import synth, utils
+    z = golden('ablation')
+
+    class _Opt:
+        model = {'modelName': name, 'out_c': 3, 'in_c': 3}
+    m = utils.chooseModel(_Opt())
+    assert list(m.state_dict().keys()) == [str(k) for k in z['keys_' + name]]
+    bn = {n for n, mod in m.named_modules() if isinstance(mod, torch.nn.BatchNorm2d)}
+    with torch.no_grad():
+        synth.det_fill_state_dict(m.state_dict(), bn)
+    m = m.cuda().eval()
+    shape = tuple(int(v) for v in z['x_cfg'][:4])
+    x = torch.from_numpy(synth.det_input(shape, int(z['x_cfg'][4])))
+    with torch.no_grad():
+        got = m(x.cuda())
+    assert len(got) == int(z['n_' + name])
+    for k, g in enumerate(got):
+        want = z['%s_%d' % (name, k)].astype(np.float32)
+        assert tuple(g.shape) == want.shape
+        _check(g, want, '%s output %d' % (name, k), amin=0.97)       # 17 near-tied classes on closed-form weights (bf16 path)

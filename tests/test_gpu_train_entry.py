@@ -97,3 +97,48 @@ def test_entry_point_reads_dataset_folders(tmp_path, monkeypatch):
     assert seen == 5
     res = train.main(['--epochs', '2', '--batch-size', '2', '--input-size', '64', '--save-dir', str(tmp_path / 'exp')])
     assert len(res) == 11 and np.isfinite(res).all()
+
+
+@pytest.mark.parametrize('precision,rtol', [('bf16', 2.5e-2), ('fp32', 2e-4)])
+def test_validate_matches_oracle_and_reference_golden(golden, precision, rtol):
+    """cdnet_amd.train_util_dam.validate (eval forward + cdnet_dam_val_sums) vs the reference's own 16-value result vector
+    (tests/golden/validate.npz; the oracle restatement is pinned to it on the CPU), whole tile and 64/16 sliding windows.
+    fp32 precision: 2e-4 (proves the loss mix); bf16 forward on the closed-form weights: losses within 2.5 %."""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import synth, train_util_dam
+    old = cdnet_amd.get_precision()
+    cdnet_amd.set_precision(precision)
+    try:
+        _validate_case(golden, rtol)
+    finally:
+        cdnet_amd.set_precision(old)
+
+
+def _validate_case(golden, rtol):
+    import torch
+    from cdnet_amd import synth, train_util_dam
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    from cdnet_amd.options import Options
+    from oracle import models as om
+    z = golden('validate')
+    B, _, H, W, seed = [int(v) for v in z['x_cfg']]
+    lab, dirn, point, weight = synth.train_targets(B, H, W, int(z['tgt_cfg'][3]))
+    x = torch.from_numpy(synth.det_input((B, 3, H, W), seed))
+    ref = om.det_fill(om.Unet())
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda()
+    opt = Options(isTrain=True).parse([])
+    size, ov = [int(v) for v in z['win_cfg']]
+    opt.train['input_size'], opt.train['val_overlap'] = size, ov
+    target0 = torch.from_numpy(lab.astype(np.int64) * 127 + (lab == 2)).unsqueeze(1)
+    sample = (x, torch.from_numpy(weight), target0, torch.from_numpy(point), torch.from_numpy(dirn))
+    got = train_util_dam.validate([sample], m, None, opt, None, all_img_test=1)
+    assert got.shape == (16,)
+    np.testing.assert_allclose(got[:4], z['whole'][:4], rtol=rtol)
+    np.testing.assert_allclose(got[4:], z['whole'][4:], atol=5e-3)
+    one = tuple(t[:1] for t in sample)
+    got = train_util_dam.validate([one], m, None, opt, None, all_img_test=0)
+    np.testing.assert_allclose(got[:4], z['split'][:4], rtol=rtol)
+    np.testing.assert_allclose(got[4:], z['split'][4:], atol=5e-3)

@@ -135,3 +135,23 @@ def test_unet_train_iteration_matches_reference(golden):
         for k in z['pick']:
             got = sd[str(k)].detach().reshape(-1)[:96].numpy()
             np.testing.assert_allclose(got, z['p%d_%s' % (it, k)], rtol=2e-3, atol=2e-5, err_msg=str(k))
+
+
+def test_validate_oracle_matches_reference_golden(golden):
+    """oracle/train.py:validate_iteration == the reference's train_util_dam.validate on the same sample (whole tile and 64/16
+    sliding windows), tests/golden/validate.npz"""
+    import torch
+    from cdnet_amd import synth
+    from oracle import models as om
+    from oracle import train as ot
+    z = golden('validate')
+    B, _, H, W, seed = [int(v) for v in z['x_cfg']]
+    lab, dirn, point, weight = synth.train_targets(B, H, W, int(z['tgt_cfg'][3]))
+    x = torch.from_numpy(synth.det_input((B, 3, H, W), seed))
+    net = om.det_fill(om.Unet())
+    t = [torch.from_numpy(a) for a in (lab, dirn, point, weight)]
+    got = ot.validate_iteration(net, x, *t)
+    np.testing.assert_allclose(got, z['whole'], rtol=2e-5, atol=1e-7)
+    size, ov = [int(v) for v in z['win_cfg']]
+    got = ot.validate_iteration(net, x[:1], *[a[:1] for a in t], split=(size, ov))
+    np.testing.assert_allclose(got, z['split'], rtol=2e-5, atol=1e-7)
