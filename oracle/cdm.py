@@ -14,7 +14,7 @@ def _l():
     return _lib
 
 
-def label_encoding(label_ch0, want_aux=False):
+def label_encoding(label_ch0, want_aux=False, want_field=False):
     """label_ch0: uint8 [H,W] (channel 0 of the 3-class label PNG).
     Returns (label3 u8 {0,127,255}, point float16 [H,W], direction u8 [H,W] in 0..8[, inst i32, centers i32 [n,2]])."""
     x = np.ascontiguousarray(label_ch0, dtype=np.uint8)
@@ -25,9 +25,14 @@ def label_encoding(label_ch0, want_aux=False):
     inst = np.empty((H, W), np.int32)
     centers = np.zeros((H * W // 4 + 1, 2), np.int32)
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    field = np.zeros((H, W, 2), np.float32) if want_field else None
+    _l().orc_set_direction_field_out(p(field, C.c_float) if want_field else None)
     n = _l().orc_label_encoding(p(x, C.c_uint8), H, W, p(label3, C.c_uint8), p(point, C.c_float), p(direction, C.c_uint8),
                                 p(inst, C.c_int32), p(centers, C.c_int32))
+    _l().orc_set_direction_field_out(None)
     out = (label3, point.astype(np.float16), direction)
     if want_aux:
         out = out + (inst, centers[:n].copy())
+    if want_field:
+        out = out + (field,)          # [H,W,2] float32: (row gradient, column gradient) the angle is taken from (:848)
     return out

@@ -69,6 +69,10 @@ static int label8(const uint8_t *mask, int H, int W, int32_t *lab)
     return cnt;
 }
 
+/* optional tap for the tests: the float32 (row, column) gradient field the angles are taken from */
+static float *g_dir_out = 0;
+void orc_set_direction_field_out(float *p) { g_dir_out = p; }
+
 /* in: channel 0 of the label PNG (u8).  out: label3 u8 {0,127,255}, point f32 (cast to f16 by the caller),
  * direction u8 0..8, and (optional) inst i32 = the dilated instance map, centers i32 [count][2].  Returns count. */
 int orc_label_encoding(const uint8_t *in, int H, int W, uint8_t *label3, float *point, uint8_t *direction,
@@ -216,6 +220,7 @@ int orc_label_encoding(const uint8_t *in, int H, int W, uint8_t *label3, float *
         direction[i] = (uint8_t)(bin + 1);
     }
     if (inst_out) memcpy(inst_out, inst, sizeof(int32_t) * n);
+    if (g_dir_out) memcpy(g_dir_out, dir, sizeof(float) * 2 * n);
     free(f); free(nd); free(lp); free(dir); free(bb); free(inst); free(lab); free(m1); free(nl); free(inside);
     return cnt;
 }
