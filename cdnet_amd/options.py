@@ -108,7 +108,10 @@ class Options:
             p.add_argument('--min-area', type=int, default=self.post['min_area'])
             p.add_argument('--radius', type=int, default=self.post['radius'])
             p.add_argument('--patch-size', type=int, default=self.test['patch_size'])
-            p.add_argument('--overlap', type=int, default=self.test['overlap'])
+            p.add_argument('--overlap', '--test-overlap', dest='overlap', type=int, default=self.test['overlap'])     # options.py:369
+            p.add_argument('--save-flag', type=lambda v: str(v).lower() not in ('0', 'false', ''), default=self.test['save_flag'])   # :373
+            p.add_argument('--test-filename', type=str, default=self.test['filename'])              # :390
+            p.add_argument('--groundtruth', type=int, default=self.test['groundtruth'])             # :400
             p.add_argument('--img-dir', type=str, default=self.test['img_dir'])
             p.add_argument('--label-dir', type=str, default=self.test['label_dir'])
             p.add_argument('--save-dir', type=str, default=self.test['save_dir'])
@@ -137,6 +140,7 @@ class Options:
         else:
             te = self.test
             te['epoch'], te['tta'], te['patch_size'], te['overlap'] = a.epoch, bool(a.tta), a.patch_size, a.overlap
+            te['save_flag'], te['filename'], te['groundtruth'] = bool(a.save_flag), a.test_filename, int(a.groundtruth)
             self.post['postproc'], self.post['min_area'], self.post['radius'] = a.postproc, a.min_area, a.radius
             te['gpu'] = list(a.gpu)
             self._derive()

@@ -97,11 +97,17 @@ def main(argv=None):
             mean, std = opt.transform['test']['normalize']
             x = (x - torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)) / torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
         r = process_image(model, x, opt)
-        Image.fromarray(r['final'].astype(np.uint16)).save(os.path.join(opt.test['save_dir'], f[:-4] + '_seg.tiff'))
+        if opt.test.get('save_flag', True):                                # test_dam.py:670-684 (save_flag)
+            Image.fromarray(r['final'].astype(np.uint16)).save(os.path.join(opt.test['save_dir'], f[:-4] + '_seg.tiff'))
         print('{:s}: {:d} nuclei'.format(f, r['count']))
         gt = ground_truth_instances(label_dir, f[:-4]) if label_dir and os.path.isdir(label_dir) else None
+        if opt.test.get('groundtruth', 0) == 1:
+            # test_dam.py:600-602: object metrics against the XML annotations (utils.nuclei_accuracy_annotation_object_level)
+            raise NotImplementedError('--groundtruth 1 (XML annotation files) is outside the accelerated path: supply instance labels')
         if gt is not None and gt.shape == r['final'].shape:                # eval_flag (test_dam.py:132, 591-660)
             res = evaluate_labels(r['final'], gt)
+            rec, prec, f1, dice_o, iou_o, haus, aji_o = utils.nuclei_accuracy_object_level(r['final'], gt)       # :603-604
+            res.update(obj_recall=rec, obj_precision=prec, obj_F1=f1, obj_dice=dice_o, obj_iou=iou_o, obj_haus=haus, obj_AJI=aji_o)
             all_results[f[:-4]] = res
             print('\tpixel_iou = {pixel_iou:.4f}, pixel_F1 = {pixel_F1:.4f}, AJI = {AJI:.4f}, Dice = {Dice:.4f}, DQ = {DQ:.4f}, '
                   'SQ = {SQ:.4f}, PQ = {PQ:.4f}'.format(**res))

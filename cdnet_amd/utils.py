@@ -153,3 +153,66 @@ class EarlyStopping:
             self.best_score = score
             self.val_loss_min = val_loss
             self.counter = 0
+
+
+def nuclei_accuracy_object_level(pred, gt):
+    """(recall, precision, F1, dice, iou, haus, AJI) of utils.nuclei_accuracy_object_level (utils.py:245-330): ground-truth objects in
+    id order, each greedily paired with the not-yet-used predicted object of largest IoU (first maximum in id order), used objects
+    removed (:312).  The pixel pass (areas + sparse pairwise intersections) runs on the device (`stats_utils.pair_table`); the
+    per-pair arithmetic is the reference's float arithmetic; the Hausdorff distance of a matched pair is scipy's
+    directed_hausdorff on both sides, exactly the call the reference makes (:6, :303).
+    pred / gt: integer label images (the reference re-labels both with skimage.measure.label: 8-connected regions of equal
+    value; `stats_utils` labelled inputs from this package already are such regions, ids are made contiguous here)."""
+    from scipy.spatial.distance import directed_hausdorff
+    from . import stats_utils
+
+    def raster_ids(a):
+        """ids 1..K in raster order of each id's first pixel - the numbering skimage.measure.label gives an instance map whose
+        ids are connected regions (a same-valued region split into several components would become several objects there)"""
+        a = np.ascontiguousarray(a).astype(np.int64)
+        vals, first = np.unique(a.ravel(), return_index=True)
+        keep = vals != 0
+        vals, first = vals[keep], first[keep]
+        lut = np.zeros(int(a.max()) + 1 if a.size else 1, np.int32)
+        lut[vals[np.argsort(first, kind='stable')]] = np.arange(1, len(vals) + 1, dtype=np.int32)
+        return lut[a].astype(np.int32)
+    p, g = raster_ids(pred), raster_ids(gt)
+    ag, ap, pairs = stats_utils.pair_table(g, p)
+    Ng, Ns = int((ag[1:] > 0).sum()), int((ap[1:] > 0).sum())
+    by_gt = {}
+    for ti, pi, inter in pairs:
+        by_gt.setdefault(int(ti), []).append((int(pi), float(inter)))
+    used = set()
+    TP = FN = 0.0
+    dice = iou = haus = C = U = count = 0.0
+    for i in range(1, Ng + 1):
+        cands = [(k, it) for k, it in sorted(by_gt.get(i, [])) if k not in used]
+        if not cands:
+            FN += 1
+            U += float(ag[i])
+            continue
+        max_iou, best, overlap_area = 0.0, None, 0.0
+        for k, it in cands:
+            tmp_iou = it / (float(ap[k]) + float(ag[i]) - it)
+            if tmp_iou > max_iou:
+                max_iou, best, overlap_area = tmp_iou, k, it
+        TP += 1
+        count += 1
+        a_p, a_g = float(ap[best]), float(ag[i])
+        dice += 2 * overlap_area / (a_p + a_g)
+        iou += overlap_area / (a_p + a_g - overlap_area)
+        seg_ind, gt_ind = np.argwhere(p == best), np.argwhere(g == i)
+        haus += max(directed_hausdorff(seg_ind, gt_ind)[0], directed_hausdorff(gt_ind, seg_ind)[0])
+        C += overlap_area
+        U += a_p + a_g - overlap_area
+        used.add(best)
+    FP = Ns - TP
+    recall = TP / (TP + FN + 1e-10)
+    precision = TP / (TP + FP + 1e-10)
+    F1 = 2 * TP / (2 * TP + FP + FN + 1e-10)
+    if count == 0:
+        count = 1
+    dice, iou, haus = dice / count, iou / count, haus / count
+    U += float(sum(int(ap[k]) for k in range(1, len(ap)) if ap[k] > 0 and k not in used))
+    AJI = float(C) / U if U > 0 else float('nan')
+    return recall, precision, F1, dice, iou, haus, AJI

@@ -86,10 +86,28 @@ def _remove_small_objects(ar, min_size=64, connectivity=1, in_place=False):
 def _label(x, connectivity=None, background=0, return_num=False):
     x = np.asarray(x)
     assert x.ndim == 2
-    # the hot path only labels binary (0/1) images with full connectivity
-    assert set(np.unique(x)).issubset({0, 1, True, False}), 'shim measure.label: binary input only'
-    lab, n = ndi.label(x != 0, structure=np.ones((3, 3), dtype=int))
-    return (lab, n) if return_num else lab
+    if set(np.unique(x)).issubset({0, 1, True, False}):
+        lab, n = ndi.label(x != 0, structure=np.ones((3, 3), dtype=int))
+        return (lab, n) if return_num else lab
+    # integer image (utils.nuclei_accuracy_object_level, test_dam.py:613): skimage labels 8-connected regions of EQUAL value,
+    # numbered in raster order of each region's first pixel
+    out = np.zeros(x.shape, np.int64)
+    firsts = []
+    nxt = 0
+    for v in np.unique(x):
+        if v == background:
+            continue
+        lab, n = ndi.label(x == v, structure=np.ones((3, 3), dtype=int))
+        for k in range(1, n + 1):
+            m = lab == k
+            nxt += 1
+            out[m] = nxt
+            firsts.append((int(np.flatnonzero(m.ravel())[0]), nxt))
+    remap = np.zeros(nxt + 1, np.int64)
+    for new, (_, old) in enumerate(sorted(firsts), start=1):
+        remap[old] = new
+    out = remap[out]
+    return (out, nxt) if return_num else out
 
 
 def _vgg16_bn_features():

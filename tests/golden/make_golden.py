@@ -611,6 +611,11 @@ def gen_aji():
         out['aji_' + name] = np.float64(aji_v)
         out['dice_' + name] = np.float64(dice)
         out['pq_' + name] = np.array(pq, dtype=np.float64)
+        import utils as ref_utils
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            obj = ref_utils.nuclei_accuracy_object_level(pred.copy(), true.copy())        # utils.py:245-330
+        out['obj_' + name] = np.array(obj, dtype=np.float64)
     out['names'] = z['names']
     save('aji', **out)
 

@@ -37,3 +37,14 @@ def test_remap_label_and_properties():
     # torch CUDA inputs are accepted as well
     t = torch.from_numpy(r).cuda()
     assert abs(stats_utils.get_fast_aji(t, t)[0] - 1.0) < 1e-12
+
+
+def test_nuclei_accuracy_object_level_matches_reference(golden):
+    """utils.nuclei_accuracy_object_level (greedy per-object matching, Hausdorff, AJI) vs the values of the reference's own function
+    (tests/golden/aji.npz `obj_*`, made with the measure.label stand-in of tests/golden/_ref_shims.py)"""
+    from cdnet_amd import utils
+    z, pp = golden('aji'), golden('postproc')
+    for name in z['names']:
+        pred, true = pp['final_' + str(name)].astype(np.int32), z['true_' + str(name)]
+        got = utils.nuclei_accuracy_object_level(pred, true)
+        np.testing.assert_allclose(np.array(got, dtype=np.float64), z['obj_' + str(name)], rtol=1e-12, atol=1e-12)
