@@ -249,7 +249,7 @@ def main():
         cdnet_amd.set_precision(precision)
         model = new_model().eval()
         x = torch.from_numpy(synth.tiles_u8(B, seed=2022 + rank).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
-        if os.environ.get('CDNET_GRAPH', '1') != '0':
+        if os.environ.get('CDNET_GRAPH', '0') == '1':
             from cdnet_amd.graphs import GraphedCallable
             g = GraphedCallable(lambda t: pipeline.infer_tiles(model, t), x)          # the whole tile pipeline = one HIP-graph launch
             dt = timed(lambda: g(x), steps, warmup)

@@ -371,6 +371,9 @@ class HighResolutionNet(nn.Module):
         """forward on packed bf16 NHWC input [N,H,W,16] (3 real channels): what cdnet_input_pack / cdnet_window_pack produce
         (sliding-window / TTA inference, cdnet_amd.utils.split_forward_views)"""
         training = self.training
+        if runtime.PRECISION != 'bf16':
+            raise NotImplementedError("HRNet18_rev1 runs on the 16-bit kernels only (fuse / up-sampling / stride-2 paths have no fp32-"
+                                      "storage variant): cdnet_amd.set_precision('bf16')")
         self._ensure_runtime()
         rt = self._rt
         x = x16

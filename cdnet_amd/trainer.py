@@ -744,11 +744,12 @@ def synthetic_batch(B, dev, seed=2022, H=256, W=256):
 
 def make_bench_step(model, B, dev, rank, world, graph=None):
     """the benchmark's training step on a fixed synthetic batch.  graph: replay forward + loss + backward from a HIP graph
-    (cdnet_amd.graphs.GraphedTrainStep; default: on for a single GPU unless CDNET_GRAPH=0) - Adam, all-reduce and re-packs stay eager"""
+    (cdnet_amd.graphs.GraphedTrainStep; measured 6 % slower than the eager launches on the DAM-Unet step - the GPU, not the
+    launch path, bounds it - so only with CDNET_GRAPH=1) - Adam, all-reduce and re-packs stay eager"""
     tr = Trainer(model, world_size=world)
     batch = synthetic_batch(B, dev, seed=2022 + rank)
     if graph is None:
-        graph = world == 1 and os.environ.get('CDNET_GRAPH', '1') != '0'
+        graph = world == 1 and os.environ.get('CDNET_GRAPH', '0') == '1'
     if graph:
         from .graphs import GraphedTrainStep
         gstep = GraphedTrainStep(tr, batch)

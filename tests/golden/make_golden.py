@@ -346,6 +346,12 @@ def gen_hrnet():
             for n, o in zip(('mask', 'point', 'direction'), m(x)):
                 out['%s_%s' % (n, tag)] = o.numpy()
             out['x_cfg_' + tag] = np.array(list(shape) + [seed])
+        # BASELINE config 5 size: one 512x512 tile, every 8th pixel of the outputs kept (float16)
+        shape, seed = (1, 3, 512, 512), 7
+        x = det_input(shape, seed, bf16_exact=True)
+        for n, o in zip(('mask', 'point', 'direction'), m(x)):
+            out['%s_c' % n] = o.numpy()[:, :, ::8, ::8].astype(np.float16)
+        out['x_cfg_c'] = np.array(list(shape) + [seed])
     out['param_count'] = np.int64(sum(p.numel() for p in m.parameters()))
     out['n_keys'] = np.int64(len(m.state_dict()))
     save('hrnet_fwd', **out)

@@ -76,3 +76,31 @@ def test_sliding_window_inference_runs_through_the_pipeline():
     # the first window's kept region [0:108, 0:108] minus HRNet's receptive-field margin sees exactly the whole image's context
     a, b = mw[:, :40, :40].float().cpu(), mf[0, :, :40, :40].float().cpu()
     assert float((a - b).abs().max()) <= 0.1 * float(b.abs().max())
+
+
+def test_eval_forward_512_matches_reference_slice_and_properties(golden):
+    """BASELINE config 5 size (512 x 512): the HIP forward against every 8th pixel of the reference model's own outputs
+    (hrnet_fwd.npz case c), plus size-independent properties: batch independence (a tile's outputs do not depend on its batch
+    neighbours), bit-identical repeat runs, finite outputs"""
+    import torch
+    from cdnet_amd import synth
+    z = golden('hrnet_fwd')
+    m = _model(float(z['gain']))
+    cfg = [int(v) for v in z['x_cfg_c']]
+    x1 = torch.from_numpy(synth.det_input(tuple(cfg[:4]), cfg[4], bf16_exact=True)).cuda()
+    x4 = torch.cat([x1, torch.flip(x1, dims=[3]), torch.flip(x1, dims=[2]), x1 * 0.5], 0).contiguous()
+    with torch.no_grad():
+        o1 = m(x1)
+        o4 = m(x4)
+        o4b = m(x4)
+    torch.cuda.synchronize()
+    for name, a, b, b2 in zip(('mask', 'point', 'direction'), o1, o4, o4b):
+        assert torch.isfinite(b).all() and torch.equal(b, b2)
+        assert torch.equal(a[0], b[0]), name + ': a tile depends on its batch neighbours'
+        want = z['%s_c' % name].astype(np.float32)
+        got = a.float().cpu().numpy()[:, :, ::8, ::8]
+        scale = float(np.abs(want).max())
+        err = np.abs(got - want)
+        assert float(err.max()) < 7e-2 * scale and float(err.mean()) < 1.2e-2 * scale, (name, float(err.max()), float(err.mean()), scale)
+    agree = (z['mask_c'].astype(np.float32).argmax(1) == o1[0].float().cpu().numpy()[:, :, ::8, ::8].argmax(1)).mean()
+    assert agree > 0.999

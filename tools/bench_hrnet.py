@@ -42,3 +42,28 @@ for _ in range(K):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / K
 print('HRNet18_rev1 train step, %d tiles 512x512: %.2f ms = %.1f tiles/s  (loss %.4f)' % (B, dt * 1e3, B / dt, float(loss[0])))
+
+# the same step with forward + loss + backward replayed from a HIP graph (cdnet_amd.graphs)
+from cdnet_amd.graphs import GraphedTrainStep, GraphedCallable
+g = GraphedTrainStep(tr, batch, warmup=1)
+for _ in range(2):
+    g(*batch)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(K):
+    loss = g(*batch)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / K
+print('HRNet18_rev1 train step (HIP graph), %d tiles 512x512: %.2f ms = %.1f tiles/s  (loss %.4f)' % (B, dt * 1e3, B / dt, float(loss[0])))
+m.eval()
+with torch.no_grad():
+    gi = GraphedCallable(lambda t_: m(t_), x)
+    for _ in range(2):
+        gi(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        gi(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+print('HRNet18_rev1 eval forward (HIP graph), %d tiles 512x512: %.2f ms = %.1f tiles/s' % (B, dt * 1e3, B / dt))
