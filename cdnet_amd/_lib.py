@@ -63,6 +63,8 @@ SIGNATURES = {
     'cdnet_window_pack_f32': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
     'cdnet_window_stitch': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
     'cdnet_label_encoding_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'cdnet_label_encoding_instances_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'cdnet_label_encoding_instances': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_label_encoding': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

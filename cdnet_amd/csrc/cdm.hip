@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void cdm_prep_kernel(const uint8_t *__restrict
 }
 
 // 2. label_instance = dilation(measure.label(m1), disk(1)) (:773-774)
-__global__ __launch_bounds__(256) void cdm_grow_kernel(const int32_t *__restrict__ lab, int H, int W, int32_t *__restrict__ inst) {
+__global__ __launch_bounds__(256) void cdm_grow_kernel(const int32_t *__restrict__ lab, int H, int W, int32_t *__restrict__ inst, int maxid) {
     const int n = blockIdx.z;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
@@ -58,7 +58,37 @@ __global__ __launch_bounds__(256) void cdm_grow_kernel(const int32_t *__restrict
     if (y < H - 1) v = max(v, s[(size_t)(y + 1) * W + x]);
     if (x > 0) v = max(v, s[(size_t)y * W + x - 1]);
     if (x < W - 1) v = max(v, s[(size_t)y * W + x + 1]);
-    inst[(size_t)n * H * W + (size_t)y * W + x] = v;
+    inst[(size_t)n * H * W + (size_t)y * W + x] = v < maxid ? v : 0;      // ids beyond max_instances are dropped (the per-id tables end there)
+}
+
+// instance-label input (:752-760): inside = label > 0 (all of it dropped when the image has fewer than 5 foreground pixels: the
+// reference's remove_small_objects(new_label, 5) sees ONE label), boundary where the cross neighbourhood's max and min ids differ
+__global__ __launch_bounds__(256) void cdm_count_fg_kernel(const int32_t *__restrict__ in, int plane, int *__restrict__ fg) {
+    const int n = blockIdx.y;
+    int c = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256) c += in[(size_t)n * plane + i] > 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&fg[n], c);
+}
+
+__global__ __launch_bounds__(256) void cdm_prep_inst_kernel(const int32_t *__restrict__ in, const int *__restrict__ fg, int H, int W,
+                                                            uint8_t *__restrict__ label3, uint8_t *__restrict__ m1, uint8_t *__restrict__ inside) {
+    const int n = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int32_t *s = in + (size_t)n * H * W;
+    const int c = s[(size_t)y * W + x];
+    int mx = c, mn = c;
+    if (y > 0) { const int v = s[(size_t)(y - 1) * W + x]; mx = max(mx, v); mn = min(mn, v); }
+    if (y < H - 1) { const int v = s[(size_t)(y + 1) * W + x]; mx = max(mx, v); mn = min(mn, v); }
+    if (x > 0) { const int v = s[(size_t)y * W + x - 1]; mx = max(mx, v); mn = min(mn, v); }
+    if (x < W - 1) { const int v = s[(size_t)y * W + x + 1]; mx = max(mx, v); mn = min(mn, v); }
+    const bool in1 = c > 0 && fg[n] >= 5;
+    const int nl = mx != mn ? 2 : (in1 ? 1 : 0);
+    const size_t o = (size_t)n * H * W + (size_t)y * W + x;
+    label3[o] = nl == 2 ? 255 : (nl == 1 ? 127 : 0);
+    m1[o] = nl == 1 ? 255 : 0;
+    inside[o] = in1 ? 255 : 0;
 }
 
 // 3. get_centerpoint2 (:650-685): centerness of every instance pixel; per-instance maximum (double bits are monotone)
@@ -225,6 +255,10 @@ __global__ __launch_bounds__(256) void cdm_gauss_kernel(const double *__restrict
     else dsth[o] = d2h_bits(a);
 }
 
+__global__ void cdm_fill_counts_kernel(int32_t *counts, int N, int v) {
+    if ((int)threadIdx.x < N) counts[threadIdx.x] = v;
+}
+
 __global__ void cdm_init_kernel(unsigned long long *best, unsigned long long *dmax, int *center, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { best[i] = 0ull; dmax[i] = 0ull; center[i] = 0x7fffffff; }
@@ -233,6 +267,30 @@ __global__ void cdm_init_kernel(unsigned long long *best, unsigned long long *dm
 inline dim3 grid_rows(int N, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4), N); }
 
 }  // namespace
+
+// the per-instance stage shared by both input kinds: centre search, distance normalisation, 11x11 stencil + angle bins, point map.
+// `inside_u8` (> 127 = new_label_inside) masks the classes; `counts[n]` = largest instance id of image n
+static int cdm_direction_stage(const uint8_t *label_ch0, const int32_t *inst, const int32_t *counts, int N, int H, int W, int maxid, const Rays &R,
+                               const GaussK &G, double *cness, double *tmp, unsigned long long *best, unsigned long long *dmax, int *center,
+                               uint8_t *direction, uint16_t *point_f16, int32_t *inst_out, int32_t *counts_out, hipStream_t st) {
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    const int plane = H * W;
+    const size_t nk = (size_t)N * maxid;
+    cdm_init_kernel<<<(unsigned)((nk + 255) / 256), 256, 0, st>>>(best, dmax, center, nk);
+    cdm_centerness_kernel<<<gr, br, 0, st>>>(inst, H, W, R, cness, best, maxid);
+    int g = cdiv(plane, 256); if (g > 1024) g = 1024;
+    cdm_argmax_kernel<<<dim3(g, N), 256, 0, st>>>(inst, cness, best, plane, maxid, center);
+    cdm_dmax_kernel<<<gr, br, 0, st>>>(inst, H, W, center, maxid, dmax);
+    cdm_direction_kernel<<<gr, br, 0, st>>>(label_ch0, inst, H, W, center, dmax, maxid, direction);
+    // point map: impulses of 255 at the centres, separable Gaussian in float64
+    if (hipMemsetAsync(cness, 0, (size_t)N * plane * 8, st) != hipSuccess) return check_launch("memset lp");
+    cdm_scatter_centers_kernel<<<dim3(cdiv(maxid, 256), N), 256, 0, st>>>(center, counts, maxid, plane, cness);
+    cdm_gauss_kernel<0><<<gr, br, 0, st>>>(cness, H, W, G, tmp, nullptr);
+    cdm_gauss_kernel<1><<<gr, br, 0, st>>>(tmp, H, W, G, nullptr, point_f16);
+    if (inst_out && hipMemcpyAsync(inst_out, inst, (size_t)N * plane * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return check_launch("copy inst");
+    if (counts_out && hipMemcpyAsync(counts_out, counts, (size_t)N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return check_launch("copy counts");
+    return check_launch("cdnet_label_encoding");
+}
 
 // workspace layout
 static size_t cdm_layout(int N, int H, int W, int maxid, size_t *o) {
@@ -282,24 +340,60 @@ extern "C" int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int 
     GaussK G;
     for (int i = 0; i < 9; ++i) G.k[i] = gauss_host[i];
     const dim3 gr = grid_rows(N, H, W), br(64, 4);
-    const int plane = H * W;
     cdm_prep_kernel<<<gr, br, 0, st>>>(label_ch0, H, W, label3, m1);
     int rc = label8_raster(m1, N, H, W, L, aux, chunk, lab, counts, st);
     if (rc) return rc;
-    cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst);
-    const size_t nk = (size_t)N * maxid;
-    cdm_init_kernel<<<(unsigned)((nk + 255) / 256), 256, 0, st>>>(best, dmax, center, nk);
-    cdm_centerness_kernel<<<gr, br, 0, st>>>(inst, H, W, R, cness, best, maxid);
-    int g = cdiv(plane, 256); if (g > 1024) g = 1024;
-    cdm_argmax_kernel<<<dim3(g, N), 256, 0, st>>>(inst, cness, best, plane, maxid, center);
-    cdm_dmax_kernel<<<gr, br, 0, st>>>(inst, H, W, center, maxid, dmax);
-    cdm_direction_kernel<<<gr, br, 0, st>>>(label_ch0, inst, H, W, center, dmax, maxid, direction);
-    // point map: impulses of 255 at the centres, separable Gaussian in float64
-    if (hipMemsetAsync(cness, 0, (size_t)N * plane * 8, st) != hipSuccess) return check_launch("memset lp");
-    cdm_scatter_centers_kernel<<<dim3(cdiv(maxid, 256), N), 256, 0, st>>>(center, counts, maxid, plane, cness);
-    cdm_gauss_kernel<0><<<gr, br, 0, st>>>(cness, H, W, G, tmp, nullptr);
-    cdm_gauss_kernel<1><<<gr, br, 0, st>>>(tmp, H, W, G, nullptr, point_f16);
-    if (inst_out && hipMemcpyAsync(inst_out, inst, (size_t)N * plane * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return check_launch("copy inst");
-    if (counts_out && hipMemcpyAsync(counts_out, counts, (size_t)N * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return check_launch("copy counts");
-    return check_launch("cdnet_label_encoding");
+    cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst, maxid);
+    return cdm_direction_stage(label_ch0, inst, counts, N, H, W, maxid, R, G, cness, tmp, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
+}
+
+
+// Instance-label input of LabelEncoding (my_transforms_direction.py:752-760, `label_level_len > 2`): labels i32 [N][H][W] hold
+// instance ids.  Boundary from the ids' cross max / min, instances through the watershed variant of postproc_other.process
+// (min_size 5), grown by disk(1); then the common stage.  Workspace: cdnet_label_encoding_instances_workspace_bytes.
+extern "C" size_t cdnet_label_encoding_instances_workspace_bytes(int N, int H, int W, int max_instances) {
+    if (N <= 0 || H <= 0 || W <= 0 || max_instances <= 0) return 0;
+    size_t o[12];
+    return align_up(cdm_layout(N, H, W, max_instances + 1, o), 256) + align_up(cdnet_watershed_workspace_bytes(N, H, W), 256) +
+           align_up((size_t)N * H * W, 256) + 256;
+}
+
+extern "C" int cdnet_label_encoding_instances(const int32_t *label_inst, int N, int H, int W, int max_instances, const double *rays_host,
+                                              const double *gauss_host, void *workspace, size_t workspace_bytes, uint8_t *label3,
+                                              uint16_t *point_f16, uint8_t *direction, int32_t *inst_out, int32_t *counts_out, void *stream) {
+    CDNET_REQUIRE(label_inst && rays_host && gauss_host && workspace && label3 && point_f16 && direction, "cdnet_label_encoding_instances: null pointer");
+    CDNET_REQUIRE(N > 0 && H > 0 && W > 0 && max_instances > 0, "cdnet_label_encoding_instances: bad size");
+    const int maxid = max_instances + 1;
+    size_t o[12];
+    const size_t base = align_up(cdm_layout(N, H, W, maxid, o), 256), wsb = align_up(cdnet_watershed_workspace_bytes(N, H, W), 256);
+    const size_t need = cdnet_label_encoding_instances_workspace_bytes(N, H, W, max_instances);
+    if (workspace_bytes < need) { set_error("cdnet_label_encoding_instances: workspace %zu < %zu bytes", workspace_bytes, need); return CDNET_E_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    uint8_t *m1 = (uint8_t *)(ws + o[0]);
+    int32_t *lab = (int32_t *)(ws + o[4]), *inst = (int32_t *)(ws + o[5]);
+    double *cness = (double *)(ws + o[6]), *tmp = (double *)(ws + o[7]);
+    unsigned long long *best = (unsigned long long *)(ws + o[8]), *dmax = (unsigned long long *)(ws + o[9]);
+    int *center = (int *)(ws + o[10]);
+    int32_t *counts = (int32_t *)(ws + o[11]);
+    void *wsw = ws + base;
+    uint8_t *inside = (uint8_t *)(ws + base + wsb);
+    int *fg = (int *)(ws + base + wsb + align_up((size_t)N * H * W, 256));
+    CDNET_REQUIRE(N <= 64, "cdnet_label_encoding_instances: at most 64 images per call");
+    Rays R;
+    for (int k = 0; k < 8; ++k) { R.s[k] = rays_host[2 * k]; R.c[k] = rays_host[2 * k + 1]; }
+    GaussK G;
+    for (int i = 0; i < 9; ++i) G.k[i] = gauss_host[i];
+    const dim3 gr = grid_rows(N, H, W), br(64, 4);
+    const int plane = H * W;
+    if (hipMemsetAsync(fg, 0, 256, st) != hipSuccess) return check_launch("memset fg");
+    int g = cdiv(plane, 256); if (g > 256) g = 256;
+    cdm_count_fg_kernel<<<dim3(g, N), 256, 0, st>>>(label_inst, plane, fg);
+    cdm_prep_inst_kernel<<<gr, br, 0, st>>>(label_inst, fg, H, W, label3, m1, inside);
+    int rc = cdnet_watershed_process(m1, N, H, W, 5, wsw, wsb, nullptr, nullptr, lab, st);
+    if (rc) return rc;
+    cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst, maxid);
+    // every id below maxid may exist (watershed marker ids are kept, not renumbered)
+    cdm_fill_counts_kernel<<<1, 64, 0, st>>>(counts, N, maxid - 1);
+    return cdm_direction_stage(inside, inst, counts, N, H, W, maxid, R, G, cness, tmp, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
 }

@@ -112,15 +112,12 @@ class TileBatches:
         if unknown:
             raise NotImplementedError('transforms {} are outside the accelerated input pipeline'.format(unknown))
         self.items = [[np.asarray(im) for im in dataset.load(i)] for i in range(len(dataset))]      # decoded once, kept on the host
-        for k, it in enumerate(self.items):
-            lab = it[2] if it[2].ndim == 2 else it[2][:, :, 0]
-            if len(np.unique(lab)) > 2:
-                # LabelEncoding's `label_level_len > 2` branch (my_transforms_direction.py:752-760: instance-level labels, boundary from
-                # per-instance dilation / erosion, instances through postproc_other.process) is not on the device path: cast to
-                # uint8 and thresholded, such a label would silently give wrong targets
-                raise NotImplementedError('label image %d holds %d distinct values: instance-level labels (the reference\'s <label_dir>/train_ins '
-                                          'layout) are not supported by the device input pipeline - supply the 3-class label PNGs'
-                                          % (k, len(np.unique(lab))))
+        # label kind, as LabelEncoding decides it per image (`label_level_len > 2`, my_transforms_direction.py:713-720): instance-level
+        # labels (the reference's <label_dir>/train_ins layout) take the instance branch of the device transform
+        kinds = {len(np.unique(it[2] if it[2].ndim == 2 else it[2][:, :, 0])) > 2 for it in self.items}
+        if len(kinds) > 1:
+            raise ValueError('the label directory mixes instance-level and 3-class label images')
+        self.instance_labels = bool(kinds and kinds.pop())
 
     def __len__(self):
         n = len(self.items)
@@ -157,5 +154,9 @@ class TileBatches:
                 img = (img - torch.tensor(mean, device=self.dev).view(1, 3, 1, 1)) / torch.tensor(std, device=self.dev).view(1, 3, 1, 1)
             weight = torch.from_numpy(np.stack([c[1] if c[1].ndim == 2 else c[1][:, :, 0] for c in crops])).to(self.dev)
             lab0 = torch.from_numpy(np.stack([c[2] if c[2].ndim == 2 else c[2][:, :, 0] for c in crops])).to(self.dev)
-            l3, point, direction = label_encoding_batch(lab0.to(torch.uint8).contiguous())
+            if self.instance_labels:
+                from .my_transforms_direction import label_encoding_instances_batch
+                l3, point, direction = label_encoding_instances_batch(lab0.to(torch.int32).contiguous())
+            else:
+                l3, point, direction = label_encoding_batch(lab0.to(torch.uint8).contiguous())
             yield img.contiguous(), weight.to(torch.uint8).unsqueeze(1), l3.to(torch.int64).unsqueeze(1), point, direction

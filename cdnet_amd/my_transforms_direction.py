@@ -57,6 +57,32 @@ def label_encoding_batch(label_ch0, max_instances=4096, want_inst=False):
     return label3, point, direction
 
 
+def label_encoding_instances_batch(label_inst, max_instances=4096, want_inst=False):
+    """label_inst: int32 cuda tensor [N,H,W] of instance ids (the reference's <label_dir>/train_ins layout).  Returns what
+    label_encoding_batch returns (my_transforms_direction.py:752-760 + :785-871)."""
+    assert label_inst.dtype == torch.int32 and label_inst.is_cuda and label_inst.dim() == 3
+    x = label_inst.contiguous()
+    N, H, W = x.shape
+    dev = x.device
+    nbytes = _lib.load().cdnet_label_encoding_instances_workspace_bytes(N, H, W, max_instances)
+    key = ('inst', dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _WS[key] = ws
+    label3 = torch.empty((N, H, W), dtype=torch.uint8, device=dev)
+    point = torch.empty((N, H, W), dtype=torch.float16, device=dev)
+    direction = torch.empty((N, H, W), dtype=torch.uint8, device=dev)
+    inst = torch.empty((N, H, W), dtype=torch.int32, device=dev) if want_inst else None
+    counts = torch.empty((N,), dtype=torch.int32, device=dev)
+    _lib.call('cdnet_label_encoding_instances', _lib.ptr(x), N, H, W, max_instances, C.cast(_RAYS, C.c_void_p), C.cast(_GAUSS, C.c_void_p),
+              _lib.ptr(ws), ws.numel(), _lib.ptr(label3), _lib.ptr(point), _lib.ptr(direction), _lib.ptr(inst), _lib.ptr(counts),
+              _lib.stream_ptr())
+    if want_inst:
+        return label3, point, direction, inst, counts
+    return label3, point, direction
+
+
 class LabelEncoding(object):
     """Encoding the label, computes boundary individually (reference class; 3-class label input)."""
 
@@ -71,8 +97,10 @@ class LabelEncoding(object):
         label = np.array(imgs[2])
         ch0 = label if label.ndim == 2 else label[:, :, 0]
         assert self.out_c == 3, 'only the 3-class encoding of the CDNet path is implemented'
-        assert len(np.unique(ch0)) <= 2, 'instance-level label input (label_level_len > 2) is outside the hot path'
-        l3, point, direction = label_encoding_batch(torch.from_numpy(np.ascontiguousarray(ch0, dtype=np.uint8)).cuda()[None])
+        if len(np.unique(ch0)) > 2:                      # instance-level label (:752-760)
+            l3, point, direction = label_encoding_instances_batch(torch.from_numpy(np.ascontiguousarray(ch0).astype(np.int32)).cuda()[None])
+        else:
+            l3, point, direction = label_encoding_batch(torch.from_numpy(np.ascontiguousarray(ch0, dtype=np.uint8)).cuda()[None])
         out_imgs[2] = Image.fromarray(l3[0].cpu().numpy())
         if self.do_direction == 1:
             out_imgs.append(point[0].cpu().numpy())

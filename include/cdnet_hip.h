@@ -393,6 +393,16 @@ size_t cdnet_label_encoding_workspace_bytes(int N, int H, int W, int max_instanc
 int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int W, int max_instances, const double *rays_host,
                          const double *gauss_host, void *workspace, size_t workspace_bytes, uint8_t *label3,
                          uint16_t *point_f16, uint8_t *direction, int32_t *inst_out, int32_t *counts_out, void *stream);
+/* The instance-label input branch of the same transform (my_transforms_direction.py:752-760, `label_level_len > 2`; the
+ * reference's default training data <label_dir>/train_ins): label_inst i32 [N][H][W] holds instance ids.  inside = id > 0 (dropped
+ * when an image has fewer than 5 foreground pixels, :755), boundary = pixels whose 4-neighbourhood holds different ids (:759:
+ * dilation(label) & ~erosion(label, disk(1)) on the integer ids), instances = dilation(postproc_other.process((new_label == 1) * 255,
+ * 'modelName', min_size=5), disk(1)) - the watershed variant (cdnet_watershed_process) - then the same centre / direction / point
+ * stage.  N <= 64.  Outputs as cdnet_label_encoding; counts = max_instances (watershed ids are not contiguous). */
+size_t cdnet_label_encoding_instances_workspace_bytes(int N, int H, int W, int max_instances);
+int cdnet_label_encoding_instances(const int32_t *label_inst, int N, int H, int W, int max_instances, const double *rays_host,
+                                   const double *gauss_host, void *workspace, size_t workspace_bytes, uint8_t *label3,
+                                   uint16_t *point_f16, uint8_t *direction, int32_t *inst, int32_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * HRNet fuse / residual sums.  Replaces the y = y + x[j] / y = y + F.interpolate(..., mode='bilinear') / relu(y) chains of

@@ -36,3 +36,35 @@ def label_encoding(label_ch0, want_aux=False, want_field=False):
     if want_field:
         out = out + (field,)          # [H,W,2] float32: (row gradient, column gradient) the angle is taken from (:848)
     return out
+
+
+def label_encoding_instances(label_inst):
+    """LabelEncoding for INSTANCE-level label input (my_transforms_direction.py:752-760 + :785-871; `label_level_len > 2`, out_c = 3):
+      new_label = (label > 0); remove_small_objects(new_label, 5) on the uint8 {0,1} image (= a label image: the whole foreground
+      vanishes only when it has fewer than 5 pixels); boundary = dilation(label) & ~erosion(label, disk(1)) on the integer instance
+      ids (bit-wise: non-zero exactly where the cross neighbourhood's max and min differ) -> 2; instances =
+      dilation(postproc_other.process((new_label == 1) * 255, 'modelName', min_size=5), disk(1)) - the WATERSHED branch (the model
+      name is neither 'unet' nor 'micronet').  Then the common per-instance stage.
+    label_inst: integer [H,W].  Returns (label3 u8 {0,127,255}, point f16, direction u8, inst i32)."""
+    from scipy import ndimage as ndi
+    from . import postproc as orc
+    lab = np.ascontiguousarray(label_inst).astype(np.int64)
+    H, W = lab.shape
+    cross = ndi.generate_binary_structure(2, 1)
+    new_label = (lab > 0).astype(np.uint8)
+    if new_label.sum() < 5:
+        new_label[:] = 0
+    inside = new_label.copy()
+    mx = ndi.grey_dilation(lab, footprint=cross, mode='nearest')
+    mn = ndi.grey_erosion(lab, footprint=cross, mode='nearest')
+    new_label[mx != mn] = 2
+    label3 = (new_label / 2 * 255).astype(np.uint8)
+    ws = orc.watershed_process((new_label == 1).astype(np.uint8) * 255, min_size=5)['labels']
+    inst = ndi.grey_dilation(ws.astype(np.int32), footprint=cross, mode='nearest').astype(np.int32)
+    point = np.empty((H, W), np.float32)
+    direction = np.empty((H, W), np.uint8)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    inst = np.ascontiguousarray(inst)
+    inside = np.ascontiguousarray(inside)
+    _l().orc_direction_from_instances(p(inst, C.c_int32), p(inside, C.c_uint8), H, W, p(point, C.c_float), p(direction, C.c_uint8), None)
+    return label3, point.astype(np.float16), direction, inst

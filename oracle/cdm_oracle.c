@@ -73,39 +73,12 @@ static int label8(const uint8_t *mask, int H, int W, int32_t *lab)
 static float *g_dir_out = 0;
 void orc_set_direction_field_out(float *p) { g_dir_out = p; }
 
-/* in: channel 0 of the label PNG (u8).  out: label3 u8 {0,127,255}, point f32 (cast to f16 by the caller),
- * direction u8 0..8, and (optional) inst i32 = the dilated instance map, centers i32 [count][2].  Returns count. */
-int orc_label_encoding(const uint8_t *in, int H, int W, uint8_t *label3, float *point, uint8_t *direction,
-                       int32_t *inst_out, int32_t *centers_out)
+/* The per-instance stage of LabelEncoding (:785-871) on a given (already dilated) instance map `inst` with ids in 1..cnt (ids
+ * without pixels are skipped) and the pre-boundary inside mask: point map f32, direction classes u8, optional centres. */
+static void direction_stage(const int32_t *inst, int cnt, const uint8_t *inside, int H, int W, float *point, uint8_t *direction,
+                            int32_t *inst_out, int32_t *centers_out)
 {
     const int n = H * W;
-    uint8_t *inside = (uint8_t *)malloc(n), *nl = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n);
-    int32_t *lab = (int32_t *)malloc(sizeof(int32_t) * n), *inst = (int32_t *)malloc(sizeof(int32_t) * n);
-    for (int i = 0; i < n; ++i) inside[i] = in[i] > 127.5 ? 1 : 0;                       /* :765-767 */
-    /* boun = dilation(new_label) & ~erosion(new_label, disk(1)); both with the 4-neighbour cross, borders ignored (:768) */
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            int dil = inside[y * W + x], ero = inside[y * W + x];
-            const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
-            for (int k = 0; k < 4; ++k) {
-                int yy = y + dy[k], xx = x + dx[k];
-                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                if (inside[yy * W + xx]) dil = 1; else ero = 0;
-            }
-            nl[y * W + x] = (dil && !ero) ? 2 : inside[y * W + x];                       /* :769 */
-        }
-    for (int i = 0; i < n; ++i) { label3[i] = (uint8_t)(nl[i] / 2.0 * 255); m1[i] = nl[i] == 1; }   /* :781, :772 */
-    int cnt = label8(m1, H, W, lab);                                                     /* :773 measure.label */
-    /* label_instance = dilation(label_instance, disk(1)): max over the cross (:774) */
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            int v = lab[y * W + x];
-            if (y > 0 && lab[(y - 1) * W + x] > v) v = lab[(y - 1) * W + x];
-            if (y < H - 1 && lab[(y + 1) * W + x] > v) v = lab[(y + 1) * W + x];
-            if (x > 0 && lab[y * W + x - 1] > v) v = lab[y * W + x - 1];
-            if (x < W - 1 && lab[y * W + x + 1] > v) v = lab[y * W + x + 1];
-            inst[y * W + x] = v;
-        }
     /* bounding boxes of the (dilated) instances */
     int *bb = (int *)malloc(sizeof(int) * 4 * (cnt + 1));
     for (int k = 0; k <= cnt; ++k) { bb[4 * k] = H; bb[4 * k + 1] = -1; bb[4 * k + 2] = W; bb[4 * k + 3] = -1; }
@@ -221,6 +194,53 @@ int orc_label_encoding(const uint8_t *in, int H, int W, uint8_t *label3, float *
     }
     if (inst_out) memcpy(inst_out, inst, sizeof(int32_t) * n);
     if (g_dir_out) memcpy(g_dir_out, dir, sizeof(float) * 2 * n);
-    free(f); free(nd); free(lp); free(dir); free(bb); free(inst); free(lab); free(m1); free(nl); free(inside);
+    free(f); free(nd); free(lp); free(dir); free(bb);
+}
+
+/* LabelEncoding's direction branch for a caller-made instance map (the instance-label input branch, :752-760, hands in
+ * dilation(postproc_other.process(...), disk(1))): inst i32 (ids need not be contiguous), inside u8 (new_label_inside). */
+void orc_direction_from_instances(const int32_t *inst, const uint8_t *inside, int H, int W, float *point, uint8_t *direction,
+                                  int32_t *centers_out)
+{
+    int cnt = 0;
+    for (int i = 0; i < H * W; ++i) if (inst[i] > cnt) cnt = inst[i];
+    direction_stage(inst, cnt, inside, H, W, point, direction, 0, centers_out);
+}
+
+/* in: channel 0 of the label PNG (u8).  out: label3 u8 {0,127,255}, point f32 (cast to f16 by the caller),
+ * direction u8 0..8, and (optional) inst i32 = the dilated instance map, centers i32 [count][2].  Returns count. */
+int orc_label_encoding(const uint8_t *in, int H, int W, uint8_t *label3, float *point, uint8_t *direction,
+                       int32_t *inst_out, int32_t *centers_out)
+{
+    const int n = H * W;
+    uint8_t *inside = (uint8_t *)malloc(n), *nl = (uint8_t *)malloc(n), *m1 = (uint8_t *)malloc(n);
+    int32_t *lab = (int32_t *)malloc(sizeof(int32_t) * n), *inst = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (int i = 0; i < n; ++i) inside[i] = in[i] > 127.5 ? 1 : 0;                       /* :765-767 */
+    /* boun = dilation(new_label) & ~erosion(new_label, disk(1)); both with the 4-neighbour cross, borders ignored (:768) */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int dil = inside[y * W + x], ero = inside[y * W + x];
+            const int dy[4] = {-1, 1, 0, 0}, dx[4] = {0, 0, -1, 1};
+            for (int k = 0; k < 4; ++k) {
+                int yy = y + dy[k], xx = x + dx[k];
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                if (inside[yy * W + xx]) dil = 1; else ero = 0;
+            }
+            nl[y * W + x] = (dil && !ero) ? 2 : inside[y * W + x];                       /* :769 */
+        }
+    for (int i = 0; i < n; ++i) { label3[i] = (uint8_t)(nl[i] / 2.0 * 255); m1[i] = nl[i] == 1; }   /* :781, :772 */
+    int cnt = label8(m1, H, W, lab);                                                     /* :773 measure.label */
+    /* label_instance = dilation(label_instance, disk(1)): max over the cross (:774) */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int v = lab[y * W + x];
+            if (y > 0 && lab[(y - 1) * W + x] > v) v = lab[(y - 1) * W + x];
+            if (y < H - 1 && lab[(y + 1) * W + x] > v) v = lab[(y + 1) * W + x];
+            if (x > 0 && lab[y * W + x - 1] > v) v = lab[y * W + x - 1];
+            if (x < W - 1 && lab[y * W + x + 1] > v) v = lab[y * W + x + 1];
+            inst[y * W + x] = v;
+        }
+    direction_stage(inst, cnt, inside, H, W, point, direction, inst_out, centers_out);
+    free(inst); free(lab); free(m1); free(nl); free(inside);
     return cnt;
 }

@@ -18,6 +18,7 @@ Fixtures:
   validate.npz     train_util_dam.validate: the 16-value result vector, whole-tile and sliding-window forward
   cdm.npz          my_transforms_direction.LabelEncoding (direction branch) on synthetic ellipse labels
                    [skimage-semantics restated: scipy stand-ins for dilation/erosion/label]
+  cdm_inst.npz     the same transform on instance-level labels (:752-760) [watershed stand-in]
   split_fwd.npz    utils.split_forward_dam stitching with a position-coding toy model
   probmaps.npz     test_dam.get_probmaps epilogue (softmax / gated argmax), re-assembled from :982-1015
   postproc.npz     test_dam.py:445-450,479-491,529-563 re-assembled (TTA mean, DDM fuse, boost, argmax,
@@ -466,6 +467,41 @@ def gen_cdm():
     save('cdm', **out)
 
 
+def gen_cdm_inst():
+    """LabelEncoding on INSTANCE-level labels (my_transforms_direction.py:752-760: boundary from the instance ids, instances
+    through postproc_other.process(..., min_size=5) = the watershed branch).  skimage.segmentation.watershed is absent here: the
+    reference code runs with oracle/postproc.py's restatement of it patched in [watershed stand-in: equal-priority ties unpinned]."""
+    import postproc_other
+    from my_transforms_direction import LabelEncoding
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import postproc as orc
+
+    def ws(image, markers, mask=None):
+        return orc.watershed(np.asarray(image).astype(np.uint8), markers, mask)
+    postproc_other.watershed = ws
+    out, names = {}, []
+    for name, (H, W, n, seed, touching) in {'a': (96, 96, 12, 3, False), 'b': (80, 128, 18, 4, True), 'c': (64, 64, 2, 5, False)}.items():
+        rs = np.random.RandomState(seed)
+        inst = _ellipse_instances(H, W, n, rs)
+        if touching:                                   # grow the instances until some touch: boundaries BETWEEN ids
+            for _ in range(2):
+                g = ndi.grey_dilation(inst, footprint=ndi.generate_binary_structure(2, 1))
+                inst = np.where(inst == 0, g, inst)
+        lab = inst.astype(np.uint8)
+        img = Image.fromarray(np.zeros((H, W, 3), np.uint8))
+        wmap = Image.fromarray(np.full((H, W), 20, np.uint8))
+        res = LabelEncoding(3, 2, 1)((img, wmap, Image.fromarray(lab)))
+        assert res[3].dtype == np.float16 and res[4].dtype == np.int64
+        out['in_' + name] = lab
+        out['label_' + name] = np.array(res[2])
+        out['point_' + name] = res[3]
+        out['direction_' + name] = res[4].astype(np.uint8)
+        names.append(name)
+    out['names'] = np.array(names)
+    save('cdm_inst', **out)
+
+
 # ----------------------------------------------------------------------------------------------
 def gen_split():
     import utils as ref_utils
@@ -627,7 +663,7 @@ def gen_aji():
 
 
 ALL = {'validate': gen_validate, 'ablation': gen_ablation, 'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
-       'cdm': gen_cdm, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
+       'cdm': gen_cdm, 'cdm_inst': gen_cdm_inst, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

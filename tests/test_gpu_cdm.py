@@ -44,3 +44,30 @@ def test_label_encoding_batched_256_tiles():
         assert np.array_equal(l3[i].cpu().numpy(), o3), i
         assert np.array_equal(dr[i].cpu().numpy(), odr), i
         assert np.abs(pt[i].cpu().numpy().astype(np.float32) - opt.astype(np.float32)).max() <= 1e-3, i
+
+
+def test_instance_label_branch_bit_exact_vs_oracle(golden):
+    """cdnet_label_encoding_instances (my_transforms_direction.py:752-760 on the device: boundary from the ids, watershed instances,
+    common stage) against the C/numpy oracle on the golden inputs and on a larger batch: label exact, direction exact, point 1e-3;
+    and against the reference's own outputs as far as the oracle is"""
+    import torch
+    from cdnet_amd import synth
+    from cdnet_amd.my_transforms_direction import label_encoding_instances_batch, LabelEncoding
+    from oracle import cdm
+    z = golden('cdm_inst')
+    cases = [z['in_' + str(n)].astype(np.int32) for n in z['names']]
+    rs = np.random.RandomState(9)
+    big = synth.ellipse_instances(256, 256, 60, rs, 5, 12, 10)
+    for lab in cases + [big.astype(np.int32)]:
+        l3, point, direction, inst, counts = label_encoding_instances_batch(torch.from_numpy(lab).cuda()[None], want_inst=True)
+        w3, wp, wd, winst = cdm.label_encoding_instances(lab)
+        assert np.array_equal(l3[0].cpu().numpy(), w3)
+        assert np.array_equal(inst[0].cpu().numpy(), winst)
+        assert np.array_equal(direction[0].cpu().numpy(), wd)
+        np.testing.assert_allclose(point[0].float().cpu().numpy(), wp.astype(np.float32), rtol=0, atol=1e-3)
+    # the reference-named transform takes the branch by itself (label_level_len > 2)
+    from PIL import Image
+    lab = cases[0]
+    res = LabelEncoding(3, 2, 1)((Image.fromarray(np.zeros(lab.shape + (3,), np.uint8)), Image.fromarray(np.full(lab.shape, 20, np.uint8)),
+                                  Image.fromarray(lab.astype(np.uint8))))
+    assert np.array_equal(np.array(res[2]), z['label_' + str(z['names'][0])])

@@ -41,3 +41,21 @@ def test_direction_mismatches_are_ill_conditioned_pixels_only(golden):
             if not (near_edge or vanishing):
                 bad += 1
     assert bad == 0, '%d of %d mismatching pixels are neither zero-gradient nor on a bin edge' % (bad, total)
+
+
+def test_instance_label_branch_matches_reference(golden):
+    """oracle.cdm.label_encoding_instances == the reference's LabelEncoding on instance-level labels (tests/golden/cdm_inst.npz,
+    generated with the watershed stand-in): 3-class label exact, point map 1e-3, direction classes equal except on vanishing
+    gradients (see test_direction_mismatches_are_ill_conditioned_pixels_only)"""
+    z = golden('cdm_inst')
+    for name in z['names']:
+        label3, point, direction, inst = cdm.label_encoding_instances(z['in_' + name])
+        assert np.array_equal(label3, z['label_' + name]), name
+        np.testing.assert_allclose(point.astype(np.float32), z['point_' + name].astype(np.float32), rtol=0, atol=1e-3)
+        want = z['direction_' + name]
+        assert (direction != want).mean() <= 2e-3, (name, int((direction != want).sum()))
+        assert np.array_equal(direction == 0, want == 0)
+    # boundaries BETWEEN touching instances exist in case b (ids differ across the 4-neighbourhood while both sides are foreground)
+    lab = z['in_b'].astype(np.int64)
+    touch = (lab[:, 1:] > 0) & (lab[:, :-1] > 0) & (lab[:, 1:] != lab[:, :-1])
+    assert touch.any() and (z['label_b'][:, 1:][touch] == 255).all()
