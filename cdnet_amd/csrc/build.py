@@ -24,6 +24,7 @@ def _newer(a, bs):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', 'hipcc')
+    flags = FLAGS + os.environ.get('CDNET_HIPCC_FLAGS', '').split()          # debug builds (e.g. -DCDNET_WS_STAMPS)
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(PKG), 'include', 'cdnet_hip.h'))
@@ -35,7 +36,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ_DIR, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or not _newer(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             procs.append((s, subprocess.Popen(cmd)))

@@ -769,26 +769,40 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Wave-specialised, weight-stationary, persistent variant for the layers whose whole weight tile fits the LDS
-// (taps * Cin * BN * 2 bytes <= ~92 KB: the 64-channel full-resolution layers of the encoder stem, the decoder's last block
-// and the three residual units - forward, backward-data and the space-to-depth backward of the last transposed conv).
+// Wave-specialised, weight-stationary, persistent variant for the 3x3 layers with 64 input channels (four 16-channel chunks;
+// the whole weight tile of a cout block - 74 KB for 64 couts - stays in LDS): the full-resolution layers of the encoder stem
+// and of the three residual units, forward and backward-data.
 //
 //   * one 8-wave workgroup per CU, persistent over a contiguous run of tiles (XCD-contiguous, like conv_fwd_kernel);
 //   * the weights of the workgroup's cout tile are loaded ONCE and stay in LDS;
-//   * waves 4..7 (producers) only move data: four 16-channel halo chunks in flight in registers (>= 2 us of HBM latency
-//     covered), transform (BatchNorm scale/shift, residual, ReLU) and write them into a two-slot LDS ring;
-//   * waves 0..3 (consumers) only read fragments, issue MFMAs and run the epilogue: a consumer wave owns 64 pixels x BN
-//     couts of the tile and its own out-tile region, so the epilogue needs no workgroup-wide synchronisation and the
-//     producers run on into the next tile meanwhile;
+//   * waves 4..7 (movers) only move data.  In: four 16-channel halo chunks in flight in registers (>= 2 us of HBM latency
+//     covered; straight-line code so that the compiler counts the loads in flight instead of draining them), transform
+//     (BatchNorm scale/shift, residual, ReLU), LDS ring of two slots.  Out: the finished tile's out image -> global memory,
+//     spread over the first three chunk steps of the NEXT tile, so that no matrix wave ever waits for the write path;
+//   * waves 0..3 (consumers) only read fragments, issue MFMAs, and at the end of a tile convert their 64 pixels x BN couts and
+//     park them in LDS as [cout][pixel] blocks (8-byte writes straight from the accumulator registers; the movers read them
+//     back with the transposing ds_read_b64_tr_b16, which yields pixel-major 16-byte vectors for NHWC stores);
 //   * one barrier per 16-channel chunk step.
 // Accumulation order, MFMA shapes and epilogue arithmetic are those of conv_fwd_kernel<16,16,16,BN,4,1,TAPS>: the results are
 // bit-identical (tests/test_gpu_conv.py compares the two).
+// Timeline of one workgroup (debug build -DCDNET_WS_STAMPS, tools/ws_stamps.py) before the write path moved to the movers: chunk
+// step 0.80 us (36 MFMAs per wave: the matrix pipe at the clock the chip holds under this load), barrier 0.22 us, conversion +
+// LDS writes 1.2 us and global stores 2.5 us per tile, both in the consumers' serial path: 8.0 us per tile, 128 us per launch.
 // ------------------------------------------------------------------------------------------------------
-// Measured in round 2 (tools/bench_conv_ws.py, bench.py): bit-identical, at parity on the isolated layer, but the whole
-// inference / training step is 3-7 % SLOWER with it than with conv_fwd_kernel (one consumer group per CU serialises MFMA phase and
-// epilogue; three co-resident conv_fwd_kernel workgroups overlap them).  Kept as a tested experiment: off unless CDNET_CONV_WS=1.
 #ifndef CDNET_CONV_WS
-#define CDNET_CONV_WS 0
+#define CDNET_CONV_WS 1
+#endif
+
+#ifdef CDNET_WS_STAMPS
+// debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): wall-clock stamps (100 MHz) of one consumer and one mover wave of one
+// workgroup, parked in LDS and dumped at the end of the kernel; read back with cdnet_debug_ws_stamps
+__device__ unsigned long long g_ws_stamps[2 * 1024];
+extern "C" __attribute__((visibility("default"))) int cdnet_debug_ws_stamps(unsigned long long *dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps)) == hipSuccess ? 0 : 1;
+}
+#define WS_STAMP(id) do { if (stamp_on && sn < 1020) { s_stamp[sn++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(id); } } while (0)
+#else
+#define WS_STAMP(id) do { } while (0)
 #endif
 
 template <int BN, int TAPS>
@@ -798,31 +812,32 @@ struct WsLds {
     static constexpr int NPIX = (TH + 2) * (TW + 2);
     static constexpr int A_BYTES = NPIX * PSTR;                   // one ring slot: the halo tile of a 16-channel chunk
     static constexpr int B_CHUNK = TAPS * CK * BN * 2;            // packed weights of one chunk
-    static constexpr int OSTR = BN * 2 + 8;
-    static constexpr int OUT_WAVE = 64 * OSTR;                    // a consumer wave's 64 pixels
+    static constexpr int IROW = 72;                               // a cout row of an out-image block: 32 pixels x 2 B + 8 (conflict-free 8-byte writes)
+    static constexpr int IBLK = 32 * IROW;                        // one block: 32 couts x 32 pixels
+    static constexpr int OUT_WAVE = 2 * (BN / 32) * IBLK;         // a consumer wave's 64 pixels x BN couts
     static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum|sumsq][BN]
-    static int bytes(int nchunk, int ctot) {
+    __host__ __device__ static int bytes(int nchunk, int ctot) {
         return nchunk * B_CHUNK + 2 * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4;
     }
 };
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));      // register staging type (HIP's uint4 struct copies defeat SROA)
+typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 
 // XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
-// BatchNorm source, packed math), 2 anything (run-time flags)
-template <int BN, int TAPS, int XF, bool DEFER>
+// BatchNorm source, packed math), 2 anything (run-time flags).  The launcher guarantees nchunk == 4.
+template <int BN, int TAPS, int XF>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     using L = WsLds<BN, TAPS>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NT = BN / 32, NPW = NT, MPW = 2;               // consumer wave wm: M tiles 2wm, 2wm+1 (64 pixels), all N tiles
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
-    constexpr int OSTR = L::OSTR;
-    constexpr int PF = 4;                                         // halo chunks in flight per producer thread
+    constexpr int PF = 4;                                         // halo chunks in flight per mover thread
+    constexpr int NCH = 4;                                        // chunks per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nchunk = A.nchunk;
     unsigned char *lds_w = smem;
-    unsigned char *lds_a = smem + nchunk * L::B_CHUNK;
+    unsigned char *lds_a = smem + NCH * L::B_CHUNK;
     unsigned char *lds_o = lds_a + 2 * L::A_BYTES;
     float *s_stats = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE);          // [2][4][2][BN]
     float *s_xf = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE + L::STATS_BYTES);
@@ -831,6 +846,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
     const int xfs = (ctot + 7) / 8 * 8;
     const int cout_tile = blockIdx.y;
+    const int cout0 = cout_tile * BN;
+#ifdef CDNET_WS_STAMPS
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NCH, ctot)) + (wave >= 4 ? 1024 : 0);
+    const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
+    int sn = 0;
+#endif
 
     // this workgroup's contiguous run of tiles; XCD k (workgroups k, k+8, ...) serves the k-th eighth of the tiles
     const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
@@ -850,14 +871,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         }
     }
     const int ntl = t_hi - t_lo;
-    const int S = ntl * nchunk;                                   // chunk steps of this workgroup
-    const int S4 = (S + 3) & ~3;                                  // barriers executed by both roles
+    const int S = ntl * NCH;                                      // chunk steps (= barriers) of this workgroup
 
     // resident weights + scale/shift table
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * nchunk * (L::B_CHUNK / 2));
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * NCH * (L::B_CHUNK / 2));
         uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
-        const int nv = nchunk * (L::B_CHUNK / 16);
+        const int nv = NCH * (L::B_CHUNK / 16);
         for (int v = tid; v < nv; v += 512) dst[v] = src[v];
         for (int c = tid; c < ctot; c += 512) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
@@ -875,13 +895,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     };
 
     if (wave >= 4) {
-        // ================================ producers ================================
+        // ================================ movers ================================
         // Straight-line code only: every load is issued unconditionally (clamped address, clamped chunk index past the end of
         // the run) and out-of-range vectors are zeroed by a mask, so that the compiler can count the loads in flight
         // (s_waitcnt vmcnt(N)) instead of draining them at a join.
         const int ptid = tid - 256;
         const int slot = ptid % VPP;
-        // the producers' vector instructions must slip in between the consumers' MFMAs on the same SIMD: raise their priority
         u32x4v pa[PF][NA];
         unsigned vm[PF];                         // bit i: vector i of the chunk is inside the image / source
         int eo[PF][NA];                          // element offsets (only read for sources with a residual operand)
@@ -901,6 +920,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
             iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
         }
+        int o_n = in_, o_y0 = iy0, o_x0 = ix0;   // out cursor: the tile the consumers are working on
+        int s_n = 0, s_y0 = 0, s_x0 = 0;         // the finished tile whose out image waits in LDS
+        bool s_ok = false;
         int ck = 0;
         // staging geometry of the current tile and source (the chunks of one source share it): element offset of each vector
         // without the chunk's channel offset, validity mask
@@ -931,13 +953,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             for (int i = 0; i < NA; ++i) {
                 const int e = ge[i] >= 0 ? ge[i] : 0;
                 eo[R][i] = e + cc0;
-                if (!(A.debug & 128)) pa[R][i] = *reinterpret_cast<const u32x4v *>(base + e);
+                pa[R][i] = *reinterpret_cast<const u32x4v *>(base + e);
             }
             vm[R] = gm;
             // advance (saturating at the last chunk of the run)
             if (ic + 1 < S) {
                 ++ic;
-                if (++ik == nchunk) {
+                if (++ik == NCH) {
                     ik = 0;
                     ix0 += TW;
                     if (ix0 >= A.W) { ix0 = 0; iy0 += TH; if (iy0 >= A.H) { iy0 = 0; ++in_; } }
@@ -948,7 +970,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             constexpr int R = decltype(rc)::value;
             int si, cc0;
             chunk_src(ck, si, cc0);
-            if (c_ + 1 < S) { if (++ck == nchunk) ck = 0; }
+            if (c_ + 1 < S) { if (++ck == NCH) ck = 0; }
             const ConvSrc &s = A.src[si];
             const float *xf = s_xf + (si ? c0n : 0) + cc0 + slot * 8;
             float sc[8], sh[8];
@@ -982,6 +1004,31 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                     *reinterpret_cast<u32x4v *>(dst0 + i * (256 / VPP) * PSTR) = val;
             }
         };
+        // ---- out path: mover wave w stores the region of consumer wave w.  Piece pc = (M tile mi, pixel half ch, cout pass kk): the four
+        // ---- 16-lane groups take four cout octets, lane i of a group receives pixel i of tile row 4w + 2mi + ch (transposing read:
+        // ---- lane 4q+p supplies the address of cout row q, pixels 4p..4p+3) -> one 16-byte NHWC store per lane
+        constexpr int KO = BN / 32, NP = 4 * KO;
+        typedef ws_s16x4 __attribute__((address_space(3))) * lptr;
+        const int pw = wave - 4;
+        const int lg = lane >> 4, li = lane & 15;
+        const unsigned char *s_img = lds_o + pw * L::OUT_WAVE + (li >> 2) * L::IROW + (li & 3) * 8;
+        auto store_pieces = [&](int p_lo, int p_hi) {
+#pragma unroll
+            for (int pc = p_lo; pc < p_hi; ++pc) {
+                const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
+                const int o = lg + 4 * kk;
+                const int ni = o >> 2, r0 = 8 * (o & 3);
+                const unsigned char *p = s_img + ((mi * NPW + ni) * 32 + r0) * L::IROW + ch * 32;
+                const ws_s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+                const ws_s16x4 t2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * L::IROW));
+                const int y = s_y0 + pw * 4 + mi * 2 + ch, x = s_x0 + li, co = cout0 + 8 * o;
+                if (s_ok && y < A.H && x < A.W && co < A.Cout) {
+                    const uint2 a = __builtin_bit_cast(uint2, t1), b2 = __builtin_bit_cast(uint2, t2);
+                    *reinterpret_cast<uint4 *>(A.out + (((size_t)s_n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = make_uint4(a.x, a.y, b2.x, b2.y);
+                }
+            }
+        };
+        constexpr int P1 = (3 * NP + 7) / 8, P2 = (6 * NP + 7) / 8;
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
@@ -993,16 +1040,21 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         commit(I0{}, 0);
         issue(I0{});
         __syncthreads();
-        // step q: the consumers work on chunk q; chunk q+1 goes into the other slot, its register set takes chunk q+5
-        // (the step count is padded to a multiple of four - the consumers idle through the padding steps - so that the loop body
-        //  has no conditional part and the number of loads in flight is the same on every path to its head)
-        for (int q0 = 0; q0 < S4; q0 += 4) {
-            commit(I1{}, q0 + 1); issue(I1{}); __syncthreads();
-            commit(I2{}, q0 + 2); issue(I2{}); __syncthreads();
-            commit(I3{}, q0 + 3); issue(I3{}); __syncthreads();
-            commit(I0{}, q0 + 4); issue(I0{}); __syncthreads();
+        // step q: the consumers work on chunk q; chunk q+1 goes into the other slot, its register set takes chunk q+5; the out image of
+        // the previous tile leaves during steps 0..2 (the consumers overwrite it at the end of step 3)
+        for (int q0 = 0; q0 < S; q0 += 4) {
+            WS_STAMP(1); commit(I1{}, q0 + 1); WS_STAMP(2); issue(I1{}); store_pieces(0, P1); WS_STAMP(3); __syncthreads();
+            WS_STAMP(1); commit(I2{}, q0 + 2); WS_STAMP(2); issue(I2{}); store_pieces(P1, P2); WS_STAMP(3); __syncthreads();
+            WS_STAMP(1); commit(I3{}, q0 + 3); WS_STAMP(2); issue(I3{}); store_pieces(P2, NP); WS_STAMP(3); __syncthreads();
+            WS_STAMP(1); commit(I0{}, q0 + 4); WS_STAMP(2); issue(I0{}); WS_STAMP(3); __syncthreads();
+            s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
+            o_x0 += TW;
+            if (o_x0 >= A.W) { o_x0 = 0; o_y0 += TH; if (o_y0 >= A.H) { o_y0 = 0; ++o_n; } }
         }
-        if (DEFER) __syncthreads();                              // the consumers' last (serial) epilogue parks its statistics
+        store_pieces(0, NP);                                     // the last tile of the run
+#ifdef CDNET_WS_STAMPS
+        if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[1024 + i] = s_stamp[i]; g_ws_stamps[1024 + sn] = 0; }
+#endif
         return;
     }
 
@@ -1017,18 +1069,19 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     }
     const int bbase = half * BN * 16 + l31 * 16;
     auto toff = [](int t) { return ((TAPS == 9 ? t / 3 : 1) * HW_ + (TAPS == 9 ? t % 3 : 1)) * PSTR; };      // folds to immediates
-    f32x16 acc[MPW][NPW];            // the tile being accumulated
-    f32x16 accB[MPW][NPW];           // DEFER: the finished tile whose epilogue rides under the next tile's MFMAs
+    f32x16 acc[MPW][NPW];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < MPW; ++mi)
+        for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NPW; ++ni)
+            for (int ni = 0; ni < NPW; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; accB[mi][ni][r] = 0.f; }
-    unsigned char *s_out = lds_o + wave * L::OUT_WAVE;          // this wave's 64 pixels x BN couts
-    const int cout0 = cout_tile * BN;
-    // epilogue constants of this lane (the same for every tile of the run): one consumer group per CU means nothing else would
-    // hide the latency of these loads if they sat inside the epilogue
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    };
+    zero_acc();
+    // this wave's out image: blocks [mi][ni] of 32 cout rows x 32 pixels; this lane owns cout row l31 of every block
+    unsigned char *s_out = lds_o + wave * L::OUT_WAVE + l31 * L::IROW + half * 8;
+    // epilogue constants of this lane (the same for every tile of the run)
     float e_osc[NPW], e_osh[NPW];
 #pragma unroll
     for (int ni = 0; ni < NPW; ++ni) {
@@ -1037,69 +1090,19 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         e_osc[ni] = (A.oscale && cok) ? A.oscale[co] : 1.f;
         e_osh[ni] = fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
     }
-    constexpr int VO = BN / 8, NV = VO, PPI = 64 / VO;           // a lane's NV out vectors: pixel lane / VO + i * PPI, channels (lane % VO) * 8 ..
-    const int qv = lane % VO, ml0 = lane / VO;
     const bool f16out = A.out_f16 != 0;
-    const bool odd = (l31 & 1) != 0;
     const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
-
-    // ---- epilogue micro-operations on an accumulator set (full tiles only in the deferred form) ----
-    // one (row pair rp, N tile ni) of M tile mi: bias/scale/shift, pair swap through DPP, 16-bit conversion, ReLU, LDS
-    auto epi_write1 = [&](float a0, float a1, int mi, int ni, int rp) {
-        const int col = ni * 32 + l31;
-        const float osc = e_osc[ni], osh = e_osh[ni];
-        unsigned char *dst = s_out + (col & ~1) * 2 + (odd ? OSTR : 0);
-        const int r = 2 * rp;
-        const int ml = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // row inside the wave's 64 pixels
-        const float v0 = fmaf(a0, osc, osh), v1 = fmaf(a1, osc, osh);
-        const float send = odd ? v0 : v1;
-        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
-        const xf_f32x2 pr = {odd ? got : v0, odd ? v1 : got};
-        const xf_s16x2 ph = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(pr, xf_h16x2));
-        const xf_s16x2 pb = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(pr, xf_bf16x2));
-        xf_s16x2 pk = f16out ? ph : pb;
-        pk = __builtin_elementwise_max(pk, lo_clamp);
-        *reinterpret_cast<unsigned *>(dst + ml * OSTR) = __builtin_bit_cast(unsigned, pk);
-    };
-    float st_sum[NPW], st_sq[NPW];
-    // statistics of one accumulator register group (full tile: no masks)
-    auto epi_stat1 = [&](float a0, float a1, float a2, float a3, int ni) {
-        st_sum[ni] += a0; st_sq[ni] = fmaf(a0, a0, st_sq[ni]);
-        st_sum[ni] += a1; st_sq[ni] = fmaf(a1, a1, st_sq[ni]);
-        st_sum[ni] += a2; st_sq[ni] = fmaf(a2, a2, st_sq[ni]);
-        st_sum[ni] += a3; st_sq[ni] = fmaf(a3, a3, st_sq[ni]);
-    };
-    auto epi_stat_flush = [&](int par) {
-        float *sp = s_stats + par * (4 * 2 * BN);
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni) {
-            const float a = st_sum[ni] + __shfl_xor(st_sum[ni], 32), b2 = st_sq[ni] + __shfl_xor(st_sq[ni], 32);
-            if (half == 0) {
-                sp[(wave * 2 + 0) * BN + ni * 32 + l31] = a;
-                sp[(wave * 2 + 1) * BN + ni * 32 + l31] = b2;
-            }
-        }
-    };
 
     int k = 0, tl = 0;                                           // chunk inside the tile, tile inside the run
     int stats_tile = -1, stats_par = 0;                         // statistics parked in LDS by a finished epilogue
-    int pend_tile = -1;                                          // DEFER: tile whose accumulators wait in accB
-    unsigned short *pend_out = nullptr;                          // its output origin for this lane (row 0 of the wave, lane's channels)
-    uint4 vv[NV / 2];
 
-    // one chunk step: TAPS x (MPW x NPW) MFMAs with the fragments of the next tap requested ahead; PART > 0 interleaves a quarter
-    // of the pending tile's epilogue (program order = issue order: the vector / LDS / store instructions ride in the MFMA shadow)
-    auto mfma_step = [&](auto part_c, const unsigned char *la, const unsigned char *lw) {
-        constexpr int PART = decltype(part_c)::value;
+    // one chunk step: TAPS x (MPW x NPW) MFMAs with the fragments of the next tap requested ahead
+    auto mfma_step = [&](const unsigned char *la, const unsigned char *lw) {
         bf16x8 af[2][MPW], bfr[2][NPW];
 #pragma unroll
         for (int mi = 0; mi < MPW; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi] + toff(0));
 #pragma unroll
         for (int ni = 0; ni < NPW; ++ni) bfr[0][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ni * 512);
-        if (PART == 1) {
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni) { st_sum[ni] = 0.f; st_sq[ni] = 0.f; }
-        }
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             if (t + 1 < TAPS) {
@@ -1111,54 +1114,44 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NPW; ++ni) {
+                for (int ni = 0; ni < NPW; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][mi], bfr[t & 1][ni], acc[mi][ni], 0, 0, 0);
-                    // ---- a slice of the pending tile's epilogue after every MFMA (slot sl of TAPS * MPW * NPW): straight-line
-                    // ---- vector / LDS / store instructions that issue in the shadow of the matrix pipe
-                    constexpr int SLOTS = TAPS * MPW * NPW;
-                    constexpr int NW = 8 * NPW, NS = 4 * MPW * NPW, NH = NV / 2;
-                    static_assert(NW + NS <= SLOTS && SLOTS / 2 + NH <= SLOTS, "epilogue slices fit the MFMA slots of a chunk step");
-                    const int sl = (t * MPW + mi) * NPW + ni;
-                    if ((PART == 1 || PART == 2) && sl < NW) {
-                        constexpr int EMI = PART == 2 ? 1 : 0;
-                        const int eni = sl / 8, erp = sl % 8;
-                        epi_write1(accB[EMI][eni][2 * erp], accB[EMI][eni][2 * erp + 1], EMI, eni, erp);
-                    }
-                    if (PART == 1 && sl >= NW && sl < NW + NS) {
-                        const int g = sl - NW;
-                        const int smi = (g / 4) / NPW, sni = (g / 4) % NPW, r0 = (g % 4) * 4;
-                        epi_stat1(accB[smi][sni][r0], accB[smi][sni][r0 + 1], accB[smi][sni][r0 + 2], accB[smi][sni][r0 + 3], sni);
-                    }
-                    if (PART == 3 || PART == 4) {
-                        // half of the lane's out vectors: LDS reads in the first slots, stores in the later ones
-                        constexpr int I0 = (PART - 3) * NH;
-                        if (sl < NH) vv[sl] = *reinterpret_cast<const uint4 *>(s_out + (ml0 + (I0 + sl) * PPI) * OSTR + qv * 16);
-                        if (sl >= SLOTS / 2 && sl < SLOTS / 2 + NH) {
-                            const int ml = ml0 + (I0 + (sl - SLOTS / 2)) * PPI;          // pixel inside the wave's four tile rows
-                            *reinterpret_cast<uint4 *>(pend_out + ((size_t)(ml / TW) * A.W + ml % TW) * A.out_cstride) = vv[sl - SLOTS / 2];
-                        }
-                    }
-                }
-        }
-        if (PART == 2) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>;
-    using P3 = std::integral_constant<int, 3>;
-    using P4 = std::integral_constant<int, 4>;
 
-    // serial epilogue of the accumulators in `acc` (partial tiles, layers with fewer than four chunks, the last tile of the run)
-    auto serial_epilogue = [&](int tile) {
-        const int n = tile / tiles_img, rr_ = tile - n * tiles_img;
-        const int ty = rr_ / tiles_x;
-        const int y0 = ty * TH, x0 = (rr_ - ty * tiles_x) * TW;
-        const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
+    // the finished tile: channel statistics of the unrounded accumulators, then bias/scale/shift, 16-bit conversion, ReLU and the
+    // [cout][pixel] LDS image (registers 4g..4g+3 of a block are four consecutive pixels of this lane's cout: one 8-byte write)
+    auto write_image = [&](auto f16_c) {
+        constexpr bool F16 = decltype(f16_c)::value;
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) {
+                const float osc = e_osc[ni], osh = e_osh[ni];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const xf_f32x2 p0 = {fmaf(acc[mi][ni][4 * g], osc, osh), fmaf(acc[mi][ni][4 * g + 1], osc, osh)};
+                    const xf_f32x2 p1 = {fmaf(acc[mi][ni][4 * g + 2], osc, osh), fmaf(acc[mi][ni][4 * g + 3], osc, osh)};
+                    xf_s16x2 k0, k1;
+                    if (F16) {
+                        k0 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p0, xf_h16x2));
+                        k1 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p1, xf_h16x2));
+                    } else {
+                        k0 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p0, xf_bf16x2));
+                        k1 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p1, xf_bf16x2));
+                    }
+                    k0 = __builtin_elementwise_max(k0, lo_clamp);
+                    k1 = __builtin_elementwise_max(k1, lo_clamp);
+                    *reinterpret_cast<uint2 *>(s_out + (mi * NPW + ni) * L::IBLK + g * 16) = make_uint2(__builtin_bit_cast(unsigned, k0), __builtin_bit_cast(unsigned, k1));
+                }
+            }
+    };
+    auto epilogue = [&](int tile) {
         if (A.stats) {
+            const int n = tile / tiles_img, rr_ = tile - n * tiles_img;
+            const int ty = rr_ / tiles_x;
+            const int y0 = ty * TH, x0 = (rr_ - ty * tiles_x) * TW;
+            const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
             const int par = (tl & 1);
             float *sp = s_stats + par * (4 * 2 * BN);
 #pragma unroll
@@ -1190,29 +1183,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             stats_tile = tile;
             stats_par = par;
         }
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) epi_write1(acc[mi][ni][2 * rp], acc[mi][ni][2 * rp + 1], mi, ni, rp);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int co = cout0 + qv * 8;
-        unsigned short *obase = A.out + (((size_t)n * A.H + y0) * A.W + x0) * A.out_cstride + A.out_coff + co;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int i = 0; i < NV / 2; ++i) vv[i] = *reinterpret_cast<const uint4 *>(s_out + (ml0 + (h2 * (NV / 2) + i) * PPI) * OSTR + qv * 16);
-#pragma unroll
-            for (int i = 0; i < NV / 2; ++i) {
-                const int m = wm * 64 + ml0 + (h2 * (NV / 2) + i) * PPI;
-                const int yl = m / TW, xl = m % TW;
-                if ((full || (y0 + yl < A.H && x0 + xl < A.W)) && co < A.Cout)
-                    *reinterpret_cast<uint4 *>(obase + ((size_t)yl * A.W + xl) * A.out_cstride) = vv[i];
-            }
-        }
+        if (f16out) write_image(std::true_type{});
+        else write_image(std::false_type{});
     };
     auto flush_stats = [&]() {
         if (stats_tile >= 0 && tid < 2 * BN) {
@@ -1228,75 +1200,31 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         stats_tile = -1;
     };
 
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    };
     __syncthreads();                                             // chunk 0 is staged
-    if (DEFER) {
-        // Every tile is full, nchunk >= 4, Cout a multiple of BN (checked by the launcher).  Straight-line tile body: the first four
-        // chunk steps of a tile carry the four quarters of the previous tile's epilogue; the first tile of the run carries none
-        // (peeled), the last tile's epilogue runs after the loop.
-        int q = 0;
-        auto la_of = [&](int qq) { return lds_a + (qq & 1) * L::A_BYTES; };
-        for (int j = 0; j < ntl; ++j) {
-            const int tile = t_lo + j;
-            if (j == 0) {
-                for (int kk = 0; kk < nchunk; ++kk) { mfma_step(P0{}, la_of(q), lds_w + kk * L::B_CHUNK); ++q; __syncthreads(); }
-            } else {
-                flush_stats();
-                mfma_step(P1{}, la_of(q), lds_w); ++q; __syncthreads();
-                mfma_step(P2{}, la_of(q), lds_w + L::B_CHUNK); ++q;
-                if (A.stats) { epi_stat_flush(j & 1); stats_tile = pend_tile; stats_par = j & 1; }
-                __syncthreads();
-                flush_stats();
-                mfma_step(P3{}, la_of(q), lds_w + 2 * L::B_CHUNK); ++q; __syncthreads();
-                mfma_step(P4{}, la_of(q), lds_w + 3 * L::B_CHUNK); ++q; __syncthreads();
-                for (int kk = 4; kk < nchunk; ++kk) { mfma_step(P0{}, la_of(q), lds_w + kk * L::B_CHUNK); ++q; __syncthreads(); }
-            }
-            // park the finished tile
-            const int n = tile / tiles_img, rr_ = tile - n * tiles_img;
-            const int ty = rr_ / tiles_x;
-            const int y0 = ty * TH, x0 = (rr_ - ty * tiles_x) * TW;
-#pragma unroll
-            for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NPW; ++ni) accB[mi][ni] = acc[mi][ni];
-            pend_tile = tile;
-            pend_out = A.out + (((size_t)n * A.H + y0 + wm * 4) * A.W + x0) * A.out_cstride + A.out_coff + cout0 + qv * 8;
-            zero_acc();
-        }
-        for (; q < S4; ++q) __syncthreads();
-        // the last tile of the run: serial epilogue (serial_epilogue reads `acc`)
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni) acc[mi][ni] = accB[mi][ni];
-        tl = ntl;
+    for (int q = 0; q < S; ++q) {
         flush_stats();
-        serial_epilogue(pend_tile);
-        __syncthreads();                                         // (the producers wait here too) the last tile's statistics are parked
-        flush_stats();
-        return;
-    }
-    for (int q = 0; q < S4; ++q) {
-        if (q >= S) { __syncthreads(); continue; }
-        flush_stats();
-        mfma_step(P0{}, lds_a + (q & 1) * L::A_BYTES, lds_w + k * L::B_CHUNK);
-        if (++k == nchunk) {
+        WS_STAMP(10);
+        mfma_step(lds_a + (q & 1) * L::A_BYTES, lds_w + k * L::B_CHUNK);
+        WS_STAMP(11);
+        if (++k == NCH) {
             k = 0;
             const int tile = t_lo + tl;
+#ifdef CDNET_WS_STAMPS
+            if (stamp_on && acc[0][0][0] == 123.456f) g_ws_stamps[1023] = 1;         // depends on the MFMA results
+            WS_STAMP(12);
+#endif
+            epilogue(tile);
             ++tl;
-            serial_epilogue(tile);
+            WS_STAMP(13);
             zero_acc();
         }
         __syncthreads();
+        WS_STAMP(14);
     }
     flush_stats();
+#ifdef CDNET_WS_STAMPS
+    if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[i] = s_stamp[i]; g_ws_stamps[sn] = 0; }
+#endif
 }
 
 // eligibility + launch of the wave-specialised kernel; returns -1 when the layer must take conv_fwd_kernel
@@ -1305,18 +1233,18 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
     using L = WsLds<BN, TAPS>;
     int ctot = 0;
     if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
+    if (A.nchunk != 4) return -1;                                // 64 input channels: the out path rides on steps 0..2 of a four-step tile
     for (int i = 0; i < A.nsrc; ++i) {
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
     }
+#ifdef CDNET_WS_STAMPS
+    const int smem = L::bytes(A.nchunk, ctot) + 2 * 1024 * 8;
+#else
     const int smem = L::bytes(A.nchunk, ctot);
+#endif
     if (smem > 160 * 1024) return -1;
     const int T = cdiv(A.W, 16) * cdiv(A.H, 16) * A.N;
-    bool any_xf = false;
-    for (int i = 0; i < A.nsrc; ++i) any_xf = any_xf || A.src[i].scale || A.src[i].relu || A.src[i].f16;
-    // measured on 3x3 64->64 @256x256 (tools/bench_conv_ws.py): plain sources 0.105-0.120 vs 0.108 ms at 16 tiles (parity), 0.41 vs
-    // 0.49 ms at 64 tiles; lazily transformed (training-mode) sources 0.122-0.130 vs 0.139 ms at 16 tiles
-    if (!(A.debug & 64) && (T < 512 || (!any_xf && T < 8192))) return -1;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -1324,22 +1252,23 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return check_launch("hipGetDeviceProperties");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int ctiles = cdiv(A.Cout, BN);
+    // a persistent workgroup pays ~3 us of start-up (weights + first chunks): worth it from a few tiles per workgroup on
+    if (!(A.debug & 64) && T < 4 * (n_cu / ctiles)) return -1;
     bool all_plain = true, all_fast = true;
     for (int i = 0; i < A.nsrc; ++i) {
         const ConvSrc &s = A.src[i];
         all_plain = all_plain && !s.scale && !s.relu && !s.res && !s.f16;
         all_fast = all_fast && s.scale && s.relu && !s.res && s.f16 == 1;
     }
-    const int ctiles = cdiv(A.Cout, BN);
     int G = n_cu / ctiles;
     G = G > T ? T : G;
     if (G >= 8) G &= ~7;
     if (G < 1) G = 1;
     dim3 grid(G, ctiles, 1);
-    auto launch = [&](auto xf_c, auto defer_c) -> int {
+    auto launch = [&](auto xf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
-        constexpr bool DF = decltype(defer_c)::value;
-        auto kern = conv_ws_kernel<BN, TAPS, XF, DF>;
+        auto kern = conv_ws_kernel<BN, TAPS, XF>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1349,16 +1278,8 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
         kern<<<grid, 512, smem, st>>>(A);
         return CDNET_OK;
     };
-    // DEFER (the finished tile's epilogue interleaved with the next tile's MFMAs) is bit-identical but measured slower
-    // (0.132 vs 0.105-0.120 ms on 64->64 @256x256 x16: the fillers cost the MFMA stream more than the serial epilogue): off unless asked for
-    static const int want_defer = getenv("CDNET_CONV_WS_DEFER") ? atoi(getenv("CDNET_CONV_WS_DEFER")) : 0;
-    const bool defer = want_defer && A.nchunk >= 4 && A.H % 16 == 0 && A.W % 16 == 0 && A.Cout % BN == 0;
     const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
-    int rc;
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    if (defer) rc = xf == 0 ? launch(std::integral_constant<int, 0>{}, T_{}) : (xf == 1 ? launch(std::integral_constant<int, 1>{}, T_{}) : launch(std::integral_constant<int, 2>{}, T_{}));
-    else rc = xf == 0 ? launch(std::integral_constant<int, 0>{}, F_{}) : (xf == 1 ? launch(std::integral_constant<int, 1>{}, F_{}) : launch(std::integral_constant<int, 2>{}, F_{}));
+    const int rc = xf == 0 ? launch(std::integral_constant<int, 0>{}) : (xf == 1 ? launch(std::integral_constant<int, 1>{}) : launch(std::integral_constant<int, 2>{}));
     if (rc != CDNET_OK) return rc;
     return check_launch("conv_ws_kernel");
 }

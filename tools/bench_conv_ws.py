@@ -1,6 +1,6 @@
 """Phase ablation of the wave-specialised persistent convolution (conv_ws_kernel) on the dominant layer (3x3 64->64 @256x256, 16
-tiles): cdnet_conv_args.debug bits 64 = force the kernel, 4 = no MFMA loop, 8 = no epilogue, 128 = producers issue no global
-loads; 32 = conv_fwd_kernel for comparison.   usage: python tools/bench_conv_ws.py [B]"""
+tiles): cdnet_conv_args.debug bits 64 = force the kernel, 32 = conv_fwd_kernel for comparison (CDNET_CONV_WS_DEFER=1 selects the
+deferred-epilogue form).   usage: python tools/bench_conv_ws.py [B]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,6 +39,5 @@ def t(dbg, train=False, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, d in (('conv_fwd_kernel', 32), ('ws full', 64), ('ws no epilogue', 64 | 8), ('ws no MFMA', 64 | 4), ('ws no MFMA, no epilogue', 64 | 12),
-                ('ws producers prio 1', 64 | 1024), ('ws producers prio 2', 64 | 2048), ('ws producers prio 3', 64 | 3072), ('ws full again', 64), ('ws no write_tile', 64 | 256), ('ws no store loop', 64 | 512), ('ws no write_tile, no store', 64 | 768), ('ws no loads', 64 | 128), ('ws no loads, no MFMA, no epilogue', 64 | 128 | 12)):
+for name, d in (('conv_fwd_kernel', 32), ('conv_ws_kernel', 64), ('conv_fwd_kernel again', 32), ('conv_ws_kernel again', 64)):
     print('%-36s plain %7.1f us   train-mode source+stats %7.1f us' % (name, t(d), t(d, True)))
