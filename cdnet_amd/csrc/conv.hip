@@ -801,14 +801,19 @@ extern "C" __attribute__((visibility("default"))) int cdnet_debug_ws_stamps(unsi
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps)) == hipSuccess ? 0 : 1;
 }
 #define WS_STAMP(id) do { if (stamp_on && sn < 1020) { s_stamp[sn++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(id); } } while (0)
+#define WS_STAMP_CYC(id) do { if (stamp_on && sn < 1020) { s_stamp[sn++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (unsigned long long)(id); } } while (0)
 #else
 #define WS_STAMP(id) do { } while (0)
+#define WS_STAMP_CYC(id) do { } while (0)
 #endif
 
-template <int BN, int TAPS>
+template <int BN, int TAPS, bool SWZ>
 struct WsLds {
     static constexpr int TH = 16, TW = 16, CK = 16;
-    static constexpr int PSTR = CK * 2 + 16;
+    // halo image: 32 B per pixel, unpadded; the two 16-byte k-halves of a pixel sit at (half ^ (halo row & 1)) * 16.  An A-fragment
+    // ds_read_b128 serves 16 lanes per LDS cycle - 8 pixels of one tile row and 8 of the next, same k-half - and with the row-parity
+    // swizzle these land on 16 distinct 16-byte bank groups (the padded 48-byte layout of conv_fwd_kernel is 2-way on two of them)
+    static constexpr int PSTR = SWZ ? CK * 2 : CK * 2 + 16;
     static constexpr int NPIX = (TH + 2) * (TW + 2);
     static constexpr int A_BYTES = NPIX * PSTR;                   // one ring slot: the halo tile of a 16-channel chunk
     static constexpr int B_CHUNK = TAPS * CK * BN * 2;            // packed weights of one chunk
@@ -826,9 +831,9 @@ typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 
 // XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
 // BatchNorm source, packed math), 2 anything (run-time flags).  The launcher guarantees nchunk == 4.
-template <int BN, int TAPS, int XF>
+template <int BN, int TAPS, int XF, bool SWZ>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
-    using L = WsLds<BN, TAPS>;
+    using L = WsLds<BN, TAPS, SWZ>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NT = BN / 32, NPW = NT, MPW = 2;               // consumer wave wm: M tiles 2wm, 2wm+1 (64 pixels), all N tiles
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
@@ -905,12 +910,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         unsigned vm[PF];                         // bit i: vector i of the chunk is inside the image / source
         int eo[PF][NA];                          // element offsets (only read for sources with a residual operand)
         // per-thread constants: halo coordinates of its NA vectors
-        int hyx[NA];
+        int hyx[NA], doff[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int pix = (ptid + i * 256) / VPP;
             const int hy = pix / HW_, hx = pix - hy * HW_;
             hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 16) | hx) : -1;
+            doff[i] = pix * PSTR + ((SWZ ? slot ^ (hy & 1) : slot) * 16);
         }
         // cursors (no integer division per chunk): the issue cursor walks chunks 0, 1, 2, ... of the run and stops on the last
         // one; the commit cursor only needs the chunk-in-tile index
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            unsigned char *dst0 = lds_a + (c_ & 1) * L::A_BYTES + (ptid / VPP) * PSTR + slot * 16;
+            unsigned char *dst0 = lds_a + (c_ & 1) * L::A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 const unsigned keep = (vm[R] >> i) & 1u ? 0xffffffffu : 0u;
                 val &= keep;
                 if (i < NA - 1 || ptid + i * 256 < NPIX * VPP)
-                    *reinterpret_cast<u32x4v *>(dst0 + i * (256 / VPP) * PSTR) = val;
+                    *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val;
             }
         };
         // ---- out path: mover wave w stores the region of consumer wave w.  Piece pc = (M tile mi, pixel half ch, cout pass kk): the four
@@ -1061,12 +1067,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     // ================================ consumers ================================
     const int wm = wave;
     const int half = lane >> 5, l31 = lane & 31;
-    int abase[MPW];
+    int abase[MPW][2];                                           // [.][parity of the tap's row offset]: the k-half swizzle follows the halo row
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi) {
         const int m = (wm * MPW + mi) * 32 + l31;
-        abase[mi] = ((m / TW) * HW_ + m % TW) * PSTR + half * 16;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) abase[mi][par] = ((m / TW) * HW_ + m % TW) * PSTR + ((SWZ ? half ^ ((m / TW + par) & 1) : half) * 16);
     }
+    auto tpar = [](int t) { return (TAPS == 9 ? t / 3 : 1) & 1; };
     const int bbase = half * BN * 16 + l31 * 16;
     auto toff = [](int t) { return ((TAPS == 9 ? t / 3 : 1) * HW_ + (TAPS == 9 ? t % 3 : 1)) * PSTR; };      // folds to immediates
     f32x16 acc[MPW][NPW];
@@ -1100,14 +1108,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     auto mfma_step = [&](const unsigned char *la, const unsigned char *lw) {
         bf16x8 af[2][MPW], bfr[2][NPW];
 #pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi] + toff(0));
+        for (int mi = 0; mi < MPW; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi][tpar(0)] + toff(0));
 #pragma unroll
         for (int ni = 0; ni < NPW; ++ni) bfr[0][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ni * 512);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             if (t + 1 < TAPS) {
 #pragma unroll
-                for (int mi = 0; mi < MPW; ++mi) af[(t + 1) & 1][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi] + toff(t + 1));
+                for (int mi = 0; mi < MPW; ++mi) af[(t + 1) & 1][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi][tpar(t + 1)] + toff(t + 1));
 #pragma unroll
                 for (int ni = 0; ni < NPW; ++ni) bfr[(t + 1) & 1][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ((t + 1) * 2) * BN * 16 + ni * 512);
             }
@@ -1203,9 +1211,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     __syncthreads();                                             // chunk 0 is staged
     for (int q = 0; q < S; ++q) {
         flush_stats();
+        WS_STAMP_CYC(130);
         WS_STAMP(10);
         mfma_step(lds_a + (q & 1) * L::A_BYTES, lds_w + k * L::B_CHUNK);
         WS_STAMP(11);
+        WS_STAMP_CYC(131);
         if (++k == NCH) {
             k = 0;
             const int tile = t_lo + tl;
@@ -1228,9 +1238,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 }
 
 // eligibility + launch of the wave-specialised kernel; returns -1 when the layer must take conv_fwd_kernel
-template <int BN, int TAPS>
+template <int BN, int TAPS, bool SWZ>
 int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
-    using L = WsLds<BN, TAPS>;
+    using L = WsLds<BN, TAPS, SWZ>;
     int ctot = 0;
     if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
     if (A.nchunk != 4) return -1;                                // 64 input channels: the out path rides on steps 0..2 of a four-step tile
@@ -1268,7 +1278,7 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
     dim3 grid(G, ctiles, 1);
     auto launch = [&](auto xf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
-        auto kern = conv_ws_kernel<BN, TAPS, XF>;
+        auto kern = conv_ws_kernel<BN, TAPS, XF, SWZ>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1467,7 +1477,9 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
     if ((use_ws || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
-        const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, st) : try_launch_conv_ws<32, 9>(A, st);
+        int rc;
+        if (A.debug & 128) rc = A.BN == 64 ? try_launch_conv_ws<64, 9, false>(A, st) : try_launch_conv_ws<32, 9, false>(A, st);     // ablation: padded halo image
+        else rc = A.BN == 64 ? try_launch_conv_ws<64, 9, true>(A, st) : try_launch_conv_ws<32, 9, true>(A, st);
         if (rc >= 0) return rc;
     }
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }

@@ -39,5 +39,5 @@ def t(dbg, train=False, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, d in (('conv_fwd_kernel', 32), ('conv_ws_kernel', 64), ('conv_fwd_kernel again', 32), ('conv_ws_kernel again', 64)):
+for name, d in (('conv_fwd_kernel', 32), ('conv_ws_kernel', 64), ('conv_ws_kernel padded halo image', 64 | 128), ('conv_fwd_kernel again', 32), ('conv_ws_kernel again', 64), ('conv_ws_kernel padded again', 64 | 128)):
     print('%-36s plain %7.1f us   train-mode source+stats %7.1f us' % (name, t(d), t(d, True)))

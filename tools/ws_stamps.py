@@ -37,6 +37,15 @@ for role, off in (('consumer', 0), ('producer', 1024)):
     n = int(np.argmax(v == 0))
     ids = (v[:n] & np.uint64(255)).astype(int)
     ts = (v[:n] >> np.uint64(8)).astype(np.int64)
+    cyc = ids >= 128
+    if cyc.any():
+        c, ci = ts[cyc], ids[cyc]
+        steps = [(c[i + 1] - c[i]) for i in range(len(c) - 1) if ci[i] == 130 and ci[i + 1] == 131]
+        rt = ts[~cyc]
+        print(role, 'shader cycles per MFMA step: mean %.0f min %d max %d; cycles first->last %d over %.2f us = %.2f GHz'
+              % (np.mean(steps), min(steps), max(steps), c[-1] - c[0], (rt[-1] - rt[0]) / 100.0, (c[-1] - c[0]) / ((rt[-1] - rt[0]) * 10.0)))
+    ids, ts = ids[~cyc], ts[~cyc]
+    n = len(ids)
     ts = (ts - ts[0]) / 100.0
     print(role, n, 'stamps, span %.1f us' % (ts[-1] if n else 0))
     # durations by (from id -> to id)
