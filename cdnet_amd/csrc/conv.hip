@@ -796,33 +796,35 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
 #ifdef CDNET_WS_STAMPS
 // debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): wall-clock stamps (100 MHz) of one consumer and one mover wave of one
 // workgroup, parked in LDS and dumped at the end of the kernel; read back with cdnet_debug_ws_stamps
-__device__ unsigned long long g_ws_stamps[2 * 1024];
+__device__ unsigned long long g_ws_stamps[2 * 1024];      // consumer stamps from 0, mover stamps from 1024 (384 each)
 extern "C" __attribute__((visibility("default"))) int cdnet_debug_ws_stamps(unsigned long long *dst) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps)) == hipSuccess ? 0 : 1;
 }
-#define WS_STAMP(id) do { if (stamp_on && sn < 1020) { s_stamp[sn++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(id); } } while (0)
-#define WS_STAMP_CYC(id) do { if (stamp_on && sn < 1020) { s_stamp[sn++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (unsigned long long)(id); } } while (0)
+#define WS_STAMP(id) do { if (stamp_on && sn < 380) { s_stamp[sn++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(id); } } while (0)
+#define WS_STAMP_CYC(id) do { if (stamp_on && sn < 380) { s_stamp[sn++] = ((unsigned long long)__builtin_readcyclecounter() << 8) | (unsigned long long)(id); } } while (0)
 #else
 #define WS_STAMP(id) do { } while (0)
 #define WS_STAMP_CYC(id) do { } while (0)
 #endif
 
-template <int BN, int TAPS, bool SWZ>
+template <int BN, int TAPS>
 struct WsLds {
     static constexpr int TH = 16, TW = 16, CK = 16;
     // halo image: 32 B per pixel, unpadded; the two 16-byte k-halves of a pixel sit at (half ^ (halo row & 1)) * 16.  An A-fragment
     // ds_read_b128 serves 16 lanes per LDS cycle - 8 pixels of one tile row and 8 of the next, same k-half - and with the row-parity
-    // swizzle these land on 16 distinct 16-byte bank groups (the padded 48-byte layout of conv_fwd_kernel is 2-way on two of them)
-    static constexpr int PSTR = SWZ ? CK * 2 : CK * 2 + 16;
+    // swizzle these land on 16 distinct 16-byte bank groups (tools/micro/lds_read_patterns.hip: 4 LDS cycles per read; the padded
+    // 48-byte layout of conv_fwd_kernel takes 7-8)
+    static constexpr int PSTR = CK * 2;
     static constexpr int NPIX = (TH + 2) * (TW + 2);
     static constexpr int A_BYTES = NPIX * PSTR;                   // one ring slot: the halo tile of a 16-channel chunk
+    static constexpr int NSLOT = 4;                               // ring slots = the four chunks of a tile
     static constexpr int B_CHUNK = TAPS * CK * BN * 2;            // packed weights of one chunk
     static constexpr int IROW = 72;                               // a cout row of an out-image block: 32 pixels x 2 B + 8 (conflict-free 8-byte writes)
     static constexpr int IBLK = 32 * IROW;                        // one block: 32 couts x 32 pixels
     static constexpr int OUT_WAVE = 2 * (BN / 32) * IBLK;         // a consumer wave's 64 pixels x BN couts
     static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum|sumsq][BN]
     __host__ __device__ static int bytes(int nchunk, int ctot) {
-        return nchunk * B_CHUNK + 2 * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4;
+        return nchunk * B_CHUNK + NSLOT * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4;
     }
 };
 
@@ -830,10 +832,11 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));      // register st
 typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 
 // XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
-// BatchNorm source, packed math), 2 anything (run-time flags).  The launcher guarantees nchunk == 4.
-template <int BN, int TAPS, int XF, bool SWZ>
+// BatchNorm source, packed math), 2 anything (run-time flags).  STATS: per-tile channel sums of the unrounded accumulators.
+// The launcher guarantees nchunk == 4 and full tiles (H, W multiples of 16).
+template <int BN, int TAPS, int XF, bool STATS>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
-    using L = WsLds<BN, TAPS, SWZ>;
+    using L = WsLds<BN, TAPS>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NT = BN / 32, NPW = NT, MPW = 2;               // consumer wave wm: M tiles 2wm, 2wm+1 (64 pixels), all N tiles
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
@@ -841,9 +844,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     constexpr int NCH = 4;                                        // chunks per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *lds_w = smem;
-    unsigned char *lds_a = smem + NCH * L::B_CHUNK;
-    unsigned char *lds_o = lds_a + 2 * L::A_BYTES;
+    // the halo ring first: its fragment addresses (slot, tap) then fit the 16-bit offset field of ds_read from one base register per M tile
+    unsigned char *lds_a = smem;
+    unsigned char *lds_w = smem + L::NSLOT * L::A_BYTES;
+    unsigned char *lds_o = lds_w + NCH * L::B_CHUNK;
     float *s_stats = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE);          // [2][4][2][BN]
     float *s_xf = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE + L::STATS_BYTES);
 
@@ -853,13 +857,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     const int cout_tile = blockIdx.y;
     const int cout0 = cout_tile * BN;
 #ifdef CDNET_WS_STAMPS
-    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NCH, ctot)) + (wave >= 4 ? 1024 : 0);
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NCH, ctot)) + (wave >= 4 ? 384 : 0);
     const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
     int sn = 0;
 #endif
 
     // this workgroup's contiguous run of tiles; XCD k (workgroups k, k+8, ...) serves the k-th eighth of the tiles
-    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
+    const int tiles_x = A.W / TW, tiles_y = A.H / TH;
     const int tiles_img = tiles_x * tiles_y;
     const int T = A.N * tiles_img;
     int t_lo, t_hi;
@@ -876,23 +880,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         }
     }
     const int ntl = t_hi - t_lo;
-    const int S = ntl * NCH;                                      // chunk steps (= barriers) of this workgroup
+    const int S = ntl * NCH;                                      // chunk steps of this workgroup
 
-    // resident weights + scale/shift table
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * NCH * (L::B_CHUNK / 2));
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
-        const int nv = NCH * (L::B_CHUNK / 16);
-        for (int v = tid; v < nv; v += 512) dst[v] = src[v];
-        for (int c = tid; c < ctot; c += 512) {
-            const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
-            const int cc = c < c0n ? c : c - c0n;
-            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
-            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
-        }
-    }
-    __syncthreads();
     if (S == 0) return;
+    // start-up: the movers put their first four halo chunks in flight and fill the scale/shift table while the consumers bring in the
+    // resident weights; one barrier, then the movers stage chunks 0 and 1
 
     auto chunk_src = [&](int k, int &si, int &cc0) {
         const int n0 = A.src[0].C / CK;
@@ -909,14 +901,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         u32x4v pa[PF][NA];
         unsigned vm[PF];                         // bit i: vector i of the chunk is inside the image / source
         int eo[PF][NA];                          // element offsets (only read for sources with a residual operand)
-        // per-thread constants: halo coordinates of its NA vectors
+        // per-thread constants: halo coordinates and LDS offsets of its NA vectors
         int hyx[NA], doff[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int pix = (ptid + i * 256) / VPP;
             const int hy = pix / HW_, hx = pix - hy * HW_;
             hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 16) | hx) : -1;
-            doff[i] = pix * PSTR + ((SWZ ? slot ^ (hy & 1) : slot) * 16);
+            doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
         }
         // cursors (no integer division per chunk): the issue cursor walks chunks 0, 1, 2, ... of the run and stops on the last
         // one; the commit cursor only needs the chunk-in-tile index
@@ -926,8 +918,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
             iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
         }
-        int o_n = in_, o_y0 = iy0, o_x0 = ix0;   // out cursor: the tile the consumers are working on
-        int s_n = 0, s_y0 = 0, s_x0 = 0;         // the finished tile whose out image waits in LDS
+        int o_n = in_, o_y0 = iy0, o_x0 = ix0;   // out cursor: the tile the consumers are accumulating
+        int s_n = 0, s_y0 = 0, s_x0 = 0;         // the finished tile whose out image the consumers park during interval A
         bool s_ok = false;
         int ck = 0;
         // staging geometry of the current tile and source (the chunks of one source share it): element offset of each vector
@@ -972,6 +964,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 }
             }
         };
+        // chunk c_ of the run (register set R = c_ % 4) -> ring slot c_ % 4
         auto commit = [&](auto rc, int c_) {
             constexpr int R = decltype(rc)::value;
             int si, cc0;
@@ -984,7 +977,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            unsigned char *dst0 = lds_a + (c_ & 1) * L::A_BYTES;
+            unsigned char *dst0 = lds_a + R * L::A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -1006,6 +999,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 }
                 const unsigned keep = (vm[R] >> i) & 1u ? 0xffffffffu : 0u;
                 val &= keep;
+#ifdef CDNET_WS_STAMPS
+                if (A.debug & 1024) { if (val[0] == 0x12345678u) *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val; continue; }
+#endif
                 if (i < NA - 1 || ptid + i * 256 < NPIX * VPP)
                     *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val;
             }
@@ -1018,9 +1014,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int pw = wave - 4;
         const int lg = lane >> 4, li = lane & 15;
         const unsigned char *s_img = lds_o + pw * L::OUT_WAVE + (li >> 2) * L::IROW + (li & 3) * 8;
-        auto store_pieces = [&](int p_lo, int p_hi) {
+        auto store_pieces = [&]() {
 #pragma unroll
-            for (int pc = p_lo; pc < p_hi; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
                 const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
                 const int o = lg + 4 * kk;
                 const int ni = o >> 2, r0 = 8 * (o & 3);
@@ -1028,13 +1024,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 const ws_s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
                 const ws_s16x4 t2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * L::IROW));
                 const int y = s_y0 + pw * 4 + mi * 2 + ch, x = s_x0 + li, co = cout0 + 8 * o;
-                if (s_ok && y < A.H && x < A.W && co < A.Cout) {
+                if (s_ok && co < A.Cout) {
                     const uint2 a = __builtin_bit_cast(uint2, t1), b2 = __builtin_bit_cast(uint2, t2);
                     *reinterpret_cast<uint4 *>(A.out + (((size_t)s_n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = make_uint4(a.x, a.y, b2.x, b2.y);
                 }
             }
         };
-        constexpr int P1 = (3 * NP + 7) / 8, P2 = (6 * NP + 7) / 8;
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
@@ -1043,21 +1038,34 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         issue(I1{});
         issue(I2{});
         issue(I3{});
+        for (int c = ptid; c < ctot; c += 256) {
+            const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
+            const int cc = c < c0n ? c : c - c0n;
+            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+        }
+        __syncthreads();                                         // table + weights
         commit(I0{}, 0);
         issue(I0{});
+        commit(I1{}, 1);
+        issue(I1{});
         __syncthreads();
-        // step q: the consumers work on chunk q; chunk q+1 goes into the other slot, its register set takes chunk q+5; the out image of
-        // the previous tile leaves during steps 0..2 (the consumers overwrite it at the end of step 3)
+        // tile j (chunks q0 .. q0+3).  Interval A: the consumers work on chunks q0, q0+1 (slots 0, 1) and park the out image of tile
+        // j-1; slots 2, 3 take chunks q0+2, q0+3.  Interval B: the consumers work on slots 2, 3; slots 0, 1 take the first two chunks
+        // of tile j+1 and the out image of tile j-1 leaves for global memory.
         for (int q0 = 0; q0 < S; q0 += 4) {
-            WS_STAMP(1); commit(I1{}, q0 + 1); WS_STAMP(2); issue(I1{}); store_pieces(0, P1); WS_STAMP(3); __syncthreads();
-            WS_STAMP(1); commit(I2{}, q0 + 2); WS_STAMP(2); issue(I2{}); store_pieces(P1, P2); WS_STAMP(3); __syncthreads();
-            WS_STAMP(1); commit(I3{}, q0 + 3); WS_STAMP(2); issue(I3{}); store_pieces(P2, NP); WS_STAMP(3); __syncthreads();
-            WS_STAMP(1); commit(I0{}, q0 + 4); WS_STAMP(2); issue(I0{}); WS_STAMP(3); __syncthreads();
+            WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); WS_STAMP(3); __syncthreads();
+#ifdef CDNET_WS_STAMPS
+            WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); if (!(A.debug & 256)) store_pieces(); WS_STAMP(3); __syncthreads();
+#else
+            WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); store_pieces(); WS_STAMP(3); __syncthreads();
+#endif
             s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
             o_x0 += TW;
             if (o_x0 >= A.W) { o_x0 = 0; o_y0 += TH; if (o_y0 >= A.H) { o_y0 = 0; ++o_n; } }
         }
-        store_pieces(0, NP);                                     // the last tile of the run
+        __syncthreads();                                         // the consumers have parked the last tile's out image
+        store_pieces();
 #ifdef CDNET_WS_STAMPS
         if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[1024 + i] = s_stamp[i]; g_ws_stamps[1024 + sn] = 0; }
 #endif
@@ -1065,6 +1073,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     }
 
     // ================================ consumers ================================
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * NCH * (L::B_CHUNK / 2));
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
+        constexpr int nv = NCH * (L::B_CHUNK / 16);
+#pragma unroll 6
+        for (int v = tid; v < nv; v += 256) dst[v] = src[v];
+    }
+    __syncthreads();                                             // table + weights
     const int wm = wave;
     const int half = lane >> 5, l31 = lane & 31;
     int abase[MPW][2];                                           // [.][parity of the tap's row offset]: the k-half swizzle follows the halo row
@@ -1072,21 +1088,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     for (int mi = 0; mi < MPW; ++mi) {
         const int m = (wm * MPW + mi) * 32 + l31;
 #pragma unroll
-        for (int par = 0; par < 2; ++par) abase[mi][par] = ((m / TW) * HW_ + m % TW) * PSTR + ((SWZ ? half ^ ((m / TW + par) & 1) : half) * 16);
+        for (int par = 0; par < 2; ++par) abase[mi][par] = ((m / TW) * HW_ + m % TW) * PSTR + ((half ^ ((m / TW + par) & 1)) * 16);
     }
     auto tpar = [](int t) { return (TAPS == 9 ? t / 3 : 1) & 1; };
     const int bbase = half * BN * 16 + l31 * 16;
     auto toff = [](int t) { return ((TAPS == 9 ? t / 3 : 1) * HW_ + (TAPS == 9 ? t % 3 : 1)) * PSTR; };      // folds to immediates
-    f32x16 acc[MPW][NPW];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    };
-    zero_acc();
+    // two accumulator sets: while one takes the current tile's MFMAs, the other (the finished tile) is converted and parked in the
+    // shadow of those MFMAs
+    f32x16 accA[MPW][NPW], accB[MPW][NPW];
     // this wave's out image: blocks [mi][ni] of 32 cout rows x 32 pixels; this lane owns cout row l31 of every block
     unsigned char *s_out = lds_o + wave * L::OUT_WAVE + l31 * L::IROW + half * 8;
     // epilogue constants of this lane (the same for every tile of the run)
@@ -1101,101 +1110,43 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     const bool f16out = A.out_f16 != 0;
     const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
 
-    int k = 0, tl = 0;                                           // chunk inside the tile, tile inside the run
-    int stats_tile = -1, stats_par = 0;                         // statistics parked in LDS by a finished epilogue
-
-    // one chunk step: TAPS x (MPW x NPW) MFMAs with the fragments of the next tap requested ahead
-    auto mfma_step = [&](const unsigned char *la, const unsigned char *lw) {
-        bf16x8 af[2][MPW], bfr[2][NPW];
+    // ---- epilogue units of a finished accumulator set (full tiles only).  Statistics: registers 4g..4g+3 of block (mi, ni) into the
+    // ---- lane's running sums, blocks in the order (ni, mi) - the summation order of conv_fwd_kernel.  Image: bias/scale/shift,
+    // ---- 16-bit conversion, ReLU; registers 4g..4g+3 are four consecutive pixels of this lane's cout: one 8-byte LDS write
+    constexpr int NU = MPW * NPW * 4;
+    float st_sum = 0.f, st_sq = 0.f;
+    auto stat_unit = [&](const f32x16 (&P)[MPW][NPW], int u, int par) {
+        const int ni = u / (MPW * 4), mi = (u / 4) % MPW, g = u % 4;
+        if (mi == 0 && g == 0) { st_sum = 0.f; st_sq = 0.f; }
 #pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi][tpar(0)] + toff(0));
-#pragma unroll
-        for (int ni = 0; ni < NPW; ++ni) bfr[0][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ni * 512);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            if (t + 1 < TAPS) {
-#pragma unroll
-                for (int mi = 0; mi < MPW; ++mi) af[(t + 1) & 1][mi] = *reinterpret_cast<const bf16x8 *>(la + abase[mi][tpar(t + 1)] + toff(t + 1));
-#pragma unroll
-                for (int ni = 0; ni < NPW; ++ni) bfr[(t + 1) & 1][ni] = *reinterpret_cast<const bf16x8 *>(lw + bbase + ((t + 1) * 2) * BN * 16 + ni * 512);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NPW; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][mi], bfr[t & 1][ni], acc[mi][ni], 0, 0, 0);
-        }
-    };
-
-    // the finished tile: channel statistics of the unrounded accumulators, then bias/scale/shift, 16-bit conversion, ReLU and the
-    // [cout][pixel] LDS image (registers 4g..4g+3 of a block are four consecutive pixels of this lane's cout: one 8-byte write)
-    auto write_image = [&](auto f16_c) {
-        constexpr bool F16 = decltype(f16_c)::value;
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni) {
-                const float osc = e_osc[ni], osh = e_osh[ni];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const xf_f32x2 p0 = {fmaf(acc[mi][ni][4 * g], osc, osh), fmaf(acc[mi][ni][4 * g + 1], osc, osh)};
-                    const xf_f32x2 p1 = {fmaf(acc[mi][ni][4 * g + 2], osc, osh), fmaf(acc[mi][ni][4 * g + 3], osc, osh)};
-                    xf_s16x2 k0, k1;
-                    if (F16) {
-                        k0 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p0, xf_h16x2));
-                        k1 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p1, xf_h16x2));
-                    } else {
-                        k0 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p0, xf_bf16x2));
-                        k1 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p1, xf_bf16x2));
-                    }
-                    k0 = __builtin_elementwise_max(k0, lo_clamp);
-                    k1 = __builtin_elementwise_max(k1, lo_clamp);
-                    *reinterpret_cast<uint2 *>(s_out + (mi * NPW + ni) * L::IBLK + g * 16) = make_uint2(__builtin_bit_cast(unsigned, k0), __builtin_bit_cast(unsigned, k1));
-                }
-            }
-    };
-    auto epilogue = [&](int tile) {
-        if (A.stats) {
-            const int n = tile / tiles_img, rr_ = tile - n * tiles_img;
-            const int ty = rr_ / tiles_x;
-            const int y0 = ty * TH, x0 = (rr_ - ty * tiles_x) * TW;
-            const bool full = (y0 + TH <= A.H) && (x0 + TW <= A.W);
-            const int par = (tl & 1);
+        for (int j = 0; j < 4; ++j) { const float v = P[mi][ni][4 * g + j]; st_sum += v; st_sq = fmaf(v, v, st_sq); }
+        if (mi == MPW - 1 && g == 3) {
             float *sp = s_stats + par * (4 * 2 * BN);
-#pragma unroll
-            for (int ni = 0; ni < NPW; ++ni) {
-                float ssum = 0.f, ssq = 0.f;
-                if (full) {
-#pragma unroll
-                    for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; ssum += v; ssq = fmaf(v, v, ssq); }
-                } else {
-#pragma unroll
-                    for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = (wm * MPW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const float v = ((y0 + m / TW) < A.H && (x0 + m % TW) < A.W) ? acc[mi][ni][r] : 0.f;
-                            ssum += v;
-                            ssq = fmaf(v, v, ssq);
-                        }
-                }
-                ssum += __shfl_xor(ssum, 32);
-                ssq += __shfl_xor(ssq, 32);
-                if (half == 0) {
-                    sp[(wave * 2 + 0) * BN + ni * 32 + l31] = ssum;
-                    sp[(wave * 2 + 1) * BN + ni * 32 + l31] = ssq;
-                }
+            const float a = st_sum + __shfl_xor(st_sum, 32), b2 = st_sq + __shfl_xor(st_sq, 32);
+            if (half == 0) {
+                sp[(wave * 2 + 0) * BN + ni * 32 + l31] = a;
+                sp[(wave * 2 + 1) * BN + ni * 32 + l31] = b2;
             }
-            stats_tile = tile;
-            stats_par = par;
         }
-        if (f16out) write_image(std::true_type{});
-        else write_image(std::false_type{});
     };
+    auto img_unit = [&](const f32x16 (&P)[MPW][NPW], int u) {
+        const int mi = u / (NPW * 4), ni = (u / 4) % NPW, g = u % 4;
+        const float osc = e_osc[ni], osh = e_osh[ni];
+        const xf_f32x2 p0 = {fmaf(P[mi][ni][4 * g], osc, osh), fmaf(P[mi][ni][4 * g + 1], osc, osh)};
+        const xf_f32x2 p1 = {fmaf(P[mi][ni][4 * g + 2], osc, osh), fmaf(P[mi][ni][4 * g + 3], osc, osh)};
+        const xf_s16x2 h0 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p0, xf_h16x2)), h1 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p1, xf_h16x2));
+        const xf_s16x2 b0 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p0, xf_bf16x2)), b1 = __builtin_bit_cast(xf_s16x2, __builtin_convertvector(p1, xf_bf16x2));
+        const xf_s16x2 k0 = __builtin_elementwise_max(f16out ? h0 : b0, lo_clamp), k1 = __builtin_elementwise_max(f16out ? h1 : b1, lo_clamp);
+        *reinterpret_cast<uint2 *>(s_out + (mi * NPW + ni) * L::IBLK + g * 16) = make_uint2(__builtin_bit_cast(unsigned, k0), __builtin_bit_cast(unsigned, k1));
+    };
+    // slot sl (0 .. 2 * 36 - 1) of interval A -> unit: statistics on the even slots from 0, then the image on the odd slots
+    constexpr int SLOTS = TAPS * MPW * NPW;                      // MFMAs of one chunk step
+    constexpr int IMG0 = STATS ? 2 * NU + 1 : 0;
+    static_assert(IMG0 + 2 * NU <= 2 * SLOTS, "the deferred epilogue fits the MFMA slots of interval A");
+
+    int stats_tile = -1, stats_par = 0;                         // statistics parked in LDS by a finished epilogue
     auto flush_stats = [&]() {
-        if (stats_tile >= 0 && tid < 2 * BN) {
+        if (STATS && stats_tile >= 0 && tid < 2 * BN) {
             // per-tile channel sums: the four waves' partials in a fixed order (deterministic)
             const int which = tid / BN, col = tid % BN;
             const float *sp = s_stats + stats_par * (4 * 2 * BN);
@@ -1208,29 +1159,99 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         stats_tile = -1;
     };
 
-    __syncthreads();                                             // chunk 0 is staged
-    for (int q = 0; q < S; ++q) {
-        flush_stats();
-        WS_STAMP_CYC(130);
-        WS_STAMP(10);
-        mfma_step(lds_a + (q & 1) * L::A_BYTES, lds_w + k * L::B_CHUNK);
-        WS_STAMP(11);
-        WS_STAMP_CYC(131);
-        if (++k == NCH) {
-            k = 0;
-            const int tile = t_lo + tl;
-#ifdef CDNET_WS_STAMPS
-            if (stamp_on && acc[0][0][0] == 123.456f) g_ws_stamps[1023] = 1;         // depends on the MFMA results
-            WS_STAMP(12);
+    // one barrier interval on accumulator set C: two chunks = 2 * TAPS taps of MPW x NPW MFMAs; the fragments of a tap are requested
+    // two taps ahead (three fragment sets): with four consumer waves reading, an LDS read issued only one tap (4 MFMAs = 128 cycles)
+    // ahead is not back in time and every tap stalls.  FIRST: the tile's first chunk starts from zero.  EPI: the interval carries the
+    // epilogue units of the finished set P after its MFMAs (program order = issue order: vector and LDS instructions ride in the MFMA shadow)
+    auto interval = [&](auto first_c, auto epi_c, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int par, int c0) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr bool EPI = decltype(epi_c)::value;
+        constexpr int NTAP = 2 * TAPS;
+        bf16x8 af[3][MPW], bfr[3][NPW];
+        const unsigned char *la = lds_a + c0 * L::A_BYTES, *lw = lds_w + c0 * L::B_CHUNK;
+        auto request = [&](int tau) {
+            const int ch = tau / TAPS, t = tau % TAPS;
+#if defined(CDNET_WS_ABL) && CDNET_WS_ABL == 1
+            if (tau >= 3) return;                              // ablation build: MFMAs on stale fragments, no LDS reads
 #endif
-            epilogue(tile);
-            ++tl;
-            WS_STAMP(13);
-            zero_acc();
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) af[tau % 3][mi] = *reinterpret_cast<const bf16x8 *>(la + ch * L::A_BYTES + abase[mi][tpar(t)] + toff(t));
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) bfr[tau % 3][ni] = *reinterpret_cast<const bf16x8 *>(lw + ch * L::B_CHUNK + bbase + (t * 2) * BN * 16 + ni * 512);
+        };
+        request(0);
+        request(1);
+#pragma unroll
+        for (int tau = 0; tau < NTAP; ++tau) {
+            if (tau + 2 < NTAP) request(tau + 2);
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni) {
+                    if (FIRST && tau == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tau % 3][mi], bfr[tau % 3][ni], z, 0, 0, 0);
+                    } else {
+                        C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tau % 3][mi], bfr[tau % 3][ni], C[mi][ni], 0, 0, 0);
+                    }
+                    if (EPI) {
+                        const int sl = (tau * MPW + mi) * NPW + ni;
+                        // (scheduling fences: keep every unit in its own MFMA gap - without them the scheduler gathers the units, and
+                        //  their temporaries push the two accumulator sets over the register budget)
+                        if (STATS && sl < 2 * NU && (sl & 1) == 0) { __builtin_amdgcn_sched_barrier(0); stat_unit(P, sl / 2, par); __builtin_amdgcn_sched_barrier(0); }
+                        if (sl >= IMG0 && sl < IMG0 + 2 * NU && ((sl - IMG0) & 1) == 0) { __builtin_amdgcn_sched_barrier(0); img_unit(P, (sl - IMG0) / 2); __builtin_amdgcn_sched_barrier(0); }
+                    }
+                }
         }
+    };
+    using F_ = std::false_type;
+    using T_ = std::true_type;
+    // tile j on set C; P = the finished tile j-1 (its epilogue rides in interval A)
+    auto tile_step = [&](auto has_prev, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int j) {
+        constexpr bool HP = decltype(has_prev)::value;
+        const int par = (j + 1) & 1;
+        WS_STAMP(10);
+#ifdef CDNET_WS_STAMPS
+        if (A.debug & 512) interval(T_{}, F_{}, C, P, par, 0); else
+#endif
+        interval(T_{}, has_prev, C, P, par, 0);
+        if (HP && STATS) { stats_tile = t_lo + j - 1; stats_par = par; }
+        WS_STAMP(11);
         __syncthreads();
         WS_STAMP(14);
+        flush_stats();
+        interval(F_{}, F_{}, C, P, par, 2);
+        WS_STAMP(12);
+        __syncthreads();
+        WS_STAMP(13);
+    };
+    // the last tile of the run: nothing left to hide behind
+    auto serial_epilogue = [&](const f32x16 (&P)[MPW][NPW], int j) {
+        const int par = j & 1;
+        if (STATS) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) stat_unit(P, u, par);
+            stats_tile = t_lo + j;
+            stats_par = par;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) img_unit(P, u);
+    };
+
+    __syncthreads();                                             // chunks 0, 1 are staged
+    tile_step(F_{}, accA, accB, 0);
+    int j = 1;
+    for (; j + 1 < ntl; j += 2) {
+        tile_step(T_{}, accB, accA, j);
+        tile_step(T_{}, accA, accB, j + 1);
     }
+    if (j < ntl) {
+        tile_step(T_{}, accB, accA, j);
+        serial_epilogue(accB, j);
+    } else {
+        serial_epilogue(accA, ntl - 1);
+    }
+    __syncthreads();
     flush_stats();
 #ifdef CDNET_WS_STAMPS
     if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[i] = s_stamp[i]; g_ws_stamps[sn] = 0; }
@@ -1238,23 +1259,24 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 }
 
 // eligibility + launch of the wave-specialised kernel; returns -1 when the layer must take conv_fwd_kernel
-template <int BN, int TAPS, bool SWZ>
+template <int BN, int TAPS>
 int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
-    using L = WsLds<BN, TAPS, SWZ>;
+    using L = WsLds<BN, TAPS>;
     int ctot = 0;
     if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
-    if (A.nchunk != 4) return -1;                                // 64 input channels: the out path rides on steps 0..2 of a four-step tile
+    if (A.nchunk != 4) return -1;                                // 64 input channels: a tile = two barrier intervals of two chunks
+    if (A.H % 16 != 0 || A.W % 16 != 0) return -1;               // full tiles only
     for (int i = 0; i < A.nsrc; ++i) {
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
     }
 #ifdef CDNET_WS_STAMPS
-    const int smem = L::bytes(A.nchunk, ctot) + 2 * 1024 * 8;
+    const int smem = L::bytes(A.nchunk, ctot) + 2 * 384 * 8;
 #else
     const int smem = L::bytes(A.nchunk, ctot);
 #endif
     if (smem > 160 * 1024) return -1;
-    const int T = cdiv(A.W, 16) * cdiv(A.H, 16) * A.N;
+    const int T = (A.W / 16) * (A.H / 16) * A.N;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -1276,9 +1298,10 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
     if (G >= 8) G &= ~7;
     if (G < 1) G = 1;
     dim3 grid(G, ctiles, 1);
-    auto launch = [&](auto xf_c) -> int {
+    auto launch = [&](auto xf_c, auto st_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
-        auto kern = conv_ws_kernel<BN, TAPS, XF, SWZ>;
+        constexpr bool STATS = decltype(st_c)::value;
+        auto kern = conv_ws_kernel<BN, TAPS, XF, STATS>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1289,7 +1312,12 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
         return CDNET_OK;
     };
     const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
-    const int rc = xf == 0 ? launch(std::integral_constant<int, 0>{}) : (xf == 1 ? launch(std::integral_constant<int, 1>{}) : launch(std::integral_constant<int, 2>{}));
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    using X2 = std::integral_constant<int, 2>;
+    int rc;
+    if (A.stats) rc = xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
+    else rc = xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
     if (rc != CDNET_OK) return rc;
     return check_launch("conv_ws_kernel");
 }
@@ -1477,9 +1505,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
     if ((use_ws || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
-        int rc;
-        if (A.debug & 128) rc = A.BN == 64 ? try_launch_conv_ws<64, 9, false>(A, st) : try_launch_conv_ws<32, 9, false>(A, st);     // ablation: padded halo image
-        else rc = A.BN == 64 ? try_launch_conv_ws<64, 9, true>(A, st) : try_launch_conv_ws<32, 9, true>(A, st);
+        const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, st) : try_launch_conv_ws<32, 9>(A, st);
         if (rc >= 0) return rc;
     }
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }

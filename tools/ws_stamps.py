@@ -9,6 +9,7 @@ import torch
 from cdnet_amd import engine, _lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+EXTRA = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 train = len(sys.argv) > 2 and sys.argv[2] == 'train'
 dev = torch.device('cuda:0')
 x = (torch.rand((B, 256, 256, 64), device=dev) - 0.3).to(torch.bfloat16)
@@ -27,6 +28,21 @@ for _ in range(5):
     else:
         engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
 torch.cuda.synchronize()
+for dbg, nm in ((32, 'conv_fwd_kernel'), (64 | EXTRA, 'conv_ws_kernel (stamped build, debug %d)' % EXTRA)):
+    engine.CONV_DEBUG = dbg
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats) if train else engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+    e0.record()
+    for _ in range(20):
+        engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats) if train else engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    print('%-32s %.1f us per launch' % (nm, e0.elapsed_time(e1) / 20 * 1e3))
+engine.CONV_DEBUG = 64 | EXTRA
+for _ in range(3):
+    engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros(2048, dtype=np.uint64)
 f = lib.cdnet_debug_ws_stamps
@@ -34,6 +50,7 @@ f.argtypes = [ctypes.c_void_p]
 assert f(buf.ctypes.data) == 0
 for role, off in (('consumer', 0), ('producer', 1024)):
     v = buf[off:off + 1024]
+    print(role, 'raw', v[:4], int((v != 0).sum()))
     n = int(np.argmax(v == 0))
     ids = (v[:n] & np.uint64(255)).astype(int)
     ts = (v[:n] >> np.uint64(8)).astype(np.int64)
