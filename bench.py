@@ -159,10 +159,11 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16'):
             traffic_src = 'profiles/%s/dominant_conv_traffic.json (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % rnd
             break
     gbs = alg_bytes / ms / 1e6
-    name = 'conv_f32_kernel' if f32 else 'conv_fwd_kernel'
+    ws = not f32 and os.environ.get('CDNET_CONV_WS', '1') != '0'          # the library's default: conv_ws_kernel on the 64-channel layers
+    name = 'conv_f32_kernel' if f32 else ('conv_ws_kernel' if ws else 'conv_fwd_kernel')
     mfma_peak = DENSE_BF16_PEAK_TFLOPS / 3 if f32 else DENSE_BF16_PEAK_TFLOPS
     return dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, ','.join(str(c) for c in cfg), B), dtype=precision,
+                kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, '64,9,0,false' if ws else ','.join(str(c) for c in cfg), B), dtype=precision,
                 ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
                 mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / mfma_peak)
 

@@ -209,11 +209,22 @@ __device__ __forceinline__ void load_chan_xf(ChanXf &t, const ConvSrc &s, const 
     t.sh[0] = cc.x; t.sh[1] = cc.y; t.sh[2] = cc.z; t.sh[3] = cc.w; t.sh[4] = d.x; t.sh[5] = d.y; t.sh[6] = d.z; t.sh[7] = d.w;
 }
 
+// Halo image of one K chunk in LDS.  16x16-pixel tiles with 16-channel chunks: 32 B per pixel, unpadded, the two 16-byte k-halves of
+// a pixel at (half ^ (halo row & 1)) * 16 - an A-fragment ds_read_b128 serves 16 lanes per LDS cycle (8 pixels of one tile row and 8
+// of the next, same k-half), and the row-parity swizzle puts them on 16 distinct 16-byte bank groups (tools/micro/lds_read_patterns.hip:
+// 4 LDS cycles per read against 7-8 for 48-byte padded pixels).  Other tile shapes keep padded pixels (CK * 2 + 16 bytes).
+template <int TH, int CK>
+struct HaloImg {
+    static constexpr bool SWZ = (TH == 16 && CK == 16);
+    static constexpr int PSTR = SWZ ? CK * 2 : CK * 2 + 16;
+    // byte offset of 16-byte slot `slot` of halo pixel `pix` in halo row `hy`
+    __device__ __forceinline__ static int off(int pix, int hy, int slot) { return pix * PSTR + (SWZ ? ((slot ^ (hy & 1)) * 16) : slot * 16); }
+};
+
 template <int TH, int TW, int CK>
 __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W,
                                             unsigned char *lds_a, int tid, const float *xf = nullptr, int xfs = 0) {
     constexpr int VPP = CK / 8;                  // 16-byte vectors per pixel
-    constexpr int PSTR = CK * 2 + 16;            // padded pixel stride in LDS (bank-conflict free b128 reads)
     constexpr int HW_ = TW + 2, NPIX = (TH + 2) * (TW + 2);
     const int slot = tid % VPP;                  // constant per thread because 256 % VPP == 0
     ChanXf t;
@@ -255,7 +266,7 @@ __device__ __forceinline__ void stage_input(const ConvSrc &s, int cc0, int n, in
                 }
             }
         }
-        *reinterpret_cast<uint4 *>(lds_a + pix * PSTR + slot * 16) = val.u;
+        *reinterpret_cast<uint4 *>(lds_a + HaloImg<TH, CK>::off(pix, hy, slot)) = val.u;
     }
 }
 
@@ -280,7 +291,7 @@ struct ConvLds {
     static constexpr bool DEEP = (CK == 16 && TH == 16);      // 16-channel chunks: prefetch ring of ADEPTH halo chunks
     static constexpr bool GLDS = CDNET_CONV_GLDS && DEEP;     // weights by global_load_lds into a double buffer
     static constexpr int ADEPTH = DEEP ? CDNET_CONV_ADEPTH : 1;
-    static constexpr int PSTR = CK * 2 + 16;
+    static constexpr int PSTR = HaloImg<TH, CK>::PSTR;
     static constexpr int A_BYTES = (TH + 2) * (TW + 2) * PSTR;
     static constexpr int B_BYTES = TAPS * CK * BN * 2;
     static constexpr int STAGE = A_BYTES + (GLDS ? 2 : 1) * B_BYTES;
@@ -402,9 +413,7 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
 #pragma unroll
         for (int i = 0; i < PF::NA; ++i) rr[i].u = *reinterpret_cast<const uint4 *>(rbase + ((S.valid & (1u << i)) ? (si ? P.eoff[1][i] : P.eoff[0][i]) : 0));
     }
-    // LDS address of vector i: pixel (tid / VPP + i * 256 / VPP), slot tid % VPP - affine in i
-    constexpr int PSTR = CK * 2 + 16;
-    unsigned char *dst0 = lds_a + (tid / PF::VPP) * PSTR + slot * 16;
+    // LDS address of vector i: pixel (tid / VPP + i * 256 / VPP), slot tid % VPP
 #pragma unroll
     for (int i = 0; i < PF::NA; ++i) {
         if (tid + i * 256 >= PF::NPIX * PF::VPP) continue;
@@ -417,7 +426,8 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
             else if (s.res) val = xform8(raw, &rr[i], t, relu, f16);
             else val = xform8(raw, nullptr, t, relu, f16);
         }
-        *reinterpret_cast<uint4 *>(dst0 + i * (256 / PF::VPP) * PSTR) = val.u;
+        const int pix = (tid + i * 256) / PF::VPP;
+        *reinterpret_cast<uint4 *>(lds_a + HaloImg<TH, CK>::off(pix, pix / (TW + 2), slot)) = val.u;
     }
 }
 
@@ -426,7 +436,8 @@ __device__ __forceinline__ void commit_chunk(const Prefetch<TH, TW, CK, BN, TAPS
 // ------------------------------------------------------------------------------------------------------
 template <int TH, int TW, int CK, int BN, int WM, int WN, int TAPS>
 __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CONV_ADEPTH <= 2 ? 3 : 2) : 1)) void conv_fwd_kernel(ConvArgs A) {
-    constexpr int PSTR = CK * 2 + 16;
+    constexpr int PSTR = HaloImg<TH, CK>::PSTR;
+    constexpr bool SWZ = HaloImg<TH, CK>::SWZ;
     constexpr int HW_ = TW + 2;
     constexpr int KC = CK / 16;
     constexpr int MT = TH * TW / 32, NT = BN / 32;
@@ -467,12 +478,14 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
     const int nchunk_total = A.nchunk;
 
     // per-lane A base for each of this wave's M tiles
-    int abase[MPW];
+    // (swizzled image: the k-half position follows the parity of the halo row = tile row + the tap's row offset)
+    int abase[MPW][SWZ ? 2 : 1];
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi) {
         const int m = (wm * MPW + mi) * 32 + l31;
         const int py = m / TW, px = m % TW;
-        abase[mi] = (py * HW_ + px) * PSTR + half * 16;
+#pragma unroll
+        for (int rp = 0; rp < (SWZ ? 2 : 1); ++rp) abase[mi][rp] = (py * HW_ + px) * PSTR + (SWZ ? ((half ^ ((py + rp) & 1)) * 16) : half * 16);
     }
     const int bbase = half * BN * 16 + (wn * NPW * 32 + l31) * 16;
 
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                 issue_a(P, P.s[k], A.src[si], si, cc0, n);
             }
         // tap offsets inside the halo tile (rows, cols): 3x3 / 1x1 fixed, sub-pixel 2x2 depends on the parity
-        int toff[TAPS];
+        int toff[TAPS], tpar[TAPS];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             int r, c;
@@ -534,6 +547,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                 c = b == 0 ? (tx == 0 ? 1 : 0) : (tx == 0 ? 2 : 1);
             } else { r = 1; c = 1; }
             toff[t] = (r * HW_ + c) * PSTR;
+            tpar[t] = SWZ ? (r & 1) : 0;
         }
         f32x16 acc[MPW][NPW];
 #pragma unroll
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
                     bf16x8 af[MPW], bfr[NPW];
 #pragma unroll
                     for (int mi = 0; mi < MPW; ++mi)
-                        af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + abase[mi] + toff[t] + kc * 32);
+                        af[mi] = *reinterpret_cast<const bf16x8 *>(lds_a + (SWZ ? (tpar[t] ? abase[mi][SWZ ? 1 : 0] : abase[mi][0]) : abase[mi][0]) + toff[t] + kc * 32);
 #pragma unroll
                     for (int ni = 0; ni < NPW; ++ni)
                         bfr[ni] = *reinterpret_cast<const bf16x8 *>(lds_b + bbase + ((t * KC + kc) * 2) * BN * 16 + ni * 512);

@@ -8,12 +8,14 @@ import sys
 
 def mean_counter(path, name):
     vals = {}
+    kn = None
     for r in csv.DictReader(open(path)):
-        if 'conv_fwd_kernel' in r['Kernel_Name'] and r['Counter_Name'] == name:
+        if ('conv_ws_kernel' in r['Kernel_Name'] or 'conv_fwd_kernel' in r['Kernel_Name']) and r['Counter_Name'] == name:
             vals.setdefault(r['Dispatch_Id'], 0.0)
+            kn = r['Kernel_Name']
             vals[r['Dispatch_Id']] += float(r['Counter_Value'])
     v = list(vals.values())
-    return sum(v) / len(v), r['Kernel_Name']
+    return sum(v) / len(v), kn
 
 
 fetch_kb, kname = mean_counter(sys.argv[1], 'FETCH_SIZE')
@@ -21,7 +23,7 @@ write_kb, _ = mean_counter(sys.argv[2], 'WRITE_SIZE')
 fetch = fetch_kb * 1024 * 2          # gfx950: FETCH_SIZE counts half of a 16 B/lane coalesced read stream
 write = write_kb * 1024
 out = {
-    'kernel': 'conv_fwd_kernel<16,16,16,64,4,1,9> 3x3 64->64 @256x256 x16 tiles',
+    'kernel': kname + ' 3x3 64->64 @256x256 x16 tiles',
     'FETCH_SIZE_KB_mean': fetch_kb, 'WRITE_SIZE_KB_mean': write_kb,
     'fetch_bytes_corrected_x2': fetch, 'write_bytes': write,
     'hbm_bytes_per_launch': fetch + write,
