@@ -95,11 +95,11 @@ __device__ __forceinline__ void init_a(APref<CI, RES, NTH> &P, int tid) {
     P.valid = 0;
 }
 
-template <int CI, bool RES, int NTH>
+template <bool NOPOOL = false, int CI, bool RES, int NTH>
 __device__ __forceinline__ void issue_a(APref<CI, RES, NTH> &P, const ConvSrc &s, int cc0, int n, int y0, int x0, int H, int W, int tid) {
     constexpr int VPP = CI / 8, NA = APref<CI, RES, NTH>::NA;
     P.valid = 0;
-    if (!RES && s.pool) return;                  // pooled sources are gathered in commit_a (4 loads per element)
+    if (!NOPOOL && !RES && s.pool) return;       // pooled sources are gathered in commit_a (4 loads per element)
     const int cbase = cc0 + (tid % VPP) * 8;
     const bool cok = cbase < s.C;
     const size_t rs = s.row_stride ? (size_t)s.row_stride : (size_t)s.Ws * s.C;
@@ -397,6 +397,17 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradArgs A) {
 // ------------------------------------------------------------------------------------------------------
 constexpr int NTP = 256;      // producer threads
 
+#ifdef CDNET_WS_STAMPS
+// debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): wall-clock stamps (100 MHz) of one consumer and one producer wave
+__device__ unsigned long long g_wg_stamps[2 * 1024];
+extern "C" __attribute__((visibility("default"))) int cdnet_debug_wgrad_stamps(unsigned long long *dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_stamps), sizeof(g_wg_stamps)) == hipSuccess ? 0 : 1;
+}
+#define WG_STAMP(id) do { if (stamp_on && sn < 1000) { g_wg_stamps[sbase + sn++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(id); } } while (0)
+#else
+#define WG_STAMP(id) do { } while (0)
+#endif
+
 template <int CI_T, int CO_T, int TAPS, bool RES, int XF>
 __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
@@ -417,9 +428,15 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
     const int tiles_img = tiles_y * tiles_x;
     const int ntiles = A.N * tiles_img;
     const int ntl = ks < ntiles ? (ntiles - ks + A.ksplit - 1) / A.ksplit : 0;      // tiles of this workgroup
+    const int ntl2 = (ntl + 1) & ~1;                                                // barrier steps of both roles (padded to even)
 
     __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
     fill_xf<CI>(s_xf, A.src, ib * CI, tid);
+#ifdef CDNET_WS_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 17 && lane == 0 && (wave == 0 || wave == 4);
+    const int sbase = wave >= 4 ? 1024 : 0;
+    int sn = 0;
+#endif
     if (wave >= 4) {
         // ------------------------------- producers -------------------------------
         const int ptid = tid - NTP;
@@ -427,35 +444,97 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
         GPref<CO, NTP> G0, G1;
         init_a(P0, ptid);
         init_a(P1, ptid);
+        // Straight-line loop body: the tile index is clamped instead of tested (the tail re-requests and re-stages the last tile into
+        // the buffer nobody reads), the source is never pooled here - with branches around the requests the compiler cannot count the
+        // loads in flight and drains them (s_waitcnt vmcnt(0) between the input and the gradient requests: one exposed memory round
+        // trip, 2.3 us, per tile - measured with the stamp build)
+        // Request addresses without per-vector multiplications: what depends on the thread only (its halo pixels' and gradient pixels'
+        // offsets inside a tile) is computed once, a tile contributes one scalar base (the stamp build showed the request phase at
+        // 2.0 us per tile - 45 quarter-rate integer multiplies and 64-bit mads per thread beside the consumers' MFMAs - against 2.0 us
+        // of matrix work: the producers, not the matrix pipe, set the tile period)
+        const ConvSrc &sA = A.src;
+        const int rs_ = sA.row_stride ? sA.row_stride : sA.Ws * sA.C;
+        constexpr int VA_ = CI / 8, VG_ = CO / 8, NA_ = APref<CI, RES, NTP>::NA, NG_ = GPref<CO, NTP>::NG, PPI_ = NTP / VG_;
+        const int cbase_a = ib * CI + (ptid % VA_) * 8;
+        const bool cok_a = cbase_a < sA.C;
+        const int co_g = cb * CO + (ptid % VG_) * 8;
+        const bool cok_g = co_g < A.Cout;
+        const int Ho_ = A.H * A.ostride, Wo_ = A.W * A.ostride;
+        int aoff[NA_], goff[NG_], gyx[NG_];
+#pragma unroll
+        for (int i = 0; i < NA_; ++i) {
+            const int hy = P0.inv[i] >> 16, hx = P0.inv[i] & 0xffff;
+            aoff[i] = P0.inv[i] >= 0 ? hy * rs_ + hx * sA.C : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NG_; ++i) {
+            const int pix = ptid / VG_ + i * PPI_;
+            const int py = pix / TW, px = pix % TW;
+            gyx[i] = (py << 16) | px;
+            goff[i] = (py * A.ostride * Wo_ + px * A.ostride) * A.Cout;
+        }
         auto issue = [&](APref<CI, RES, NTP> &P, GPref<CO, NTP> &G, int j) {
+            j = j < ntl ? j : ntl - 1;
             const int tile = ks + j * A.ksplit;
             const int n = tile / tiles_img, rem = tile - n * tiles_img;
             const int ty = rem / tiles_x;
             const int y0 = ty * TH, x0 = (rem - ty * tiles_x) * TW;
-            issue_a(P, A.src, ib * CI, n, y0, x0, A.H, A.W, ptid);
-            issue_g(G, A.g, cb * CO, A.Cout, n, y0, x0, A.H, A.W, A.ostride, pa, pb, ptid);
+            // (scalar) element offset of halo pixel (0, 0), channel cbase_a; may point before the image at the border - used only when ok
+            const long long abase = ((long long)n * sA.Hs + (y0 - 1 - sA.off_y)) * rs_ + (long long)(x0 - 1 - sA.off_x) * sA.C + cbase_a;
+            const unsigned short *pa0 = sA.x + abase;
+            const unsigned short *pr0 = RES ? sA.res + abase : nullptr;
+            unsigned valid = 0;
+#pragma unroll
+            for (int i = 0; i < NA_; ++i) {
+                const int hy = P.inv[i] >> 16, hx = P.inv[i] & 0xffff;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool ok = P.inv[i] >= 0 && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
+                                (unsigned)(y - sA.off_y) < (unsigned)sA.Hs && (unsigned)(x - sA.off_x) < (unsigned)sA.Ws;
+                P.a[i] = *reinterpret_cast<const u32x4 *>(ok ? pa0 + aoff[i] : sA.x);
+                if (RES) P.r[i] = *reinterpret_cast<const u32x4 *>(ok ? pr0 + aoff[i] : sA.res);
+                valid |= (ok ? 1u : 0u) << i;
+            }
+            P.valid = valid;
+            const unsigned short *pg0 = A.g + (((long long)n * Ho_ + (y0 * A.ostride + pa)) * Wo_ + (x0 * A.ostride + pb)) * A.Cout + co_g;
+            unsigned gvalid = 0;
+#pragma unroll
+            for (int i = 0; i < NG_; ++i) {
+                const bool ok = cok_g && y0 + (gyx[i] >> 16) < A.H && x0 + (gyx[i] & 0xffff) < A.W;
+                G.g[i] = *reinterpret_cast<const u32x4 *>(ok ? pg0 + goff[i] : A.g);
+                gvalid |= (ok ? 1u : 0u) << i;
+            }
+            G.valid = gvalid;
         };
         auto commit = [&](const APref<CI, RES, NTP> &P, const GPref<CO, NTP> &G, int bufi) {
             unsigned char *nb = smem + bufi * STAGE;
             commit_a<XF>(P, A.src, ib * CI, 0, 0, 0, A.H, A.W, nb, ptid, s_xf);
             commit_g(G, nb + A_BYTES, ptid);
         };
-        if (ntl > 0) issue(P0, G0, 0);
-        if (ntl > 1) issue(P1, G1, 1);
-        if (ntl > 0) commit(P0, G0, 0);
-        if (ntl > 2) issue(P0, G0, 2);
+        if (ntl == 0) { __syncthreads(); return; }
+        issue(P0, G0, 0);
+        issue(P1, G1, 1);
+        commit(P0, G0, 0);
+        issue(P0, G0, 2);
         __syncthreads();
-        for (int j = 0; j < ntl; j += 2) {
+        for (int j = 0; j < ntl2; j += 2) {
             // consumers are on tile j (buffer 0): fill buffer 1 with tile j+1, then start the loads of tile j+3
-            if (j + 1 < ntl) commit(P1, G1, 1);
-            if (j + 3 < ntl) issue(P1, G1, j + 3);
+            WG_STAMP(1);
+            commit(P1, G1, 1);
+            WG_STAMP(2);
+            issue(P1, G1, j + 3);
+            WG_STAMP(3);
             __syncthreads();
-            if (j + 1 >= ntl) break;
             // consumers are on tile j+1 (buffer 1): fill buffer 0 with tile j+2, start the loads of tile j+4
-            if (j + 2 < ntl) commit(P0, G0, 0);
-            if (j + 4 < ntl) issue(P0, G0, j + 4);
+            WG_STAMP(1);
+            commit(P0, G0, 0);
+            WG_STAMP(2);
+            issue(P0, G0, j + 4);
+            WG_STAMP(3);
             __syncthreads();
         }
+#ifdef CDNET_WS_STAMPS
+        if (stamp_on) g_wg_stamps[sbase + sn] = 0;
+#endif
         return;
     }
     // ------------------------------- consumers -------------------------------
@@ -480,30 +559,55 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     __syncthreads();
-    for (int j = 0; j < ntl; ++j) {
+    for (int j = 0; j < ntl2; ++j) {
+        if (j >= ntl) { __syncthreads(); continue; }          // padding step
         const unsigned char *buf = smem + (j & 1) * STAGE;
-        if (!(A.debug & 1))
-#pragma unroll 2
-        for (int ky = 0; ky < TH; ++ky) {                 // one k-step = one tile row of 16 pixels
-            const int gaddr = g_lane + ky * TW * PG;
-            s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + gaddr));
-            s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + gaddr + 4 * PG));
-            s16x8 gv;
-            gv[0] = g0[0]; gv[1] = g0[1]; gv[2] = g0[2]; gv[3] = g0[3];
-            gv[4] = g1[0]; gv[5] = g1[1]; gv[6] = g1[2]; gv[7] = g1[3];
-            const bf16x8 gf = __builtin_bit_cast(bf16x8, gv);
-            const int abase = a_lane + ky * HALO_W * PA;
+        WG_STAMP(10);
+        auto frag = [&](int off, int pstr) -> bf16x8 {
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + off));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + off + 4 * pstr));
+            s16x8 av;
+            av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
+            av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        if (A.debug & 1) {
+        } else if (TAPS == 9) {
+            // 3x3: the k-step of tile row ky multiplies halo rows ky, ky+1, ky+2 (three column shifts each) - consecutive k-steps share
+            // two of the three rows.  A ring of four halo rows of fragments: every k-step reads ONE new halo row (3 fragments) and one
+            // gradient fragment for its 9 MFMAs (0.9 KB of LDS per MFMA instead of 2), one k-step ahead of their use.
+            bf16x8 row[4][3], gq[2];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + abase + tap_off(t)));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + abase + tap_off(t) + 4 * PA));
-                s16x8 av;
-                av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
-                av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), gf, acc[t], 0, 0, 0);
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) row[r][kx] = frag(a_lane + (r * HALO_W + kx) * PA, PA);
+            gq[0] = frag(g_lane, PG);
+#pragma unroll
+            for (int ky = 0; ky < TH; ++ky) {
+                if (ky + 1 < TH) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) row[(ky + 3) & 3][kx] = frag(a_lane + ((ky + 3) * HALO_W + kx) * PA, PA);
+                    gq[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG, PG);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this k-step's MFMAs (the scheduler sinks them to their use)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row[(ky + t / 3) & 3][t % 3], gq[ky & 1], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 2
+            for (int ky = 0; ky < TH; ++ky) {             // one k-step = one tile row of 16 pixels
+                const bf16x8 gf = frag(g_lane + ky * TW * PG, PG);
+                const int abase = a_lane + ky * HALO_W * PA;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(abase + tap_off(t), PA), gf, acc[t], 0, 0, 0);
             }
         }
+        WG_STAMP(11);
         __syncthreads();
+        WG_STAMP(12);
     }
     // slab [ks][par][ib][cb][tap][CI][CO]; D rows = ci (regs + lane half), cols = co (lane & 31)
     float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
@@ -515,6 +619,10 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
             const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
         }
+    WG_STAMP(13);
+#ifdef CDNET_WS_STAMPS
+    if (stamp_on) g_wg_stamps[sbase + sn] = 0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
