@@ -171,24 +171,36 @@ __device__ __forceinline__ void load_feat64(const HeadFeat &f, size_t pix, const
 }
 
 // 16 channels [16q, 16q+16) of the feature at one pixel (q = lane & 3): four lanes share a pixel
-__device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q, const float *s_sc, const float *s_sh, float *v) {
-    if (f.f16 == 2) { load_feat_f32<16>(f, pix, q * 16, s_sc, s_sh, v); return; }
+// 16 channels (slot q of 4) of one pixel of a 16-bit feature: the raw vectors first (so that a kernel can put the loads of all its
+// features in flight before it touches any of them), the lazily applied transform second
+struct FeatRaw16 {
+    uint4 r[2], s[2];
+};
+__device__ __forceinline__ void load_raw16(const HeadFeat &f, size_t pix, int q, FeatRaw16 &R) {
     const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64 + q * 16);
-    const uint4 *ps = f.res ? reinterpret_cast<const uint4 *>(f.res + pix * 64 + q * 16) : nullptr;
+    R.r[0] = pr[0];
+    R.r[1] = pr[1];
+    R.s[0] = R.s[1] = make_uint4(0, 0, 0, 0);
+    if (f.res) {
+        const uint4 *ps = reinterpret_cast<const uint4 *>(f.res + pix * 64 + q * 16);
+        R.s[0] = ps[0];
+        R.s[1] = ps[1];
+    }
+}
+__device__ __forceinline__ void feat_from_raw16(const HeadFeat &f, const FeatRaw16 &R, int q, const float *s_sc, const float *s_sh, float *v) {
+    const bool has_res = f.res != nullptr;
     const bool fast = f.f16 && f.scale && f.relu;        // training-mode feature: packed math (xform.h)
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
-        uint4 r = pr[h2];
-        uint4 rr = make_uint4(0, 0, 0, 0);
-        if (ps) rr = ps[h2];
-        if (f.f16 && !f.scale && f.relu && ps) {           // eval-mode residual unit output: relu(raw + res)
+        const uint4 r = R.r[h2], rr = R.s[h2];
+        if (f.f16 && !f.scale && f.relu && has_res) {      // eval-mode residual unit output: relu(raw + res)
             xf_addrelu_f16_to_f32(__builtin_bit_cast(xf_u32x4, r), __builtin_bit_cast(xf_u32x4, rr), v + h2 * 8);
             continue;
         }
         if (fast) {
             const xf_u32x4 a = __builtin_bit_cast(xf_u32x4, r), b = __builtin_bit_cast(xf_u32x4, rr);
             const int c0 = q * 16 + h2 * 8;
-            if (ps) xf_bnrelu_f16_to_f32<true>(a, b, s_sc + c0, s_sh + c0, v + h2 * 8);
+            if (has_res) xf_bnrelu_f16_to_f32<true>(a, b, s_sc + c0, s_sh + c0, v + h2 * 8);
             else xf_bnrelu_f16_to_f32<false>(a, a, s_sc + c0, s_sh + c0, v + h2 * 8);
             continue;
         }
@@ -198,9 +210,9 @@ __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q
         for (int j = 0; j < 8; ++j) {
             const int c = q * 16 + h2 * 8 + j;
             float x = f.f16 ? h2f(h[j]) : bf2f(h[j]);
-            if (f.scale || ps || f.relu) {
+            if (f.scale || has_res || f.relu) {
                 if (f.scale) x = fmaf(x, s_sc[c], s_sh[c]);
-                if (ps) x += f.f16 ? h2f(hr[j]) : bf2f(hr[j]);
+                if (has_res) x += f.f16 ? h2f(hr[j]) : bf2f(hr[j]);
                 if (f.relu) x = fmaxf(x, 0.f);
                 x = bf2f(f2bf(x));
             }
@@ -208,11 +220,21 @@ __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q
         }
     }
 }
+__device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q, const float *s_sc, const float *s_sh, float *v) {
+    if (f.f16 == 2) { load_feat_f32<16>(f, pix, q * 16, s_sc, s_sh, v); return; }
+    FeatRaw16 R;
+    load_raw16(f, pix, q, R);
+    feat_from_raw16(f, R, q, s_sc, s_sh, v);
+}
 
 __device__ __forceinline__ float quad_sum(float v) { return xf_quad_sum(v); }        // sum over the 4 lanes of a pixel
 
-// four lanes per pixel, 16 channels each: 4x the parallelism and a quarter of the registers of one-thread-per-pixel
-__global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
+// four lanes per pixel, 16 channels each: 4x the parallelism and a quarter of the registers of one-thread-per-pixel.
+// FM: the storage / transform of all three features, decided by the launcher - 0 plain bf16 (eval mode with fused epilogues),
+// 1 fp16 raw x scale + shift + residual -> ReLU (training-mode residual-unit outputs), 2 anything (run-time flags; with them the
+// kernel is 9 000 instructions of branches and every join drains the loads in flight)
+template <int FM>
+__global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
                                                            int N, int plane, float *__restrict__ mask,
                                                            float *__restrict__ point, float *__restrict__ dirn) {
     __shared__ HeadW w;
@@ -233,16 +255,59 @@ __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat
     __syncthreads();
     const size_t total = (size_t)N * plane;
     const int q = threadIdx.x & 3;
+    const bool all16 = FM != 2 || (f1.f16 != 2 && f2.f16 != 2 && f3.f16 != 2);
+    // FM 0 / 1: fixed conversions of the raw vectors
+    auto conv = [&](const HeadFeat &f, const FeatRaw16 &R, int k, float *v) {
+        if (FM == 0) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const unsigned short *h = reinterpret_cast<const unsigned short *>(&R.r[h2]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[h2 * 8 + j] = bf2f(h[j]);
+            }
+        } else if (FM == 1) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                xf_bnrelu_f16_to_f32<true>(__builtin_bit_cast(xf_u32x4, R.r[h2]), __builtin_bit_cast(xf_u32x4, R.s[h2]), s_sc[k] + q * 16 + h2 * 8,
+                                           s_sh[k] + q * 16 + h2 * 8, v + h2 * 8);
+        } else {
+            feat_from_raw16(f, R, q, s_sc[k], s_sh[k], v);
+        }
+    };
+    auto fetch = [&](const HeadFeat &f, size_t pix, FeatRaw16 &R) {
+        if (FM == 2) { load_raw16(f, pix, q, R); return; }
+        const uint4 *pr = reinterpret_cast<const uint4 *>(f.raw + pix * 64 + q * 16);
+        R.r[0] = pr[0];
+        R.r[1] = pr[1];
+        if (FM == 1) {
+            const uint4 *ps = reinterpret_cast<const uint4 *>(f.res + pix * 64 + q * 16);
+            R.s[0] = ps[0];
+            R.s[1] = ps[1];
+        }
+    };
     for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        // the head weights stay in LDS: without this fence the compiler hoists all 208 of a lane's weight reads out of the loop
+        // (286-402 registers, one wave per SIMD - or, under a register bound, spills them)
+        asm volatile("" ::: "memory");
         const size_t i = base + (threadIdx.x >> 2);
         const bool ok = i < total;
         const size_t ii = ok ? i : total - 1;                 // keep all lanes alive for the shuffles
         const size_t n = ii / plane, p = ii - n * plane;
         float v[16];
-        load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+        // 16-bit features: all three features' vectors in flight at once (one memory round trip per pixel instead of three)
+        FeatRaw16 R1, R2, R3;
+        if (all16) {
+            fetch(f3, ii, R3);
+            fetch(f2, ii, R2);
+            fetch(f1, ii, R1);
+            conv(f3, R3, 2, v);
+        } else {
+            load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+        }
         const float pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         const float g1 = 1.f + 1.f / (1.f + expf(-(w.a1 * pt)));
-        load_feat16(f2, ii, q, s_sc[1], s_sh[1], v);
+        if (all16) conv(f2, R2, 1, v);
+        else load_feat16(f2, ii, q, s_sc[1], s_sh[1], v);
         float d[9], q2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -250,7 +315,8 @@ __global__ __launch_bounds__(256) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat
             q2 = fmaf(w.a2[k], d[k], q2);
         }
         const float g2 = 1.f + 1.f / (1.f + expf(-q2));
-        load_feat16(f1, ii, q, s_sc[0], s_sh[0], v);
+        if (all16) conv(f1, R1, 0, v);
+        else load_feat16(f1, ii, q, s_sc[0], s_sh[0], v);
         float mk[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -608,8 +674,14 @@ extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_hea
     CDNET_REQUIRE(f1 && f2 && f3 && head_weights && mask && point && direction, "cdnet_dam_head_forward: null pointer");
     CDNET_REQUIRE(f1->raw && f2->raw && f3->raw && N > 0 && H > 0 && W > 0, "cdnet_dam_head_forward: bad args");
     static_assert(sizeof(HeadW) == CDNET_HEAD_WEIGHT_FLOATS * 4, "head weight block layout");
-    dam_head_fwd_kernel<<<lin_grid((size_t)N * H * W * 4), 256, 0, (hipStream_t)stream>>>(
-        mk_feat(*f1), mk_feat(*f2), mk_feat(*f3), reinterpret_cast<const HeadW *>(head_weights), N, H * W, mask, point, direction);
+    const HeadFeat a = mk_feat(*f1), b = mk_feat(*f2), c = mk_feat(*f3);
+    auto plain = [](const HeadFeat &f) { return f.f16 == 0 && !f.scale && !f.relu && !f.res; };
+    auto train = [](const HeadFeat &f) { return f.f16 == 1 && f.scale && f.relu && f.res; };
+    const int grid = lin_grid((size_t)N * H * W * 4);
+    const HeadW *hw = reinterpret_cast<const HeadW *>(head_weights);
+    if (plain(a) && plain(b) && plain(c)) dam_head_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
+    else if (train(a) && train(b) && train(c)) dam_head_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
+    else dam_head_fwd_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
     return check_launch("cdnet_dam_head_forward");
 }
 

@@ -685,6 +685,50 @@ __device__ __forceinline__ void feat8(const HeadFeat &f, size_t pix, int c0, con
     }
 }
 
+// the same in two steps for 16-bit features: the raw vectors first (a kernel puts the loads of all its features in flight before it
+// touches any of them - one memory round trip per pixel instead of one per feature), the lazily applied transform second.
+// FM: 0 the feature is plain bf16 (a materialised tensor), 1 fp16 raw x scale + shift + residual -> ReLU (a lazily transformed
+// training-mode residual-unit output), 2 anything (run-time flags)
+struct FeatRaw8 {
+    uint4 r, s;
+};
+template <int FM>
+__device__ __forceinline__ void load_raw8(const HeadFeat &f, size_t pix, int c0, FeatRaw8 &R) {
+    R.r = *reinterpret_cast<const uint4 *>(f.raw + pix * 64 + c0);
+    R.s = make_uint4(0, 0, 0, 0);
+    if (FM == 1 || (FM == 2 && f.res)) R.s = *reinterpret_cast<const uint4 *>(f.res + pix * 64 + c0);
+}
+template <int FM>
+__device__ __forceinline__ void feat_from_raw8(const HeadFeat &f, const FeatRaw8 &R, int c0, const float *s_sc, const float *s_sh, float *v) {
+    const xf_u32x4 a = __builtin_bit_cast(xf_u32x4, R.r), b = __builtin_bit_cast(xf_u32x4, R.s);
+    if (FM == 1) { xf_bnrelu_f16_to_f32<true>(a, b, s_sc + c0, s_sh + c0, v); return; }
+    if (FM == 0) {
+        V16 r0;
+        r0.u = R.r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf2f(r0.h[j]);
+        return;
+    }
+    if (f.f16 && f.scale && f.relu) {
+        if (f.res) xf_bnrelu_f16_to_f32<true>(a, b, s_sc + c0, s_sh + c0, v);
+        else xf_bnrelu_f16_to_f32<false>(a, a, s_sc + c0, s_sh + c0, v);
+        return;
+    }
+    V16 r, rr;
+    r.u = R.r; rr.u = R.s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = f.f16 ? h2f(r.h[j]) : bf2f(r.h[j]);
+        if (f.scale || f.res || f.relu) {
+            if (f.scale) x = fmaf(x, s_sc[c0 + j], s_sh[c0 + j]);
+            if (f.res) x += f.f16 ? h2f(rr.h[j]) : bf2f(rr.h[j]);
+            if (f.relu) x = fmaxf(x, 0.f);
+            x = bf2f(f2bf(x));
+        }
+        v[j] = x;
+    }
+}
+
 __device__ __forceinline__ void feat64(const HeadFeat &f, size_t pix, const float *s_sc, const float *s_sh, float *v) {
     if (f.f16 == 2) {
 #pragma unroll
@@ -748,6 +792,10 @@ __device__ __forceinline__ void store16_grad(unsigned short *base, size_t e, con
 // Kernel 1: four lanes per pixel (16 channels each).  Recomputes the head, writes the three feature gradients, the 13
 // per-pixel coefficients {dpt, du[9], dm[3]} (f32 [px][16]) for the weight-gradient kernel, and per-block partial sums of
 // the 23 scalar parameter gradients (biases and gate weights).
+// FM: the storage of all three features (see FeatRaw8) - with a compile-time transform all three features' loads and the pixel's
+// upstream gradients are in flight together; the run-time format tests of FM 2 make 6 000 instructions of branches whose joins
+// drain the loads
+template <int FM>
 __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
                                                            const float *__restrict__ dmask, const float *__restrict__ dpoint,
                                                            const float *__restrict__ ddir, int N, int plane,
@@ -784,12 +832,39 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         const bool ok = i < total;
         const size_t ii = ok ? i : total - 1;
         const size_t n = ii / plane, p = ii - n * plane;
+        // (the head weights stay in LDS: without this fence the compiler hoists a lane's 208 weight reads out of the loop)
+        asm volatile("" ::: "memory");
         float v[16];
-        feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+        FeatRaw8 R3[2], R2[2], R1[2];
+        constexpr bool all16 = FM != 2;             // the generic instantiation keeps one feature at a time (registers)
+        if (all16) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                load_raw8<FM>(f3, ii, q * 16 + h2 * 8, R3[h2]);
+                load_raw8<FM>(f2, ii, q * 16 + h2 * 8, R2[h2]);
+                load_raw8<FM>(f1, ii, q * 16 + h2 * 8, R1[h2]);
+            }
+        }
+        // upstream gradients of this pixel: in flight with the features
+        float go_m[3], go_d[9], go_p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) go_m[k] = ok ? dmask[(n * 3 + k) * plane + p] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) go_d[k] = ok ? ddir[(n * 9 + k) * plane + p] : 0.f;
+        go_p = ok ? dpoint[n * plane + p] : 0.f;
+        auto feat = [&](const HeadFeat &f, const FeatRaw8 (&R)[2], int k) {
+            if (all16) {
+                feat_from_raw8<FM>(f, R[0], q * 16, s_sc[k], s_sh[k], v);
+                feat_from_raw8<FM>(f, R[1], q * 16 + 8, s_sc[k], s_sh[k], v + 8);
+            } else {
+                feat16(f, ii, q, s_sc[k], s_sh[k], v);
+            }
+        };
+        feat(f3, R3, 2);
         const float pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         const float sg1 = 1.f / (1.f + expf(-(w.a1 * pt)));
         const float g1 = 1.f + sg1;
-        feat16(f2, ii, q, s_sc[1], s_sh[1], v);
+        feat(f2, R2, 1);
         float u[9], d[9], q2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -799,12 +874,12 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         }
         const float sg2 = 1.f / (1.f + expf(-q2));
         const float g2 = 1.f + sg2;
-        feat16(f1, ii, q, s_sc[0], s_sh[0], v);
+        feat(f1, R1, 0);
         float dm[3], dg2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float mk = quad_sum(xf_dot16(w.wm[k] + q * 16, v));
-            const float go = ok ? dmask[(n * 3 + k) * plane + p] : 0.f;
+            const float go = go_m[k];
             dg2 = fmaf(go, mk, dg2);
             dm[k] = go * g2;
             sg[k] += go;
@@ -818,7 +893,7 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         float du[9], dg1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const float dd = (ok ? ddir[(n * 9 + k) * plane + p] : 0.f) + dq2 * w.a2[k];
+            const float dd = go_d[k] + dq2 * w.a2[k];
             sg[3 + k] += dd;
             sg[14 + k] = fmaf(dq2, d[k], sg[14 + k]);
             dg1 = fmaf(dd, u[k], dg1);
@@ -828,7 +903,7 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
         for (int k = 0; k < 9; ++k) xf_axpy16(du[k], w.wd[k] + q * 16, v, k != 0);
         if (ok) store16_grad(df2, ii * 64 + q * 16, v, f32);
         const float dsg1 = dg1 * sg1 * (1.f - sg1);
-        const float dpt = (ok ? dpoint[n * plane + p] : 0.f) + dsg1 * w.a1;
+        const float dpt = go_p + dsg1 * w.a1;
         sg[12] += dpt;
         sg[13] = fmaf(dsg1, pt, sg[13]);
         xf_axpy16(dpt, w.wp + q * 16, v, false);
@@ -864,6 +939,7 @@ __global__ __launch_bounds__(256) void dam_head_bwd_kernel(HeadFeat f1, HeadFeat
 
 // Kernel 2: weight gradients  dW[row][c] = sum_px coef[px][row] * F_row(px, c),  rows = {dpt x F3, du[9] x F2, dm[3] x F1}.
 // thread = (8 channels, pixel group); 104 accumulators; per-block partials in the HeadW layout.
+template <int FM>
 __global__ __launch_bounds__(256) void dam_head_wgrad_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const float *__restrict__ coef,
                                                              int N, int plane, float *__restrict__ partial) {
     __shared__ float s_sc[3][64], s_sh[3][64];
@@ -890,15 +966,21 @@ __global__ __launch_bounds__(256) void dam_head_wgrad_kernel(HeadFeat f1, HeadFe
         const float4 c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3];
         const float cf[13] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x};
         float x[8];
-        feat8(f3, ip, c8, s_sc[2], s_sh[2], x);
+        FeatRaw8 R3, R2, R1;
+        constexpr bool all16 = FM != 2;
+        if (all16) { load_raw8<FM>(f3, ip, c8, R3); load_raw8<FM>(f2, ip, c8, R2); load_raw8<FM>(f1, ip, c8, R1); }
+        if (all16) feat_from_raw8<FM>(f3, R3, c8, s_sc[2], s_sh[2], x);
+        else feat8(f3, ip, c8, s_sc[2], s_sh[2], x);
 #pragma unroll
         for (int q = 0; q < 8; ++q) gw[0][q] = fmaf(cf[0], x[q], gw[0][q]);
-        feat8(f2, ip, c8, s_sc[1], s_sh[1], x);
+        if (all16) feat_from_raw8<FM>(f2, R2, c8, s_sc[1], s_sh[1], x);
+        else feat8(f2, ip, c8, s_sc[1], s_sh[1], x);
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
             for (int q = 0; q < 8; ++q) gw[1 + j][q] = fmaf(cf[1 + j], x[q], gw[1 + j][q]);
-        feat8(f1, ip, c8, s_sc[0], s_sh[0], x);
+        if (all16) feat_from_raw8<FM>(f1, R1, c8, s_sc[0], s_sh[0], x);
+        else feat8(f1, ip, c8, s_sc[0], s_sh[0], x);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -1554,9 +1636,20 @@ extern "C" int cdnet_dam_head_backward(const cdnet_head_feat *f1, const cdnet_he
     if (workspace_floats < need) { set_error("cdnet_dam_head_backward: workspace %zu < %zu floats", workspace_floats, need); return CDNET_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     float *partial = workspace, *coef = workspace + (size_t)nb * HEADW_FLOATS;
-    dam_head_bwd_kernel<<<nb, 256, 0, st>>>(mk_hf(*f1), mk_hf(*f2), mk_hf(*f3), reinterpret_cast<const HeadW *>(head_weights), dmask,
-                                            dpoint, ddir, N, H * W, df1, df2, df3, coef, partial);
-    dam_head_wgrad_kernel<<<nb, 256, 0, st>>>(mk_hf(*f1), mk_hf(*f2), mk_hf(*f3), coef, N, H * W, partial);
+    const HeadFeat a = mk_hf(*f1), b = mk_hf(*f2), c = mk_hf(*f3);
+    auto plain = [](const HeadFeat &f) { return f.f16 == 0 && !f.scale && !f.relu && !f.res; };
+    auto train = [](const HeadFeat &f) { return f.f16 == 1 && f.scale && f.relu && f.res; };
+    const HeadW *hw = reinterpret_cast<const HeadW *>(head_weights);
+    if (plain(a) && plain(b) && plain(c)) {
+        dam_head_bwd_kernel<0><<<nb, 256, 0, st>>>(a, b, c, hw, dmask, dpoint, ddir, N, H * W, df1, df2, df3, coef, partial);
+        dam_head_wgrad_kernel<0><<<nb, 256, 0, st>>>(a, b, c, coef, N, H * W, partial);
+    } else if (train(a) && train(b) && train(c)) {
+        dam_head_bwd_kernel<1><<<nb, 256, 0, st>>>(a, b, c, hw, dmask, dpoint, ddir, N, H * W, df1, df2, df3, coef, partial);
+        dam_head_wgrad_kernel<1><<<nb, 256, 0, st>>>(a, b, c, coef, N, H * W, partial);
+    } else {
+        dam_head_bwd_kernel<2><<<nb, 256, 0, st>>>(a, b, c, hw, dmask, dpoint, ddir, N, H * W, df1, df2, df3, coef, partial);
+        dam_head_wgrad_kernel<2><<<nb, 256, 0, st>>>(a, b, c, coef, N, H * W, partial);
+    }
     reduce_partials_kernel<<<cdiv(HEADW_FLOATS, 4), 256, 0, st>>>(workspace, nb, HEADW_FLOATS, dhead_weights);
     return check_launch("cdnet_dam_head_backward");
 }
