@@ -1088,11 +1088,16 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 
     // ================================ consumers ================================
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.w + (size_t)cout_tile * NCH * (L::B_CHUNK / 2));
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_w);
-        constexpr int nv = NCH * (L::B_CHUNK / 16);
-#pragma unroll 6
-        for (int v = tid; v < nv; v += 256) dst[v] = src[v];
+        const u32x4v *src = reinterpret_cast<const u32x4v *>(A.w + (size_t)cout_tile * NCH * (L::B_CHUNK / 2));
+        u32x4v *dst = reinterpret_cast<u32x4v *>(lds_w);
+        constexpr int nv = NCH * (L::B_CHUNK / 16), NW = (nv + 255) / 256;
+        // all of a thread's vectors in flight at once (one memory round trip for the 74 KB; the accumulators are not live yet)
+        u32x4v wv[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wv[i] = src[tid + i * 256 < nv ? tid + i * 256 : 0];
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (tid + i * 256 < nv) dst[tid + i * 256] = wv[i];
     }
     __syncthreads();                                             // table + weights
     const int wm = wave;
