@@ -24,6 +24,7 @@ SIGNATURES = {
     'cdnet_upsample_bilinear_backward': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_s2d_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_grad_sum': (_i, [_vp, _i, _vp, C.c_longlong, _i, _vp, _vp]),
+    'cdnet_grad_sum_f32': (_i, [_vp, _i, _vp, C.c_longlong, _i, _vp, _vp]),
     'cdnet_label_pair_histogram': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_remap_label': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'cdnet_watershed_workspace_bytes': (_sz, [_i, _i, _i]),

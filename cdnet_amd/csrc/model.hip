@@ -595,6 +595,7 @@ __global__ __launch_bounds__(256) void s2d_to_nhwc_kernel(const unsigned short *
 // gradient of a fuse / residual sum: out = [mask > 0] * (sum of up to 6 gradient contributions, each possibly a channel slice)
 struct GradSumArgs { const unsigned short *g[6]; int cstride[6], coff[6]; int nterm; const unsigned short *mask; size_t npix; int C; unsigned short *out; };
 
+template <bool F32>
 __global__ __launch_bounds__(256) void grad_sum_kernel(const GradSumArgs A) {
     const int VPP = A.C / 8;
     const size_t total = A.npix * VPP;
@@ -604,26 +605,41 @@ __global__ __launch_bounds__(256) void grad_sum_kernel(const GradSumArgs A) {
         float acc[8], v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        auto load8 = [&](const unsigned short *base, size_t e) {
+            if (F32) {
+                const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(base) + e);
+                const float4 a = p[0], b = p[1];
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+                bf8_to_f32(*reinterpret_cast<const uint4 *>(base + e), v);
+            }
+        };
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             if (k < A.nterm) {
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(A.g[k] + pix * A.cstride[k] + A.coff[k] + slot * 8), v);
+                load8(A.g[k], pix * A.cstride[k] + A.coff[k] + slot * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += v[j];
             }
         }
         if (A.mask) {
-            bf8_to_f32(*reinterpret_cast<const uint4 *>(A.mask + pix * A.C + slot * 8), v);
+            load8(A.mask, pix * A.C + slot * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = v[j] > 0.f ? acc[j] : 0.f;
         }
-        unsigned short oh[8];
+        if (F32) {
+            float4 *o = reinterpret_cast<float4 *>(reinterpret_cast<float *>(A.out) + pix * A.C + slot * 8);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+            unsigned short oh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oh[j] = f2bf(acc[j]);
-        uint4 ou;
-        ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
-        ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
-        *reinterpret_cast<uint4 *>(A.out + pix * A.C + slot * 8) = ou;
+            for (int j = 0; j < 8; ++j) oh[j] = f2bf(acc[j]);
+            uint4 ou;
+            ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
+            ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
+            *reinterpret_cast<uint4 *>(A.out + pix * A.C + slot * 8) = ou;
+        }
     }
 }
 
@@ -760,7 +776,14 @@ extern "C" int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int 
     return check_launch("cdnet_s2d_to_nhwc");
 }
 
+static int grad_sum_impl(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream, bool f32);
 extern "C" int cdnet_grad_sum(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream) {
+    return grad_sum_impl(terms, nterm, mask, npix, C, out, stream, false);
+}
+extern "C" int cdnet_grad_sum_f32(const cdnet_grad_term *terms, int nterm, const float *mask, long long npix, int C, float *out, void *stream) {
+    return grad_sum_impl(terms, nterm, reinterpret_cast<const uint16_t *>(mask), npix, C, reinterpret_cast<uint16_t *>(out), stream, true);
+}
+static int grad_sum_impl(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream, bool f32) {
     CDNET_REQUIRE(terms && out && nterm >= 1 && nterm <= 6 && npix > 0 && C % 8 == 0 && C >= 8, "cdnet_grad_sum: bad args");
     GradSumArgs A;
     for (int k = 0; k < 6; ++k) { A.g[k] = nullptr; A.cstride[k] = C; A.coff[k] = 0; }
@@ -771,6 +794,7 @@ extern "C" int cdnet_grad_sum(const cdnet_grad_term *terms, int nterm, const uin
         CDNET_REQUIRE(A.g[k] && A.cstride[k] % 8 == 0 && A.coff[k] % 8 == 0 && A.coff[k] + C <= A.cstride[k], "cdnet_grad_sum: channel slice");
     }
     A.nterm = nterm; A.mask = mask; A.npix = (size_t)npix; A.C = C; A.out = out;
-    grad_sum_kernel<<<lin_grid((size_t)npix * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    if (f32) grad_sum_kernel<true><<<lin_grid((size_t)npix * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    else grad_sum_kernel<false><<<lin_grid((size_t)npix * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
     return check_launch("cdnet_grad_sum");
 }

@@ -1397,74 +1397,89 @@ __global__ void val_sums_reduce_kernel(const float *__restrict__ partial, int nc
 //   dF[c] = sum_k dlogit_k * w[k][c];  dW[k][c] = sum_px dlogit_k * F[c];  db[k] = sum_px dlogit_k.
 // Per-block partial sums [K*64 | K], reduced in a fixed order by reduce_partials_kernel (deterministic).
 // ======================================================================================================
-constexpr int FC_KMAX = 4;
+constexpr int FC_KMAX = 4;            // plain UNet classifier (3 classes): 4 lanes per pixel x 16 channels
+constexpr int FC_KWIDE = 12;          // the ablation heads' 9-class direction classifier: 8 lanes per pixel x 8 channels
 
+// KM: classes the instantiation holds accumulators for; LPP lanes share a pixel (64 / LPP channels each)
+template <int KM, int LPP>
 __global__ __launch_bounds__(256) void final_conv_bwd_kernel(HeadFeat f, const float *__restrict__ w, const float *__restrict__ dl,
                                                              int K, int N, int plane, unsigned short *__restrict__ df,
                                                              float *__restrict__ partial) {
-    __shared__ float s_w[FC_KMAX * 64], s_sc[64], s_sh[64];
-    __shared__ float s_red[4][FC_KMAX * 64 + FC_KMAX];
+    constexpr int CH = 64 / LPP, PPB = 256 / LPP, ROW = KM * 64 + KM;
+    static_assert(CH == 16 || CH == 8, "16 or 8 channels per lane");
+    __shared__ float s_w[KM * 64], s_sc[64], s_sh[64];
+    __shared__ float s_red[4][ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < K * 64; i += 256) s_w[i] = w[i];
     if (tid < 64) { s_sc[tid] = f.scale ? f.scale[tid] : 1.f; s_sh[tid] = f.scale ? f.shift[tid] : 0.f; }
     __syncthreads();
-    const int q = tid & 3;
-    float gw[FC_KMAX][16], gb[FC_KMAX];
+    const int q = tid % LPP;
+    float gw[KM][CH], gb[KM];
 #pragma unroll
-    for (int k = 0; k < FC_KMAX; ++k) {
+    for (int k = 0; k < KM; ++k) {
         gb[k] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) gw[k][c] = 0.f;
+        for (int c = 0; c < CH; ++c) gw[k][c] = 0.f;
     }
     const size_t total = (size_t)N * plane;
-    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
-        const size_t i = base + (tid >> 2);
+    for (size_t base = (size_t)blockIdx.x * PPB; base < total; base += (size_t)gridDim.x * PPB) {
+        const size_t i = base + (tid / LPP);
         const bool ok = i < total;
         const size_t ii = ok ? i : total - 1;
         const size_t n = ii / plane, p = ii - n * plane;
-        float v[16], d[FC_KMAX];
-        feat16(f, ii, q, s_sc, s_sh, v);
+        float v[CH], d[KM];
+        if (CH == 16) feat16(f, ii, q, s_sc, s_sh, v);
+        else feat8(f, ii, q * 8, s_sc, s_sh, v);
 #pragma unroll
-        for (int k = 0; k < FC_KMAX; ++k) d[k] = (ok && k < K) ? dl[(n * K + k) * plane + p] : 0.f;
-        float o[16];
+        for (int k = 0; k < KM; ++k) d[k] = (ok && k < K) ? dl[(n * K + k) * plane + p] : 0.f;
+        float o[CH];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < CH; ++c) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < FC_KMAX; ++k) {
-                t = fmaf(d[k], s_w[(k < K ? k : 0) * 64 + q * 16 + c], t);
+            for (int k = 0; k < KM; ++k) {
+                t = fmaf(d[k], s_w[(k < K ? k : 0) * 64 + q * CH + c], t);
                 gw[k][c] = fmaf(d[k], v[c], gw[k][c]);
             }
             o[c] = t;
         }
 #pragma unroll
-        for (int k = 0; k < FC_KMAX; ++k) gb[k] += d[k];
-        if (ok) store16_grad(df, ii * 64 + q * 16, o, f.f16 == 2);
+        for (int k = 0; k < KM; ++k) gb[k] += d[k];
+        if (ok) {
+            if (CH == 16) store16_grad(df, ii * 64 + q * 16, o, f.f16 == 2);
+            else if (f.f16 == 2) stf8(df, ii * 64 + q * 8, o);
+            else {
+                V16 ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ov.h[j] = f2bf(o[j]);
+                *reinterpret_cast<uint4 *>(df + ii * 64 + q * 8) = ov.u;
+            }
+        }
     }
-    // lanes with the same q own the same channels: butterfly over the 16 pixel slots of the wave, then one row per wave
+    // lanes with the same q own the same channels: butterfly over the pixel slots of the wave, then one row per wave
 #pragma unroll
-    for (int k = 0; k < FC_KMAX; ++k) {
+    for (int k = 0; k < KM; ++k) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < CH; ++c) {
             float t = gw[k][c];
 #pragma unroll
-            for (int m = 4; m < 64; m <<= 1) t += __shfl_xor(t, m);
-            if (lane < 4) s_red[wave][k * 64 + lane * 16 + c] = t;
+            for (int m = LPP; m < 64; m <<= 1) t += __shfl_xor(t, m);
+            if (lane < LPP) s_red[wave][k * 64 + lane * CH + c] = t;
         }
         float t = gb[k];
 #pragma unroll
-        for (int m = 4; m < 64; m <<= 1) t += __shfl_xor(t, m);
-        if (lane == 0) s_red[wave][FC_KMAX * 64 + k] = t;
+        for (int m = LPP; m < 64; m <<= 1) t += __shfl_xor(t, m);
+        if (lane == 0) s_red[wave][KM * 64 + k] = t;
     }
     __syncthreads();
-    for (int j = tid; j < FC_KMAX * 64 + FC_KMAX; j += 256)
-        partial[(size_t)blockIdx.x * (FC_KMAX * 64 + FC_KMAX) + j] = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
+    for (int j = tid; j < ROW; j += 256)
+        partial[(size_t)blockIdx.x * ROW + j] = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
 }
 
-__global__ void final_conv_scatter_kernel(const float *__restrict__ sums, int K, float *__restrict__ dw, float *__restrict__ db) {
+__global__ void final_conv_scatter_kernel(const float *__restrict__ sums, int K, int KM, float *__restrict__ dw, float *__restrict__ db) {
     const int t = threadIdx.x + blockIdx.x * blockDim.x;
     if (t < K * 64) dw[t] = sums[t];
-    if (t < K) db[t] = sums[FC_KMAX * 64 + t];
+    if (t < K) db[t] = sums[KM * 64 + t];
 }
 
 
@@ -1732,22 +1747,25 @@ extern "C" int cdnet_adam_step(float *param, const float *grad, float *exp_avg, 
     return check_launch("cdnet_adam_step");
 }
 
-extern "C" size_t cdnet_final_conv1x1_backward_workspace_floats(void) { return (size_t)1025 * (FC_KMAX * 64 + FC_KMAX); }
+extern "C" size_t cdnet_final_conv1x1_backward_workspace_floats(void) { return (size_t)1025 * (FC_KWIDE * 64 + FC_KWIDE); }
 
 extern "C" int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
                                             uint16_t *df, float *workspace, size_t workspace_floats, float *dw, float *db, void *stream) {
     CDNET_REQUIRE(f && f->raw && w && dlogits && df && workspace && dw && db, "cdnet_final_conv1x1_backward: null pointer");
-    CDNET_REQUIRE(K >= 1 && K <= FC_KMAX && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1_backward: K=%d must be in [1,%d]", K, FC_KMAX);
+    CDNET_REQUIRE(K >= 1 && K <= FC_KWIDE && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1_backward: K=%d must be in [1,%d]", K, FC_KWIDE);
     if (workspace_floats < cdnet_final_conv1x1_backward_workspace_floats()) { set_error("cdnet_final_conv1x1_backward: workspace too small"); return CDNET_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)N * H * W;
-    int nb = (int)((npix + 63) / 64);
+    const bool wide = K > FC_KMAX;
+    const int KM = wide ? FC_KWIDE : FC_KMAX;
+    int nb = (int)((npix + (wide ? 31 : 63)) / (wide ? 32 : 64));
     if (nb > 1024) nb = 1024;
-    constexpr int ROW = FC_KMAX * 64 + FC_KMAX;
+    const int ROW = KM * 64 + KM;
     float *sums = workspace + (size_t)1024 * ROW;
-    final_conv_bwd_kernel<<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
+    if (wide) final_conv_bwd_kernel<FC_KWIDE, 8><<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
+    else final_conv_bwd_kernel<FC_KMAX, 4><<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
     reduce_partials_kernel<<<cdiv(ROW, 4), 256, 0, st>>>(workspace, nb, ROW, sums);
-    final_conv_scatter_kernel<<<1, 256, 0, st>>>(sums, K, dw, db);
+    final_conv_scatter_kernel<<<cdiv(K * 64, 256), 256, 0, st>>>(sums, K, KM, dw, db);
     return check_launch("cdnet_final_conv1x1_backward");
 }
 

@@ -1,9 +1,11 @@
 """`Unet` of the reference's models/dam/model_unet_MandDandP.py (ablation of the direction-aware-mask head: mask + point + 9-class direction, no attention gates;
 forward :246-268).  Same constructor, state_dict keys and return tuple; encoder, decoder and residual units are the kernels of
-model_unet_rev1, the heads are plain 1x1 classifiers (cdnet_final_conv1x1).  Inference only on the accelerated path."""
+model_unet_rev1, the heads are plain 1x1 classifiers (cdnet_final_conv1x1).  Training: cdnet_amd.trainer.AblationTrainer."""
 from .model_unet_rev1 import Unet as _Rev1
 
 
 class Unet(_Rev1):
     VARIANT = 'MandDandP'
     DIRECTION_OUT = 9
+    # parameters the reference's forward never touches (no gradient, never stepped)
+    UNUSED_PREFIXES = ('final_conv.', 'child0.', 'child_conv1.', 'directionAtt.', 'maskAtt.')

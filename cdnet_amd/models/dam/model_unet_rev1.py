@@ -184,6 +184,8 @@ class Unet(nn.Module):
             out += [up, c2]
         for ru in self._rt['ru']:
             out += ru.layers()
+        if 'ru_res' in self._rt:
+            out += self._rt['ru_res'].layers()
         return out
 
     def head_weight_block(self):
@@ -255,8 +257,9 @@ class Unet(nn.Module):
         """ablation heads: plain 1x1 classifiers on the features, no attention gates (cdnet_final_conv1x1)"""
         import ctypes as C
         f1m, f2, f3 = feats
-        if self.training:
-            raise NotImplementedError('the ablation heads (model_unet_MandD*) run inference only on the accelerated path')
+        if self.training and self.DIRECTION_OUT != 9:
+            raise NotImplementedError('training of the 5- / 17-class ablation heads (model_unet_MandD4 / MandD16) is not on the accelerated path')
+        self._last_feats = feats
         N, H, W, _ = f1m.x.shape
         dev = f1m.x.device
 

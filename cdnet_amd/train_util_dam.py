@@ -93,7 +93,13 @@ def validate(val_loader, model, criterion, opt, logger, get_process_worktime=1, 
         x = input.to(dev).float()
         with torch.no_grad():
             if all_img_test == 1:
-                mask, point, direction = model(x)
+                out = model(x)
+                if len(out) == 2:                    # two-output ablation head (train_util_dam.py:481-487, direction = 1, mseloss = 0): no point term
+                    mask, direction = out
+                    point = torch.zeros((mask.shape[0], 1) + tuple(mask.shape[2:]), dtype=torch.float32, device=dev)
+                    point_t = torch.zeros_like(point_t)
+                else:
+                    mask, point, direction = out
             else:
                 outs = [utils.split_forward_dam(model, x[b:b + 1], opt.train['input_size'], opt.train['val_overlap'], opt) for b in range(x.shape[0])]
                 mask, point, direction = [torch.cat([o[k] for o in outs], 0).contiguous() for k in range(3)]

@@ -50,7 +50,7 @@ class FlatState:
         # a model that computes on zero-padded parameter copies (HRNet) hands those over; its own parameters stay views
         named = model.trainer_named_parameters() if hasattr(model, 'trainer_named_parameters') else dict(model.named_parameters())
         unused = [n for n in named if n.startswith(tuple(getattr(model, 'UNUSED_PREFIXES', ())))]
-        head = [n for n in HEAD_PARAMS if n in named]
+        head = [n for n in HEAD_PARAMS if n in named and n not in unused]
         rest = [n for n in named if n not in head and n not in unused]
         self.order = head + rest + unused
         sizes = [named[n].numel() for n in self.order]
@@ -179,7 +179,8 @@ class Trainer:
         for k, g in enumerate(gl):
             assert not g.pooled and g.oy == 0 and g.ox == 0
             arr[k].g, arr[k].cstride, arr[k].coff = g.t.data_ptr(), g.cstride or Cc, g.coff
-        _lib.call('cdnet_grad_sum', C.byref(arr), len(gl), None if mask is None else _lib.ptr(mask), npix, Cc, _lib.ptr(out), _lib.stream_ptr())
+        entry = 'cdnet_grad_sum_f32' if out.dtype == torch.float32 else 'cdnet_grad_sum'
+        _lib.call(entry, C.byref(arr), len(gl), None if mask is None else _lib.ptr(mask), npix, Cc, _lib.ptr(out), _lib.stream_ptr())
 
     def cat_grad(self, o, grads):
         """gradient of a concatenation buffer (several consumers, several writers): summed once per backward"""
@@ -324,6 +325,15 @@ class Trainer:
         a.shift = L.shift.data_ptr() if has_bn else None
         a.mean = L.save_mean.data_ptr() if has_bn else None
         a.invstd = L.save_invstd.data_ptr() if has_bn else None
+        if len(gl) > 3:
+            # more consumers than the kernel takes gradient sources (an ablation head's first residual unit feeds two units, four
+            # backward-data terms): fold the plain same-size terms beyond the second into one tensor first
+            plain = [g for g in gl if not g.pooled and g.oy == 0 and g.ox == 0 and (g.Hg, g.Wg) == (Ho, Wo)]
+            rest = [g for g in gl if g not in plain]
+            assert len(rest) <= 2 and len(plain) >= 2, (L.name, len(gl))
+            d = self.buf(('gsum', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
+            self.grad_sum(plain, None, No * Ho * Wo, Co, d)
+            gl = rest + [_G(d, Ho, Wo)]
         a.ngin = len(gl)
         assert 1 <= len(gl) <= 3, (L.name, len(gl))
         for k, g in enumerate(gl):
@@ -664,6 +674,63 @@ class UNetTrainer(Trainer):
         self.backward(dlogits)
         self.allreduce_and_step()
         return self.unet_losses
+
+
+class AblationTrainer(Trainer):
+    """Train iteration of the ablation heads (models/dam/model_unet_MandD.py / model_unet_MandDandP.py through
+    train_util_dam.train, which unpacks the model's outputs by their number, :152-166): the same five-term loss - without the point
+    term for the two-output model (options direction = 1, mseloss = 0) - plain 1x1 classifiers instead of the gated head
+    (cdnet_final_conv1x1 / cdnet_final_conv1x1_backward), everything else the rev1 tape.  9-class direction maps only."""
+
+    def __init__(self, model, **kw):
+        assert getattr(model, 'VARIANT', 'rev1') in ('MandD', 'MandDandP') and model.DIRECTION_OUT == 9, \
+            'AblationTrainer serves model_unet_MandD / model_unet_MandDandP (9 direction classes)'
+        super().__init__(model, **kw)
+
+    def loss_and_grads(self, outputs, label, dirlab, point_t, weight):
+        if len(outputs) == 3:
+            return super().loss_and_grads(outputs[0], outputs[1], outputs[2], label, dirlab, point_t, weight)
+        mask, direction = outputs
+        B, _, H, W = mask.shape
+        point = self.buf('zero_point', (B, 1, H, W), torch.float32)
+        pt = self.buf('zero_point_t', (B, H, W), torch.float16)
+        point.zero_()
+        pt.zero_()
+        dmask, _, ddir = super().loss_and_grads(mask, point, direction, label, dirlab, pt, weight)
+        return dmask, None, ddir
+
+    def backward(self, dmask, dpoint, ddir):
+        m = self.model
+        f1m, f2, f3 = m._last_feats
+        N, H, W, _ = f1m.x.shape
+        grads = {}
+
+        def add(t, g):
+            grads.setdefault(id(t), []).append(g)
+        lib = _lib.load()
+        ws = self._slab(lib.cdnet_final_conv1x1_backward_workspace_floats())
+        params = []
+        for name, f, conv, dl in (('m', f1m, m.mask_conv, dmask), ('d', f2, m.direction_conv, ddir), ('p', f3, m.point_conv, dpoint)):
+            if f is None or dl is None:
+                continue
+            K = conv.out_channels
+            df = self.buf('dF' + name, (N, H, W, 64), runtime.act_dtype())
+            hf = runtime.head_feat(f)
+            w = conv.weight.detach().reshape(K, 64)
+            _lib.call('cdnet_final_conv1x1_backward', C.byref(hf), _lib.ptr(w), _lib.ptr(dl), K, N, H, W, _lib.ptr(df), _lib.ptr(ws),
+                      ws.numel(), _lib.ptr(conv.weight.grad), _lib.ptr(conv.bias.grad), _lib.stream_ptr())
+            add(getattr(f, 'grad_to', (f.x,))[0], _G(df, H, W))
+            params += [conv.weight, conv.bias]
+        self._overlap_begin()
+        self._overlap_done(params)
+        self._backward_tape(grads, add)
+
+    def train_step(self, x, label, dirlab, point_t, weight):
+        out = self.forward(x)
+        g = self.loss_and_grads(out, label, dirlab, point_t, weight)
+        self.backward(*g)
+        self.allreduce_and_step()
+        return self.losses
 
 
 class BucketReducer:

@@ -121,8 +121,10 @@ def get_optimizer(args, model, world_size=1):
     fused device optimiser lives inside cdnet_amd.trainer.Trainer."""
     if args.train['optimizer'].lower() != 'adam':
         raise NotImplementedError("only the reference's default optimizer 'adam' is on the hot path")
-    from .trainer import Trainer
-    return Trainer(model, lr=args.train['lr'], weight_decay=args.train['weight_decay'], world_size=world_size), None
+    from .trainer import Trainer, AblationTrainer
+    # the ablation heads (model_unet_MandD / model_unet_MandDandP) train with plain classifiers instead of the gated head
+    cls = AblationTrainer if getattr(model, 'VARIANT', 'rev1') != 'rev1' else Trainer
+    return cls(model, lr=args.train['lr'], weight_decay=args.train['weight_decay'], world_size=world_size), None
 
 
 def adjust_learning_rate(args, trainer, epoch):

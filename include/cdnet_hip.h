@@ -257,7 +257,8 @@ size_t cdnet_bias_grad_workspace_floats(int C);
 int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);
 int cdnet_bias_grad_f32(const float *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);   /* fp32-precision path */
 /* backward of that classifier (plain-UNet training, train_util.py:126-200 loss.backward()): dlogits f32 [N][K][H][W] ->
- * df bf16 NHWC [N][H][W][64] (gradient of the activated feature), dw f32 [K][64], db f32 [K].  K <= 4.
+ * df bf16 NHWC [N][H][W][64] (gradient of the activated feature), dw f32 [K][64], db f32 [K].  K <= 12 (the 3-class mask and
+ * 9-class direction classifiers of the ablation heads, models/dam/model_unet_MandD*.py).
  * workspace: cdnet_final_conv1x1_backward_workspace_floats() floats. */
 size_t cdnet_final_conv1x1_backward_workspace_floats(void);
 int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
@@ -439,6 +440,8 @@ typedef struct cdnet_grad_term {
     int cstride, coff;
 } cdnet_grad_term;
 int cdnet_grad_sum(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream);
+/* the same over fp32 tensors (fp32 precision mode: `g` of every term, mask and out point at float data; strides in elements) */
+int cdnet_grad_sum_f32(const cdnet_grad_term *terms, int nterm, const float *mask, long long npix, int C, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Instance metrics (stats_utils.py): one pass over a ground-truth and a predicted label image [N][plane] i32 gives the

@@ -81,6 +81,12 @@ def dam_unet_forward(net, x):
         x = conv_bn(torch.cat([u, skip], 1), blk.conv2, blk.bn2)
     f1 = residual_unit(x, net.mask_feature)
     f2 = residual_unit(f1, net.direction_feature)
+    if getattr(net, 'variant', 'rev1') != 'rev1':               # ablation heads: plain classifiers, no gates
+        direction = net.direction_conv(f2)
+        mask = net.mask_conv(residual_unit(f1, net.residual))
+        if net.variant == 'MandDandP':
+            return mask, net.point_conv(residual_unit(f2, net.point_feature)), direction
+        return mask, direction
     f3 = residual_unit(f2, net.point_feature)
     point = net.point_conv(f3)
     direction = net.direction_conv(net.directionAtt(f2, point))

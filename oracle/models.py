@@ -126,8 +126,11 @@ class Unet(nn.Module):                                   # model_unet_rev1.py:18
     SKIPS = ('5', '12', '22', '32', '42')
     BB_OUT = '43'
 
-    def __init__(self, classes=3, decoder_filters=(256, 128, 64, 32, 16)):
+    def __init__(self, classes=3, decoder_filters=(256, 128, 64, 32, 16), variant='rev1'):
+        """variant: 'rev1' (UNet2RevA1_vgg16) or the ablation heads 'MandD' (models/dam/model_unet_MandD.py:246-268: mask + direction,
+        no gates, no point branch) / 'MandDandP' (model_unet_MandDandP.py: plus the point branch) - same parameters plus `residual`"""
         super().__init__()
+        self.variant = variant
         self.backbone = vgg16_bn_features()
         skip_ch = [64, 128, 256, 512, 512]
         fin = [512] + list(decoder_filters[:-1])
@@ -144,6 +147,8 @@ class Unet(nn.Module):                                   # model_unet_rev1.py:18
         self.direction_conv = nn.Conv2d(64, 9, kernel_size=1)
         self.maskAtt = revAttention(9)
         self.mask_conv = nn.Conv2d(64, 3, kernel_size=1)
+        if variant != 'rev1':
+            self.residual = ResidualUnit(64, 64)                                             # model_unet_MandD.py:234
 
     def forward(self, x):
         feats = {}
@@ -157,6 +162,12 @@ class Unet(nn.Module):                                   # model_unet_rev1.py:18
             x = blk(x, feats[skip_name])
         f1 = self.mask_feature(x)
         f2 = self.direction_feature(f1)
+        if self.variant != 'rev1':
+            direction = self.direction_conv(f2)
+            mask = self.mask_conv(self.residual(f1))
+            if self.variant == 'MandDandP':
+                return mask, self.point_conv(self.point_feature(f2)), direction
+            return mask, direction
         f3 = self.point_feature(f2)
         point = self.point_conv(f3)
         direction = self.direction_conv(self.directionAtt(f2, point))

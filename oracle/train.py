@@ -83,6 +83,15 @@ def dam_losses(mask_logits, point_out, dir_logits, label, direction, point_targe
     return dict(ce=ce, dice=dice, dce=dce, wdice=wdice, mse=mse, total=total)
 
 
+def ablation_losses(outputs, label, direction, point_target, weight_png, quirk_sample0=True):
+    """the same loss for the ablation heads (train_util_dam.py:152-166 unpacks by the number of outputs): three outputs as the
+    rev1 model; two outputs (mask, direction; options direction = 1, mseloss = 0) without the point term"""
+    if len(outputs) == 3:
+        return dam_losses(outputs[0], outputs[1], outputs[2], label, direction, point_target, weight_png, quirk_sample0)
+    zero = torch.zeros((outputs[0].shape[0], 1) + tuple(outputs[0].shape[2:]))
+    return dam_losses(outputs[0], zero, outputs[1], label, direction, torch.zeros_like(point_target), weight_png, quirk_sample0)
+
+
 def make_adam(model, lr=1e-3, weight_decay=1e-4):
     return torch.optim.Adam(model.parameters(), lr=lr, betas=(0.9, 0.99), weight_decay=weight_decay)
 

@@ -1,0 +1,126 @@
+"""Training step of the ablation heads (models/dam/model_unet_MandD.py / model_unet_MandDandP.py through train_util_dam.train):
+cdnet_amd.trainer.AblationTrainer against the oracle (oracle.models.Unet(variant=...), oracle.train.ablation_losses).
+  * loss values vs the fp32 oracle, 2e-3 relative (bf16 path);
+  * gradients of the linearised network in fp32 precision vs the oracle's autograd: median relative error <= 2e-3, worst <= 5e-2
+    (the conditioning argument of tests/test_gpu_fp32.py);
+  * the parameters the reference's forward never touches get no gradient and are never stepped; six Adam steps track the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(variant, B=2, S=64, seed=0):
+    import importlib
+    import torch
+    from cdnet_amd import synth
+    from oracle import models as om
+    torch.manual_seed(seed)
+    ref = om.Unet(variant=variant)
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
+            torch.nn.init.normal_(mod.bias, 0, 0.2)
+    Unet = importlib.import_module('cdnet_amd.models.dam.model_unet_' + variant).Unet
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    m.load_state_dict(ref.state_dict())
+    lab, dirn, point, weight = synth.train_targets(B, S, S, 21)
+    x = torch.from_numpy(synth.det_input((B, 3, S, S), 9))
+    t = [torch.from_numpy(a) for a in (lab, dirn, point, weight)]
+    return m.cuda(), ref, x, t
+
+
+def _hip(m, x, t):
+    import torch
+    from cdnet_amd import trainer
+    tr = trainer.AblationTrainer(m)
+    dev = torch.device('cuda:0')
+    out = tr.forward(x.to(dev))
+    g = tr.loss_and_grads(out, t[0].to(dev), t[1].to(dev), t[2].to(dev), t[3][:, 0].contiguous().to(dev))
+    tr.backward(*g)
+    torch.cuda.synchronize()
+    return tr, {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if not n.startswith(m.UNUSED_PREFIXES)}
+
+
+def _oracle(ref, x, t, linear=False):
+    from oracle import emulate
+    from oracle import train as ot
+    ref.train()
+    ref.zero_grad()
+    if linear:
+        emulate.QUANT, emulate.NORELU = False, True
+        try:
+            out = emulate.dam_unet_forward(ref, x)
+        finally:
+            emulate.QUANT, emulate.NORELU = True, False
+    else:
+        out = ref(x)
+    L = ot.ablation_losses(out, t[0], t[1], t[2], t[3])
+    L['total'].backward()
+    return {k: float(v) for k, v in L.items()}, {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize('variant', ['MandD', 'MandDandP'])
+def test_ablation_loss_values_and_unused_parameters(variant):
+    m, ref, x, t = _setup(variant)
+    tr, g = _hip(m, x, t)
+    L, rg = _oracle(ref, x, t)
+    got = tr.losses.cpu().numpy()[:6]
+    want = [L[k] for k in ('total', 'dce', 'wdice', 'mse', 'ce', 'dice')]
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-6)
+    if variant == 'MandD':
+        assert want[3] == 0.0 and got[3] == 0.0                    # no point branch, no MSE term
+    # exactly the parameters autograd reaches in the reference get a gradient here
+    assert set(g.keys()) == set(rg.keys()), set(g.keys()) ^ set(rg.keys())
+
+
+@pytest.mark.parametrize('variant', ['MandD', 'MandDandP'])
+def test_ablation_linearised_gradients_fp32(variant):
+    import cdnet_amd
+    from cdnet_amd import runtime
+    cdnet_amd.set_precision('fp32')
+    runtime.DEBUG_NORELU = True
+    try:
+        m, ref, x, t = _setup(variant)
+        tr, g = _hip(m, x, t)
+        L, rg = _oracle(ref, x, t, linear=True)
+    finally:
+        runtime.DEBUG_NORELU = False
+        cdnet_amd.set_precision('bf16')
+    np.testing.assert_allclose(tr.losses.cpu().numpy()[:5], [L[k] for k in ('total', 'dce', 'wdice', 'mse', 'ce')], rtol=2e-4, atol=1e-7)
+    rel = {n: float((g[n] - w).norm() / w.norm()) for n, w in rg.items() if w.norm() >= 1e-6}
+    worst = max(rel, key=rel.get)
+    assert np.median(list(rel.values())) <= 2e-3, np.median(list(rel.values()))
+    assert rel[worst] <= 5e-2, (worst, rel[worst])
+    for n in ('mask_conv.weight', 'direction_conv.weight', 'residual.conv2.weight', 'mask_feature.conv1.weight'):
+        assert rel[n] <= 2e-3, (n, rel[n])
+
+
+def test_ablation_short_training_run_tracks_the_oracle():
+    import torch
+    from cdnet_amd import trainer
+    from oracle import train as ot
+    m, ref, x, t = _setup('MandD')
+    p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    tr = trainer.AblationTrainer(m)
+    dev = torch.device('cuda:0')
+    batch = (x.to(dev), t[0].to(dev), t[1].to(dev), t[2].to(dev), t[3][:, 0].contiguous().to(dev))
+    opt = ot.make_adam(ref)
+    ours, theirs = [], []
+    for _ in range(6):
+        ours.append(float(tr.train_step(*batch)[0]))
+        ref.train()
+        L = ot.ablation_losses(ref(x), *t)
+        opt.zero_grad()
+        L['total'].backward()
+        opt.step()
+        theirs.append(float(L['total']))
+    print('MandD trajectory', ours, theirs)
+    np.testing.assert_allclose(ours[0], theirs[0], rtol=2e-3)
+    np.testing.assert_allclose(ours, theirs, rtol=5e-2)
+    assert ours[-1] < ours[0] * 0.95
+    sd = m.state_dict()
+    for n, p in ref.named_parameters():
+        if n.startswith(m.UNUSED_PREFIXES):
+            assert torch.equal(sd[n].cpu(), p0[n]), n
