@@ -847,21 +847,24 @@ typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 
 // XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
 // BatchNorm source, packed math), 2 anything (run-time flags).  STATS: per-tile channel sums of the unrounded accumulators.
-// The launcher guarantees nchunk == 4 and full tiles (H, W multiples of 16).
-template <int BN, int TAPS, int XF, bool STATS>
+// STREAM: more than four chunks per tile (128+ input channels, two-source layers) - the weight tile no longer fits the LDS; its
+// chunks then stream through a four-slot ring by LDS-DMA, two chunks ahead of the consumers, beside the halo ring.
+// The launcher guarantees nchunk % 4 == 0 (== 4 without STREAM) and full tiles (H, W multiples of 16).
+template <int BN, int TAPS, int XF, bool STATS, bool STREAM>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     using L = WsLds<BN, TAPS>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NT = BN / 32, NPW = NT, MPW = 2;               // consumer wave wm: M tiles 2wm, 2wm+1 (64 pixels), all N tiles
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
     constexpr int PF = 4;                                         // halo chunks in flight per mover thread
-    constexpr int NCH = 4;                                        // chunks per tile
+    constexpr int NWS = 4;                                        // weight slots in LDS (the whole tile without STREAM)
+    const int NCH = STREAM ? A.nchunk : 4;                        // chunks per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the halo ring first: its fragment addresses (slot, tap) then fit the 16-bit offset field of ds_read from one base register per M tile
     unsigned char *lds_a = smem;
     unsigned char *lds_w = smem + L::NSLOT * L::A_BYTES;
-    unsigned char *lds_o = lds_w + NCH * L::B_CHUNK;
+    unsigned char *lds_o = lds_w + NWS * L::B_CHUNK;
     float *s_stats = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE);          // [2][4][2][BN]
     float *s_xf = reinterpret_cast<float *>(lds_o + 4 * L::OUT_WAVE + L::STATS_BYTES);
 
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     const int cout_tile = blockIdx.y;
     const int cout0 = cout_tile * BN;
 #ifdef CDNET_WS_STAMPS
-    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NCH, ctot)) + (wave >= 4 ? 384 : 0);
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NWS, ctot)) + (wave >= 4 ? 384 : 0);
     const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
     int sn = 0;
 #endif
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int pw = wave - 4;
         const int lg = lane >> 4, li = lane & 15;
         const unsigned char *s_img = lds_o + pw * L::OUT_WAVE + (li >> 2) * L::IROW + (li & 3) * 8;
-        auto store_pieces = [&]() {
+        auto store_pieces = [&](bool now) {
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
@@ -1038,11 +1041,46 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 const ws_s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
                 const ws_s16x4 t2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * L::IROW));
                 const int y = s_y0 + pw * 4 + mi * 2 + ch, x = s_x0 + li, co = cout0 + 8 * o;
-                if (s_ok && co < A.Cout) {
+                if (now && s_ok && co < A.Cout) {
                     const uint2 a = __builtin_bit_cast(uint2, t1), b2 = __builtin_bit_cast(uint2, t2);
                     *reinterpret_cast<uint4 *>(A.out + (((size_t)s_n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = make_uint4(a.x, a.y, b2.x, b2.y);
                 }
             }
+        };
+        // STREAM: weight chunk wk of the tile -> weight slot wk & 3 by LDS-DMA (the packed chunk is the LDS image; one 1 KB
+        // wave-instruction per 64 vectors, the four mover waves take them in turn); the cursor wraps at the end of a tile
+        int wk = 0;
+        auto dma_w = [&]() {
+            constexpr int NVEC = L::B_CHUNK / 16;
+            static_assert(NVEC % 64 == 0, "whole wave-instructions");
+            const unsigned short *wsrc = A.w + ((size_t)cout_tile * NCH + wk) * (L::B_CHUNK / 2);
+            unsigned char *wdst = lds_w + (wk & 3) * L::B_CHUNK;
+#pragma unroll
+            for (int i = 0; i < (NVEC / 64 + 3) / 4; ++i) {
+                const int v0 = (i * 4 + pw) * 64;
+                if (v0 < NVEC)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)(v0 + lane) * 8),
+                                                     (__attribute__((address_space(3))) void *)(wdst + v0 * 16), 16, 0, 0);
+            }
+            if (++wk == NCH) wk = 0;
+        };
+        // vmcnt(N) alone (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14): wait until only the N youngest
+        // vector-memory operations of this wave are outstanding - the halo requests issued after the DMA stay in flight
+        auto wait_vm = [](auto n_c) {
+            constexpr int N = decltype(n_c)::value;
+            __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+        };
+        using NHL = std::integral_constant<int, 2 * NA>;          // halo requests of one interval (two chunks)
+        // the movers' barrier of the streaming loop by hand: __syncthreads() carries a workgroup release fence, and with an LDS-DMA in the
+        // wave's history the compiler turns that fence into s_waitcnt vmcnt(0) - draining the halo requests in flight every interval.
+        // What the consumers need is: this wave's LDS writes done (lgkmcnt(0)), its weight DMA landed (everything older than the N
+        // youngest vector-memory operations), then the barrier.
+        auto stream_sync = [](auto n_c) {
+            constexpr int N = decltype(n_c)::value;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -1060,26 +1098,52 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         }
         __syncthreads();                                         // table + weights
         commit(I0{}, 0);
-        issue(I0{});
         commit(I1{}, 1);
+        if (STREAM) { dma_w(); dma_w(); }
+        issue(I0{});
         issue(I1{});
+        if (STREAM) wait_vm(NHL{});                              // weight chunks 0, 1 have landed (the two halo chunks requested after them stay in flight)
         __syncthreads();
+        const int NIT = NCH / 4;                                 // loop iterations (four chunks = two barrier intervals) per tile
+        int it = 0;
         // tile j (chunks q0 .. q0+3).  Interval A: the consumers work on chunks q0, q0+1 (slots 0, 1) and park the out image of tile
         // j-1; slots 2, 3 take chunks q0+2, q0+3.  Interval B: the consumers work on slots 2, 3; slots 0, 1 take the first two chunks
         // of tile j+1 and the out image of tile j-1 leaves for global memory.
-        for (int q0 = 0; q0 < S; q0 += 4) {
-            WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); WS_STAMP(3); __syncthreads();
-#ifdef CDNET_WS_STAMPS
-            WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); if (!(A.debug & 256)) store_pieces(); WS_STAMP(3); __syncthreads();
-#else
-            WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); store_pieces(); WS_STAMP(3); __syncthreads();
-#endif
-            s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
-            o_x0 += TW;
-            if (o_x0 >= A.W) { o_x0 = 0; o_y0 += TH; if (o_y0 >= A.H) { o_y0 = 0; ++o_n; } }
+        if (!STREAM) {
+            for (int q0 = 0; q0 < S; q0 += 4) {
+                WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); WS_STAMP(3); __syncthreads();
+                WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); store_pieces(true); WS_STAMP(3); __syncthreads();
+                s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
+                o_x0 += TW;
+                if (o_x0 >= A.W) { o_x0 = 0; o_y0 += TH; if (o_y0 >= A.H) { o_y0 = 0; ++o_n; } }
+            }
+        } else {
+            // per interval: the weight DMA of the two chunks after the ones being consumed first, (second interval of a tile: the
+            // previous tile's out image), the halo commits and requests last - the explicit wait then leaves exactly the halo
+            // requests of this interval in flight
+            // (every LDS access of the interval - out-image reads, halo commits - comes BEFORE the DMA: the compiler cannot tell that
+            //  the DMA's destination does not alias them and guards any later LDS access of this wave with s_waitcnt vmcnt(0),
+            //  which would drain the halo requests in flight)
+            for (int q0 = 0; q0 < S; q0 += 4) {
+                commit(I2{}, q0 + 2); commit(I3{}, q0 + 3);
+                dma_w(); dma_w();
+                issue(I2{}); issue(I3{});
+                stream_sync(NHL{});
+                store_pieces(it == 0);
+                commit(I0{}, q0 + 4); commit(I1{}, q0 + 5);
+                dma_w(); dma_w();
+                issue(I0{}); issue(I1{});
+                stream_sync(NHL{});
+                if (++it == NIT) {
+                    it = 0;
+                    s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
+                    o_x0 += TW;
+                    if (o_x0 >= A.W) { o_x0 = 0; o_y0 += TH; if (o_y0 >= A.H) { o_y0 = 0; ++o_n; } }
+                }
+            }
         }
         __syncthreads();                                         // the consumers have parked the last tile's out image
-        store_pieces();
+        store_pieces(true);
 #ifdef CDNET_WS_STAMPS
         if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[1024 + i] = s_stamp[i]; g_ws_stamps[1024 + sn] = 0; }
 #endif
@@ -1087,10 +1151,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     }
 
     // ================================ consumers ================================
-    {
-        const u32x4v *src = reinterpret_cast<const u32x4v *>(A.w + (size_t)cout_tile * NCH * (L::B_CHUNK / 2));
+    if (!STREAM) {
+        const u32x4v *src = reinterpret_cast<const u32x4v *>(A.w + (size_t)cout_tile * 4 * (L::B_CHUNK / 2));
         u32x4v *dst = reinterpret_cast<u32x4v *>(lds_w);
-        constexpr int nv = NCH * (L::B_CHUNK / 16), NW = (nv + 255) / 256;
+        constexpr int nv = 4 * (L::B_CHUNK / 16), NW = (nv + 255) / 256;
         // all of a thread's vectors in flight at once (one memory round trip for the 74 KB; the accumulators are not live yet)
         u32x4v wv[NW];
 #pragma unroll
@@ -1243,6 +1307,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         WS_STAMP(12);
         __syncthreads();
         WS_STAMP(13);
+        if (STREAM) {
+            // the rest of a long tile: intervals alternate between the two halves of the rings
+            const int NI = NCH / 2;
+            for (int i = 2; i < NI; ++i) {
+                interval(F_{}, F_{}, C, P, par, (i & 1) * 2);
+                __syncthreads();
+            }
+        }
     };
     // the last tile of the run: nothing left to hide behind
     auto serial_epilogue = [&](const f32x16 (&P)[MPW][NPW], int j) {
@@ -1283,16 +1355,17 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
     using L = WsLds<BN, TAPS>;
     int ctot = 0;
     if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
-    if (A.nchunk != 4) return -1;                                // 64 input channels: a tile = two barrier intervals of two chunks
+    if (A.nchunk < 4 || A.nchunk % 4 != 0) return -1;            // whole pairs of barrier intervals (two chunks each) per tile
+    const bool stream = A.nchunk != 4;                           // 128+ input channels / two sources: the weight chunks stream through the LDS
     if (A.H % 16 != 0 || A.W % 16 != 0) return -1;               // full tiles only
     for (int i = 0; i < A.nsrc; ++i) {
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
     }
 #ifdef CDNET_WS_STAMPS
-    const int smem = L::bytes(A.nchunk, ctot) + 2 * 384 * 8;
+    const int smem = L::bytes(4, ctot) + 2 * 384 * 8;
 #else
-    const int smem = L::bytes(A.nchunk, ctot);
+    const int smem = L::bytes(4, ctot);
 #endif
     if (smem > 160 * 1024) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
@@ -1304,8 +1377,11 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int ctiles = cdiv(A.Cout, BN);
-    // a persistent workgroup pays ~3 us of start-up (weights + first chunks): worth it from a few tiles per workgroup on
-    if (!(A.debug & 64) && T < 4 * (n_cu / ctiles)) return -1;
+    // a persistent workgroup pays ~3 us of start-up (weights + first chunks): worth it from a few tiles' worth of chunks per workgroup on
+    const int Gmax = n_cu / ctiles > 0 ? n_cu / ctiles : 1;
+    if (!(A.debug & 64) && ((long long)T * A.nchunk < 16LL * Gmax || T < Gmax)) return -1;
+    static const int want_stream = getenv("CDNET_CONV_WS_STREAM") ? atoi(getenv("CDNET_CONV_WS_STREAM")) : 1;
+    if (stream && !want_stream && !(A.debug & 64)) return -1;
     bool all_plain = true, all_fast = true;
     for (int i = 0; i < A.nsrc; ++i) {
         const ConvSrc &s = A.src[i];
@@ -1317,10 +1393,11 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
     if (G >= 8) G &= ~7;
     if (G < 1) G = 1;
     dim3 grid(G, ctiles, 1);
-    auto launch = [&](auto xf_c, auto st_c) -> int {
+    auto launch2 = [&](auto xf_c, auto st_c, auto sm_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
         constexpr bool STATS = decltype(st_c)::value;
-        auto kern = conv_ws_kernel<BN, TAPS, XF, STATS>;
+        constexpr bool STREAM = decltype(sm_c)::value;
+        auto kern = conv_ws_kernel<BN, TAPS, XF, STATS, STREAM>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1329,6 +1406,9 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
         }
         kern<<<grid, 512, smem, st>>>(A);
         return CDNET_OK;
+    };
+    auto launch = [&](auto xf_c, auto st_c) -> int {
+        return stream ? launch2(xf_c, st_c, std::true_type{}) : launch2(xf_c, st_c, std::false_type{});
     };
     const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
     using X0 = std::integral_constant<int, 0>;

@@ -237,7 +237,9 @@ def _run_both(fn):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 64, 64), (1, 64, 64, 40, 56), (3, 16, 64, 33, 17), (2, 32, 32, 48, 32), (2, 64, 16, 32, 48),
-                                  (16, 64, 64, 256, 256)])
+                                  (16, 64, 64, 256, 256),
+                                  # streamed weights (more than four 16-channel chunks per tile): 128, 256, 192 input channels
+                                  (2, 128, 64, 64, 64), (1, 256, 128, 32, 48), (2, 192, 32, 32, 32), (4, 512, 64, 16, 32)])
 def test_ws_kernel_bit_identical_plain_stats_and_folded(case):
     import torch
     from cdnet_amd import engine
