@@ -3,6 +3,7 @@ kernel configuration and thin call wrappers.  No compute happens here - every fu
 into libcdnet_hip.so (torch tensors only provide device memory and the current stream).
 """
 import ctypes as C
+import os
 import torch
 
 from . import _lib
@@ -104,12 +105,16 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
         ck //= 2
     assert ck >= 16, 'source channels must be multiples of 16: %s' % (src_channels,)
     if small:
-        if ck >= 32:
+        # 16x16-pixel layers with long channel loops (the bottleneck convolutions): the persistent producer / consumer kernel keeps four
+        # chunks of loads in flight per workgroup - 128 workgroups of it beat 512 workgroups that each expose every chunk's latency
+        # (512 -> 512 @16x16 x16: 54 -> measured in tools/bench_conv_stream.py)
+        ws16 = taps == 9 and not transposed and H % 16 == 0 and W % 16 == 0 and min(H, W) == 16 and ctot % 64 == 0 and 256 <= ctot <= 768 \
+            and os.environ.get('CDNET_WS16', '1') == '1'
+        if ck >= 32 and not ws16:
             return (8, 32, 64)
     if ck == 64:
         ck = 32                       # 2 workgroups per CU (LDS) beat one fat one
     bn = 64 if Cout > 32 else 32
-    import os
     if (ctot <= 128 and bn == 64) or (os.environ.get('CDNET_CK16', '1') == '1' and ck >= 16):
         ck = 16                       # 34 KB of LDS and <= 168 VGPRs: three workgroups per CU hide the staging latency (measured)
     if ck == 16 and bn > 64:
