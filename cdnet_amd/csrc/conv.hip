@@ -837,8 +837,8 @@ struct WsLds {
     static constexpr int IBLK = 32 * IROW;                        // one block: 32 couts x 32 pixels
     static constexpr int OUT_WAVE = 2 * (BN / 32) * IBLK;         // a consumer wave's 64 pixels x BN couts
     static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum|sumsq][BN]
-    __host__ __device__ static int bytes(int nchunk, int ctot) {
-        return nchunk * B_CHUNK + NSLOT * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4;
+    __host__ __device__ static int bytes(int nchunk, int ctot, int xf_rows = 2) {
+        return nchunk * B_CHUNK + NSLOT * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + xf_rows * ((ctot + 7) / 8 * 8) * 4;
     }
 };
 
@@ -846,7 +846,11 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));      // register st
 typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 
 // XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
-// BatchNorm source, packed math), 2 anything (run-time flags).  STATS: per-tile channel sums of the unrounded accumulators.
+// BatchNorm source, packed math), 2 anything (run-time flags), 3 BatchNorm-backward source (ConvSrc.relu == 3: x = the bf16
+// gradient w.r.t. the activated output, res = the fp16 raw forward output, scale = a [7][C] table scale | shift | mean | invstd |
+// k1 | k2 | k3 - the movers apply the second BatchNorm-backward pass, k1 * (dz - k2 - xhat * k3) with dz = the ReLU-masked
+// gradient, while they stage: backward-data without the stored dRaw tensor on its critical path).
+// STATS: per-tile channel sums of the unrounded accumulators.
 // STREAM: more than four chunks per tile (128+ input channels, two-source layers) - the weight tile no longer fits the LDS; its
 // chunks then stream through a four-slot ring by LDS-DMA, two chunks ahead of the consumers, beside the halo ring.
 // The launcher guarantees nchunk % 4 == 0 (== 4 without STREAM) and full tiles (H, W multiples of 16).
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     const int cout_tile = blockIdx.y;
     const int cout0 = cout_tile * BN;
 #ifdef CDNET_WS_STAMPS
-    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NWS, ctot)) + (wave >= 4 ? 384 : 0);
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NWS, ctot, XF == 3 ? 7 : 2)) + (wave >= 4 ? 384 : 0);
     const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
     int sn = 0;
 #endif
@@ -916,6 +920,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int ptid = tid - 256;
         const int slot = ptid % VPP;
         u32x4v pa[PF][NA];
+        u32x4v pr[XF == 3 ? PF : 1][NA];         // XF 3: the raw forward output beside the gradient
         unsigned vm[PF];                         // bit i: vector i of the chunk is inside the image / source
         int eo[PF][NA];                          // element offsets (only read for sources with a residual operand)
         // per-thread constants: halo coordinates and LDS offsets of its NA vectors
@@ -969,6 +974,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 const int e = ge[i] >= 0 ? ge[i] : 0;
                 eo[R][i] = e + cc0;
                 pa[R][i] = *reinterpret_cast<const u32x4v *>(base + e);
+                if (XF == 3) pr[XF == 3 ? R : 0][i] = *reinterpret_cast<const u32x4v *>(s.res + cc0 + e);
             }
             vm[R] = gm;
             // advance (saturating at the last chunk of the run)
@@ -994,13 +1000,33 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
+            float bmu[8], bis[8], bk1[8], bk2[8], bk3[8];
+            if (XF == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bmu[j] = xf[2 * xfs + j]; bis[j] = xf[3 * xfs + j]; bk1[j] = xf[4 * xfs + j]; bk2[j] = xf[5 * xfs + j]; bk3[j] = xf[6 * xfs + j];
+                }
+            }
             unsigned char *dst0 = lds_a + R * L::A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
                 if (XF == 0) val = pa[R][i];
                 else if (XF == 1) val = xf_bnrelu_f16<false>(pa[R][i], pa[R][i], sc, sh);
-                else {
+                else if (XF == 3) {
+                    // the arithmetic of bn_bwd_apply_flat_kernel<1, false> (train.hip), element for element
+                    V16 g8, r8, o8;
+                    g8.u = __builtin_bit_cast(uint4, pa[R][i]);
+                    r8.u = __builtin_bit_cast(uint4, pr[XF == 3 ? R : 0][i]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = h2f(r8.h[j]);
+                        const float v = fmaf(x, sc[j], sh[j]);
+                        const float dz = !(bf2f(f2bf(v)) > 0.f) ? 0.f : bf2f(g8.h[j]);
+                        o8.h[j] = f2bf(bk1[j] * (dz - bk2[j] - (x - bmu[j]) * bis[j] * bk3[j]));
+                    }
+                    val = __builtin_bit_cast(u32x4v, o8.u);
+                } else {
                     ChanXf t;
                     t.on = s.scale != nullptr;
 #pragma unroll
@@ -1093,8 +1119,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         for (int c = ptid; c < ctot; c += 256) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
             const int cc = c < c0n ? c : c - c0n;
-            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
-            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+            if (XF == 3) {
+#pragma unroll
+                for (int r = 0; r < 7; ++r) s_xf[r * xfs + c] = Sx.scale[r * Sx.C + cc];
+            } else {
+                s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+                s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+            }
         }
         __syncthreads();                                         // table + weights
         commit(I0{}, 0);
@@ -1351,21 +1382,24 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 
 // eligibility + launch of the wave-specialised kernel; returns -1 when the layer must take conv_fwd_kernel
 template <int BN, int TAPS>
-int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
+int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) {
     using L = WsLds<BN, TAPS>;
     int ctot = 0;
     if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
     if (A.nchunk < 4 || A.nchunk % 4 != 0) return -1;            // whole pairs of barrier intervals (two chunks each) per tile
     const bool stream = A.nchunk != 4;                           // 128+ input channels / two sources: the weight chunks stream through the LDS
     if (A.H % 16 != 0 || A.W % 16 != 0) return -1;               // full tiles only
+    bool bnb = false;
     for (int i = 0; i < A.nsrc; ++i) {
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
+        bnb = bnb || A.src[i].relu == 3;
     }
+    if (bnb && (A.nsrc != 1 || !A.src[0].res || !A.src[0].scale || A.src[0].f16 != 0)) return -1;
 #ifdef CDNET_WS_STAMPS
-    const int smem = L::bytes(4, ctot) + 2 * 384 * 8;
+    const int smem = L::bytes(4, ctot, bnb ? 7 : 2) + 2 * 384 * 8;
 #else
-    const int smem = L::bytes(4, ctot);
+    const int smem = L::bytes(4, ctot, bnb ? 7 : 2);
 #endif
     if (smem > 160 * 1024) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
@@ -1412,12 +1446,15 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st) {
     auto launch = [&](auto xf_c, auto st_c) -> int {
         return stream ? launch2(xf_c, st_c, std::true_type{}) : launch2(xf_c, st_c, std::false_type{});
     };
-    const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
+    const int xf = bnb ? 3 : (all_plain ? 0 : (all_fast ? 1 : 2));
+    if (dry_run) return CDNET_OK;
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
     using X2 = std::integral_constant<int, 2>;
+    using X3 = std::integral_constant<int, 3>;
     int rc;
-    if (A.stats) rc = xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
+    if (xf == 3) rc = A.stats ? -1 : launch(X3{}, std::false_type{});
+    else if (A.stats) rc = xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
     else rc = xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
     if (rc != CDNET_OK) return rc;
     return check_launch("conv_ws_kernel");
@@ -1609,11 +1646,25 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, st) : try_launch_conv_ws<32, 9>(A, st);
         if (rc >= 0) return rc;
     }
+    for (int i = 0; i < A.nsrc; ++i)
+        CDNET_REQUIRE(A.src[i].relu != 3, "cdnet_conv_forward: a BatchNorm-backward source (relu = 3) needs the producer / consumer kernel "
+                                          "(ask cdnet_conv_ws_eligible first)");
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }
     if (A.debug & 32) { ConvArgs B = A; B.debug = 0; if (B.taps == 9) return dispatch_conv<9>(B, st); if (B.taps == 4) return dispatch_conv<4>(B, st); return dispatch_conv<1>(B, st); }
     if (A.taps == 9) return dispatch_conv<9>(A, st);
     if (A.taps == 4) return dispatch_conv<4>(A, st);
     return dispatch_conv<1>(A, st);
+}
+
+/* 1 when cdnet_conv_forward would run these arguments on conv_ws_kernel (the only kernel that takes BatchNorm-backward sources) */
+extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
+    if (!args) return 0;
+    const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
+    static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
+    if (A.f32 || !use_ws || (A.debug & 32)) return 0;
+    if (!(A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32))) return 0;
+    const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, nullptr, true) : try_launch_conv_ws<32, 9>(A, nullptr, true);
+    return rc == CDNET_OK ? 1 : 0;
 }
 
 extern "C" int cdnet_src_materialize(const cdnet_conv_src *src, int N, int H, int W, uint16_t *out, void *stream) {

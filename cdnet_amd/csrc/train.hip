@@ -1630,6 +1630,63 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     return check_launch("cdnet_bn_backward");
 }
 
+// The two passes of cdnet_bn_backward as separate calls, for the plain case (one same-size gradient source, BatchNorm + ReLU, no
+// residual, 16-bit tensors): `stats` = reduce + finalize and the [7][C] table scale | shift | mean | invstd | k1 | k2 | k3 that both
+// the apply pass and a fused consumer (cdnet_conv_src.relu = 3) read; `apply` = the second pass alone.  The trainer runs `stats`
+// on the main chain, backward-data with the fused source right behind it, and `apply` + the weight gradient on the side stream.
+static bool bn_plain_case(const BnBwdArgs &A) {
+    const GradIn &g = A.gin[0];
+    return A.ngin == 1 && !g.pooled && g.oy == 0 && g.ox == 0 && g.Hg == A.H && g.Wg == A.W && A.mean && A.scale && A.shift && A.invstd && !A.res &&
+           A.relu == 1 && A.f16 != 2 && (g.cstride == 0 || g.cstride == A.C) && g.coff == 0;
+}
+
+__global__ void bn_ktab_copy_kernel(const float *scale, const float *shift, const float *mean, const float *invstd, int C, float *ktab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { ktab[c] = scale[c]; ktab[C + c] = shift[c]; ktab[2 * C + c] = mean[c]; ktab[3 * C + c] = invstd[c]; }
+}
+
+extern "C" int cdnet_bn_backward_stats(const cdnet_bn_bwd_args *a, const float *gamma, float *dgamma, float *dbeta, float *workspace,
+                                       size_t workspace_floats, float *ktab, void *stream) {
+    BnBwdArgs A;
+    int rc = fill_bn_args(a, A, "cdnet_bn_backward_stats");
+    if (rc) return rc;
+    CDNET_REQUIRE(bn_plain_case(A) && gamma && workspace && ktab, "cdnet_bn_backward_stats: plain case only (one same-size gradient, BatchNorm + ReLU, no residual)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)A.N * A.H * A.W;
+    CDNET_REQUIRE(npix * (size_t)A.C < ((size_t)1 << 32) && npix < ((size_t)1 << 31), "cdnet_bn_backward_stats: tensor too large for 32-bit pixel indexing");
+    const int ppb = 256 / (A.C / 8);
+    int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
+    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    const size_t need = (size_t)nb * 2 * A.C;
+    if (workspace_floats < need) { set_error("cdnet_bn_backward_stats: workspace %zu < %zu floats", workspace_floats, need); return CDNET_E_WORKSPACE; }
+    A.partial = workspace;
+    A.draw = nullptr; A.dz_out = nullptr; A.rev = 0;
+    bn_ktab_copy_kernel<<<cdiv(A.C, 256), 256, 0, st>>>(A.scale, A.shift, A.mean, A.invstd, A.C, ktab);
+    bn_bwd_reduce_flat_kernel<1, false><<<nb, 256, 0, st>>>(A);
+    bn_bwd_finalize_kernel<<<A.C, 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, ktab + 4 * A.C, ktab + 5 * A.C,
+                                                 ktab + 6 * A.C);
+    return check_launch("cdnet_bn_backward_stats");
+}
+
+extern "C" int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *a, const float *ktab, uint16_t *draw, void *stream) {
+    BnBwdArgs A;
+    int rc = fill_bn_args(a, A, "cdnet_bn_backward_apply");
+    if (rc) return rc;
+    CDNET_REQUIRE(bn_plain_case(A) && ktab && draw, "cdnet_bn_backward_apply: plain case only");
+    const size_t npix = (size_t)A.N * A.H * A.W;
+    const int ppb = 256 / (A.C / 8);
+    int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
+    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
+    A.rev = rev;
+    A.draw = draw; A.dz_out = nullptr;
+    A.k1 = const_cast<float *>(ktab) + 4 * A.C; A.k2 = const_cast<float *>(ktab) + 5 * A.C; A.k3 = const_cast<float *>(ktab) + 6 * A.C;
+    bn_bwd_apply_flat_kernel<1, false><<<nb, 256, 0, (hipStream_t)stream>>>(A);
+    return check_launch("cdnet_bn_backward_apply");
+}
+
 extern "C" size_t cdnet_bn_backward_workspace_floats(int C) { return (size_t)BN_MAX_BLOCKS * 2 * C + 3 * (size_t)C; }
 
 static HeadFeat mk_hf(const cdnet_head_feat &f) {

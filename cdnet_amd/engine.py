@@ -36,7 +36,9 @@ class Src:
 
     def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0), view=None):
         assert x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.is_contiguous()
-        assert res is None or res.dtype == x.dtype
+        # relu = 3: BatchNorm-backward source (x = bf16 gradient, res = the layer's fp16 raw forward output, scale = the [7][C] table
+        # of cdnet_bn_backward_stats); every other source keeps its residual branch in the storage type of x
+        assert res is None or res.dtype == x.dtype or (relu == 3 and x.dtype == torch.bfloat16 and res.dtype == torch.float16)
         self.x, self.scale, self.shift, self.relu, self.pool, self.res, self.off = x, scale, shift, relu, pool, res, off
         if view is None:
             assert x.dim() == 4
@@ -190,7 +192,7 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -234,5 +236,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
         assert eres.f32 == f32
         a.eres, a.eres_scale, a.eres_shift = eres.x.data_ptr(), _dp(eres.scale), _dp(eres.shift)
         a.eres_f16, a.eres_relu = int(eres.f16), int(eres.relu)
+    if query_ws:                         # would this launch run on the producer / consumer kernel? (nothing is launched)
+        return bool(_lib.load().cdnet_conv_ws_eligible(C.byref(a)))
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

@@ -296,11 +296,25 @@ class Trainer:
         """one convolution layer: BatchNorm / residual / ReLU backward of its output, weight gradient (side stream), input gradient"""
         srcs, out, Hl, Wl = L.saved
         No, Ho, Wo, Co = out.shape
+        params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
+        if side is not None and self._fusable(L, srcs, out, gl, Hl, Wl):
+            # the second BatchNorm-backward pass leaves the critical chain: statistics here, backward-data applies the pass while it
+            # stages (cdnet_conv_src.relu = 3), the stored dRaw is produced beside it on the side stream for the weight gradient alone
+            a, ktab = self._bn_backward_stats(L, out, gl[0])
+            ev = self._event(k)
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
+                _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(draw), _lib.stream_ptr())
+                self._weight_backward(L, srcs, draw, Hl, Wl)
+                self._overlap_done(params)
+            self._input_backward(L, srcs, Src(gl[0].t, ktab, ktab, relu=3, res=out), Hl, Wl, add)
+            return
         if L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
             g = self._bn_backward(L, out, gl, add)
         else:
             g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
-        params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
         if side is None:
             self._weight_backward(L, srcs, g, Hl, Wl)
             self._overlap_done(params)
@@ -313,6 +327,56 @@ class Trainer:
                 self._weight_backward(L, srcs, g, Hl, Wl)
                 self._overlap_done(params)         # (a bucket released here is ordered after both streams' work so far)
         self._input_backward(L, srcs, g, Hl, Wl, add)
+
+    def _fusable(self, L, srcs, out, gl, H, W):
+        """plain BatchNorm + ReLU layer with one same-size gradient source whose backward-data launch runs on the producer / consumer
+        kernel (bf16 mode, 3x3, <= 256 output channels): see _layer_backward"""
+        # measured (bench.py, 16 tiles): the fused launch costs +45 us (the movers' per-element arithmetic makes them the slower half of the
+        # kernel) against the 30 us apply pass it takes off the chain, and the apply pass then competes with the chain from the side stream:
+        # 1 646 vs 1 683 tiles/s - off unless CDNET_BN_FUSE=1 (bit-identical either way: tests/test_gpu_train_step.py)
+        if os.environ.get('CDNET_BN_FUSE', '0') != '1' or runtime.act_dtype() != torch.bfloat16:
+            return False
+        No, Ho, Wo, Co = out.shape
+        if L.bn is None or len(gl) != 1 or getattr(L, 'node_res', None) is not None or not getattr(L, 'node_relu', True):
+            return False
+        g = gl[0]
+        if g.pooled or g.oy or g.ox or g.coff or (g.cstride not in (0, Co)) or (g.Hg, g.Wg) != (Ho, Wo):
+            return False
+        if L.kind != 'conv3' or L.transposed or not getattr(L, 'needs_input_grad', True) or Co > 256 or Co % 64:
+            return False
+        if out.dtype != torch.float16 or g.t.dtype != torch.bfloat16 or getattr(runtime, 'DEBUG_NORELU', False):
+            return False
+        key = ('fusable', L.name, No, H, W)
+        hit = self._bufs.get(key)
+        if hit is None:
+            cin_total = sum(s.C for s in srcs)
+            wpb, cfgb = L.backward_pack(cin_total, H, W)
+            ktab = self.buf(('ktab', L.name), (7, Co), torch.float32)
+            gin = self.buf(('din', L.name), (No, H, W, cin_total), runtime.act_dtype())
+            hit = engine.conv_forward([Src(g.t, ktab, ktab, relu=3, res=out)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W, query_ws=True)
+            self._bufs[key] = hit
+        return hit
+
+    def _bn_backward_stats(self, L, out, g):
+        a = BnBwdArgs()
+        No, Ho, Wo, Co = out.shape
+        a.raw = out.data_ptr()
+        a.res = None
+        a.scale, a.shift = L.scale.data_ptr(), L.shift.data_ptr()
+        a.mean, a.invstd = L.save_mean.data_ptr(), L.save_invstd.data_ptr()
+        a.ngin = 1
+        a.gin[0].g = g.t.data_ptr()
+        a.gin[0].Hg, a.gin[0].Wg, a.gin[0].oy, a.gin[0].ox = g.Hg, g.Wg, 0, 0
+        a.gin[0].pooled, a.gin[0].coff, a.gin[0].cstride = 0, 0, Co
+        a.f16 = 1
+        a.relu = 1
+        a.N, a.H, a.W, a.C = No, Ho, Wo, Co
+        ktab = self.buf(('ktab', L.name), (7, Co), torch.float32)
+        ws = self._bn_ws(Co)
+        bn = L.bn
+        _lib.call('cdnet_bn_backward_stats', C.byref(a), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.weight.grad), _lib.ptr(bn.bias.grad),
+                  _lib.ptr(ws), ws.numel(), _lib.ptr(ktab), _lib.stream_ptr())
+        return a, ktab
 
     def _bn_backward(self, L, out, gl, add):
         a = BnBwdArgs()
@@ -409,9 +473,10 @@ class Trainer:
                           _lib.ptr(ws), ws.numel(), _lib.ptr(L.bias.grad), _lib.stream_ptr())
 
     def _input_backward(self, L, srcs, g, H, W, add):
+        """g: the gradient w.r.t. the layer's raw output, or a prepared Src (BatchNorm-backward source of the fused path)"""
         if not getattr(L, 'needs_input_grad', True):
             return
-        N = g.shape[0]
+        N = g.N if isinstance(g, Src) else g.shape[0]
         Cout = L.Cout
         cin_total = sum(s.C for s in srcs)
         # input gradient: forward convolution with the backward-data pack
@@ -427,7 +492,7 @@ class Trainer:
             return
         if not L.transposed:
             gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())
-            engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
+            engine.conv_forward([g if isinstance(g, Src) else Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
         else:
             # space-to-depth view of g [N,2H,2W,Cout]: two row-parity sources of 2*Cout channels each
             gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())

@@ -174,3 +174,22 @@ def test_full_size_step_is_deterministic_and_learns():
     assert torch.equal(p1, p2) and np.array_equal(l1, l2)
     assert l1[-1, 0] < l1[0, 0]
     assert (l1[:, 6:] >= 0).all() and (l1[:, 6:] <= 1).all()          # the pixel-level metrics are ratios
+
+
+def test_fused_batchnorm_backward_source_is_bit_identical(monkeypatch):
+    """the second BatchNorm-backward pass applied by backward-data while it stages (cdnet_conv_src.relu = 3, producer / consumer
+    kernel; the stored dRaw then only feeds the weight gradient on the side stream) == the separate apply pass, bit for bit, on
+    every parameter gradient of a 128x128 step (full 16x16 tiles on the first three levels, so the fused path is taken)"""
+    import torch
+    from cdnet_amd import engine
+    grads = []
+    monkeypatch.setattr(engine, 'CONV_DEBUG', 64)          # the producer / consumer kernel also on launches this small
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('CDNET_BN_FUSE', fuse)
+        m, ref, x, t = _setup(B=2, S=128)
+        tr, g = _hip_grads(m, x, t)
+        if fuse == '1':
+            assert any(v is True for k, v in tr._bufs.items() if isinstance(k, tuple) and k and k[0] == 'fusable'), 'fused path not taken'
+        grads.append(g)
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
