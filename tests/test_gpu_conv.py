@@ -269,17 +269,21 @@ def test_ws_kernel_bit_identical_plain_stats_and_folded(case):
     _close(_nchw(bb[0]), want, 'ws plain')
 
 
-def test_ws_kernel_bit_identical_two_sources_residual_and_fused_epilogue():
+@pytest.mark.parametrize('chans', [(16, 48), (64, 64), (64, 128)])
+def test_ws_kernel_bit_identical_two_sources_residual_and_fused_epilogue(chans):
+    """two lazily transformed sources (a padded small one with an offset, one with a residual branch): 16 + 48 channels = the resident
+    form, 64 + 64 and 64 + 128 = the streamed-weights form; full 16x16 tiles so that the producer / consumer kernel takes the launch"""
     import torch
     from cdnet_amd import engine
     g = torch.Generator().manual_seed(3)
-    N, H, W = 2, 44, 52
-    a = _nhwc(torch.randn((N, 16, H - 1, W - 2), generator=g), torch.float16)          # padded small source (decoder up branch)
-    sa, ha = (torch.rand((16,), generator=g) + 0.5).cuda(), (torch.randn((16,), generator=g) * 0.3).cuda()
-    bsrc = _nhwc(torch.randn((N, 48, H, W), generator=g), torch.float16)
-    res = _nhwc(torch.randn((N, 48, H, W), generator=g), torch.float16)
-    sb, hb = (torch.rand((48,), generator=g) + 0.5).cuda(), (torch.randn((48,), generator=g) * 0.3).cuda()
-    w = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).cuda()
+    N, H, W = 2, 48, 64
+    ca, cb = chans
+    a = _nhwc(torch.randn((N, ca, H - 1, W - 2), generator=g), torch.float16)          # padded small source (decoder up branch)
+    sa, ha = (torch.rand((ca,), generator=g) + 0.5).cuda(), (torch.randn((ca,), generator=g) * 0.3).cuda()
+    bsrc = _nhwc(torch.randn((N, cb, H, W), generator=g), torch.float16)
+    res = _nhwc(torch.randn((N, cb, H, W), generator=g), torch.float16)
+    sb, hb = (torch.rand((cb,), generator=g) + 0.5).cuda(), (torch.randn((cb,), generator=g) * 0.3).cuda()
+    w = (torch.randn((64, ca + cb, 3, 3), generator=g) * 0.05).cuda()
     cfg = (16, 16, 64)
     wp = engine.pack_weights(w, cfg, 0)
     e = _nhwc(torch.randn((N, 64, H, W), generator=g), torch.float16)
@@ -289,7 +293,9 @@ def test_ws_kernel_bit_identical_two_sources_residual_and_fused_epilogue():
     def run():
         srcs = [engine.Src(a, sa, ha, relu=True, off=(1, 1)), engine.Src(bsrc, sb, hb, relu=True, res=res)]
         o1, st = engine.conv_forward(srcs, wp, 64, cfg, stats=True, H=H, W=W, out_dtype=torch.float16)
-        o2, _ = engine.conv_forward(srcs, wp, 64, cfg, bias=bias, H=H, W=W, eres=engine.Src(e, esc, esh, relu=True))       # fused residual epilogue
+        o2, _ = engine.conv_forward(srcs, wp, 64, cfg, bias=bias, H=H, W=W, eres=engine.Src(e, esc, esh, relu=True))       # fused residual epilogue (conv_fwd_kernel in both runs)
+        # the launch really is the producer / consumer kernel's
+        assert engine.conv_forward(srcs, wp, 64, cfg, stats=True, H=H, W=W, out_dtype=torch.float16, query_ws=True) == (engine.CONV_DEBUG == 64)
         return o1.clone(), st.clone(), o2.clone()
     x, y = _run_both(run)
     for u, v in zip(x, y):
@@ -302,7 +308,7 @@ def test_ws_kernel_backward_data_view_sources():
     import torch
     from cdnet_amd import engine
     g = torch.Generator().manual_seed(4)
-    N, Cin, Cout, H, W = 2, 32, 16, 24, 40
+    N, Cin, Cout, H, W = 2, 32, 16, 32, 48          # full 16x16 tiles: the launch is the producer / consumer kernel's
     w = (torch.randn((Cin, Cout, 4, 4), generator=g) * 0.1).cuda()
     dy = _nhwc(torch.randn((N, Cout, 2 * H, 2 * W), generator=g))
     cfg = (16, 16, 32)
