@@ -25,6 +25,7 @@ SIGNATURES = {
     'cdnet_s2d_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_bn_backward_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'cdnet_bn_backward_apply': (_i, [_vp, _vp, _vp, _vp]),
+    'cdnet_bn_backward_finalize': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'cdnet_conv_ws_eligible': (_i, [_vp]),
     'cdnet_grad_sum': (_i, [_vp, _i, _vp, C.c_longlong, _i, _vp, _vp]),
     'cdnet_grad_sum_f32': (_i, [_vp, _i, _vp, C.c_longlong, _i, _vp, _vp]),

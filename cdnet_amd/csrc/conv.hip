@@ -854,7 +854,13 @@ typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 // STREAM: more than four chunks per tile (128+ input channels, two-source layers) - the weight tile no longer fits the LDS; its
 // chunks then stream through a four-slot ring by LDS-DMA, two chunks ahead of the consumers, beside the halo ring.
 // The launcher guarantees nchunk % 4 == 0 (== 4 without STREAM) and full tiles (H, W multiples of 16).
-template <int BN, int TAPS, int XF, bool STATS, bool STREAM>
+// BNS (cdnet_conv_args.ws == 2, backward-data launches): the output is the gradient w.r.t. the activated output of a BatchNorm + ReLU
+// layer whose only consumer this convolution was - the movers, who hold every finished output vector in registers on its way to
+// global memory, also fetch the matching vector of that layer's raw forward output and accumulate the first BatchNorm-backward
+// pass (sum of dz, sum of dz * xhat per channel): eres = raw fp16 [N][H][W][Cout], oscale | oshift | eres_scale | eres_shift = that
+// layer's BatchNorm scale | shift | mean | invstd (f32 [Cout] each), stats = f32 partial rows [4 * gridDim.x][2][Cout] for the
+// finalize pass (cdnet_bn_backward_finalize).
+template <int BN, int TAPS, int XF, bool STATS, bool STREAM, bool BNS = false>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     using L = WsLds<BN, TAPS>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
@@ -1057,6 +1063,35 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int pw = wave - 4;
         const int lg = lane >> 4, li = lane & 15;
         const unsigned char *s_img = lds_o + pw * L::OUT_WAVE + (li >> 2) * L::IROW + (li & 3) * 8;
+        // BNS: the raw forward vectors of the finished tile (requested one interval before they are used) and this lane's running sums
+        // for its KO cout octets
+        u32x4v rawv[BNS ? NP : 1];
+        float bs1[BNS ? KO : 1][8], bs2[BNS ? KO : 1][8], bsc[BNS ? KO : 1][8], bsh[BNS ? KO : 1][8], bmu_[BNS ? KO : 1][8], bis_[BNS ? KO : 1][8];
+        if (BNS) {
+#pragma unroll
+            for (int kk = 0; kk < KO; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = cout0 + 8 * (lg + 4 * kk) + j;
+                    const bool cok = c < A.Cout;
+                    bs1[kk][j] = 0.f; bs2[kk][j] = 0.f;
+                    bsc[kk][j] = cok ? A.oscale[c] : 1.f;
+                    bsh[kk][j] = cok ? A.oshift[c] : 0.f;
+                    bmu_[kk][j] = cok ? A.eres_scale[c] : 0.f;
+                    bis_[kk][j] = cok ? A.eres_shift[c] : 0.f;
+                }
+        }
+        auto request_raw = [&](int rn, int ry0, int rx0) {
+            if (!BNS) return;
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
+                const int o = lg + 4 * kk;
+                const int y = ry0 + pw * 4 + mi * 2 + ch, x = rx0 + li, co = cout0 + 8 * o;
+                const size_t e = co < A.Cout ? (((size_t)rn * A.H + y) * A.W + x) * A.Cout + co : 0;
+                rawv[BNS ? pc : 0] = *reinterpret_cast<const u32x4v *>(A.eres + e);
+            }
+        };
         auto store_pieces = [&](bool now) {
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
@@ -1070,6 +1105,20 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 if (now && s_ok && co < A.Cout) {
                     const uint2 a = __builtin_bit_cast(uint2, t1), b2 = __builtin_bit_cast(uint2, t2);
                     *reinterpret_cast<uint4 *>(A.out + (((size_t)s_n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = make_uint4(a.x, a.y, b2.x, b2.y);
+                    if (BNS) {
+                        // the arithmetic of bn_bwd_reduce_flat_kernel<1, false> (train.hip), element for element
+                        V16 g8, r8;
+                        g8.u = make_uint4(a.x, a.y, b2.x, b2.y);
+                        r8.u = __builtin_bit_cast(uint4, rawv[BNS ? pc : 0]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xr = h2f(r8.h[j]);
+                            const float v = fmaf(xr, bsc[BNS ? kk : 0][j], bsh[BNS ? kk : 0][j]);
+                            const float dz = !(bf2f(f2bf(v)) > 0.f) ? 0.f : bf2f(g8.h[j]);
+                            bs1[BNS ? kk : 0][j] += dz;
+                            bs2[BNS ? kk : 0][j] = fmaf(dz, (xr - bmu_[BNS ? kk : 0][j]) * bis_[BNS ? kk : 0][j], bs2[BNS ? kk : 0][j]);
+                        }
+                    }
                 }
             }
         };
@@ -1142,7 +1191,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         // of tile j+1 and the out image of tile j-1 leaves for global memory.
         if (!STREAM) {
             for (int q0 = 0; q0 < S; q0 += 4) {
-                WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); WS_STAMP(3); __syncthreads();
+                WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); request_raw(s_n, s_y0, s_x0); WS_STAMP(3); __syncthreads();
                 WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); store_pieces(true); WS_STAMP(3); __syncthreads();
                 s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
                 o_x0 += TW;
@@ -1159,7 +1208,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 commit(I2{}, q0 + 2); commit(I3{}, q0 + 3);
                 dma_w(); dma_w();
                 issue(I2{}); issue(I3{});
-                stream_sync(NHL{});
+                if (BNS && it == 0) {
+                    request_raw(s_n, s_y0, s_x0);
+                    stream_sync(std::integral_constant<int, 2 * NA + (BNS ? NP : 0)>{});      // the raw requests are younger than the halo requests
+                } else {
+                    stream_sync(NHL{});
+                }
                 store_pieces(it == 0);
                 commit(I0{}, q0 + 4); commit(I1{}, q0 + 5);
                 dma_w(); dma_w();
@@ -1173,8 +1227,23 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 }
             }
         }
+        request_raw(s_n, s_y0, s_x0);
         __syncthreads();                                         // the consumers have parked the last tile's out image
         store_pieces(true);
+        if (BNS) {
+            // one partial row per mover wave: the 16 lanes of a group hold the same cout octets for 16 different pixels
+            float *row = A.stats + (size_t)(blockIdx.x * 4 + pw) * 2 * A.Cout;
+#pragma unroll
+            for (int kk = 0; kk < KO; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = bs1[BNS ? kk : 0][j], b2 = bs2[BNS ? kk : 0][j];
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
+                    const int c = cout0 + 8 * (lg + 4 * kk) + j;
+                    if (li == 0 && c < A.Cout) { row[c] = a; row[A.Cout + c] = b2; }
+                }
+        }
 #ifdef CDNET_WS_STAMPS
         if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[1024 + i] = s_stamp[i]; g_ws_stamps[1024 + sn] = 0; }
 #endif
@@ -1218,8 +1287,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     for (int ni = 0; ni < NPW; ++ni) {
         const int co = cout0 + ni * 32 + l31;
         const bool cok = co < A.Cout;
-        e_osc[ni] = (A.oscale && cok) ? A.oscale[co] : 1.f;
-        e_osh[ni] = fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
+        e_osc[ni] = (!BNS && A.oscale && cok) ? A.oscale[co] : 1.f;
+        e_osh[ni] = BNS ? 0.f : fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
     }
     const bool f16out = A.out_f16 != 0;
     const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
@@ -1385,7 +1454,10 @@ template <int BN, int TAPS>
 int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) {
     using L = WsLds<BN, TAPS>;
     int ctot = 0;
-    if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
+    const bool bns = A.ws == 2;                                  // BatchNorm-backward statistics of the output beside the stores (eres = raw)
+    if (A.eres && !bns) return -1;                               // fused residual epilogues stay on conv_fwd_kernel
+    if (bns && (!A.eres || !A.oscale || !A.oshift || !A.eres_scale || !A.eres_shift || !A.stats || A.bias || A.orelu || A.out_f16 ||
+                A.out_cstride != A.Cout || A.out_coff)) return -1;
     if (A.nchunk < 4 || A.nchunk % 4 != 0) return -1;            // whole pairs of barrier intervals (two chunks each) per tile
     const bool stream = A.nchunk != 4;                           // 128+ input channels / two sources: the weight chunks stream through the LDS
     if (A.H % 16 != 0 || A.W % 16 != 0) return -1;               // full tiles only
@@ -1447,12 +1519,24 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) 
         return stream ? launch2(xf_c, st_c, std::true_type{}) : launch2(xf_c, st_c, std::false_type{});
     };
     const int xf = bnb ? 3 : (all_plain ? 0 : (all_fast ? 1 : 2));
+    if (bns && xf != 0) return -1;
     if (dry_run) return CDNET_OK;
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
     using X2 = std::integral_constant<int, 2>;
     using X3 = std::integral_constant<int, 3>;
     int rc;
+    if (bns) {
+        auto kern = stream ? conv_ws_kernel<BN, TAPS, 0, false, true, true> : conv_ws_kernel<BN, TAPS, 0, false, false, true>;
+        static bool attr_done[2] = {false, false};
+        if (!attr_done[stream]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(conv_ws)");
+            attr_done[stream] = true;
+        }
+        kern<<<grid, 512, smem, st>>>(A);
+        return check_launch("conv_ws_kernel");
+    }
     if (xf == 3) rc = A.stats ? -1 : launch(X3{}, std::false_type{});
     else if (A.stats) rc = xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
     else rc = xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
@@ -1612,7 +1696,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         for (int i = 0; i < A.nsrc; ++i) ctot_xf += A.src[i].C;
         CDNET_REQUIRE(ctot_xf <= XF_MAX, "cdnet_conv_forward: %d source channels exceed the %d-entry scale/shift table", ctot_xf, XF_MAX);
     }
-    CDNET_REQUIRE(A.ws == 0, "cdnet_conv_forward: ws must be 0 (reserved)");
+    CDNET_REQUIRE(A.ws == 0 || A.ws == 2, "cdnet_conv_forward: ws must be 0 or 2 (BatchNorm-backward statistics epilogue)");
     if (A.f32) {
         CDNET_REQUIRE(A.f32 == 1, "cdnet_conv_forward: f32 must be 0 or 1");
         for (int i = 0; i < A.nsrc; ++i)
@@ -1621,7 +1705,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         for (int i = 0; i < A.nsrc; ++i)
             CDNET_REQUIRE(A.src[i].f16 == 0 || A.src[i].f16 == 1, "cdnet_conv_forward: fp32 sources need args.f32 = 1");
     }
-    if (A.eres) {
+    if (A.eres && A.ws != 2) {
         CDNET_REQUIRE(A.ostride == 1 && A.npar == 1 && A.out_coff == 0 && A.out_cstride == A.Cout && !A.stats && !A.orelu &&
                       !A.out_f16 && ((A.eres_scale == nullptr) == (A.eres_shift == nullptr)),
                       "cdnet_conv_forward: fused residual epilogue needs a dense bf16 output, no statistics and no ReLU before the add");
@@ -1649,6 +1733,8 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     for (int i = 0; i < A.nsrc; ++i)
         CDNET_REQUIRE(A.src[i].relu != 3, "cdnet_conv_forward: a BatchNorm-backward source (relu = 3) needs the producer / consumer kernel "
                                           "(ask cdnet_conv_ws_eligible first)");
+    CDNET_REQUIRE(A.ws != 2, "cdnet_conv_forward: the BatchNorm-backward statistics epilogue (ws = 2) needs the producer / consumer kernel "
+                             "(ask cdnet_conv_ws_eligible first)");
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }
     if (A.debug & 32) { ConvArgs B = A; B.debug = 0; if (B.taps == 9) return dispatch_conv<9>(B, st); if (B.taps == 4) return dispatch_conv<4>(B, st); return dispatch_conv<1>(B, st); }
     if (A.taps == 9) return dispatch_conv<9>(A, st);

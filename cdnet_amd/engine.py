@@ -192,7 +192,7 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -236,6 +236,11 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
         assert eres.f32 == f32
         a.eres, a.eres_scale, a.eres_shift = eres.x.data_ptr(), _dp(eres.scale), _dp(eres.shift)
         a.eres_f16, a.eres_relu = int(eres.f16), int(eres.relu)
+    if bns is not None:                  # BatchNorm-backward statistics of the output beside the stores (cdnet_conv_args.ws = 2)
+        raw, sc, sh, mu, inv, partial = bns
+        assert eres is None and stats is None and bias is None and oscale is None and oshift is None and tuple(raw.shape) == tuple(out.shape)
+        a.ws = 2
+        a.eres, a.oscale, a.oshift, a.eres_scale, a.eres_shift, a.stats = raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), partial.data_ptr()
     if query_ws:                         # would this launch run on the producer / consumer kernel? (nothing is launched)
         return bool(_lib.load().cdnet_conv_ws_eligible(C.byref(a)))
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())

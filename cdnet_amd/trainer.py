@@ -264,6 +264,17 @@ class Trainer:
         """walk the forward tape backwards: BatchNorm(+ReLU, residual, pool/pad/concat routing) backward, then the
         weight and input gradients of every convolution that received a gradient"""
         self._cat_cache = {}
+        # who reads what: a BatchNorm layer whose raw output has exactly one reader - a 3x3 convolution - gets the first pass of its
+        # backward (the channel sums) from that reader's backward-data launch (_input_backward), see _stats_fusable
+        self._readers, self._producer, self._bn_partials = {}, {}, {}
+        for Lt in self.tape:
+            if isinstance(Lt, runtime.FuseNode):
+                continue
+            for sx in Lt.saved[0]:
+                self._readers[id(sx.x)] = self._readers.get(id(sx.x), 0) + 1
+                if sx.res is not None:
+                    self._readers[id(sx.res)] = self._readers.get(id(sx.res), 0) + 1
+            self._producer[id(Lt.saved[1])] = Lt
         side = self._side_stream()
         if self._packb_pending:
             torch.cuda.current_stream().wait_event(self._event('packb'))      # backward-data packs made beside the forward
@@ -297,7 +308,13 @@ class Trainer:
         srcs, out, Hl, Wl = L.saved
         No, Ho, Wo, Co = out.shape
         params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
-        if side is not None and self._fusable(L, srcs, out, gl, Hl, Wl):
+        part = self._bn_partials.pop(id(out), None)
+        if part is not None:
+            # the reader's backward-data launch left the channel sums: finalize + second pass only
+            a, ktab = self._bn_backward_stats(L, out, gl[0], partial=part)
+            g = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
+            _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(g), _lib.stream_ptr())
+        elif side is not None and self._fusable(L, srcs, out, gl, Hl, Wl):
             # the second BatchNorm-backward pass leaves the critical chain: statistics here, backward-data applies the pass while it
             # stages (cdnet_conv_src.relu = 3), the stored dRaw is produced beside it on the side stream for the weight gradient alone
             a, ktab = self._bn_backward_stats(L, out, gl[0])
@@ -311,7 +328,9 @@ class Trainer:
                 self._overlap_done(params)
             self._input_backward(L, srcs, Src(gl[0].t, ktab, ktab, relu=3, res=out), Hl, Wl, add)
             return
-        if L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
+        if part is not None:
+            pass
+        elif L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
             g = self._bn_backward(L, out, gl, add)
         else:
             g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
@@ -357,7 +376,7 @@ class Trainer:
             self._bufs[key] = hit
         return hit
 
-    def _bn_backward_stats(self, L, out, g):
+    def _bn_backward_stats(self, L, out, g, partial=None):
         a = BnBwdArgs()
         No, Ho, Wo, Co = out.shape
         a.raw = out.data_ptr()
@@ -372,11 +391,46 @@ class Trainer:
         a.relu = 1
         a.N, a.H, a.W, a.C = No, Ho, Wo, Co
         ktab = self.buf(('ktab', L.name), (7, Co), torch.float32)
-        ws = self._bn_ws(Co)
         bn = L.bn
+        if partial is not None:
+            _lib.call('cdnet_bn_backward_finalize', C.byref(a), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.weight.grad), _lib.ptr(bn.bias.grad),
+                      _lib.ptr(partial), partial.shape[0], _lib.ptr(ktab), _lib.stream_ptr())
+            return a, ktab
+        ws = self._bn_ws(Co)
         _lib.call('cdnet_bn_backward_stats', C.byref(a), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.weight.grad), _lib.ptr(bn.bias.grad),
                   _lib.ptr(ws), ws.numel(), _lib.ptr(ktab), _lib.stream_ptr())
         return a, ktab
+
+    def _stats_fusable(self, L, srcs, H, W, N, wpb, cfgb, cin_total):
+        """the single lazily transformed BatchNorm + ReLU source of a 3x3 convolution that is its only reader, and a backward-data
+        launch that runs on the producer / consumer kernel: returns (producer layer, partial-row buffer) or None"""
+        # measured (bench.py, 16 tiles): 11 reduce passes per step disappear (-0.9 ms of kernel time) but the launches that carry the sums
+        # cost +16 ... +33 us each (the movers' per-element arithmetic) and the step does not get shorter (1 643-1 659 vs 1 656-1 666
+        # tiles/s): off unless CDNET_BN_STATS_FUSE=1
+        if os.environ.get('CDNET_BN_STATS_FUSE', '0') != '1' or runtime.act_dtype() != torch.bfloat16 or getattr(runtime, 'DEBUG_NORELU', False):
+            return None
+        if L.kind != 'conv3' or L.transposed or len(srcs) != 1:
+            return None
+        sx = srcs[0]
+        if getattr(sx, 'is_input', False) or sx.scale is None or sx.shift is None or sx.relu is not True or sx.res is not None or sx.pool \
+                or tuple(sx.off) != (0, 0) or sx.x.dtype != torch.float16 or hasattr(sx, 'grad_to') or sx.row_stride:
+            return None
+        P = self._producer.get(id(sx.x))
+        if P is None or P.bn is None or getattr(P, 'node_res', None) is not None or getattr(P, 'node_relu', True) is not True \
+                or self._readers.get(id(sx.x), 0) != 1 or tuple(sx.x.shape) != (N, H, W, cin_total):
+            return None
+        key = ('statsfusable', L.name, N, H, W)
+        hit = self._bufs.get(key)
+        if hit is None:
+            part = torch.zeros((1024, 2, cin_total), dtype=torch.float32, device=self.dev)
+            gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())
+            gdummy = self.buf(('draw', L.name), (N, H, W, L.Cout), runtime.act_dtype())
+            ok = engine.conv_forward([Src(gdummy)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W, query_ws=True,
+                                     bns=(sx.x, P.scale, P.shift, P.save_mean, P.save_invstd, part))
+            hit = self._bufs[key] = (part if ok else False)
+        if hit is False:
+            return None
+        return P, hit
 
     def _bn_backward(self, L, out, gl, add):
         a = BnBwdArgs()
@@ -492,7 +546,15 @@ class Trainer:
             return
         if not L.transposed:
             gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())
-            engine.conv_forward([g if isinstance(g, Src) else Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
+            fuse = None if isinstance(g, Src) else self._stats_fusable(L, srcs, H, W, N, wpb, cfgb, cin_total)
+            if fuse is not None:
+                # this launch also leaves the channel sums of the BatchNorm backward of its only source's producer
+                P, part = fuse
+                engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W,
+                                    bns=(srcs[0].x, P.scale, P.shift, P.save_mean, P.save_invstd, part))
+                self._bn_partials[id(srcs[0].x)] = part
+            else:
+                engine.conv_forward([g if isinstance(g, Src) else Src(g)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W)
         else:
             # space-to-depth view of g [N,2H,2W,Cout]: two row-parity sources of 2*Cout channels each
             gin = self.buf(('din', L.name), (N, H, W, cin_total), runtime.act_dtype())

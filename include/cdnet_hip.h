@@ -330,6 +330,12 @@ size_t cdnet_bn_backward_workspace_floats(int C);
 int cdnet_bn_backward_stats(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, float *workspace,
                             size_t workspace_floats, float *ktab, void *stream);
 int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *args, const float *ktab, uint16_t *draw, void *stream);
+/* The finalize pass alone, over partial rows f32 [nb][2][C] produced by the backward-data launch that computed this layer's output
+ * gradient: cdnet_conv_args.ws = 2 with eres = the layer's raw fp16 forward output [N][H][W][Cout], oscale / oshift / eres_scale /
+ * eres_shift = its BatchNorm scale / shift / batch mean / invstd (f32 [Cout]), stats = the partial rows (4 per workgroup of the
+ * producer / consumer kernel, at most 1024: zero-fill the buffer once and pass nb = 1024).  The first BatchNorm-backward pass then costs no pass of its own over the two tensors. */
+int cdnet_bn_backward_finalize(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, const float *partial,
+                               int nb, float *ktab, void *stream);
 int cdnet_bn_backward(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, float *workspace,
                       size_t workspace_floats, uint16_t *draw, uint16_t *dz_out, void *stream);
 

@@ -193,3 +193,36 @@ def test_fused_batchnorm_backward_source_is_bit_identical(monkeypatch):
         grads.append(g)
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+def test_channel_sums_from_the_backward_data_launch_match_the_separate_pass(monkeypatch):
+    """first BatchNorm-backward pass (sum dz, sum dz * xhat) accumulated by the movers of the backward-data launch that produced the
+    gradient (cdnet_conv_args.ws = 2 + cdnet_bn_backward_finalize) against the separate reduce pass: same arithmetic per element,
+    another summation order - the sums of the first fused layer met by backward agree to 2e-6, everything below within the usual
+    conditioning of this network's gradients"""
+    import torch
+    from cdnet_amd import engine
+    grads, taken = [], None
+    monkeypatch.setattr(engine, 'CONV_DEBUG', 64)          # the producer / consumer kernel also on launches this small
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('CDNET_BN_STATS_FUSE', fuse)
+        m, ref, x, t = _setup(B=2, S=128)
+        tr, g = _hip_grads(m, x, t)
+        if fuse == '1':
+            taken = [k[1] for k, v in tr._bufs.items() if isinstance(k, tuple) and k and k[0] == 'statsfusable' and v is not False]
+        grads.append(g)
+    assert len(taken) >= 6, taken
+    # the first fused layer met by backward (point_feature.conv1: its gradient arrives from point_feature.conv2's backward-data launch,
+    # everything upstream of it is identical in both runs): the channel sums themselves, to fp32 summation-order accuracy
+    for n in ('point_feature.bn1.weight', 'point_feature.bn1.bias'):
+        a, b = grads[0][n], grads[1][n]
+        assert float((a - b).norm() / a.norm()) <= 2e-6, (n, float((a - b).norm() / a.norm()))
+    # everything below inherits the usual amplification of a 1e-7 perturbation through ReLU / max-pool decisions (DESIGN.md section 6)
+    rel = {}
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        if float(a.norm()) >= 1e-6:
+            rel[n] = float((a - b).norm() / a.norm())
+    worst = max(rel, key=rel.get)
+    assert np.median(list(rel.values())) <= 3e-2, np.median(list(rel.values()))      # measured 1e-2 (the oracle moves as much under a 1e-6 weight perturbation)
+    assert rel[worst] <= 1e-1, (worst, rel[worst])
