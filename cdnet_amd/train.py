@@ -38,6 +38,23 @@ class _SyntheticLoader:
         return len(self.items)
 
 
+def _dataset_layout(opt, x, logger=None):
+    """directories and file suffixes of split `x` as the reference lays them out (train.py:216-288): with validation = 1 the targets
+    are instance-level label files under <label_dir>/<x>_ins ('label.mat' for CPM2017 / MultiOrgan, 'label.npy' otherwise; CPM2017
+    validates on its test split), with validation = 0 three-class 'label.png' under <label_dir>/<x>.  Falls back to the other
+    layout when only that one exists on disk."""
+    tr = opt.train
+    split = 'test' if (opt.dataset == 'CPM2017' and x == 'val' and tr['validation'] == 1) else x
+    img, wmap = '{:s}/{:s}'.format(tr['img_dir'], split), '{:s}/{:s}'.format(tr['weight_map_dir'], split)
+    ins = ('{:s}/{:s}_ins'.format(tr['label_dir'], split), ['weight.png', 'label.mat' if opt.dataset in ('CPM2017', 'MultiOrgan') else 'label.npy'])
+    png = ('{:s}/{:s}'.format(tr['label_dir'], split), ['weight.png', 'label.png'])
+    first, second = (ins, png) if tr['validation'] == 1 else (png, ins)
+    pick = first if os.path.isdir(first[0]) or not os.path.isdir(second[0]) else second
+    if pick is second and logger is not None:
+        logger.info('{:s} not found: using {:s} ({:s})'.format(first[0], second[0], second[1][1]))
+    return [img, wmap, pick[0]], pick[1]
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--synthetic', type=int, default=0, help='number of synthetic batches per epoch (0 = read the dataset folders)')
@@ -79,9 +96,8 @@ def main(argv=None):
     else:
         # train.py:262-290 without validation split: <img_dir>/train, <weight_map_dir>/train, <label_dir>/train
         from .data_folder import DataFolder, TileBatches
-        sub = 'train'
-        dir_list = ['{:s}/{:s}'.format(opt.train[k], sub) for k in ('img_dir', 'weight_map_dir', 'label_dir')]
-        dset = DataFolder(dir_list, ['weight.png', 'label.png'], [3, 1, 3])
+        dir_list, post_fix = _dataset_layout(opt, 'train', logger)
+        dset = DataFolder(dir_list, post_fix, [3, 1, 3])
         loader = TileBatches(dset, opt.transform['train'], B, dev, seed=opt.train['seed'] + 1000 * rank, logger=logger)
         logger.info('{:d} training images in {:s}'.format(len(dset), dir_list[0]))
     # validation set (train.py:262-290: <img_dir>/val etc.) for the best-checkpoint / early-stopping logic of train.py:348-447
@@ -91,9 +107,9 @@ def main(argv=None):
             val_loader = _SyntheticLoader(max(1, own.synthetic_val), B, dev, seed=opt.train['seed'] + 777 + 1000 * rank)
         else:
             from .data_folder import DataFolder, TileBatches
-            vdirs = ['{:s}/val'.format(opt.train[k]) for k in ('img_dir', 'weight_map_dir', 'label_dir')]
+            vdirs, vfix = _dataset_layout(opt, 'val', logger)
             if all(os.path.isdir(d) for d in vdirs):
-                vset = DataFolder(vdirs, ['weight.png', 'label.png'], [3, 1, 3])
+                vset = DataFolder(vdirs, vfix, [3, 1, 3])
                 vt = {k: v for k, v in opt.transform['train'].items() if k in ('random_crop', 'label_encoding', 'to_tensor', 'normalize')}
                 val_loader = TileBatches(vset, vt, 1, dev, seed=opt.train['seed'], shuffle=False, logger=logger)
             else:

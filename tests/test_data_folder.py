@@ -69,3 +69,26 @@ def test_constant_label_is_redrawn(tmp_path):
     ds = DataFolder(dirs, ['weight.png', 'label.png'], [3, 1, 3], data_transform=transform)
     out = ds[0]
     assert len(calls) == 3 and len(torch.unique(out[2])) > 1
+
+
+def test_dataset_layout_follows_the_reference(tmp_path):
+    """train.py:216-288: validation = 1 reads instance-level targets from <label_dir>/<split>_ins ('label.mat' for CPM2017 / MultiOrgan,
+    'label.npy' otherwise; CPM2017 validates on its test split), validation = 0 three-class 'label.png' from <label_dir>/<split>; when
+    only the other layout is on disk it is taken instead"""
+    import os
+    import types
+    from cdnet_amd import train
+    d = str(tmp_path)
+    for sub in ('images/train', 'weight_maps/train', 'labels/train_ins', 'labels/val', 'labels/test_ins'):
+        os.makedirs(os.path.join(d, sub))
+    opt = types.SimpleNamespace(dataset='MoNuSeg', train={'img_dir': d + '/images', 'weight_map_dir': d + '/weight_maps', 'label_dir': d + '/labels', 'validation': 1})
+    dirs, fix = train._dataset_layout(opt, 'train')
+    assert dirs == [d + '/images/train', d + '/weight_maps/train', d + '/labels/train_ins'] and fix == ['weight.png', 'label.npy']
+    dirs, fix = train._dataset_layout(opt, 'val')                      # only the png layout exists for this split
+    assert dirs[2] == d + '/labels/val' and fix == ['weight.png', 'label.png']
+    opt.train['validation'] = 0
+    dirs, fix = train._dataset_layout(opt, 'train')                    # only the instance layout exists for this split
+    assert dirs[2] == d + '/labels/train_ins' and fix[1] == 'label.npy'
+    opt.dataset, opt.train['validation'] = 'CPM2017', 1
+    dirs, fix = train._dataset_layout(opt, 'val')
+    assert dirs == [d + '/images/test', d + '/weight_maps/test', d + '/labels/test_ins'] and fix == ['weight.png', 'label.mat']
