@@ -97,10 +97,9 @@ def test_infer_image_pipeline_tta_windows_vs_whole_and_oracle():
             if xf & 4: a = np.rot90(a, k=3, axes=(-2, -1))
             return np.ascontiguousarray(a)
         probs.append(unflip(p)); points.append(unflip(t)); dcms.append(unflip(d)[None])
-    try:
-        want = orc.postprocess_views(np.stack(probs), np.stack(points), np.stack(dcms))
-    except AssertionError:
-        pytest.skip('random-weight network produced a constant direction view')
+    # (seeded weights and input: no view of this network has a constant direction map - the oracle asserts that, as the reference would
+    #  divide by zero in generate_dd_map's normalisation; a failure here is a failure, not a skip)
+    want = orc.postprocess_views(np.stack(probs), np.stack(points), np.stack(dcms))
     assert np.array_equal(r['pred'].cpu().numpy(), want['pred'])
     assert np.array_equal(r['final'].cpu().numpy(), want['final'])
     assert r['count'] == want['count']
