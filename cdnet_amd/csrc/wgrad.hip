@@ -714,31 +714,47 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
     wg_f32x4 pa_[NA][2], pg_[NG][2];
     int ea[NA];                          // element offset of the thread's i-th input vector, -1 = zero fill (tensors < 2^31 elements)
     unsigned gvalid = 0;
+    // what depends on the thread only - halo coordinates and in-tile offsets of its vectors - is computed once; a tile contributes one
+    // base offset (no integer divisions or 64-bit multiplies per vector and tile between the MFMA phases)
+    int hyx[NA], aoff[NA], gyx[NG], goff[NG];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int v = tid + i * NT32, pix = v / VA;
+        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+        hyx[i] = v < NPIX_A * VA ? ((hy << 16) | hx) : -1;
+        aoff[i] = hy * (int)rs + hx * s.C;
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int pix = tid / VG + i * (NT32 / VG);
+        const int py = pix / TW, px = pix % TW;
+        gyx[i] = (py << 16) | px;
+        goff[i] = (py * A.ostride * Wo + px * A.ostride) * A.Cout;
+    }
     auto issue = [&](int j) {
         const int tile = ks + j * A.ksplit;
         const int n = tile / tiles_img, rem = tile - n * tiles_img;
         const int ty = rem / tiles_x;
         const int y0 = ty * TH, x0 = (rem - ty * tiles_x) * TW;
+        const int abase_e = (n * s.Hs + (y0 - 1 - s.off_y)) * (int)rs + (x0 - 1 - s.off_x) * s.C + cbase;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int v = tid + i * NT32, pix = v / VA;
-            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+            const int hy = hyx[i] >> 16, hx = hyx[i] & 0xffff;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             const int ys = y - s.off_y, xs = x - s.off_x;
-            const bool ok = v < NPIX_A * VA && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
+            const bool ok = hyx[i] >= 0 && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
                             (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
-            ea[i] = ok ? (int)((size_t)n * s.Hs * rs + (size_t)ys * rs + (size_t)xs * s.C + cbase) : -1;
+            ea[i] = ok ? abase_e + aoff[i] : -1;
             const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sx + (ok ? ea[i] : 0));
             pa_[i][0] = pp[0];
             pa_[i][1] = pp[1];
         }
         gvalid = 0;
+        const size_t gbase_e = (((size_t)n * Ho + (y0 * A.ostride + pa)) * Wo + (x0 * A.ostride + pb)) * A.Cout + co;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-            const int pix = tid / VG + i * (NT32 / VG);
-            const int y = y0 + pix / TW, x = x0 + pix % TW;
-            const bool ok = cok_g && y < A.H && x < A.W;
-            const size_t e = ok ? (((size_t)n * Ho + (y * A.ostride + pa)) * Wo + (x * A.ostride + pb)) * A.Cout + co : 0;
+            const bool ok = cok_g && y0 + (gyx[i] >> 16) < A.H && x0 + (gyx[i] & 0xffff) < A.W;
+            const size_t e = ok ? gbase_e + goff[i] : 0;
             const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(gx + e);
             pg_[i][0] = pp[0];
             pg_[i][1] = pp[1];
@@ -809,17 +825,53 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
         commit();
         __syncthreads();
         if (j + 1 < ntl) issue(j + 1);
-#pragma unroll 2
-        for (int ky = 0; ky < TH; ++ky) {
-            const int gaddr = g_lane + ky * TW * PG;
-            const bf16x8 gh = frag2(gaddr, PG), gl = frag2(gaddr + G_BYTES, PG);
-            const int abase = a_lane + ky * HALO_W * PA;
+        if (TAPS == 9) {
+            // consecutive k-steps share two of their three halo rows: a ring of four rows of (hi, lo) fragments, every k-step reads one
+            // new row and one gradient fragment pair for its 27 MFMAs, one k-step ahead of their use (as wgrad_ws_kernel)
+            bf16x8 rh[4][3], rl[4][3], gqh[2], gql[2];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const bf16x8 ah = frag2(abase + tap_off(t), PA), al = frag2(abase + tap_off(t) + A_BYTES, PA);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[t], 0, 0, 0);
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    rh[r][kx] = frag2(a_lane + (r * HALO_W + kx) * PA, PA);
+                    rl[r][kx] = frag2(a_lane + (r * HALO_W + kx) * PA + A_BYTES, PA);
+                }
+            gqh[0] = frag2(g_lane, PG);
+            gql[0] = frag2(g_lane + G_BYTES, PG);
+#pragma unroll
+            for (int ky = 0; ky < TH; ++ky) {
+                if (ky + 1 < TH) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        rh[(ky + 3) & 3][kx] = frag2(a_lane + ((ky + 3) * HALO_W + kx) * PA, PA);
+                        rl[(ky + 3) & 3][kx] = frag2(a_lane + ((ky + 3) * HALO_W + kx) * PA + A_BYTES, PA);
+                    }
+                    gqh[(ky + 1) & 1] = frag2(g_lane + (ky + 1) * TW * PG, PG);
+                    gql[(ky + 1) & 1] = frag2(g_lane + (ky + 1) * TW * PG + G_BYTES, PG);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const bf16x8 ah = rh[(ky + t / 3) & 3][t % 3], al = rl[(ky + t / 3) & 3][t % 3];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gqh[ky & 1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gql[ky & 1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gqh[ky & 1], acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 2
+            for (int ky = 0; ky < TH; ++ky) {
+                const int gaddr = g_lane + ky * TW * PG;
+                const bf16x8 gh = frag2(gaddr, PG), gl = frag2(gaddr + G_BYTES, PG);
+                const int abase = a_lane + ky * HALO_W * PA;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const bf16x8 ah = frag2(abase + tap_off(t), PA), al = frag2(abase + tap_off(t) + A_BYTES, PA);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[t], 0, 0, 0);
+                }
             }
         }
     }
