@@ -200,7 +200,7 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):       # launched by torch.distributed.run (also with one rank)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
     import cdnet_amd
@@ -326,7 +326,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline_infer() if mode == 'infer' else cpu_baseline_train()
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()                    # rank 0 times the roofline kernel after the timed region: leave together
         dist.destroy_process_group()
 
