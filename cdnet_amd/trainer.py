@@ -102,7 +102,7 @@ class Trainer:
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.quirk = int(quirk_sample0)
         self.world = world_size
-        self.bucket = int(bucket_mb * (1 << 20) // 4)
+        self.bucket = int(float(os.environ.get('CDNET_BUCKET_MB', bucket_mb)) * (1 << 20) // 4)
         self.flat = FlatState(model)
         model._head_flat = self.flat.P[:self.flat.n_head] if self.flat.n_head == 855 else None
         self.dev = self.flat.P.device
