@@ -9,6 +9,7 @@ import torch
 from cdnet_amd import engine, _lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+BNS = os.environ.get('WS_BNS') == '1'          # backward-data launch that also accumulates the BatchNorm-backward channel sums
 EXTRA = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 train = len(sys.argv) > 2 and sys.argv[2] == 'train'
 dev = torch.device('cuda:0')
@@ -21,27 +22,28 @@ wp = engine.pack_weights(w, cfg, 0)
 out = torch.empty((B, 256, 256, 64), dtype=torch.bfloat16, device=dev)
 outh = torch.empty((B, 256, 256, 64), dtype=torch.float16, device=dev)
 stats = torch.empty((B * 256, 2, 64), dtype=torch.float32, device=dev)
+bns = (raw, sc, sh, sc * 0.1, sc, torch.zeros((1024, 2, 64), dtype=torch.float32, device=dev)) if BNS else None
 engine.CONV_DEBUG = 64
 for _ in range(5):
     if train:
         engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats)
     else:
-        engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+        engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out, bns=bns)
 torch.cuda.synchronize()
-for dbg, nm in ((32, 'conv_fwd_kernel'), (64 | EXTRA, 'conv_ws_kernel (stamped build, debug %d)' % EXTRA)):
+for dbg, nm in ((32, 'conv_fwd_kernel'), (64 | EXTRA, 'conv_ws_kernel (stamped build, debug %d)' % EXTRA))[(1 if BNS else 0):]:
     engine.CONV_DEBUG = dbg
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
-        engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats) if train else engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+        engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats) if train else engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out, bns=bns)
     e0.record()
     for _ in range(20):
-        engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats) if train else engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+        engine.conv_forward([engine.Src(raw, sc, sh, relu=True)], wp, 64, cfg, out=outh, stats=stats) if train else engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out, bns=bns)
     e1.record()
     torch.cuda.synchronize()
     print('%-32s %.1f us per launch' % (nm, e0.elapsed_time(e1) / 20 * 1e3))
 engine.CONV_DEBUG = 64 | EXTRA
 for _ in range(3):
-    engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+    engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out, bns=bns)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros(2048, dtype=np.uint64)
