@@ -201,7 +201,14 @@ __device__ __forceinline__ void load8(const float *p, int c0, float *o, float df
 
 // Both passes are pure streaming (HBM bound): every thread keeps BN_U independent pixels in flight per iteration.
 constexpr int BN_U = 4;
-constexpr int BN_MAX_BLOCKS = 2048;
+constexpr int BN_MAX_BLOCKS = 2048;      // workspace rows
+// blocks actually launched by the streaming passes: two 256-thread workgroups per CU keep 64-98 KB of loads in flight per CU, and the
+// finalize pass (one workgroup per channel walking the partial rows with a 2 * C stride) has a quarter of the rows to sum - measured
+// (bench.py, 16 tiles): 2048 blocks 1 641 tiles/s, 1024 1 645-1 655, 768 1 652-1 655, 512 1 654-1 663, 256 1 605-1 609
+static int bn_blocks_cap() {
+    static const int v = getenv("CDNET_BN_BLOCKS") ? atoi(getenv("CDNET_BN_BLOCKS")) : 512;
+    return v < 1 ? 1 : (v > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : v);
+}
 
 template <bool F32 = false>
 __device__ __forceinline__ void dz8_at(const BnBwdArgs &A, unsigned p, unsigned HW, int c0, const float *sc, const float *sh, const float *mu,
@@ -1575,7 +1582,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     CDNET_REQUIRE(npix * (size_t)A.C < ((size_t)1 << 32) && npix < ((size_t)1 << 31), "cdnet_bn_backward: tensor too large for 32-bit pixel indexing");
     const int ppb = 256 / (A.C / 8);
     int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
-    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     if (nb < 1) nb = 1;
     bool simple = true, window = false;               // every gradient source a same-size, un-shifted tensor?
     int npool = 0, kp = 0, nflat = 0;
@@ -1591,7 +1598,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     if (window) {
         const size_t nwin = (size_t)A.N * ((A.H + 1) / 2) * ((A.W + 1) / 2);
         nb = (int)((nwin + ppb - 1) / ppb);
-        if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+        if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     }
     A.draw = draw; A.dz_out = dz_out;
     // The apply pass re-reads what the reduce pass just streamed (raw + gradients, up to 2 x 134 MB against 256 MB of
@@ -1606,7 +1613,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     if (flat32) {
         const int ppb4 = 256 / (A.C / 4);
         nb = (int)((npix + (size_t)ppb4 * BN_U - 1) / ((size_t)ppb4 * BN_U));
-        if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+        if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
         if (nb < 1) nb = 1;
     }
     if (A.mean) {
@@ -1680,7 +1687,7 @@ extern "C" int cdnet_bn_backward_stats(const cdnet_bn_bwd_args *a, const float *
     CDNET_REQUIRE(npix * (size_t)A.C < ((size_t)1 << 32) && npix < ((size_t)1 << 31), "cdnet_bn_backward_stats: tensor too large for 32-bit pixel indexing");
     const int ppb = 256 / (A.C / 8);
     int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
-    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     if (nb < 1) nb = 1;
     const size_t need = (size_t)nb * 2 * A.C;
     if (workspace_floats < need) { set_error("cdnet_bn_backward_stats: workspace %zu < %zu floats", workspace_floats, need); return CDNET_E_WORKSPACE; }
@@ -1717,7 +1724,7 @@ extern "C" int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *a, const float *
     const size_t npix = (size_t)A.N * A.H * A.W;
     const int ppb = 256 / (A.C / 8);
     int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
-    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
+    if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     if (nb < 1) nb = 1;
     static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
     A.rev = rev;
