@@ -61,8 +61,12 @@ SIGNATURES = {
     'cdnet_dam_head_backward': (_i, [_vp] * 7 + [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'cdnet_dam_loss_workspace_floats': (_sz, [_i, _i]),
     'cdnet_dam_loss': (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    'cdnet_dam_loss_classes_workspace_floats': (_sz, [_i, _i, _i]),
+    'cdnet_dam_loss_classes': (_i, [_vp] * 7 + [_i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_dam_val_sums_workspace_floats': (_sz, [_i, _i]),
     'cdnet_dam_val_sums': (_i, [_vp] * 8 + [_i, _i, _i, _vp, _sz, _vp, _vp]),
+    'cdnet_dam_val_sums_classes_workspace_floats': (_sz, [_i, _i, _i]),
+    'cdnet_dam_val_sums_classes': (_i, [_vp] * 8 + [_i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     'cdnet_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'cdnet_window_pack': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),
     'cdnet_window_pack_f32': (_i, [_vp] + [_i] * 9 + [_vp, _vp]),

@@ -1018,18 +1018,26 @@ __global__ __launch_bounds__(256) void dam_head_wgrad_kernel(HeadFeat f1, HeadFe
 // ======================================================================================================
 // Loss (train_util_dam.py:167-276) - two passes over the logits
 // ======================================================================================================
-// per-sample sums (K_SUMS floats):
+// per-sample sums (lsums<ND>() floats; ND = number of direction classes, 5 / 9 / 17 - options.py:45 "4 8 16" + background):
 //   0..2  I_c   sum p_c [label==c]      3..5  P_c   sum p_c          6..8  T_c   sum [label==c]
-//   9..17 Pw_i  sum w q_i               18..26 Tw_j sum w t_j
-//   27..35 S[j][j]  36..44 S[next(j)][j]  45..53 S[prev(j)][j]   (S[i][j] = sum w q_i t_j, j = target class)
-//   54 ce  55 dce  56 mse
-//   57 tp  58 fp  59 fn   of the pixel-level metric (argmax direction == 1 vs direction label == 1, train_util_dam.py:279-281)
-constexpr int K_SUMS = 60;
-__device__ __forceinline__ int dnext(int i) { return i == 8 ? 1 : i + 1; }      // cyclic over 1..8 (loss.py:231-258)
-__device__ __forceinline__ int dprev(int i) { return i == 1 ? 8 : i - 1; }
+//   PW+i  Pw_i  sum w q_i               TW+j  Tw_j sum w t_j
+//   SS+j  S[j][j]  SN+j  S[next(j)][j]  SP+j  S[prev(j)][j]   (S[i][j] = sum w q_i t_j, j = target class)
+//   SC+0 ce  +1 dce  +2 mse
+//   SC+3 tp  +4 fp  +5 fn   of the pixel-level metric (argmax direction == 1 vs direction label == 1, train_util_dam.py:279-281)
+// For ND = 9 this is the 60-float layout the first version fixed (PW 9, TW 18, SS 27, SN 36, SP 45, SC 54).
+template <int ND> struct LossLay {
+    static constexpr int PW = 9, TW = 9 + ND, SS = 9 + 2 * ND, SN = 9 + 3 * ND, SP = 9 + 4 * ND, SC = 9 + 5 * ND, SUMS = SC + 6;
+    // coefficient block per sample: dice alpha[3], beta[3]; wdice: bsum[ND], a_self[ND], a_next[ND], a_prev[ND]
+    //   a_self[j]  multiplies row i=j,        a_next[j] row i=next(j),  a_prev[j] row i=prev(j)  when the pixel's target is j
+    static constexpr int COEF = 6 + 4 * ND;
+    static constexpr int TPB = ND > 9 ? 128 : 256;      // reduce kernel: SUMS x TPB floats of LDS (<= 64 KB)
+};
+constexpr int K_SUMS = LossLay<9>::SUMS;
+template <int ND> __device__ __forceinline__ int dnext(int i) { return i == ND - 1 ? 1 : i + 1; }      // cyclic over 1..ND-1 (loss.py:231-258)
+template <int ND> __device__ __forceinline__ int dprev(int i) { return i == 1 ? ND - 1 : i - 1; }
 
 struct LossIn {
-    const float *mask, *point, *dirn;        // f32 NCHW logits [B][3][P], [B][1][P], [B][9][P]
+    const float *mask, *point, *dirn;        // f32 NCHW logits [B][3][P], [B][1][P], [B][ND][P]
     const unsigned char *label, *dirlab;     // u8 [B][P]
     const unsigned short *point_t;           // f16 [B][P]
     const unsigned char *weight;             // u8 [B][P]  (png weight map; /20 on the fly)
@@ -1039,12 +1047,12 @@ struct LossIn {
 };
 
 // per sample: is the direction label constant (the one-hot of a single class, train_util_dam.py:131-137)?  The same scan
-// validates the label content: a mask class > 2 or a direction class > 8 would index past the per-class accumulators, so
+// validates the label content: a mask class > 2 or a direction class >= nd would index past the per-class accumulators, so
 // it raises *err (the finalize kernel then poisons every loss with NaN - the reference's NLLLoss fails loudly on such targets)
 // and the accumulation kernels clamp their indices.
 // one workgroup of 1024 threads per sample, 16 label bytes per thread and load (the first version walked them a byte at a time with
 // 256 threads: 64 us on the step's critical chain for 2 MB)
-__global__ __launch_bounds__(1024) void loss_single_kernel(const unsigned char *dirlab, const unsigned char *label, int P, int *single, int *err) {
+__global__ __launch_bounds__(1024) void loss_single_kernel(const unsigned char *dirlab, const unsigned char *label, int P, int nd, int *single, int *err) {
     __shared__ int s_min[16], s_max[16], s_lmax[16];
     const unsigned char *d = dirlab + (size_t)blockIdx.x * P;
     const unsigned char *l = label + (size_t)blockIdx.x * P;
@@ -1082,10 +1090,22 @@ __global__ __launch_bounds__(1024) void loss_single_kernel(const unsigned char *
             mn = s_min[i] < mn ? s_min[i] : mn; mx = s_max[i] > mx ? s_max[i] : mx; lm = s_lmax[i] > lm ? s_lmax[i] : lm;
         }
         single[blockIdx.x] = (mn == mx) ? 1 : 0;
-        if (mx > 8 || lm > 2) atomicOr(err, 1);
+        if (mx > nd - 1 || lm > 2) atomicOr(err, 1);
     }
 }
 
+template <int NC>
+__device__ __forceinline__ void softmax_n(const float *l, float *p, float *logp) {
+    float m = l[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) m = fmaxf(m, l[c]);
+    float e[NC], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { e[c] = expf(l[c] - m); s += e[c]; }
+    const float ls = logf(s);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { p[c] = e[c] / s; logp[c] = l[c] - m - ls; }
+}
 __device__ __forceinline__ void softmax3(const float *l, float *p, float *logp) {
     const float m = fmaxf(l[0], fmaxf(l[1], l[2]));
     float e[3], s = 0.f;
@@ -1095,103 +1115,98 @@ __device__ __forceinline__ void softmax3(const float *l, float *p, float *logp) 
 #pragma unroll
     for (int c = 0; c < 3; ++c) { p[c] = e[c] / s; logp[c] = l[c] - m - ls; }
 }
-__device__ __forceinline__ void softmax9(const float *l, float *p, float *logp) {
-    float m = l[0];
-#pragma unroll
-    for (int c = 1; c < 9; ++c) m = fmaxf(m, l[c]);
-    float e[9], s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) { e[c] = expf(l[c] - m); s += e[c]; }
-    const float ls = logf(s);
-#pragma unroll
-    for (int c = 0; c < 9; ++c) { p[c] = e[c] / s; logp[c] = l[c] - m - ls; }
-}
+__device__ __forceinline__ void softmax9(const float *l, float *p, float *logp) { softmax_n<9>(l, p, logp); }
 
-// target class of the weighted dice for pixel i of sample b: -1 = all nine one-hot channels are zero
+// target class of the weighted dice for pixel i of sample b: -1 = all one-hot channels are zero
+template <int ND>
 __device__ __forceinline__ int dice_target(const LossIn &L, int b, int i) {
     if (L.single[b]) return 0;
     int t = L.dirlab[(size_t)b * L.P + i];
-    t = t > 8 ? 8 : t;
+    t = t > ND - 1 ? ND - 1 : t;
     if (L.quirk0) return L.label[i] != 0 ? t : -1;               // sample 0's label
     return L.label[(size_t)b * L.P + i] != 0 ? t : -1;
 }
 
 // grid (chunks, B); private accumulators live in LDS ([k][tid]) because several are indexed by the target class
-__global__ __launch_bounds__(256) void loss_reduce_kernel(LossIn L, float *__restrict__ partial) {
-    __shared__ float acc[K_SUMS][256];
+template <int ND>
+__global__ __launch_bounds__(LossLay<ND>::TPB) void loss_reduce_kernel(LossIn L, float *__restrict__ partial) {
+    using Y = LossLay<ND>;
+    constexpr int TPB = Y::TPB;
+    __shared__ float acc[Y::SUMS][TPB];
     const int tid = threadIdx.x, b = blockIdx.y;
 #pragma unroll
-    for (int k = 0; k < K_SUMS; ++k) acc[k][tid] = 0.f;
+    for (int k = 0; k < Y::SUMS; ++k) acc[k][tid] = 0.f;
     const size_t ob = (size_t)b * L.P;
-    for (int i = blockIdx.x * 256 + tid; i < L.P; i += gridDim.x * 256) {
-        float l3[3], p3[3], lp3[3], l9[9], p9[9], lp9[9];
+    for (int i = blockIdx.x * TPB + tid; i < L.P; i += gridDim.x * TPB) {
+        float l3[3], p3[3], lp3[3], l9[ND], p9[ND], lp9[ND];
 #pragma unroll
         for (int c = 0; c < 3; ++c) l3[c] = L.mask[((size_t)b * 3 + c) * L.P + i];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) l9[c] = L.dirn[((size_t)b * 9 + c) * L.P + i];
+        for (int c = 0; c < ND; ++c) l9[c] = L.dirn[((size_t)b * ND + c) * L.P + i];
         softmax3(l3, p3, lp3);
-        softmax9(l9, p9, lp9);
+        softmax_n<ND>(l9, p9, lp9);
         const float w = (float)L.weight[ob + i] / 20.f;
         int lab = L.label[ob + i], dl = L.dirlab[ob + i];
-        lab = lab > 2 ? 2 : lab; dl = dl > 8 ? 8 : dl;           // (out-of-range content is reported through *err, see loss_single_kernel)
+        lab = lab > 2 ? 2 : lab; dl = dl > ND - 1 ? ND - 1 : dl;   // (out-of-range content is reported through *err, see loss_single_kernel)
         acc[lab][tid] += p3[lab];
         acc[6 + lab][tid] += 1.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[3 + c][tid] += p3[c];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) acc[9 + c][tid] = fmaf(w, p9[c], acc[9 + c][tid]);
-        const int t = dice_target(L, b, i);
+        for (int c = 0; c < ND; ++c) acc[Y::PW + c][tid] = fmaf(w, p9[c], acc[Y::PW + c][tid]);
+        const int t = dice_target<ND>(L, b, i);
         if (t >= 0) {
-            acc[18 + t][tid] += w;
-            acc[27 + t][tid] = fmaf(w, p9[t], acc[27 + t][tid]);
+            acc[Y::TW + t][tid] += w;
+            acc[Y::SS + t][tid] = fmaf(w, p9[t], acc[Y::SS + t][tid]);
             if (t >= 1) {
-                acc[36 + t][tid] = fmaf(w, p9[dnext(t)], acc[36 + t][tid]);
-                acc[45 + t][tid] = fmaf(w, p9[dprev(t)], acc[45 + t][tid]);
+                acc[Y::SN + t][tid] = fmaf(w, p9[dnext<ND>(t)], acc[Y::SN + t][tid]);
+                acc[Y::SP + t][tid] = fmaf(w, p9[dprev<ND>(t)], acc[Y::SP + t][tid]);
             }
         }
-        acc[54][tid] -= lp3[lab] * w;
-        acc[55][tid] -= lp9[dl] * w;
+        acc[Y::SC][tid] -= lp3[lab] * w;
+        acc[Y::SC + 1][tid] -= lp9[dl] * w;
         const float dpt = L.point[ob + i] - h2f(L.point_t[ob + i]);
-        acc[56][tid] = fmaf(dpt, dpt, acc[56][tid]);
-        {   // np.argmax over the 9 direction classes (first maximum), "inside" = class 1 (utils.py:76-78)
+        acc[Y::SC + 2][tid] = fmaf(dpt, dpt, acc[Y::SC + 2][tid]);
+        {   // np.argmax over the direction classes (first maximum), "inside" = class 1 (utils.py:76-78)
             int am = 0;
             float best = l9[0];
 #pragma unroll
-            for (int c = 1; c < 9; ++c) if (l9[c] > best) { best = l9[c]; am = c; }
+            for (int c = 1; c < ND; ++c) if (l9[c] > best) { best = l9[c]; am = c; }
             const bool pi = am == 1, ti = dl == 1;
-            if (pi && ti) acc[57][tid] += 1.f;
-            if (pi && !ti) acc[58][tid] += 1.f;
-            if (!pi && ti) acc[59][tid] += 1.f;
+            if (pi && ti) acc[Y::SC + 3][tid] += 1.f;
+            if (pi && !ti) acc[Y::SC + 4][tid] += 1.f;
+            if (!pi && ti) acc[Y::SC + 5][tid] += 1.f;
         }
     }
     __syncthreads();
-    if (tid < K_SUMS) {
+    if (tid < Y::SUMS) {
         float s = 0.f;
-        for (int k = 0; k < 256; ++k) s += acc[tid][k];
-        partial[((size_t)b * gridDim.x + blockIdx.x) * K_SUMS + tid] = s;
+        for (int k = 0; k < TPB; ++k) s += acc[tid][k];
+        partial[((size_t)b * gridDim.x + blockIdx.x) * Y::SUMS + tid] = s;
     }
 }
 
-// coefficient block per sample (K_COEF floats): dice alpha[3], beta[3]; wdice: bsum[9], a_self[9], a_next[9], a_prev[9]
-//   a_self[j]  multiplies row i=j,        a_next[j] row i=next(j),  a_prev[j] row i=prev(j)  when the pixel's target is j
-constexpr int K_COEF = 6 + 36;
+constexpr int K_COEF = LossLay<9>::COEF;
 // single block: per-sample sums -> loss terms (5 + total) and the pass-2 coefficients
+template <int ND>
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int nchunk, int B, int P,
                                                             float *__restrict__ sums, float *__restrict__ coef,
                                                             float *__restrict__ losses, const int *__restrict__ err) {
-    __shared__ float s_sum[64 * K_SUMS];      // B <= 64
+    using Y = LossLay<ND>;
+    constexpr int NS = Y::SUMS;
+    __shared__ float s_sum[64 * NS];      // B <= 64
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < B * K_SUMS; idx += 256) {
-        const int b = idx / K_SUMS, k = idx % K_SUMS;
+    for (int idx = tid; idx < B * NS; idx += 256) {
+        const int b = idx / NS, k = idx % NS;
         // four independent chains of loads (a single dependent chain of nchunk L2 round trips dominated this kernel)
-        const float *pp = partial + (size_t)b * nchunk * K_SUMS + k;
+        const float *pp = partial + (size_t)b * nchunk * NS + k;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int ch = 0;
         for (; ch + 3 < nchunk; ch += 4) {
-            s0 += pp[(size_t)ch * K_SUMS]; s1 += pp[(size_t)(ch + 1) * K_SUMS];
-            s2 += pp[(size_t)(ch + 2) * K_SUMS]; s3 += pp[(size_t)(ch + 3) * K_SUMS];
+            s0 += pp[(size_t)ch * NS]; s1 += pp[(size_t)(ch + 1) * NS];
+            s2 += pp[(size_t)(ch + 2) * NS]; s3 += pp[(size_t)(ch + 3) * NS];
         }
-        for (; ch < nchunk; ++ch) s0 += pp[(size_t)ch * K_SUMS];
+        for (; ch < nchunk; ++ch) s0 += pp[(size_t)ch * NS];
         const float s = (s0 + s1) + (s2 + s3);
         s_sum[idx] = s;
         if (sums) sums[idx] = s;
@@ -1199,67 +1214,68 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
     __syncthreads();
     const float fB = (float)B;
     for (int b = tid; b < B; b += 256) {
-        const float *S = s_sum + b * K_SUMS;
-        float *cf = coef + (size_t)b * K_COEF;
+        const float *S = s_sum + b * NS;
+        float *cf = coef + (size_t)b * Y::COEF;
         for (int c = 0; c < 3; ++c) {
             const float I = S[c], U = S[3 + c] + S[6 + c];
             cf[c] = -2.f / (fB * (U + 1.f));
             cf[3 + c] = 2.f * (I + 1.f) / (fB * (U + 1.f) * (U + 1.f));
         }
         // row i, column j terms: alpha_ij = -2/(B (U_ij+1)), beta_ij = 2 (S_ij+1)/(B (U_ij+1)^2), U_ij = Pw_i + Tw_j
-        float bsum[9];
-        for (int i = 0; i < 9; ++i) bsum[i] = 0.f;
-        for (int j = 0; j < 9; ++j) {
+        float bsum[ND];
+        for (int i = 0; i < ND; ++i) bsum[i] = 0.f;
+        for (int j = 0; j < ND; ++j) {
             {   // (i=j, j)
-                const float U = S[9 + j] + S[18 + j], Sij = S[27 + j], m = j == 0 ? 2.f : 1.f;
-                cf[6 + 9 + j] = m * -2.f / (fB * (U + 1.f));
+                const float U = S[Y::PW + j] + S[Y::TW + j], Sij = S[Y::SS + j], m = j == 0 ? 2.f : 1.f;
+                cf[6 + ND + j] = m * -2.f / (fB * (U + 1.f));
                 bsum[j] += m * 2.f * (Sij + 1.f) / (fB * (U + 1.f) * (U + 1.f));
             }
             if (j >= 1) {
-                const int in = dnext(j), ip = dprev(j);
-                {   const float U = S[9 + in] + S[18 + j], Sij = S[36 + j];
-                    cf[6 + 18 + j] = -2.f / (fB * (U + 1.f));
+                const int in = dnext<ND>(j), ip = dprev<ND>(j);
+                {   const float U = S[Y::PW + in] + S[Y::TW + j], Sij = S[Y::SN + j];
+                    cf[6 + 2 * ND + j] = -2.f / (fB * (U + 1.f));
                     bsum[in] += 2.f * (Sij + 1.f) / (fB * (U + 1.f) * (U + 1.f)); }
-                {   const float U = S[9 + ip] + S[18 + j], Sij = S[45 + j];
-                    cf[6 + 27 + j] = -2.f / (fB * (U + 1.f));
+                {   const float U = S[Y::PW + ip] + S[Y::TW + j], Sij = S[Y::SP + j];
+                    cf[6 + 3 * ND + j] = -2.f / (fB * (U + 1.f));
                     bsum[ip] += 2.f * (Sij + 1.f) / (fB * (U + 1.f) * (U + 1.f)); }
-            } else { cf[6 + 18] = 0.f; cf[6 + 27] = 0.f; }
+            } else { cf[6 + 2 * ND] = 0.f; cf[6 + 3 * ND] = 0.f; }
         }
-        for (int i = 0; i < 9; ++i) cf[6 + i] = bsum[i];
+        for (int i = 0; i < ND; ++i) cf[6 + i] = bsum[i];
     }
-    // the 28 batch-mean dice ratios, one thread each (they were ~450 serial divisions on thread 0):
-    // [0,3) mask dice c; [3,12) wdice(i,i); [12,20) wdice(i,prev(i)), i=1..8; [20,28) wdice(i,next(i)), i=1..8
-    __shared__ float s_term[28];
-    if (tid < 28) {
+    // the 3 ND + 1 batch-mean dice ratios, one thread each (they were ~450 serial divisions on thread 0):
+    // [0,3) mask dice c; [3,3+ND) wdice(i,i); then wdice(i,prev(i)), i=1..ND-1; then wdice(i,next(i)), i=1..ND-1
+    constexpr int T_PREV = 3 + ND, T_NEXT = T_PREV + ND - 1, NT = T_NEXT + ND - 1;
+    __shared__ float s_term[NT];
+    if (tid < NT) {
         int num, da, db;                      // mean_b 2 (S[num] + 1) / (S[da] + S[db] + 1)
         if (tid < 3) { num = tid; da = 3 + tid; db = 6 + tid; }
-        else if (tid < 12) { const int i = tid - 3; num = 27 + i; da = 9 + i; db = 18 + i; }
-        else if (tid < 20) { const int i = tid - 12 + 1, j = dprev(i); num = 36 + j; da = 9 + i; db = 18 + j; }
-        else { const int i = tid - 20 + 1, j = dnext(i); num = 45 + j; da = 9 + i; db = 18 + j; }
+        else if (tid < T_PREV) { const int i = tid - 3; num = Y::SS + i; da = Y::PW + i; db = Y::TW + i; }
+        else if (tid < T_NEXT) { const int i = tid - T_PREV + 1, j = dprev<ND>(i); num = Y::SN + j; da = Y::PW + i; db = Y::TW + j; }
+        else { const int i = tid - T_NEXT + 1, j = dnext<ND>(i); num = Y::SP + j; da = Y::PW + i; db = Y::TW + j; }
         float acc = 0.f;
-        for (int b = 0; b < B; ++b) { const float *S = s_sum + b * K_SUMS; acc += 2.f * (S[num] + 1.f) / (S[da] + S[db] + 1.f); }
+        for (int b = 0; b < B; ++b) { const float *S = s_sum + b * NS; acc += 2.f * (S[num] + 1.f) / (S[da] + S[db] + 1.f); }
         s_term[tid] = 1.f - acc / fB;
     }
     __syncthreads();
     if (tid == 0) {
         const float n = (float)B * (float)P;
         float ce = 0.f, dce = 0.f, mse = 0.f;
-        for (int b = 0; b < B; ++b) { ce += s_sum[b * K_SUMS + 54]; dce += s_sum[b * K_SUMS + 55]; mse += s_sum[b * K_SUMS + 56]; }
+        for (int b = 0; b < B; ++b) { ce += s_sum[b * NS + Y::SC]; dce += s_sum[b * NS + Y::SC + 1]; mse += s_sum[b * NS + Y::SC + 2]; }
         ce /= n; dce /= n; mse /= n;
         float dice = 0.f;
         for (int c = 0; c < 3; ++c) dice += s_term[c];
         float wd = 0.f;
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < ND; ++i) {
             if (i == 0) wd += 2.f * s_term[3];
-            else wd += s_term[3 + i] - (1.f - s_term[12 + i - 1]) - (1.f - s_term[20 + i - 1]);
+            else wd += s_term[3 + i] - (1.f - s_term[T_PREV + i - 1]) - (1.f - s_term[T_NEXT + i - 1]);
         }
-        wd /= 9.f;
+        wd /= (float)ND;
         losses[0] = ce + dice + dce + wd + mse;
         losses[1] = dce; losses[2] = wd; losses[3] = mse; losses[4] = ce; losses[5] = dice;
         // pixel-level metrics, mean over the samples (utils.py:67-110): accuracy, IoU, recall, precision, F1
         double m[5] = {0, 0, 0, 0, 0};
         for (int b = 0; b < B; ++b) {
-            const double tp = s_sum[b * K_SUMS + 57], fp = s_sum[b * K_SUMS + 58], fn = s_sum[b * K_SUMS + 59];
+            const double tp = s_sum[b * NS + Y::SC + 3], fp = s_sum[b * NS + Y::SC + 4], fn = s_sum[b * NS + Y::SC + 5];
             const double tn = (double)P - tp - fp - fn;
             const double precision = tp / (tp + fp + 1e-10), recall = tp / (tp + fn + 1e-10);
             m[0] += (tp + tn) / (tp + fp + tn + fn + 1e-10);
@@ -1276,23 +1292,24 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restr
 }
 
 // pass 2: gradients w.r.t. the logits (f32 NCHW, same layout as the logits)
+template <int ND>
 __global__ __launch_bounds__(256) void loss_grad_kernel(LossIn L, const float *__restrict__ coef, float *__restrict__ dmask,
                                                         float *__restrict__ dpoint, float *__restrict__ ddir) {
     const int b = blockIdx.y;
-    const float *cf = coef + (size_t)b * K_COEF;
+    const float *cf = coef + (size_t)b * LossLay<ND>::COEF;
     const float inv_n = 1.f / ((float)L.B * (float)L.P);
     const size_t ob = (size_t)b * L.P;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < L.P; i += gridDim.x * 256) {
-        float l3[3], p3[3], lp3[3], l9[9], p9[9], lp9[9];
+        float l3[3], p3[3], lp3[3], l9[ND], p9[ND], lp9[ND];
 #pragma unroll
         for (int c = 0; c < 3; ++c) l3[c] = L.mask[((size_t)b * 3 + c) * L.P + i];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) l9[c] = L.dirn[((size_t)b * 9 + c) * L.P + i];
+        for (int c = 0; c < ND; ++c) l9[c] = L.dirn[((size_t)b * ND + c) * L.P + i];
         softmax3(l3, p3, lp3);
-        softmax9(l9, p9, lp9);
+        softmax_n<ND>(l9, p9, lp9);
         const float w = (float)L.weight[ob + i] / 20.f;
         int lab = L.label[ob + i], dl = L.dirlab[ob + i];
-        lab = lab > 2 ? 2 : lab; dl = dl > 8 ? 8 : dl;           // (out-of-range content is reported through *err, see loss_single_kernel)
+        lab = lab > 2 ? 2 : lab; dl = dl > ND - 1 ? ND - 1 : dl;   // (out-of-range content is reported through *err, see loss_single_kernel)
         // mask: dice gradient w.r.t. probabilities, through the softmax, plus the weighted CE
         float gp[3], dot = 0.f;
 #pragma unroll
@@ -1300,27 +1317,27 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossIn L, const float *_
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             dmask[((size_t)b * 3 + c) * L.P + i] = p3[c] * (gp[c] - dot) + w * inv_n * (p3[c] - (c == lab ? 1.f : 0.f));
-        // direction: weighted cyclic dice (average over 9 classes) + weighted CE
-        const int t = dice_target(L, b, i);
-        float gq[9], dot9 = 0.f;
+        // direction: weighted cyclic dice (average over the ND classes) + weighted CE
+        const int t = dice_target<ND>(L, b, i);
+        float gq[ND], dotq = 0.f;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) gq[c] = cf[6 + c];
+        for (int c = 0; c < ND; ++c) gq[c] = cf[6 + c];
         if (t >= 0) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) {
+            for (int c = 0; c < ND; ++c) {
                 float a = 0.f;
-                if (c == t) a = cf[6 + 9 + t];
-                else if (t >= 1 && c == dnext(t)) a = cf[6 + 18 + t];
-                else if (t >= 1 && c == dprev(t)) a = cf[6 + 27 + t];
+                if (c == t) a = cf[6 + ND + t];
+                else if (t >= 1 && c == dnext<ND>(t)) a = cf[6 + 2 * ND + t];
+                else if (t >= 1 && c == dprev<ND>(t)) a = cf[6 + 3 * ND + t];
                 gq[c] += a;
             }
         }
 #pragma unroll
-        for (int c = 0; c < 9; ++c) { gq[c] *= w * (1.f / 9.f); dot9 = fmaf(p9[c], gq[c], dot9); }
+        for (int c = 0; c < ND; ++c) { gq[c] *= w * (1.f / (float)ND); dotq = fmaf(p9[c], gq[c], dotq); }
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
-            ddir[((size_t)b * 9 + c) * L.P + i] = p9[c] * (gq[c] - dot9) + w * inv_n * (p9[c] - (c == dl ? 1.f : 0.f));
-        dpoint[ob + i] = 2.f * inv_n * (L.point[ob + i] - h2f(L.point_t[ob + i]));
+        for (int c = 0; c < ND; ++c)
+            ddir[((size_t)b * ND + c) * L.P + i] = p9[c] * (gq[c] - dotq) + w * inv_n * (p9[c] - (c == dl ? 1.f : 0.f));
+        if (dpoint) dpoint[ob + i] = 2.f * inv_n * (L.point[ob + i] - h2f(L.point_t[ob + i]));
     }
 }
 
@@ -1353,32 +1370,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 //   37 sum w * -log q_dir (:553-559)   38 sum (point - target / 255)^2 (:575-580)
 //   39 tp  40 fp  41 fn  of (argmax mask == 1) vs (label == 1)  (utils.accuracy_pixel_level, :585-590)
 // ======================================================================================================
-constexpr int V_SUMS = 42;
+// For ND direction classes (5 / 9 / 17) the three direction blocks are ND wide: IQ = 10, PQ = 10 + ND, TQ = 10 + 2 ND, then the five
+// scalars at VS = 10 + 3 ND (42 floats for ND = 9, the layout above).
+template <int ND> struct ValLay {
+    static constexpr int IQ = 10, PQ = 10 + ND, TQ = 10 + 2 * ND, VS = 10 + 3 * ND, SUMS = VS + 5;
+    static constexpr int TPB = ND > 9 ? 128 : 256;
+};
+constexpr int V_SUMS = ValLay<9>::SUMS;
 
 struct ValIn {
     const float *mask, *point, *dirn;
     const unsigned char *label, *dirlab, *weight;
     const unsigned short *point_t;
-    int lut[9];                              // direction class value -> channel (rank among the batch's unique values), -1 = absent
+    int lut[17];                             // direction class value -> channel (rank among the batch's unique values), -1 = absent
     int B, P;
 };
 
-__global__ __launch_bounds__(256) void val_sums_kernel(ValIn L, float *__restrict__ partial) {
-    __shared__ float acc[V_SUMS][256];
+template <int ND>
+__global__ __launch_bounds__(ValLay<ND>::TPB) void val_sums_kernel(ValIn L, float *__restrict__ partial) {
+    using Y = ValLay<ND>;
+    constexpr int TPB = Y::TPB;
+    __shared__ float acc[Y::SUMS][TPB];
     const int tid = threadIdx.x, b = blockIdx.y;
 #pragma unroll
-    for (int k = 0; k < V_SUMS; ++k) acc[k][tid] = 0.f;
+    for (int k = 0; k < Y::SUMS; ++k) acc[k][tid] = 0.f;
     const size_t ob = (size_t)b * L.P;
-    for (int i = blockIdx.x * 256 + tid; i < L.P; i += gridDim.x * 256) {
-        float l3[3], p3[3], lp3[3], l9[9], p9[9], lp9[9];
+    for (int i = blockIdx.x * TPB + tid; i < L.P; i += gridDim.x * TPB) {
+        float l3[3], p3[3], lp3[3], l9[ND], p9[ND], lp9[ND];
 #pragma unroll
         for (int c = 0; c < 3; ++c) l3[c] = L.mask[((size_t)b * 3 + c) * L.P + i];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) l9[c] = L.dirn[((size_t)b * 9 + c) * L.P + i];
+        for (int c = 0; c < ND; ++c) l9[c] = L.dirn[((size_t)b * ND + c) * L.P + i];
         softmax3(l3, p3, lp3);
-        softmax9(l9, p9, lp9);
+        softmax_n<ND>(l9, p9, lp9);
         int lab = L.label[ob + i], dl = L.dirlab[ob + i];
-        lab = lab > 2 ? 2 : lab; dl = dl > 8 ? 8 : dl;
+        lab = lab > 2 ? 2 : lab; dl = dl > ND - 1 ? ND - 1 : dl;
         const float w = (float)L.weight[ob + i] / 20.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -1390,36 +1416,36 @@ __global__ __launch_bounds__(256) void val_sums_kernel(ValIn L, float *__restric
         const bool fg0 = L.label[i] != 0;                     // sample 0's foreground (the reference indexes target[0])
         const int tch = (fg0 && L.lut[dl] >= 0) ? L.lut[dl] : -1;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            acc[19 + c][tid] += p9[c];
-            if (c == tch) { acc[10 + c][tid] += p9[c]; acc[28 + c][tid] += 1.f; }
+        for (int c = 0; c < ND; ++c) {
+            acc[Y::PQ + c][tid] += p9[c];
+            if (c == tch) { acc[Y::IQ + c][tid] += p9[c]; acc[Y::TQ + c][tid] += 1.f; }
         }
-        acc[37][tid] -= w * lp9[dl];
+        acc[Y::VS][tid] -= w * lp9[dl];
         const float dpt = L.point[ob + i] - h2f(L.point_t[ob + i]) / 255.f;
-        acc[38][tid] = fmaf(dpt, dpt, acc[38][tid]);
+        acc[Y::VS + 1][tid] = fmaf(dpt, dpt, acc[Y::VS + 1][tid]);
         int am = 0;                                            // np.argmax: first maximum
         if (l3[1] > l3[am]) am = 1;
         if (l3[2] > l3[am]) am = 2;
         const bool pi = am == 1, ti = lab == 1;
-        if (pi && ti) acc[39][tid] += 1.f;
-        if (pi && !ti) acc[40][tid] += 1.f;
-        if (!pi && ti) acc[41][tid] += 1.f;
+        if (pi && ti) acc[Y::VS + 2][tid] += 1.f;
+        if (pi && !ti) acc[Y::VS + 3][tid] += 1.f;
+        if (!pi && ti) acc[Y::VS + 4][tid] += 1.f;
     }
     __syncthreads();
-    if (tid < V_SUMS) {
+    if (tid < Y::SUMS) {
         float s = 0.f;
-        for (int k = 0; k < 256; ++k) s += acc[tid][k];
-        partial[((size_t)b * gridDim.x + blockIdx.x) * V_SUMS + tid] = s;
+        for (int k = 0; k < TPB; ++k) s += acc[tid][k];
+        partial[((size_t)b * gridDim.x + blockIdx.x) * Y::SUMS + tid] = s;
     }
 }
 
 // sums[b][k] = sum over chunks, fixed order
-__global__ void val_sums_reduce_kernel(const float *__restrict__ partial, int nchunk, int B, float *__restrict__ sums) {
+__global__ void val_sums_reduce_kernel(const float *__restrict__ partial, int nchunk, int B, int nsums, float *__restrict__ sums) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * V_SUMS) return;
-    const int b = idx / V_SUMS, k = idx % V_SUMS;
+    if (idx >= B * nsums) return;
+    const int b = idx / nsums, k = idx % nsums;
     double s = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) s += (double)partial[((size_t)b * nchunk + ch) * V_SUMS + k];
+    for (int ch = 0; ch < nchunk; ++ch) s += (double)partial[((size_t)b * nchunk + ch) * nsums + k];
     sums[idx] = (float)s;
 }
 
@@ -1430,6 +1456,7 @@ __global__ void val_sums_reduce_kernel(const float *__restrict__ partial, int nc
 // ======================================================================================================
 constexpr int FC_KMAX = 4;            // plain UNet classifier (3 classes): 4 lanes per pixel x 16 channels
 constexpr int FC_KWIDE = 12;          // the ablation heads' 9-class direction classifier: 8 lanes per pixel x 8 channels
+constexpr int FC_KMOST = 20;          // model_unet_MandD16's 17-class direction classifier: same 8 x 8 split, 20 accumulator rows
 
 // KM: classes the instantiation holds accumulators for; LPP lanes share a pixel (64 / LPP channels each)
 template <int KM, int LPP>
@@ -1777,67 +1804,112 @@ extern "C" size_t cdnet_dam_head_backward_workspace_floats(int N, int H, int W) 
     return (size_t)1024 * HEADW_FLOATS + (size_t)N * H * W * 16;
 }
 
-extern "C" size_t cdnet_dam_loss_workspace_floats(int B, int P) {
-    int nchunk = cdiv(P, 256 * 8);
-    if (nchunk > 64) nchunk = 64;
-    return (size_t)B * nchunk * K_SUMS + (size_t)B * K_COEF + (size_t)B * K_SUMS + 16 + (size_t)B;   // partial | coef | sums | pad | single(int)
+static int loss_nchunk(int P, int tpb) {
+    int nchunk = cdiv(P, tpb * 8);
+    return nchunk > 64 ? 64 : nchunk;
+}
+
+template <int ND>
+static size_t dam_loss_ws(int B, int P) {
+    using Y = LossLay<ND>;
+    const int nchunk = loss_nchunk(P, Y::TPB);
+    return (size_t)B * nchunk * Y::SUMS + (size_t)B * Y::COEF + (size_t)B * Y::SUMS + 16 + (size_t)B;   // partial | coef | sums | pad | single(int)
+}
+
+template <int ND>
+static int dam_loss_impl(LossIn L, int B, int P, float *workspace, float *losses, float *dmask, float *dpoint, float *ddir, hipStream_t st) {
+    using Y = LossLay<ND>;
+    const int nchunk = loss_nchunk(P, Y::TPB);
+    float *partial = workspace;
+    float *coef = partial + (size_t)B * nchunk * Y::SUMS;
+    float *sums = coef + (size_t)B * Y::COEF;
+    int *err = reinterpret_cast<int *>(sums + (size_t)B * Y::SUMS);          // first word of the 16-float pad
+    int *single = reinterpret_cast<int *>(sums + (size_t)B * Y::SUMS + 16);
+    if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return check_launch("cdnet_dam_loss(memset)");
+    L.single = single;
+    loss_single_kernel<<<B, 1024, 0, st>>>(L.dirlab, L.label, P, ND, single, err);
+    loss_reduce_kernel<ND><<<dim3(nchunk, B), Y::TPB, 0, st>>>(L, partial);
+    loss_finalize_kernel<ND><<<1, 256, 0, st>>>(partial, nchunk, B, P, sums, coef, losses, err);
+    if (dmask) loss_grad_kernel<ND><<<dim3(lin_grid((size_t)P, 256), B), 256, 0, st>>>(L, coef, dmask, dpoint, ddir);
+    return check_launch("cdnet_dam_loss");
+}
+
+extern "C" size_t cdnet_dam_loss_classes_workspace_floats(int B, int P, int direction_classes) {
+    return direction_classes == 5 ? dam_loss_ws<5>(B, P) : direction_classes == 17 ? dam_loss_ws<17>(B, P) : dam_loss_ws<9>(B, P);
+}
+extern "C" size_t cdnet_dam_loss_workspace_floats(int B, int P) { return dam_loss_ws<9>(B, P); }
+
+extern "C" int cdnet_dam_loss_classes(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
+                                      const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W, int direction_classes,
+                                      int quirk_sample0, float *workspace, size_t workspace_floats, float *losses, float *dmask,
+                                      float *dpoint, float *ddir, void *stream) {
+    CDNET_REQUIRE(mask && point && dirn && label && dirlab && point_target_f16 && weight_u8 && workspace && losses,
+                  "cdnet_dam_loss: null pointer");
+    CDNET_REQUIRE(B >= 1 && B <= 64 && H > 0 && W > 0, "cdnet_dam_loss: batch %d not in [1,64]", B);
+    CDNET_REQUIRE(direction_classes == 5 || direction_classes == 9 || direction_classes == 17,
+                  "cdnet_dam_loss: direction_classes %d must be 5, 9 or 17 (options.py:45)", direction_classes);
+    const int P = H * W;
+    if (workspace_floats < cdnet_dam_loss_classes_workspace_floats(B, P, direction_classes)) { set_error("cdnet_dam_loss: workspace too small"); return CDNET_E_WORKSPACE; }
+    if (dmask) CDNET_REQUIRE(dpoint && ddir, "cdnet_dam_loss: all three gradient outputs or none");
+    LossIn L;
+    L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.point_t = point_target_f16;
+    L.weight = weight_u8; L.single = nullptr; L.B = B; L.P = P; L.quirk0 = quirk_sample0;
+    hipStream_t st = (hipStream_t)stream;
+    if (direction_classes == 5) return dam_loss_impl<5>(L, B, P, workspace, losses, dmask, dpoint, ddir, st);
+    if (direction_classes == 17) return dam_loss_impl<17>(L, B, P, workspace, losses, dmask, dpoint, ddir, st);
+    return dam_loss_impl<9>(L, B, P, workspace, losses, dmask, dpoint, ddir, st);
 }
 
 extern "C" int cdnet_dam_loss(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
                               const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W, int quirk_sample0,
                               float *workspace, size_t workspace_floats, float *losses, float *dmask, float *dpoint, float *ddir,
                               void *stream) {
-    CDNET_REQUIRE(mask && point && dirn && label && dirlab && point_target_f16 && weight_u8 && workspace && losses,
-                  "cdnet_dam_loss: null pointer");
-    CDNET_REQUIRE(B >= 1 && B <= 64 && H > 0 && W > 0, "cdnet_dam_loss: batch %d not in [1,64]", B);
-    const int P = H * W;
-    if (workspace_floats < cdnet_dam_loss_workspace_floats(B, P)) { set_error("cdnet_dam_loss: workspace too small"); return CDNET_E_WORKSPACE; }
-    int nchunk = cdiv(P, 256 * 8);
-    if (nchunk > 64) nchunk = 64;
-    float *partial = workspace;
-    float *coef = partial + (size_t)B * nchunk * K_SUMS;
-    float *sums = coef + (size_t)B * K_COEF;
-    int *err = reinterpret_cast<int *>(sums + (size_t)B * K_SUMS);          // first word of the 16-float pad
-    int *single = reinterpret_cast<int *>(sums + (size_t)B * K_SUMS + 16);
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return check_launch("cdnet_dam_loss(memset)");
-    LossIn L;
-    L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.point_t = point_target_f16;
-    L.weight = weight_u8; L.single = single; L.B = B; L.P = P; L.quirk0 = quirk_sample0;
-    loss_single_kernel<<<B, 1024, 0, st>>>(dirlab, label, P, single, err);
-    loss_reduce_kernel<<<dim3(nchunk, B), 256, 0, st>>>(L, partial);
-    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, nchunk, B, P, sums, coef, losses, err);
-    if (dmask) {
-        CDNET_REQUIRE(dpoint && ddir, "cdnet_dam_loss: all three gradient outputs or none");
-        loss_grad_kernel<<<dim3(lin_grid((size_t)P, 256), B), 256, 0, st>>>(L, coef, dmask, dpoint, ddir);
-    }
-    return check_launch("cdnet_dam_loss");
+    return cdnet_dam_loss_classes(mask, point, dirn, label, dirlab, point_target_f16, weight_u8, B, H, W, 9, quirk_sample0, workspace,
+                                  workspace_floats, losses, dmask, dpoint, ddir, stream);
 }
 
-extern "C" size_t cdnet_dam_val_sums_workspace_floats(int B, int P) {
-    int nchunk = cdiv(P, 256 * 8);
-    if (nchunk > 64) nchunk = 64;
-    return (size_t)B * nchunk * V_SUMS;
+template <int ND>
+static int val_sums_impl(ValIn L, int B, int P, float *workspace, float *sums, hipStream_t st) {
+    using Y = ValLay<ND>;
+    const int nchunk = loss_nchunk(P, Y::TPB);
+    val_sums_kernel<ND><<<dim3(nchunk, B), Y::TPB, 0, st>>>(L, workspace);
+    val_sums_reduce_kernel<<<cdiv(B * Y::SUMS, 256), 256, 0, st>>>(workspace, nchunk, B, Y::SUMS, sums);
+    return check_launch("cdnet_dam_val_sums");
+}
+
+extern "C" size_t cdnet_dam_val_sums_classes_workspace_floats(int B, int P, int direction_classes) {
+    if (direction_classes == 5) return (size_t)B * loss_nchunk(P, ValLay<5>::TPB) * ValLay<5>::SUMS;
+    if (direction_classes == 17) return (size_t)B * loss_nchunk(P, ValLay<17>::TPB) * ValLay<17>::SUMS;
+    return (size_t)B * loss_nchunk(P, ValLay<9>::TPB) * ValLay<9>::SUMS;
+}
+extern "C" size_t cdnet_dam_val_sums_workspace_floats(int B, int P) { return cdnet_dam_val_sums_classes_workspace_floats(B, P, 9); }
+
+extern "C" int cdnet_dam_val_sums_classes(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
+                                          const uint16_t *point_target_f16, const uint8_t *weight_u8, const int *dir_rank_host,
+                                          int direction_classes, int B, int H, int W, float *workspace, size_t workspace_floats, float *sums,
+                                          void *stream) {
+    CDNET_REQUIRE(mask && point && dirn && label && dirlab && point_target_f16 && weight_u8 && dir_rank_host && workspace && sums,
+                  "cdnet_dam_val_sums: null pointer");
+    CDNET_REQUIRE(B >= 1 && B <= 64 && H > 0 && W > 0, "cdnet_dam_val_sums: batch %d not in [1,64]", B);
+    CDNET_REQUIRE(direction_classes == 5 || direction_classes == 9 || direction_classes == 17,
+                  "cdnet_dam_val_sums: direction_classes %d must be 5, 9 or 17 (options.py:45)", direction_classes);
+    const int P = H * W;
+    if (workspace_floats < cdnet_dam_val_sums_classes_workspace_floats(B, P, direction_classes)) { set_error("cdnet_dam_val_sums: workspace too small"); return CDNET_E_WORKSPACE; }
+    ValIn L;
+    L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.weight = weight_u8; L.point_t = point_target_f16;
+    for (int k = 0; k < 17; ++k) L.lut[k] = k < direction_classes ? dir_rank_host[k] : -1;
+    L.B = B; L.P = P;
+    hipStream_t st = (hipStream_t)stream;
+    if (direction_classes == 5) return val_sums_impl<5>(L, B, P, workspace, sums, st);
+    if (direction_classes == 17) return val_sums_impl<17>(L, B, P, workspace, sums, st);
+    return val_sums_impl<9>(L, B, P, workspace, sums, st);
 }
 
 extern "C" int cdnet_dam_val_sums(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
                                   const uint16_t *point_target_f16, const uint8_t *weight_u8, const int *dir_rank_host, int B, int H, int W,
                                   float *workspace, size_t workspace_floats, float *sums, void *stream) {
-    CDNET_REQUIRE(mask && point && dirn && label && dirlab && point_target_f16 && weight_u8 && dir_rank_host && workspace && sums,
-                  "cdnet_dam_val_sums: null pointer");
-    CDNET_REQUIRE(B >= 1 && B <= 64 && H > 0 && W > 0, "cdnet_dam_val_sums: batch %d not in [1,64]", B);
-    const int P = H * W;
-    if (workspace_floats < cdnet_dam_val_sums_workspace_floats(B, P)) { set_error("cdnet_dam_val_sums: workspace too small"); return CDNET_E_WORKSPACE; }
-    int nchunk = cdiv(P, 256 * 8);
-    if (nchunk > 64) nchunk = 64;
-    ValIn L;
-    L.mask = mask; L.point = point; L.dirn = dirn; L.label = label; L.dirlab = dirlab; L.weight = weight_u8; L.point_t = point_target_f16;
-    for (int k = 0; k < 9; ++k) L.lut[k] = dir_rank_host[k];
-    L.B = B; L.P = P;
-    hipStream_t st = (hipStream_t)stream;
-    val_sums_kernel<<<dim3(nchunk, B), 256, 0, st>>>(L, workspace);
-    val_sums_reduce_kernel<<<cdiv(B * V_SUMS, 256), 256, 0, st>>>(workspace, nchunk, B, sums);
-    return check_launch("cdnet_dam_val_sums");
+    return cdnet_dam_val_sums_classes(mask, point, dirn, label, dirlab, point_target_f16, weight_u8, dir_rank_host, 9, B, H, W, workspace,
+                                      workspace_floats, sums, stream);
 }
 
 extern "C" int cdnet_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
@@ -1851,22 +1923,24 @@ extern "C" int cdnet_adam_step(float *param, const float *grad, float *exp_avg, 
     return check_launch("cdnet_adam_step");
 }
 
-extern "C" size_t cdnet_final_conv1x1_backward_workspace_floats(void) { return (size_t)1025 * (FC_KWIDE * 64 + FC_KWIDE); }
+extern "C" size_t cdnet_final_conv1x1_backward_workspace_floats(void) { return (size_t)1025 * (FC_KMOST * 64 + FC_KMOST); }
 
 extern "C" int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
                                             uint16_t *df, float *workspace, size_t workspace_floats, float *dw, float *db, void *stream) {
     CDNET_REQUIRE(f && f->raw && w && dlogits && df && workspace && dw && db, "cdnet_final_conv1x1_backward: null pointer");
-    CDNET_REQUIRE(K >= 1 && K <= FC_KWIDE && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1_backward: K=%d must be in [1,%d]", K, FC_KWIDE);
+    CDNET_REQUIRE(K >= 1 && K <= FC_KMOST && N > 0 && H > 0 && W > 0, "cdnet_final_conv1x1_backward: K=%d must be in [1,%d]", K, FC_KMOST);
     if (workspace_floats < cdnet_final_conv1x1_backward_workspace_floats()) { set_error("cdnet_final_conv1x1_backward: workspace too small"); return CDNET_E_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)N * H * W;
     const bool wide = K > FC_KMAX;
-    const int KM = wide ? FC_KWIDE : FC_KMAX;
+    const bool most = K > FC_KWIDE;
+    const int KM = most ? FC_KMOST : wide ? FC_KWIDE : FC_KMAX;
     int nb = (int)((npix + (wide ? 31 : 63)) / (wide ? 32 : 64));
     if (nb > 1024) nb = 1024;
     const int ROW = KM * 64 + KM;
     float *sums = workspace + (size_t)1024 * ROW;
-    if (wide) final_conv_bwd_kernel<FC_KWIDE, 8><<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
+    if (most) final_conv_bwd_kernel<FC_KMOST, 8><<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
+    else if (wide) final_conv_bwd_kernel<FC_KWIDE, 8><<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
     else final_conv_bwd_kernel<FC_KMAX, 4><<<nb, 256, 0, st>>>(mk_hf(*f), w, dlogits, K, N, H * W, df, workspace);
     reduce_partials_kernel<<<cdiv(ROW, 4), 256, 0, st>>>(workspace, nb, ROW, sums);
     final_conv_scatter_kernel<<<cdiv(K * 64, 256), 256, 0, st>>>(sums, K, KM, dw, db);

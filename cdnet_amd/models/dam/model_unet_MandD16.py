@@ -1,9 +1,9 @@
 """`Unet` of the reference's models/dam/model_unet_MandD16.py (ablation of the direction-aware-mask head: mask + 16+1-class direction;
 forward :246-268).  Same constructor, state_dict keys and return tuple; encoder, decoder and residual units are the kernels of
-model_unet_rev1, the heads are plain 1x1 classifiers (cdnet_final_conv1x1).  Inference only on the accelerated path."""
-from .model_unet_rev1 import Unet as _Rev1
+model_unet_rev1, the heads are plain 1x1 classifiers (cdnet_final_conv1x1).  Trains through
+cdnet_amd.trainer.AblationTrainer (cdnet_dam_loss_classes with direction_classes = 17)."""
+from .model_unet_MandD import Unet as _MandD
 
 
-class Unet(_Rev1):
-    VARIANT = 'MandD'
+class Unet(_MandD):
     DIRECTION_OUT = 17

@@ -257,8 +257,6 @@ class Unet(nn.Module):
         """ablation heads: plain 1x1 classifiers on the features, no attention gates (cdnet_final_conv1x1)"""
         import ctypes as C
         f1m, f2, f3 = feats
-        if self.training and self.DIRECTION_OUT != 9:
-            raise NotImplementedError('training of the 5- / 17-class ablation heads (model_unet_MandD4 / MandD16) is not on the accelerated path')
         self._last_feats = feats
         N, H, W, _ = f1m.x.shape
         dev = f1m.x.device

@@ -208,6 +208,19 @@ def train_targets(B, H, W, seed, n=6):
     return lab, dirn, point.astype(np.float16), weight
 
 
+def remap_direction(dirn, classes):
+    """the 0..8 direction classes of train_targets as a 4+1 / 8+1 / 16+1 class map (options.py:45): 8 -> 4 directions by pairing
+    neighbours, 8 -> 16 by splitting every direction on the pixel checkerboard - fixed recipe for fixtures and tests."""
+    d = np.asarray(dirn).astype(np.int64)
+    if classes == 9:
+        return d.astype(np.uint8)
+    if classes == 5:
+        return np.where(d > 0, (d - 1) // 2 + 1, 0).astype(np.uint8)
+    assert classes == 17, classes
+    yy, xx = np.mgrid[:d.shape[-2], :d.shape[-1]]
+    return np.where(d > 0, 2 * d - ((yy + xx) & 1), 0).astype(np.uint8)
+
+
 def crc(*arrays):
     c = 0
     for a in arrays:

@@ -109,21 +109,23 @@ def validate(val_loader, model, criterion, opt, logger, get_process_worktime=1, 
         if len(uniq) < opt.direction_classes:
             raise IndexError('validate: the batch holds %d of the %d direction classes (the reference indexes unique_number[k] for '
                              'every k, train_util_dam.py:467)' % (len(uniq), opt.direction_classes))
-        rank = (C.c_int * 9)(*[(uniq.index(v) if v in uniq else -1) for v in range(9)])
-        need = lib.cdnet_dam_val_sums_workspace_floats(B, H * W)
+        ND = direction.shape[1]                     # 9, or 5 / 17 for the 4- / 16-direction ablation models
+        rank = (C.c_int * ND)(*[(uniq.index(v) if v in uniq else -1) for v in range(ND)])
+        need = lib.cdnet_dam_val_sums_classes_workspace_floats(B, H * W, ND)
         if ws is None or ws.numel() < need:
             ws = torch.empty((need,), dtype=torch.float32, device=dev)
-        sums = torch.empty((B, 42), dtype=torch.float32, device=dev)
-        _lib.call('cdnet_dam_val_sums', _lib.ptr(mask.contiguous()), _lib.ptr(point.contiguous()), _lib.ptr(direction.contiguous()), _lib.ptr(label),
-                  _lib.ptr(dirlab), _lib.ptr(point_t), _lib.ptr(w), C.cast(rank, C.c_void_p), B, H, W, _lib.ptr(ws), ws.numel(), _lib.ptr(sums),
-                  _lib.stream_ptr())
+        sums = torch.empty((B, 15 + 3 * ND), dtype=torch.float32, device=dev)
+        _lib.call('cdnet_dam_val_sums_classes', _lib.ptr(mask.contiguous()), _lib.ptr(point.contiguous()), _lib.ptr(direction.contiguous()),
+                  _lib.ptr(label), _lib.ptr(dirlab), _lib.ptr(point_t), _lib.ptr(w), C.cast(rank, C.c_void_p), ND, B, H, W, _lib.ptr(ws),
+                  ws.numel(), _lib.ptr(sums), _lib.stream_ptr())
         S = sums.cpu().numpy().astype(np.float64)
         n = float(B * H * W)
-        ce, dce, mse = S[:, 9].sum() / n, S[:, 37].sum() / n, S[:, 38].sum() / n
+        iq, pq, tq, vs = 10, 10 + ND, 10 + 2 * ND, 10 + 3 * ND
+        ce, dce, mse = S[:, 9].sum() / n, S[:, vs].sum() / n, S[:, vs + 1].sum() / n
         dice = sum(1.0 - np.mean(2.0 * (S[:, c] + 1.0) / (S[:, 3 + c] + S[:, 6 + c] + 1.0)) for c in range(3))          # loss.py:135-176
-        ddice = sum(1.0 - np.mean(2.0 * (S[:, 10 + c] + 1.0) / (S[:, 19 + c] + S[:, 28 + c] + 1.0)) for c in range(9))
+        ddice = sum(1.0 - np.mean(2.0 * (S[:, iq + c] + 1.0) / (S[:, pq + c] + S[:, tq + c] + 1.0)) for c in range(ND))
         loss = ce + dice + dce + ddice + mse
-        tp, fp, fn = S[:, 39], S[:, 40], S[:, 41]
+        tp, fp, fn = S[:, vs + 2], S[:, vs + 3], S[:, vs + 4]
         tn = H * W - tp - fp - fn
         precision, recall = tp / (tp + fp + 1e-10), tp / (tp + fn + 1e-10)
         m = [np.mean((tp + tn) / (tp + fp + tn + fn + 1e-10)), np.mean(tp / (tp + fp + fn + 1e-10)), np.mean(recall), np.mean(precision),

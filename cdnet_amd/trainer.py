@@ -220,7 +220,8 @@ class Trainer:
     def loss_and_grads(self, mask, point, direction, label, dirlab, point_t, weight):
         B, _, H, W = mask.shape
         lib = _lib.load()
-        need = lib.cdnet_dam_loss_workspace_floats(B, H * W)
+        ND = direction.shape[1]                       # 5 / 9 / 17 direction classes (options.py:45)
+        need = lib.cdnet_dam_loss_classes_workspace_floats(B, H * W, ND)
         if self._ws_loss is None or self._ws_loss.numel() < need:
             self._ws_loss = torch.empty((need,), dtype=torch.float32, device=self.dev)
         dmask = self.buf('dmask', mask.shape, torch.float32)
@@ -228,8 +229,8 @@ class Trainer:
         ddir = self.buf('ddir', direction.shape, torch.float32)
         assert label.dtype == torch.uint8 and dirlab.dtype == torch.uint8 and weight.dtype == torch.uint8
         assert point_t.dtype == torch.float16
-        _lib.call('cdnet_dam_loss', _lib.ptr(mask), _lib.ptr(point), _lib.ptr(direction), _lib.ptr(label.contiguous()),
-                  _lib.ptr(dirlab.contiguous()), _lib.ptr(point_t.contiguous()), _lib.ptr(weight.contiguous()), B, H, W,
+        _lib.call('cdnet_dam_loss_classes', _lib.ptr(mask), _lib.ptr(point), _lib.ptr(direction), _lib.ptr(label.contiguous()),
+                  _lib.ptr(dirlab.contiguous()), _lib.ptr(point_t.contiguous()), _lib.ptr(weight.contiguous()), B, H, W, ND,
                   self.quirk, _lib.ptr(self._ws_loss), self._ws_loss.numel(), _lib.ptr(self.losses), _lib.ptr(dmask),
                   _lib.ptr(dpoint), _lib.ptr(ddir), _lib.stream_ptr())
         return dmask, dpoint, ddir
@@ -807,11 +808,12 @@ class AblationTrainer(Trainer):
     """Train iteration of the ablation heads (models/dam/model_unet_MandD.py / model_unet_MandDandP.py through
     train_util_dam.train, which unpacks the model's outputs by their number, :152-166): the same five-term loss - without the point
     term for the two-output model (options direction = 1, mseloss = 0) - plain 1x1 classifiers instead of the gated head
-    (cdnet_final_conv1x1 / cdnet_final_conv1x1_backward), everything else the rev1 tape.  9-class direction maps only."""
+    (cdnet_final_conv1x1 / cdnet_final_conv1x1_backward), everything else the rev1 tape.  The direction branch has 5, 9 or 17
+    classes (model_unet_MandD4 / MandD / MandD16; cdnet_dam_loss_classes)."""
 
     def __init__(self, model, **kw):
-        assert getattr(model, 'VARIANT', 'rev1') in ('MandD', 'MandDandP') and model.DIRECTION_OUT == 9, \
-            'AblationTrainer serves model_unet_MandD / model_unet_MandDandP (9 direction classes)'
+        assert getattr(model, 'VARIANT', 'rev1') in ('MandD', 'MandDandP') and model.DIRECTION_OUT in (5, 9, 17), \
+            'AblationTrainer serves model_unet_MandD / MandD4 / MandD16 / MandDandP'
         super().__init__(model, **kw)
 
     def loss_and_grads(self, outputs, label, dirlab, point_t, weight):

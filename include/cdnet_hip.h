@@ -257,8 +257,8 @@ size_t cdnet_bias_grad_workspace_floats(int C);
 int cdnet_bias_grad(const uint16_t *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);
 int cdnet_bias_grad_f32(const float *grad_out, size_t npix, int C, float *workspace, size_t workspace_floats, float *db, void *stream);   /* fp32-precision path */
 /* backward of that classifier (plain-UNet training, train_util.py:126-200 loss.backward()): dlogits f32 [N][K][H][W] ->
- * df bf16 NHWC [N][H][W][64] (gradient of the activated feature), dw f32 [K][64], db f32 [K].  K <= 12 (the 3-class mask and
- * 9-class direction classifiers of the ablation heads, models/dam/model_unet_MandD*.py).
+ * df bf16 NHWC [N][H][W][64] (gradient of the activated feature), dw f32 [K][64], db f32 [K].  K <= 20 (the 3-class mask and
+ * 5- / 9- / 17-class direction classifiers of the ablation heads, models/dam/model_unet_MandD*.py).
  * workspace: cdnet_final_conv1x1_backward_workspace_floats() floats. */
 size_t cdnet_final_conv1x1_backward_workspace_floats(void);
 int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const float *dlogits, int K, int N, int H, int W,
@@ -361,6 +361,15 @@ int cdnet_dam_loss(const float *mask, const float *point, const float *direction
                    const uint8_t *dirlab, const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W,
                    int quirk_sample0, float *workspace, size_t workspace_floats, float *losses, float *dmask,
                    float *dpoint, float *ddir, void *stream);
+/* the same loss for direction maps of direction_classes = 5, 9 or 17 classes (options.py:45 "4 8 16" + background; the 4- and
+ * 16-direction ablation models models/dam/model_unet_MandD4.py / model_unet_MandD16.py): direction / ddir f32 [B][classes][H][W],
+ * dirlab u8 0..classes-1; loss.py:216-260 runs its cyclic neighbour terms over 1..classes-1 and averages over `classes`.
+ * cdnet_dam_loss is this entry with 9 classes. */
+size_t cdnet_dam_loss_classes_workspace_floats(int B, int P, int direction_classes);
+int cdnet_dam_loss_classes(const float *mask, const float *point, const float *direction, const uint8_t *label,
+                           const uint8_t *dirlab, const uint16_t *point_target_f16, const uint8_t *weight_u8, int B, int H, int W,
+                           int direction_classes, int quirk_sample0, float *workspace, size_t workspace_floats, float *losses,
+                           float *dmask, float *dpoint, float *ddir, void *stream);
 
 /* validate() loss mix of train_util_dam.py:367-636 (default options): per-sample sums of ONE pass over the logits, combined on the
  * host by cdnet_amd.train_util_dam.validate.  sums f32 [B][CDNET_VAL_SUMS]:
@@ -375,6 +384,14 @@ size_t cdnet_dam_val_sums_workspace_floats(int B, int P);
 int cdnet_dam_val_sums(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
                        const uint16_t *point_target_f16, const uint8_t *weight_u8, const int *dir_rank_host, int B, int H, int W,
                        float *workspace, size_t workspace_floats, float *sums, void *stream);
+/* the same for direction_classes = ND in {5, 9, 17} (model_unet_MandD4 / MandD16): dir_rank_host holds ND entries and
+ * sums f32 [B][15 + 3 ND]: 0..9 as above, the three direction blocks at 10, 10 + ND, 10 + 2 ND (ND wide each), the five scalars
+ * {weighted direction CE, MSE, tp, fp, fn} at 10 + 3 ND.  cdnet_dam_val_sums is this entry with ND = 9. */
+size_t cdnet_dam_val_sums_classes_workspace_floats(int B, int P, int direction_classes);
+int cdnet_dam_val_sums_classes(const float *mask, const float *point, const float *dirn, const uint8_t *label, const uint8_t *dirlab,
+                               const uint16_t *point_target_f16, const uint8_t *weight_u8, const int *dir_rank_host,
+                               int direction_classes, int B, int H, int W, float *workspace, size_t workspace_floats, float *sums,
+                               void *stream);
 
 /* torch.optim.Adam step (utils.py:915-918: betas (0.9, 0.99), L2 weight decay added to the gradient) on flat fp32
  * buffers; `step` is 1-based; grad_scale multiplies the gradient first (1/world_size after an all-reduce). */

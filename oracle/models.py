@@ -126,7 +126,7 @@ class Unet(nn.Module):                                   # model_unet_rev1.py:18
     SKIPS = ('5', '12', '22', '32', '42')
     BB_OUT = '43'
 
-    def __init__(self, classes=3, decoder_filters=(256, 128, 64, 32, 16), variant='rev1'):
+    def __init__(self, classes=3, decoder_filters=(256, 128, 64, 32, 16), variant='rev1', direction_classes=9):
         """variant: 'rev1' (UNet2RevA1_vgg16) or the ablation heads 'MandD' (models/dam/model_unet_MandD.py:246-268: mask + direction,
         no gates, no point branch) / 'MandDandP' (model_unet_MandDandP.py: plus the point branch) - same parameters plus `residual`"""
         super().__init__()
@@ -144,8 +144,8 @@ class Unet(nn.Module):                                   # model_unet_rev1.py:18
         self.point_feature = ResidualUnit(64, 64)
         self.point_conv = nn.Conv2d(64, 1, kernel_size=1)
         self.directionAtt = revAttention(1)
-        self.direction_conv = nn.Conv2d(64, 9, kernel_size=1)
-        self.maskAtt = revAttention(9)
+        self.direction_conv = nn.Conv2d(64, direction_classes, kernel_size=1)    # 5 / 17: model_unet_MandD4.py / MandD16.py
+        self.maskAtt = revAttention(direction_classes)
         self.mask_conv = nn.Conv2d(64, 3, kernel_size=1)
         if variant != 'rev1':
             self.residual = ResidualUnit(64, 64)                                             # model_unet_MandD.py:234

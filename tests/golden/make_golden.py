@@ -13,6 +13,7 @@ Fixtures:
   unet_fwd.npz     models/unet.py UNet forward+backward, det_fill weights
   dam_fwd.npz      models/dam/model_unet_rev1.py Unet forward (train-mode BN and eval-mode BN) + grads
   losses.npz       loss.py dice / weighted-dice, log-softmax NLL, MSE on fixed logits
+  losses_classes.npz  the direction terms on 5- and 17-class direction maps
   train_iter.npz   train_util_dam.train: two iterations on a 1-batch loader (losses + params after Adam)
   ablation.npz     models/dam/model_unet_MandD{,4,16,andP}.py eval forward (heads without attention gates)
   validate.npz     train_util_dam.validate: the 16-value result vector, whole-tile and sliding-window forward
@@ -234,6 +235,27 @@ def gen_losses():
          ce=np.float64(ce.item()), dice=np.float64(dice.item()), dce=np.float64(dce.item()),
          wdice=np.float64(wdice.item()), mse=np.float64(mse.item()), total=np.float64(total.item()),
          g_mask=lo_mask.grad.numpy(), g_dir=lo_dir.grad.numpy(), g_pt=lo_pt.grad.numpy())
+
+
+def gen_losses_classes():
+    """the direction terms (weighted NLL + loss.py WeightMulticlassDiceLoss) on 4+1- and 16+1-class direction maps
+    (options.py:45; models/dam/model_unet_MandD4.py / model_unet_MandD16.py)"""
+    from loss import WeightMulticlassDiceLoss
+    B, H, W = 3, 40, 48
+    lab, dirn, point, weight = _synthetic_targets(B, H, W, 11)
+    w = torch.from_numpy(weight).float().div(20).squeeze(1)
+    crit = torch.nn.NLLLoss(reduction='none')
+    out = {'cfg': np.array([B, H, W, 11, 5])}       # targets: synth.remap_direction(train_targets(B,H,W,11)); logits: RandomState(5 + C)
+    for C in (5, 17):
+        d = torch.from_numpy(synth.remap_direction(dirn, C).astype(np.int64))
+        lo_dir = torch.from_numpy((np.random.RandomState(5 + C).randn(B, C, H, W) * 2).astype(np.float32)).requires_grad_(True)
+        dce = (crit(F.log_softmax(lo_dir, 1), d) * w).mean()
+        onehot = F.one_hot(d, C).permute(0, 3, 1, 2).float()
+        wdice = WeightMulticlassDiceLoss()(F.softmax(lo_dir, 1), onehot, w)
+        (dce + wdice).backward()
+        out['c%d_dce' % C], out['c%d_wdice' % C] = np.float64(dce.item()), np.float64(wdice.item())
+        out['c%d_g_dir' % C] = lo_dir.grad.numpy()
+    save('losses_classes', **out)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -662,7 +684,7 @@ def gen_aji():
     save('aji', **out)
 
 
-ALL = {'validate': gen_validate, 'ablation': gen_ablation, 'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
+ALL = {'validate': gen_validate, 'ablation': gen_ablation, 'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'losses_classes': gen_losses_classes, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
        'cdm': gen_cdm, 'cdm_inst': gen_cdm_inst, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':

@@ -183,7 +183,10 @@ def _sync_worker(rank, world, port, out):
     tr.flat.step_count = 7 + rank
     tr.sync_from_rank0()
     means = tr.reduce_scalars(np.arange(11, dtype=np.float64) * (rank + 1))
-    out.put((rank, sd, tr.flat.P.clone(), tr.flat.M.clone(), tr.flat.step_count, np.asarray(means)))
+    # numpy copies travel by value; torch tensors on an mp queue are shared through a descriptor server of this process, which
+    # may be gone by the time the parent unpickles them
+    out.put((rank, {k: v.numpy().copy() for k, v in sd.items()}, tr.flat.P.numpy().copy(), tr.flat.M.numpy().copy(),
+             tr.flat.step_count, np.asarray(means)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -202,8 +205,11 @@ def test_parameter_broadcast_and_scalar_mean_two_ranks():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    t = torch.from_numpy
     sd0, P0, M0, step0, mean0 = got[0]
     sd1, P1, M1, step1, mean1 = got[1]
+    sd0, sd1 = {k: t(v) for k, v in sd0.items()}, {k: t(v) for k, v in sd1.items()}
+    P0, P1, M0, M1 = t(P0), t(P1), t(M0), t(M1)
     torch.manual_seed(1000)
     want = _TinyNet().state_dict()                         # rank 0's initialisation
     for k in sd0:

@@ -1,4 +1,4 @@
-"""Training step of the ablation heads (models/dam/model_unet_MandD.py / model_unet_MandDandP.py through train_util_dam.train):
+"""Training step of the ablation heads (models/dam/model_unet_MandD.py / MandD4 / MandD16 / MandDandP through train_util_dam.train):
 cdnet_amd.trainer.AblationTrainer against the oracle (oracle.models.Unet(variant=...), oracle.train.ablation_losses).
   * loss values vs the fp32 oracle, 2e-3 relative (bf16 path);
   * gradients of the linearised network in fp32 precision vs the oracle's autograd: median relative error <= 2e-3, worst <= 5e-2
@@ -16,7 +16,8 @@ def _setup(variant, B=2, S=64, seed=0):
     from cdnet_amd import synth
     from oracle import models as om
     torch.manual_seed(seed)
-    ref = om.Unet(variant=variant)
+    classes = {'MandD4': 5, 'MandD16': 17}.get(variant, 9)          # options.py:45 direction_classes of the 4- / 16-direction ablations
+    ref = om.Unet(variant='MandD' if classes != 9 else variant, direction_classes=classes)
     for mod in ref.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
@@ -26,6 +27,7 @@ def _setup(variant, B=2, S=64, seed=0):
     assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
     m.load_state_dict(ref.state_dict())
     lab, dirn, point, weight = synth.train_targets(B, S, S, 21)
+    dirn = synth.remap_direction(dirn, classes)
     x = torch.from_numpy(synth.det_input((B, 3, S, S), 9))
     t = [torch.from_numpy(a) for a in (lab, dirn, point, weight)]
     return m.cuda(), ref, x, t
@@ -61,7 +63,7 @@ def _oracle(ref, x, t, linear=False):
     return {k: float(v) for k, v in L.items()}, {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize('variant', ['MandD', 'MandDandP'])
+@pytest.mark.parametrize('variant', ['MandD', 'MandDandP', 'MandD4', 'MandD16'])
 def test_ablation_loss_values_and_unused_parameters(variant):
     m, ref, x, t = _setup(variant)
     tr, g = _hip(m, x, t)
@@ -69,13 +71,13 @@ def test_ablation_loss_values_and_unused_parameters(variant):
     got = tr.losses.cpu().numpy()[:6]
     want = [L[k] for k in ('total', 'dce', 'wdice', 'mse', 'ce', 'dice')]
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-6)
-    if variant == 'MandD':
+    if variant != 'MandDandP':
         assert want[3] == 0.0 and got[3] == 0.0                    # no point branch, no MSE term
     # exactly the parameters autograd reaches in the reference get a gradient here
     assert set(g.keys()) == set(rg.keys()), set(g.keys()) ^ set(rg.keys())
 
 
-@pytest.mark.parametrize('variant', ['MandD', 'MandDandP'])
+@pytest.mark.parametrize('variant', ['MandD', 'MandDandP', 'MandD4', 'MandD16'])
 def test_ablation_linearised_gradients_fp32(variant):
     import cdnet_amd
     from cdnet_amd import runtime
@@ -97,11 +99,12 @@ def test_ablation_linearised_gradients_fp32(variant):
         assert rel[n] <= 2e-3, (n, rel[n])
 
 
-def test_ablation_short_training_run_tracks_the_oracle():
+@pytest.mark.parametrize('variant', ['MandD', 'MandD16'])
+def test_ablation_short_training_run_tracks_the_oracle(variant):
     import torch
     from cdnet_amd import trainer
     from oracle import train as ot
-    m, ref, x, t = _setup('MandD')
+    m, ref, x, t = _setup(variant)
     p0 = {n: p.detach().clone() for n, p in ref.named_parameters()}
     tr = trainer.AblationTrainer(m)
     dev = torch.device('cuda:0')
@@ -116,7 +119,7 @@ def test_ablation_short_training_run_tracks_the_oracle():
         L['total'].backward()
         opt.step()
         theirs.append(float(L['total']))
-    print('MandD trajectory', ours, theirs)
+    print(variant, 'trajectory', ours, theirs)
     np.testing.assert_allclose(ours[0], theirs[0], rtol=2e-3)
     np.testing.assert_allclose(ours, theirs, rtol=5e-2)
     assert ours[-1] < ours[0] * 0.95
@@ -124,3 +127,33 @@ def test_ablation_short_training_run_tracks_the_oracle():
     for n, p in ref.named_parameters():
         if n.startswith(m.UNUSED_PREFIXES):
             assert torch.equal(sd[n].cpu(), p0[n]), n
+
+
+@pytest.mark.parametrize('variant', ['MandD', 'MandD4', 'MandD16'])
+def test_ablation_validate_matches_oracle(variant):
+    """train_util_dam.validate on the two-output models (cdnet_dam_val_sums_classes with 9 / 5 / 17 direction classes) vs
+    oracle.train.validate_losses on the oracle network's eval outputs, fp32 precision: losses 2e-4, pixel metrics 5e-3"""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import train_util_dam
+    from cdnet_amd.options import Options
+    from oracle import train as ot
+    cdnet_amd.set_precision('fp32')
+    try:
+        m, ref, x, t = _setup(variant)
+        lab, dirn, point, weight = t
+        classes = m.DIRECTION_OUT
+        assert len(torch.unique(dirn)) == classes
+        opt = Options(isTrain=True).parse([])
+        opt.direction_classes = classes
+        target0 = (lab.long() * 127 + (lab == 2).long()).unsqueeze(1)
+        got = train_util_dam.validate([(x, weight, target0, point, dirn)], m, None, opt, None, all_img_test=1)
+    finally:
+        cdnet_amd.set_precision('bf16')
+    ref.eval()
+    with torch.no_grad():
+        mask, direction = ref(x)
+        L = ot.validate_losses(mask, torch.zeros_like(mask[:, :1]), direction, lab, dirn, torch.zeros_like(point), weight)
+    want = [float(L[k]) for k in ('total', 'dce', 'ddice', 'mse')]
+    np.testing.assert_allclose(got[:4], want, rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(got[4:9], ot.pixel_metrics(mask.argmax(1).numpy(), lab.numpy()), atol=5e-3)

@@ -233,6 +233,57 @@ def test_loss_values_and_gradients(golden):
         assert _rel(dm.cpu(), lm.grad) < 1e-4 and _rel(dd.cpu(), ld.grad) < 1e-4 and _rel(dp.cpu(), lp.grad) < 1e-4
 
 
+@pytest.mark.parametrize('C', [5, 17])
+def test_loss_other_direction_class_counts(golden, C):
+    """cdnet_dam_loss_classes on 4+1 / 16+1 direction classes (model_unet_MandD4 / MandD16): the direction terms and their gradient
+    against the reference's golden (plain one-hot target = quirk off, every pixel labelled foreground so that no one-hot row is
+    masked), then the masked / quirk variants against the oracle"""
+    import torch
+    from cdnet_amd import synth, _lib
+    from oracle import train as ot
+    z = golden('losses_classes')
+    B, H, W, tseed, lseed = [int(v) for v in z['cfg']]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def run(lm, lp, ld, lab, dirn, point, weight, quirk):
+        ws = torch.empty((_lib.load().cdnet_dam_loss_classes_workspace_floats(B, H * W, C),), dtype=torch.float32, device='cuda')
+        losses = torch.zeros(11, device='cuda')
+        dm, dp, dd = torch.empty_like(lm, device='cuda'), torch.empty_like(lp, device='cuda'), torch.empty_like(ld, device='cuda')
+        keep = [lm.detach().cuda(), lp.detach().cuda(), ld.detach().cuda(), dev(lab), dev(dirn), dev(point), dev(weight[:, 0])]
+        _lib.call('cdnet_dam_loss_classes', *[_lib.ptr(t) for t in keep], B, H, W, C, quirk,
+                  _lib.ptr(ws), ws.numel(), _lib.ptr(losses), _lib.ptr(dm), _lib.ptr(dp), _lib.ptr(dd), _lib.stream_ptr())
+        return losses.cpu().numpy(), dm.cpu(), dp.cpu(), dd.cpu()
+
+    lab, dirn, point, weight = synth.train_targets(B, H, W, tseed)
+    dirn = synth.remap_direction(dirn, C)
+    ld = torch.from_numpy((np.random.RandomState(lseed + C).randn(B, C, H, W) * 2).astype(np.float32)).requires_grad_(True)
+    rs = np.random.RandomState(3)
+    lm = torch.from_numpy((rs.randn(B, 3, H, W) * 2).astype(np.float32)).requires_grad_(True)
+    lp = torch.from_numpy(rs.randn(B, 1, H, W).astype(np.float32)).requires_grad_(True)
+    # golden: one-hot of the direction map without the foreground mask == label 1 everywhere
+    losses, _, _, dd = run(lm, lp, ld, np.ones_like(lab), dirn, point, weight, 0)
+    np.testing.assert_allclose(losses[1:3], [float(z['c%d_dce' % C]), float(z['c%d_wdice' % C])], rtol=2e-5, atol=2e-6)
+    assert _rel(dd, torch.from_numpy(z['c%d_g_dir' % C])) < 1e-4
+    # masked one-hot, sample-0 quirk, a constant sample: vs the oracle
+    for quirk in (1, 0):
+        d2 = dirn.copy()
+        if quirk:
+            d2[B - 1] = 0
+        for t in (lm, lp, ld):
+            t.grad = None
+        L = ot.dam_losses(lm, lp, ld, torch.from_numpy(lab), torch.from_numpy(d2), torch.from_numpy(point), torch.from_numpy(weight),
+                          quirk_sample0=bool(quirk))
+        L['total'].backward()
+        losses, dm, dp, dd = run(lm, lp, ld, lab, d2, point, weight, quirk)
+        np.testing.assert_allclose(losses[:6], [float(L[k]) for k in ('total', 'dce', 'wdice', 'mse', 'ce', 'dice')], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(losses[6:], ot.pixel_metrics(ld.detach().argmax(1).numpy(), d2), rtol=1e-6, atol=1e-7)
+        assert _rel(dm, lm.grad) < 1e-4 and _rel(dd, ld.grad) < 1e-4 and _rel(dp, lp.grad) < 1e-4
+    # a direction class beyond the map's range poisons the losses (no silent clamp)
+    bad = dirn.copy()
+    bad[0, 0, 0] = C
+    assert np.isnan(run(lm, lp, ld, lab, bad, point, weight, 1)[0]).all()
+
+
 def test_adam_matches_torch():
     import torch
     from cdnet_amd import _lib

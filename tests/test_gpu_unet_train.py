@@ -27,12 +27,14 @@ def _setup(B=2, S=64, seed=0):
     return m.cuda(), ref, x, torch.from_numpy(lab), torch.from_numpy(weight)
 
 
-def test_final_conv_backward_kernel():
+@pytest.mark.parametrize('K', [3, 5, 9, 17])
+def test_final_conv_backward_kernel(K):
+    """K = 3: the plain UNet / mask classifier; 5 / 9 / 17: the direction classifiers of the ablation heads (MandD4 / MandD / MandD16)"""
     import ctypes as C
     import torch
     from cdnet_amd import _lib, runtime
     g = torch.Generator().manual_seed(4)
-    N, H, W, K = 2, 24, 40, 3
+    N, H, W = 2, 24, 40
     f = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16)
     w = torch.randn((K, 64), generator=g)
     dl = torch.randn((N, K, H, W), generator=g)

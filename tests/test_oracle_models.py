@@ -71,6 +71,24 @@ def test_dam_unet_matches_reference(golden):
             np.testing.assert_allclose(o.numpy(), z['evalragged_' + n], rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('C', [5, 17])
+def test_direction_losses_other_class_counts_match_reference(golden, C):
+    """4+1 / 16+1 direction classes (options.py:45; the MandD4 / MandD16 ablation models): weighted NLL + cyclic weighted dice"""
+    z = golden('losses_classes')
+    B, H, W, tseed, lseed = [int(v) for v in z['cfg']]
+    lab, dirn, point, weight = synth.train_targets(B, H, W, tseed)
+    d = torch.from_numpy(synth.remap_direction(dirn, C).astype(np.int64))
+    assert int(d.max()) == C - 1
+    lo_dir = torch.from_numpy((np.random.RandomState(lseed + C).randn(B, C, H, W) * 2).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy(weight).float().div(20).squeeze(1)
+    dce = (torch.nn.functional.nll_loss(torch.log_softmax(lo_dir, 1), d, reduction='none') * w).mean()
+    oh = torch.nn.functional.one_hot(d, C).permute(0, 3, 1, 2).float()
+    wd = ot.weight_multiclass_dice(torch.softmax(lo_dir, 1), oh, w)
+    assert abs(float(dce) - float(z['c%d_dce' % C])) < 2e-6 and abs(float(wd) - float(z['c%d_wdice' % C])) < 2e-6
+    (dce + wd).backward()
+    np.testing.assert_allclose(lo_dir.grad.numpy(), z['c%d_g_dir' % C], rtol=1e-4, atol=1e-9)
+
+
 def test_losses_match_reference(golden):
     z = golden('losses')
     B, H, W, tseed, lseed = [int(v) for v in z['cfg']]
