@@ -221,6 +221,32 @@ def remap_direction(dirn, classes):
     return np.where(d > 0, 2 * d - ((yy + xx) & 1), 0).astype(np.uint8)
 
 
+def stub_outputs(lab, dirn, point, seed, classes=9):
+    """(mask, point, direction) logits of a model that almost reproduces its targets: one-hot of the label shifted by one row, every
+    third instance dropped (missed objects), one spurious disk per sample (false positive), Gaussian noise - inputs for metric branches
+    that need object-like predictions (validate's do_object_metric, tests/golden/validate_obj.npz).  float32 NCHW."""
+    from scipy import ndimage as ndi
+    rs = np.random.RandomState(seed)
+    lab = np.roll(np.asarray(lab).astype(np.int64), 1, axis=1)
+    B, H, W = lab.shape
+    yy, xx = np.mgrid[:H, :W]
+    for b in range(B):
+        comp, n = ndi.label(lab[b] > 0, structure=np.ones((3, 3), dtype=int))
+        for k in range(1, n + 1, 3):
+            lab[b][comp == k] = 0
+        free = np.argwhere(ndi.binary_dilation(lab[b] > 0, iterations=8) == 0)
+        if len(free):
+            cy, cx = free[rs.randint(len(free))]
+            d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+            lab[b][d2 <= 25] = 2
+            lab[b][d2 <= 16] = 1
+    mask = (6.0 * (lab[:, None] == np.arange(3)[None, :, None, None]) + rs.randn(B, 3, H, W)).astype(np.float32)
+    d = np.asarray(dirn).astype(np.int64)
+    direction = (4.0 * (d[:, None] == np.arange(classes)[None, :, None, None]) + rs.randn(B, classes, H, W)).astype(np.float32)
+    pt = (np.asarray(point).astype(np.float32) / 255.0 + 0.05 * rs.randn(B, H, W).astype(np.float32))[:, None]
+    return mask, pt.astype(np.float32), direction
+
+
 def crc(*arrays):
     c = 0
     for a in arrays:

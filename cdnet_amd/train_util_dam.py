@@ -71,13 +71,12 @@ def validate(val_loader, model, criterion, opt, logger, get_process_worktime=1, 
     opt.train['input_size'] / opt.train['val_overlap'] (:474); validate's OWN loss mix - unweighted mask CE + multi-class dice +
     weighted direction CE + plain dice on the background-gated direction probabilities + MSE against point / 255 - from one pass of
     `cdnet_dam_val_sums` over the logits, combined here in float64; the pixel metrics of the mask arg-max (:585-590).  With
-    do_object_metric = 0 (the reference's call, train.py:348) the object slots are 0 and obj_iou = pixel_iou (:617-619)."""
+    do_object_metric = 0 (the reference's call, train.py:348) the object slots are 0 and obj_iou = pixel_iou (:617-619); with 1 they
+    are utils.nuclei_accuracy_object_level of sample 0's post-processed inside class (:588-604)."""
     import ctypes as C
     from . import _lib
     assert opt.model['direction'] == 1 and opt.model['mseloss'] == 1 and opt.train['alpha'] == 0 and opt.model['dice'] == 1, \
         'validate implements the default configuration (direction + point branches, dice = 1, no variance term)'
-    if do_object_metric:
-        raise NotImplementedError('do_object_metric = 1 (Hausdorff-based object metrics) is outside the accelerated path')
     results = utils.AverageMeter(16)
     model.eval()
     dev = next(model.parameters()).device
@@ -130,7 +129,16 @@ def validate(val_loader, model, criterion, opt, logger, get_process_worktime=1, 
         precision, recall = tp / (tp + fp + 1e-10), tp / (tp + fn + 1e-10)
         m = [np.mean((tp + tn) / (tp + fp + tn + fn + 1e-10)), np.mean(tp / (tp + fp + fn + 1e-10)), np.mean(recall), np.mean(precision),
              np.mean(2 * precision * recall / (precision + recall + 1e-10))]
-        results.update([loss, dce, ddice, mse, m[0], m[1], m[2], m[3], m[4], 0, 0, 0, 0, m[1], 0, 0])
+        obj = [0, 0, 0, 0, m[1], 0, 0]                       # :606-609: without the object metrics obj_iou = pixel_iou
+        if do_object_metric == 1:
+            # :588-604: SAMPLE 0's inside class through fill holes / remove small / label / dilate (the device chain of the inference
+            # post-processing), scored against the labelled inside class of its target
+            from . import postproc
+            pred0 = (mask[:1].argmax(1) == 1).to(torch.uint8)
+            labeled = postproc.cc_chain(pred0, fg_value=1, min_area=opt.post['min_area'], radius=opt.post['radius'])['final'][0]
+            gt0 = (label[0] == 1).to(torch.uint8) * 255
+            obj = list(utils.nuclei_accuracy_object_level(labeled.cpu().numpy(), gt0.cpu().numpy()))
+        results.update([loss, dce, ddice, mse, m[0], m[1], m[2], m[3], m[4]] + obj)
     if logger is not None:
         logger.info('\t=> Val Avg:   \tLoss {r[0]:.4f}\tloss_direction_CE {r[1]:.4f}\tloss_direction_dice {r[2]:.4f}\tloss_mse {r[3]:.4f}'
                     '\tPixel_Acc {r[4]:.4f}\tPixel_IoU {r[5]:.4f}\tpixel_Recall {r[6]:.4f}\tpixel_Precision {r[7]:.4f}\tpixel_F1 {r[8]:.4f}'

@@ -157,28 +157,48 @@ class EarlyStopping:
             self.counter = 0
 
 
+def measure_label(a):
+    """skimage.measure.label semantics (:248-249): 8-connected regions of EQUAL value, background 0, ids 1..K in raster order of
+    each region's first pixel.  Instance maps from this package already are such regions (one lookup table); a binary image
+    (validate's 0/255 target, train_util_dam.py:600-602) or a value that occurs in several separate regions is split here."""
+    from scipy import ndimage as ndi
+    a = np.ascontiguousarray(a).astype(np.int64)
+    comp, _ = ndi.label(a != 0, structure=np.ones((3, 3), dtype=int))
+    key = comp * (int(a.max()) + 1 if a.size else 1) + a              # (foreground component, value)
+    key[a == 0] = 0
+    vals, inv = np.unique(key.ravel(), return_inverse=True)
+    lab = inv.reshape(a.shape).astype(np.int64)                         # 0 = background (key 0 sorts first), 1..K otherwise
+    if vals[0] != 0:
+        lab += 1
+    # two regions of one value inside one foreground component touch only through other values: split them
+    nxt = int(lab.max())
+    for k, sl in enumerate(ndi.find_objects(lab), start=1):
+        if sl is None:
+            continue
+        sub, n = ndi.label(lab[sl] == k, structure=np.ones((3, 3), dtype=int))
+        for j in range(2, n + 1):
+            nxt += 1
+            lab[sl][sub == j] = nxt
+    ids, first = np.unique(lab.ravel(), return_index=True)
+    keep = ids != 0
+    ids, first = ids[keep], first[keep]
+    lut = np.zeros(nxt + 1, np.int32)
+    lut[ids[np.argsort(first, kind='stable')]] = np.arange(1, len(ids) + 1, dtype=np.int32)
+    return lut[lab].astype(np.int32)
+
+
 def nuclei_accuracy_object_level(pred, gt):
     """(recall, precision, F1, dice, iou, haus, AJI) of utils.nuclei_accuracy_object_level (utils.py:245-330): ground-truth objects in
     id order, each greedily paired with the not-yet-used predicted object of largest IoU (first maximum in id order), used objects
     removed (:312).  The pixel pass (areas + sparse pairwise intersections) runs on the device (`stats_utils.pair_table`); the
     per-pair arithmetic is the reference's float arithmetic; the Hausdorff distance of a matched pair is scipy's
     directed_hausdorff on both sides, exactly the call the reference makes (:6, :303).
-    pred / gt: integer label images (the reference re-labels both with skimage.measure.label: 8-connected regions of equal
-    value; `stats_utils` labelled inputs from this package already are such regions, ids are made contiguous here)."""
+    pred / gt: integer label or binary images; both are re-labelled like the reference does with skimage.measure.label (8-connected
+    regions of equal value, raster-order ids)."""
     from scipy.spatial.distance import directed_hausdorff
     from . import stats_utils
 
-    def raster_ids(a):
-        """ids 1..K in raster order of each id's first pixel - the numbering skimage.measure.label gives an instance map whose
-        ids are connected regions (a same-valued region split into several components would become several objects there)"""
-        a = np.ascontiguousarray(a).astype(np.int64)
-        vals, first = np.unique(a.ravel(), return_index=True)
-        keep = vals != 0
-        vals, first = vals[keep], first[keep]
-        lut = np.zeros(int(a.max()) + 1 if a.size else 1, np.int32)
-        lut[vals[np.argsort(first, kind='stable')]] = np.arange(1, len(vals) + 1, dtype=np.int32)
-        return lut[a].astype(np.int32)
-    p, g = raster_ids(pred), raster_ids(gt)
+    p, g = measure_label(pred), measure_label(gt)
     ag, ap, pairs = stats_utils.pair_table(g, p)
     Ng, Ns = int((ag[1:] > 0).sum()), int((ap[1:] > 0).sum())
     by_gt = {}

@@ -351,6 +351,39 @@ def gen_validate():
          whole=np.array(whole, dtype=np.float64), split=np.array(split, dtype=np.float64))
 
 
+class _StubModel(torch.nn.Module):
+    """returns prescribed outputs (validate()'s metric branches need object-like predictions, which no closed-form weight fill gives)"""
+
+    def __init__(self, outs):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+        self.outs = [torch.from_numpy(o) for o in outs]
+
+    def forward(self, x):
+        return tuple(o.to(x.device) for o in self.outs)
+
+
+def gen_validate_obj():
+    """train_util_dam.validate with do_object_metric = 1 (:588-604): sample 0's mask arg-max through fill holes / remove small /
+    label / dilate, then utils.nuclei_accuracy_object_level against the labelled inside class of its target.  The model is a stub
+    that returns synth.stub_outputs (the closed-form weights predict no objects at all)."""
+    import io, contextlib
+    import train_util_dam
+    B, H, W = 2, 96, 96
+    lab, dirn, point, weight = _synthetic_targets(B, H, W, 23)
+    x = det_input((B, 3, H, W), 10)
+    target0 = torch.from_numpy(lab * 127 + (lab == 2)).long().unsqueeze(1)
+    sample = (x, torch.from_numpy(weight), target0, torch.from_numpy(point), torch.from_numpy(dirn))
+    m = _StubModel(synth.stub_outputs(lab, dirn, point, 77))
+    opt = _Opt()
+    opt.train.update(input_size=64, val_overlap=16)
+    opt.post = dict(min_area=20, radius=2)
+    crit = torch.nn.NLLLoss(reduction='none')
+    with contextlib.redirect_stdout(io.StringIO()):
+        row = train_util_dam.validate([sample], m, crit, opt, _Logger(), all_img_test=1, do_object_metric=1)
+    save('validate_obj', tgt_cfg=np.array([B, H, W, 23]), stub_seed=np.int64(77), post=np.array([20, 2]), row=np.array(row, dtype=np.float64))
+
+
 def gen_hrnet():
     """HRNet18_rev1 (seg_hrnet_rev1.HighResolutionNet) eval forward; closed-form weights with every Conv2d scaled by 0.45
     (the un-scaled fill overflows through the 30 residual additions)"""
@@ -684,7 +717,7 @@ def gen_aji():
     save('aji', **out)
 
 
-ALL = {'validate': gen_validate, 'ablation': gen_ablation, 'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'losses_classes': gen_losses_classes, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
+ALL = {'validate': gen_validate, 'validate_obj': gen_validate_obj, 'ablation': gen_ablation, 'ddm': gen_ddm, 'unet': gen_unet, 'dam': gen_dam, 'losses': gen_losses, 'losses_classes': gen_losses_classes, 'train_iter': gen_train_iter, 'unet_train_iter': gen_unet_train_iter, 'hrnet': gen_hrnet, 'hrnet_train': gen_hrnet_train,
        'cdm': gen_cdm, 'cdm_inst': gen_cdm_inst, 'split': gen_split, 'probmaps': gen_probmaps, 'postproc': gen_postproc, 'aji': gen_aji}
 
 if __name__ == '__main__':

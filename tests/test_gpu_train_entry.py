@@ -142,3 +142,39 @@ def _validate_case(golden, rtol):
     got = train_util_dam.validate([one], m, None, opt, None, all_img_test=0)
     np.testing.assert_allclose(got[:4], z['split'][:4], rtol=rtol)
     np.testing.assert_allclose(got[4:], z['split'][4:], atol=5e-3)
+
+
+def test_validate_object_metrics_match_reference_golden(golden):
+    """validate(do_object_metric = 1) (train_util_dam.py:588-604): sample 0's mask arg-max through the device fill-holes / remove-small /
+    label / dilate chain, then utils.nuclei_accuracy_object_level - against the reference's own 16-value row for the same prescribed
+    model outputs (tests/golden/validate_obj.npz: a stub model returning synth.stub_outputs, because no closed-form weight fill predicts
+    objects).  Losses 2e-5 (identical logits), object slots 1e-9."""
+    import torch
+    from cdnet_amd import synth, train_util_dam
+    from cdnet_amd.options import Options
+    z = golden('validate_obj')
+    B, H, W, tseed = [int(v) for v in z['tgt_cfg']]
+    lab, dirn, point, weight = synth.train_targets(B, H, W, tseed)
+    outs = [torch.from_numpy(o).cuda() for o in synth.stub_outputs(lab, dirn, point, int(z['stub_seed']))]
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            return tuple(outs)
+    opt = Options(isTrain=True).parse([])
+    opt.post['min_area'], opt.post['radius'] = int(z['post'][0]), int(z['post'][1])
+    x = torch.zeros((B, 3, H, W))
+    target0 = torch.from_numpy(lab.astype(np.int64) * 127 + (lab == 2)).unsqueeze(1)
+    sample = (x, torch.from_numpy(weight), target0, torch.from_numpy(point), torch.from_numpy(dirn))
+    got = train_util_dam.validate([sample], Stub().cuda(), None, opt, None, all_img_test=1, do_object_metric=1)
+    want = z['row']
+    assert want[9] < 1 and want[10] < 1 and want[15] > 0.1            # the fixture has misses, false positives and real overlaps
+    np.testing.assert_allclose(got[:4], want[:4], rtol=2e-5)
+    np.testing.assert_allclose(got[4:9], want[4:9], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(got[9:], want[9:], rtol=1e-9, atol=1e-12)
+    # and without the object metrics the slots are zero except obj_iou = pixel_iou (:606-609)
+    got0 = train_util_dam.validate([sample], Stub().cuda(), None, opt, None, all_img_test=1, do_object_metric=0)
+    assert list(got0[9:13]) == [0, 0, 0, 0] and got0[13] == got0[5] and list(got0[14:]) == [0, 0]
