@@ -35,11 +35,22 @@ def _label3(target0, boundary=2):
     return t.to(torch.uint8)
 
 
+def _check_branches(opt, model):
+    """the option combinations the reference's loops accept for the model at hand (train_util_dam.py:152-166): three outputs ->
+    direction = 1 and mseloss = 1 (the defaults); the two-output ablation models (mask + direction) -> direction = 1 and mseloss = 0
+    (with mseloss = 1 the reference would read the direction logits as the point map).  alpha = 0: no variance term."""
+    two = getattr(model, 'VARIANT', 'rev1') == 'MandD'
+    assert opt.model['direction'] == 1 and opt.train['alpha'] == 0, 'the fused loss implements direction = 1, alpha = 0'
+    if two:
+        assert opt.model['mseloss'] in (0, 1), opt.model['mseloss']       # 0 is the reference's setting; 1 is tolerated (no point term either way)
+    else:
+        assert opt.model['mseloss'] == 1, 'three-output models train with the point branch (mseloss = 1)'
+
+
 def train(train_loader, model, optimizer, criterion, epoch, opt, logger, get_process_worktime=1, get_process_detail=1,
           accuracy_tensor=0):
     trainer = optimizer
-    assert opt.model['direction'] == 1 and opt.model['mseloss'] == 1 and opt.train['alpha'] == 0, \
-        'the fused loss implements the default configuration (direction + point branches, no variance term)'
+    _check_branches(opt, trainer.model)
     results = utils.AverageMeter(11)
     dev = trainer.dev
     for i, sample in enumerate(train_loader):
@@ -75,8 +86,8 @@ def validate(val_loader, model, criterion, opt, logger, get_process_worktime=1, 
     are utils.nuclei_accuracy_object_level of sample 0's post-processed inside class (:588-604)."""
     import ctypes as C
     from . import _lib
-    assert opt.model['direction'] == 1 and opt.model['mseloss'] == 1 and opt.train['alpha'] == 0 and opt.model['dice'] == 1, \
-        'validate implements the default configuration (direction + point branches, dice = 1, no variance term)'
+    _check_branches(opt, model)
+    assert opt.model['dice'] == 1, 'validate implements the default configuration (dice = 1)'
     results = utils.AverageMeter(16)
     model.eval()
     dev = next(model.parameters()).device

@@ -157,3 +157,27 @@ def test_ablation_validate_matches_oracle(variant):
     want = [float(L[k]) for k in ('total', 'dce', 'ddice', 'mse')]
     np.testing.assert_allclose(got[:4], want, rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(got[4:9], ot.pixel_metrics(mask.argmax(1).numpy(), lab.numpy()), atol=5e-3)
+
+
+def test_train_entry_with_two_output_model_and_reference_options():
+    """train_util_dam.train with model_unet_MandD4 chosen through utils.chooseModel / get_optimizer and the option combination the
+    reference needs for a two-output model (direction = 1, mseloss = 0, direction_classes = 5; train_util_dam.py:157-163) == one
+    oracle iteration: losses 3e-3 (bf16 path), no point term"""
+    import torch
+    from cdnet_amd import synth, train_util_dam, utils
+    from cdnet_amd.options import Options
+    from oracle import train as ot
+    _, ref, x, t = _setup('MandD4')
+    opt = Options(isTrain=True)
+    opt.model['modelName'], opt.model['mseloss'], opt.direction_classes = 'model_unet_MandD4', 0, 5
+    m = utils.chooseModel(opt)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda()
+    trainer, _ = utils.get_optimizer(opt, m)
+    lab, dirn, point, weight = t
+    target0 = (lab.long() * 127 + (lab == 2).long()).unsqueeze(1)
+    got = train_util_dam.train([(x, weight, target0, point, dirn)], m, trainer, None, 0, opt, None)
+    ref.train()
+    L = ot.ablation_losses(ref(x), lab, dirn, point, weight)
+    assert got.shape == (11,) and got[3] == 0.0 and got[5] == -1.0
+    np.testing.assert_allclose(got[:5], [float(L[k]) for k in ('total', 'dce', 'wdice', 'mse', 'ce')], rtol=3e-3, atol=1e-7)
