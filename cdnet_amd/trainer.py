@@ -33,6 +33,13 @@ class BnBwdArgs(C.Structure):
                 ('f16', C.c_int), ('relu', C.c_int), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('C', C.c_int)]
 
 
+# workgroups of one weight-gradient launch while it runs beside the input-gradient chain (bf16 mode; see _weight_backward):
+# layers of up to 128 x 128 pixels / larger ones
+_WGRAD_WGS_DEEP = int(os.environ.get('CDNET_WGRAD_WGS_DEEP', '128'))
+_WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
+_WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
+
+
 class _G:
     """a gradient contribution for a stored tensor"""
     __slots__ = ('t', 'Hg', 'Wg', 'oy', 'ox', 'pooled', 'coff', 'cstride')
@@ -506,7 +513,13 @@ class Trainer:
             CI, CO = ci_t * 32, (4 // ci_t) * 32
             other = -(-s.C // CI) * -(-Cout // CO) * npar
             ntiles = N * (-(-H // 8)) * (-(-W // 16))
-            ksplit = max(1, min(ntiles, 256 // other if other < 256 else 1))      # one 8-wave workgroup per CU
+            # beside the input-gradient chain the weight-gradient kernels take fewer workgroups than there are CUs: a full grid of
+            # them holds every CU's LDS, and the chain's producer / consumer convolutions (one 157 KB workgroup per CU) then queue
+            # behind it - measured 1 663 -> 1 745 / 1 730 -> 1 813 tiles/s (two boxes).  fp32 mode keeps the full grid: its
+            # weight-gradient stream is nearly as long as the chain (-1.7 % with the caps).
+            capped = self._side_stream() is not None and runtime.PRECISION != 'fp32'
+            cap = 256 if not capped else (_WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW else _WGRAD_WGS_SHALLOW)
+            ksplit = max(1, min(ntiles, cap // other if other < cap else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
             slab = self._slab(nslab)
             cs = engine.ConvSrc()
