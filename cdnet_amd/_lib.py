@@ -117,10 +117,21 @@ def call(name, *args):
     check(getattr(load(), name)(*args), name)
 
 
+_RAW_STREAM = None
+
+
 def stream_ptr():
-    """The current PyTorch HIP stream as a void* for the ABI."""
-    import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current PyTorch HIP stream as a void* for the ABI (the raw-handle query: torch.cuda.current_stream() builds a Stream object
+    through several Python layers, ~4 us - on every one of the ~250 launches of a training step)."""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        get, dev = getattr(torch._C, '_cuda_getCurrentRawStream', None), getattr(torch._C, '_cuda_getDevice', None)
+        if get is not None and dev is not None:
+            _RAW_STREAM = lambda: get(dev())
+        else:
+            _RAW_STREAM = lambda: torch.cuda.current_stream().cuda_stream
+    return C.c_void_p(_RAW_STREAM())
 
 
 def ptr(t):

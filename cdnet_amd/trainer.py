@@ -40,6 +40,23 @@ _WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
 _WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
 
 
+class _on_stream:
+    """`with torch.cuda.stream(s)` without its bookkeeping (device checks, Stream objects: ~15 us per use, once per layer of the
+    backward pass): make `s` current, restore the previous stream on exit"""
+    __slots__ = ('s', 'prev')
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_stream()
+        torch.cuda.set_stream(self.s)
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
+
+
 class _G:
     """a gradient contribution for a stored tensor"""
     __slots__ = ('t', 'Hg', 'Wg', 'oy', 'ox', 'pooled', 'coff', 'cstride')
@@ -123,6 +140,7 @@ class Trainer:
         self._cat_cache = {}
         self._wstream, self._events = None, {}
         self._packb_pending = False
+        self._side_active = False
         self._forwards, self._bn_base = 0, 0                 # training forwards run here / counted in a loaded checkpoint
         if world_size > 1:
             self.sync_from_rank0()                           # replicas start identical whatever each rank's RNG / checkpoint did
@@ -284,6 +302,7 @@ class Trainer:
                     self._readers[id(sx.res)] = self._readers.get(id(sx.res), 0) + 1
             self._producer[id(Lt.saved[1])] = Lt
         side = self._side_stream()
+        self._side_active = side is not None
         if self._packb_pending:
             torch.cuda.current_stream().wait_event(self._event('packb'))      # backward-data packs made beside the forward
             self._packb_pending = False
@@ -329,7 +348,7 @@ class Trainer:
             ev = self._event(k)
             ev.record()
             side.wait_event(ev)
-            with torch.cuda.stream(side):
+            with _on_stream(side):
                 draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
                 _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(draw), _lib.stream_ptr())
                 self._weight_backward(L, srcs, draw, Hl, Wl)
@@ -345,15 +364,19 @@ class Trainer:
         if side is None:
             self._weight_backward(L, srcs, g, Hl, Wl)
             self._overlap_done(params)
+            self._input_backward(L, srcs, g, Hl, Wl, add)
         else:
-            # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient chain
+            # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient chain.  The chain's
+            # next kernel is issued first (under rocprofv3, whose interception slows every launch call, the chain otherwise sits idle
+            # in the 512-channel layers while the host is still issuing the side stream's launches; without the profiler the host
+            # keeps its lead either way)
             ev = self._event(k)
-            ev.record()
+            ev.record()             # (recorded after backward-data instead, the weight gradient overlaps the HBM-bound BatchNorm passes of
+            self._input_backward(L, srcs, g, Hl, Wl, add)      # the next layer rather than the convolution: -2 %)
             side.wait_event(ev)
-            with torch.cuda.stream(side):
+            with _on_stream(side):
                 self._weight_backward(L, srcs, g, Hl, Wl)
                 self._overlap_done(params)         # (a bucket released here is ordered after both streams' work so far)
-        self._input_backward(L, srcs, g, Hl, Wl, add)
 
     def _fusable(self, L, srcs, out, gl, H, W):
         """plain BatchNorm + ReLU layer with one same-size gradient source whose backward-data launch runs on the producer / consumer
@@ -517,7 +540,7 @@ class Trainer:
             # them holds every CU's LDS, and the chain's producer / consumer convolutions (one 157 KB workgroup per CU) then queue
             # behind it - measured 1 663 -> 1 745 / 1 730 -> 1 813 tiles/s (two boxes).  fp32 mode keeps the full grid: its
             # weight-gradient stream is nearly as long as the chain (-1.7 % with the caps).
-            capped = self._side_stream() is not None and runtime.PRECISION != 'fp32'
+            capped = self._side_active and runtime.PRECISION != 'fp32'
             cap = 256 if not capped else (_WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW else _WGRAD_WGS_SHALLOW)
             ksplit = max(1, min(ntiles, cap // other if other < cap else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
@@ -670,7 +693,7 @@ class Trainer:
                 ev = self._event('adam')
                 ev.record()
                 side.wait_event(ev)
-                with torch.cuda.stream(side):
+                with _on_stream(side):
                     _lib.call('cdnet_pack_conv_weights_batch', C.byref(arr), n, _lib.ptr(table), table.numel(), int(first[0]), _lib.stream_ptr())
                     self._event('packb').record()
                 self._packb_pending = True
