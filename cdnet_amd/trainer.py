@@ -37,6 +37,7 @@ class BnBwdArgs(C.Structure):
 # layers of up to 128 x 128 pixels / larger ones
 _WGRAD_WGS_DEEP = int(os.environ.get('CDNET_WGRAD_WGS_DEEP', '128'))
 _WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
+_WGRAD_WGS_F32 = int(os.environ.get('CDNET_WGRAD_WGS_F32', '256'))
 _WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
 
 
@@ -540,8 +541,12 @@ class Trainer:
             # them holds every CU's LDS, and the chain's producer / consumer convolutions (one 157 KB workgroup per CU) then queue
             # behind it - measured 1 663 -> 1 745 / 1 730 -> 1 813 tiles/s (two boxes).  fp32 mode keeps the full grid: its
             # weight-gradient stream is nearly as long as the chain (-1.7 % with the caps).
-            capped = self._side_active and runtime.PRECISION != 'fp32'
-            cap = 256 if not capped else (_WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW else _WGRAD_WGS_SHALLOW)
+            if not self._side_active:
+                cap = 256
+            elif runtime.PRECISION == 'fp32':
+                cap = _WGRAD_WGS_F32
+            else:
+                cap = _WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW else _WGRAD_WGS_SHALLOW
             ksplit = max(1, min(ntiles, cap // other if other < cap else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
             slab = self._slab(nslab)
