@@ -546,7 +546,7 @@ class Trainer:
             elif runtime.PRECISION == 'fp32':
                 cap = _WGRAD_WGS_F32
             else:
-                cap = _WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW else _WGRAD_WGS_SHALLOW
+                cap = _WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW or H * W > 65536 else _WGRAD_WGS_SHALLOW    # (512 x 512 layers of HRNet: 128 again)
             ksplit = max(1, min(ntiles, cap // other if other < cap else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
             slab = self._slab(nslab)
