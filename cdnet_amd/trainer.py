@@ -541,8 +541,8 @@ class Trainer:
             # them holds every CU's LDS, and the chain's producer / consumer convolutions (one 157 KB workgroup per CU) then queue
             # behind it - measured 1 663 -> 1 745 / 1 730 -> 1 813 tiles/s (two boxes).  fp32 mode keeps the full grid: its
             # weight-gradient stream is nearly as long as the chain (-1.7 % with the caps).
-            if not self._side_active:
-                cap = 256
+            if not self._side_active or not getattr(L, 'needs_input_grad', True):
+                cap = 256                                   # (the first layer's weight gradient runs after the chain has ended: whole chip)
             elif runtime.PRECISION == 'fp32':
                 cap = _WGRAD_WGS_F32
             else:
