@@ -68,26 +68,41 @@ __device__ __forceinline__ void store_tile_f32(const ConvArgs &A, const f32x16 (
     const int Ho = A.H * A.ostride, Wo = A.W * A.ostride;
     float *out = reinterpret_cast<float *>(A.out);
     const float *eres = reinterpret_cast<const float *>(A.eres);
-    const bool full = y0 + 16 <= A.H && x0 + TW <= A.W && cout0 + (nblock0 + NPW) * 32 <= A.Cout && !A.eres && A.ostride == 1 && TW == 16;
+    const bool full = y0 + 16 <= A.H && x0 + TW <= A.W && cout0 + (nblock0 + NPW) * 32 <= A.Cout && A.ostride == 1 && TW == 16;
     if (full) {
-        const int cs = A.out_cstride;
+        const int cs = A.out_cstride, ce = A.Cout;                    // (the residual input is a dense [N][H][W][Cout] tensor)
         float *tb = out + (((size_t)n * A.H + y0) * A.W + x0) * cs + A.out_coff;
+        const float *te = eres ? eres + (((size_t)n * A.H + y0) * A.W + x0) * ce : nullptr;
 #pragma unroll
         for (int ni = 0; ni < NPW; ++ni) {
             const int co = cout0 + (nblock0 + ni) * 32 + l31;
             const float osc = A.oscale ? A.oscale[co] : 1.f;
             const float osh = fmaf(A.bias ? A.bias[co] : 0.f, osc, A.oshift ? A.oshift[co] : 0.f);
+            const float esc = (eres && A.eres_scale) ? A.eres_scale[co] : 1.f;
+            const float esh = (eres && A.eres_shift) ? A.eres_shift[co] : 0.f;
             float *ob = tb + co;
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi) {
                 // block (mblock0 + mi): rows 2 (mblock0 + mi), +1 of the tile; this lane: pixel 4 half + (r & 3) + 8 (r >> 2) of the 32
-                const int rowb = ((mblock0 + mi) * 2) * A.W * cs + 4 * half * cs;
+                const int rowb = ((mblock0 + mi) * 2) * A.W + 4 * half;
+                float ev[16];
+                if (eres) {                        // the other branch of the residual unit, requested up front
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = (r & 3) + 8 * (r >> 2);
+                        ev[r] = te[(rowb + (p / 16) * A.W + (p % 16)) * ce + co];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int p = (r & 3) + 8 * (r >> 2);            // + 4 half: 0..31 -> (row p / 16, column p % 16); 4 half never carries
-                    const int off = rowb + ((p / 16) * A.W + (p % 16)) * cs;
+                    const int off = (rowb + (p / 16) * A.W + (p % 16)) * cs;
                     float v = fmaf(acc[mi][ni][r], osc, osh);
                     if (A.orelu) v = fmaxf(v, 0.f);
+                    if (eres) {
+                        v = fmaf(ev[r], esc, esh) + v;
+                        if (A.eres_relu) v = fmaxf(v, 0.f);
+                    }
                     ob[off] = v;
                 }
             }
