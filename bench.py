@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime starts: see cdnet_amd/__init__.py (stream -> hardware queue aliasing)
 
 DENSE_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16/f16 MFMA
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # ibid.: v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate (no TF32/xf32 on gfx950)

@@ -6,6 +6,15 @@ the path runs in hand-written HIP kernels behind the C ABI declared in include/c
 """
 __version__ = '0.1.0'
 
+import os as _os
+
+# HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), round robin in creation order.  Two streams on one queue
+# run one after the other: once RCCL has made its streams (torch.distributed, any world size) the trainer's weight-gradient stream
+# could land on the compute stream's queue - measured 1 780 -> 1 456 tiles/s under torch.distributed.run.  More queues make that rarer
+# (read by the HIP runtime when it initialises, so this must run before the first GPU call), and the trainer also checks the stream it
+# picks (Trainer._pick_side_stream).
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 
 def set_precision(p):
     """Arithmetic of the convolution stack: 'bf16' (16-bit NHWC activations, bf16 MFMA operands, fp32 accumulation) or
