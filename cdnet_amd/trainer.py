@@ -936,26 +936,31 @@ class AblationTrainer(Trainer):
 
 
 class BucketReducer:
-    """Releases fixed-size buckets of a flat gradient buffer to the all-reduce as soon as they are complete.
+    """Releases buckets of a flat gradient buffer to the all-reduce as soon as they are complete.
     The buffer is laid out in forward order and backward fills it from the end: `pending` maps the start offset of
-    every tensor that still waits for its gradient to its end offset; a bucket [k*B, (k+1)*B) is launched (async
-    all-reduce, top-down) once no pending tensor reaches into or above it.  Every rank runs the same schedule, so the
+    every tensor that still waits for its gradient to its end offset; a bucket [a, b) is launched (async all-reduce,
+    top-down) once no pending tensor reaches into or above it.  Bucket boundaries are counted from the TOP of the used
+    range (n, n - B, n - 2B, ..., 0): the remainder bucket is then the lowest one - the one that completes last, with the
+    first layers' gradients at the very end of backward, and whose collective nothing is left to hide (59 MB of
+    gradients in 25 MB buckets: a 6 MB tail instead of a 25 MB one).  Every rank runs the same schedule, so the
     collectives are issued in the same order everywhere.  Backend-agnostic (RCCL on the GPUs, gloo in the CPU tests)."""
 
     def __init__(self, flat, n_used, bucket_elems, pending):
         self.flat, self.n, self.bucket = flat, n_used, bucket_elems
         self.pending = dict(pending)
         self.works = []
-        self.next = -(-n_used // bucket_elems)       # buckets with index >= next are in flight
+        self.bounds = [n_used]                       # descending bucket boundaries
+        while self.bounds[-1] > 0:
+            self.bounds.append(max(0, self.bounds[-1] - bucket_elems))
+        self.next = 0                                # buckets [bounds[j + 1], bounds[j]) with j < next are in flight
         self.early = 0                               # buckets released before finish() (overlap actually happened)
 
     def _launch(self, top):
         import torch.distributed as dist
-        while self.next > 0 and (self.next - 1) * self.bucket >= top:
-            k = self.next - 1
-            a, b = k * self.bucket, min(self.n, (k + 1) * self.bucket)
+        while self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] >= top:
+            a, b = self.bounds[self.next + 1], self.bounds[self.next]
             self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
-            self.next = k
+            self.next += 1
 
     def done(self, offsets):
         for off in offsets:

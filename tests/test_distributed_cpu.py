@@ -112,6 +112,17 @@ def test_overlapped_bucket_schedule_two_ranks():
     assert 0 < early < total                               # most buckets were in flight before the first layer's gradient existed
 
 
+def test_bucket_boundaries_count_from_the_top():
+    """the remainder bucket is the lowest one - the one that completes last (first layers) and whose all-reduce nothing hides"""
+    from cdnet_amd.trainer import BucketReducer
+    red = BucketReducer(torch.zeros(1200), 1000, 300, {0: 1000})
+    assert red.bounds == [1000, 700, 400, 100, 0]
+    red = BucketReducer(torch.zeros(900), 900, 300, {0: 900})
+    assert red.bounds == [900, 600, 300, 0]
+    red = BucketReducer(torch.zeros(10), 10, 300, {0: 10})
+    assert red.bounds == [10, 0]
+
+
 def test_hrnet_parameters_live_in_padded_flat_storage():
     """HRNet18_rev1 computes on zero-padded parameter copies (18/36/72 -> 32/48/80 channels): the module's own parameters are
     strided views of that storage, also after the trainer re-homes it into its flat buffers (host logic only, no kernels)"""
