@@ -238,3 +238,35 @@ def test_head_forward_backward_fp32():
         assert _rel(_nchw(df[k]), f[k].grad) < 1e-5, (k, _rel(_nchw(df[k]), f[k].grad))
     want = torch.cat([p.grad.reshape(-1) for p in ps])
     assert _rel(dhw.cpu(), want) < 1e-5
+
+
+@pytest.mark.parametrize('eres', [False, True])
+def test_conv_fp32_full_tile_epilogue_is_bit_identical_to_the_general_one(eres):
+    """conv_f32_kernel's full-tile epilogue (one base pointer, 32-bit offsets, statistics without bounds tests) against the general
+    per-element one (cdnet_conv_args.debug bit 16): the same arithmetic, so outputs and per-tile statistics agree bit for bit"""
+    import torch
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(5)
+    N, Cin, Cout, H, W, cfg = 2, 64, 64, 48, 64, (16, 16, 64)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.1
+    wp = engine.pack_weights(w.cuda(), cfg, 0, split=True)
+    src = engine.Src(_nhwc(x), sc.cuda(), sh.cuda(), relu=True)
+    kw = {}
+    if eres:
+        kw = dict(oscale=(torch.rand(Cout, generator=g) + 0.5).cuda(), oshift=(torch.randn(Cout, generator=g) * 0.1).cuda(),
+                  eres=engine.Src(_nhwc(torch.randn((N, Cout, H, W), generator=g)), relu=True))
+    outs = []
+    for dbg in (16, 0):
+        engine.CONV_DEBUG = dbg
+        try:
+            out = torch.empty((N, H, W, Cout), dtype=torch.float32, device='cuda')
+            o, st = engine.conv_forward([src], wp, Cout, cfg, taps=9, out=out, stats=None if eres else True, **kw)
+            torch.cuda.synchronize()
+        finally:
+            engine.CONV_DEBUG = 0
+        outs.append((o.clone(), None if st is None else st.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if not eres:
+        assert torch.equal(outs[0][1], outs[1][1])
