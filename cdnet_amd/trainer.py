@@ -682,16 +682,33 @@ class Trainer:
     def allreduce_and_step(self):
         f = self.flat
         gscale = 1.0
+        ranges = [(0, f.n_used)]
         if self._reduce_active():
             if getattr(self, '_ar', None) is not None:
-                self._ar.finish()                        # whatever backward did not release yet, then wait for all
+                # whatever backward did not release yet; then the optimiser follows the collectives bucket by bucket (top-down, the
+                # order they were launched in): the last bucket's all-reduce - the first layers' gradients, complete only when backward
+                # ends - runs while Adam already updates the ranges above it
+                ranges = self._ar.finish(wait=False)
+                works = self._ar.works
                 self._ar = None
             else:
                 bucketed_allreduce(f.G, f.n_used, self.bucket)
+                works = None
             gscale = 1.0 / self.world
+        else:
+            works = None
         f.step_count += 1
-        _lib.call('cdnet_adam_step', _lib.ptr(f.P), _lib.ptr(f.G), _lib.ptr(f.M), _lib.ptr(f.V), f.n_used, self.lr,
-                  self.betas[0], self.betas[1], self.eps, self.wd, f.step_count, gscale, _lib.stream_ptr())
+
+        def adam(a, b):
+            sl = slice(a, b)
+            _lib.call('cdnet_adam_step', _lib.ptr(f.P[sl]), _lib.ptr(f.G[sl]), _lib.ptr(f.M[sl]), _lib.ptr(f.V[sl]), b - a, self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.wd, f.step_count, gscale, _lib.stream_ptr())
+        if works is None:
+            adam(0, f.n_used)
+        else:
+            for w, (a, b) in zip(works, ranges):
+                w.wait()                                 # (the current stream waits, not the host)
+                adam(a, b)
         runtime.WEIGHTS_EPOCH[0] += 1
         self._repack_all()
 
@@ -969,10 +986,13 @@ class BucketReducer:
         self._launch(max(self.pending.values()) if self.pending else 0)
         self.early += len(self.works) - before
 
-    def finish(self):
+    def finish(self, wait=True):
+        """launch what is left; wait=False returns the buckets' ranges in launch order instead (the caller waits per bucket)"""
         self._launch(0)
-        for w in self.works:
-            w.wait()
+        if wait:
+            for w in self.works:
+                w.wait()
+        return [(self.bounds[j + 1], self.bounds[j]) for j in range(len(self.works))]
 
 
 def bucketed_allreduce(flat, n, bucket_elems):
