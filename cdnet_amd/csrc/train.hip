@@ -1032,7 +1032,6 @@ template <int ND> struct LossLay {
     static constexpr int COEF = 6 + 4 * ND;
     static constexpr int TPB = ND > 9 ? 128 : 256;      // reduce kernel: SUMS x TPB floats of LDS (<= 64 KB)
 };
-constexpr int K_SUMS = LossLay<9>::SUMS;
 template <int ND> __device__ __forceinline__ int dnext(int i) { return i == ND - 1 ? 1 : i + 1; }      // cyclic over 1..ND-1 (loss.py:231-258)
 template <int ND> __device__ __forceinline__ int dprev(int i) { return i == 1 ? ND - 1 : i - 1; }
 
@@ -1186,7 +1185,6 @@ __global__ __launch_bounds__(LossLay<ND>::TPB) void loss_reduce_kernel(LossIn L,
     }
 }
 
-constexpr int K_COEF = LossLay<9>::COEF;
 // single block: per-sample sums -> loss terms (5 + total) and the pass-2 coefficients
 template <int ND>
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ partial, int nchunk, int B, int P,
@@ -1376,7 +1374,7 @@ template <int ND> struct ValLay {
     static constexpr int IQ = 10, PQ = 10 + ND, TQ = 10 + 2 * ND, VS = 10 + 3 * ND, SUMS = VS + 5;
     static constexpr int TPB = ND > 9 ? 128 : 256;
 };
-constexpr int V_SUMS = ValLay<9>::SUMS;
+static_assert(ValLay<9>::SUMS == CDNET_VAL_SUMS, "cdnet_dam_val_sums row layout");
 
 struct ValIn {
     const float *mask, *point, *dirn;
