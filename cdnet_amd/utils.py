@@ -46,42 +46,59 @@ def split_forward_views(model, image, size, overlap, xforms=(0,), direction_clas
     assert image.dim() == 3 and image.is_cuda and image.dtype == torch.float32
     Cc, H0, W0 = image.shape
     image = image.contiguous()
-    packs, geo = [], []
+    from . import runtime
+    f32 = runtime.PRECISION == 'fp32'
+    geo = []
     for xf in xforms:
         hv, wv = (W0, H0) if xf & 4 else (H0, W0)
         stride, th, tw, ny, nx = window_grid(hv, wv, size, overlap)
-        from . import runtime
-        f32 = runtime.PRECISION == 'fp32'
-        t = torch.empty((ny * nx, th, tw, 16), dtype=runtime.act_dtype(), device=image.device)
-        _lib.call('cdnet_window_pack_f32' if f32 else 'cdnet_window_pack', _lib.ptr(image), Cc, H0, W0, int(xf), th, tw, stride, ny, nx,
-                  _lib.ptr(t), _lib.stream_ptr())
-        packs.append(t)
         geo.append((hv, wv, stride, th, tw, ny, nx))
-    # batch windows of equal shape through the network
+
+    def pack(i, dst):
+        hv, wv, stride, th, tw, ny, nx = geo[i]
+        _lib.call('cdnet_window_pack_f32' if f32 else 'cdnet_window_pack', _lib.ptr(image), Cc, H0, W0, int(xforms[i]), th, tw, stride, ny, nx,
+                  _lib.ptr(dst), _lib.stream_ptr())
+
+    def stitch(i, logits, off):
+        hv, wv, stride, th, tw, ny, nx = geo[i]
+        n = ny * nx
+        st = []
+        for t_ in logits:
+            K = t_.shape[1]
+            o = torch.empty((K, hv, wv), dtype=torch.float32, device=image.device)
+            src = t_[off:off + n]                          # (a batch slice of a contiguous tensor is contiguous)
+            _lib.call('cdnet_window_stitch', _lib.ptr(src), K, th, tw, stride, overlap, ny, nx, hv, wv, _lib.ptr(o), _lib.stream_ptr())
+            st.append(o)
+        return tuple(st)
+
+    # windows of equal shape go through the network together, in batches of WHOLE views whenever a view's windows fit one batch: the
+    # window tensors are then packed straight into the batch and stitched straight out of the network's outputs (the first version
+    # concatenated all windows, cut 64-window batches across views and concatenated the outputs again: 1.1 GB of copies per 1000 x 1000
+    # image with 8 views, and a last batch of 8 windows)
     outs = [None] * len(xforms)
     by_shape = {}
-    for i, t in enumerate(packs):
-        by_shape.setdefault(tuple(t.shape[1:3]), []).append(i)
-    for shape, idxs in by_shape.items():
-        tiles = torch.cat([packs[i] for i in idxs], 0) if len(idxs) > 1 else packs[idxs[0]]
-        res = []
-        for s in range(0, tiles.shape[0], max_batch):
-            res.append(model.forward_packed(tiles[s:s + max_batch]))
-        mask = torch.cat([r[0] for r in res], 0)
-        point = torch.cat([r[1] for r in res], 0)
-        direction = torch.cat([r[2] for r in res], 0)
-        off = 0
+    for i, g_ in enumerate(geo):
+        by_shape.setdefault((g_[3], g_[4], g_[5] * g_[6]), []).append(i)
+    for (th, tw, n), idxs in by_shape.items():
+        if n <= max_batch:
+            per = max(1, max_batch // n)
+            per = -(-len(idxs) // -(-len(idxs) // per))    # equal-sized batches (8 views x 25 windows: 4 x 50, not 2 x 64 + ...)
+            for g0 in range(0, len(idxs), per):
+                grp = idxs[g0:g0 + per]
+                tiles = torch.empty((len(grp) * n, th, tw, 16), dtype=runtime.act_dtype(), device=image.device)
+                for k, i in enumerate(grp):
+                    pack(i, tiles[k * n:(k + 1) * n])
+                logits = model.forward_packed(tiles)
+                for k, i in enumerate(grp):
+                    outs[i] = stitch(i, logits, k * n)
+            continue
+        # a view with more windows than one batch holds: batches cut across the view, outputs gathered before the stitch
         for i in idxs:
-            hv, wv, stride, th, tw, ny, nx = geo[i]
-            n = ny * nx
-            st = []
-            for t_, K in ((mask, mask.shape[1]), (point, 1), (direction, direction.shape[1])):
-                o = torch.empty((K, hv, wv), dtype=torch.float32, device=image.device)
-                src = t_[off:off + n].contiguous()
-                _lib.call('cdnet_window_stitch', _lib.ptr(src), K, th, tw, stride, overlap, ny, nx, hv, wv, _lib.ptr(o), _lib.stream_ptr())
-                st.append(o)
-            outs[i] = tuple(st)
-            off += n
+            tiles = torch.empty((n, th, tw, 16), dtype=runtime.act_dtype(), device=image.device)
+            pack(i, tiles)
+            res = [model.forward_packed(tiles[s_:s_ + max_batch]) for s_ in range(0, n, max_batch)]
+            logits = [torch.cat([r[k] for r in res], 0) for k in range(len(res[0]))]
+            outs[i] = stitch(i, logits, 0)
     return outs
 
 
