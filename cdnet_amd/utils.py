@@ -40,7 +40,7 @@ def window_grid(h0, w0, size, overlap):
     return stride, min(size, h), min(size, w), ny, nx
 
 
-def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=64):
+def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=256):
     """Sliding-window forward of one image [3,H,W] (cuda float32) for several TTA views at once.
     Returns a list (one entry per view) of stitched logits (mask [3,hv,wv], point [1,hv,wv], direction [9,hv,wv])."""
     assert image.dim() == 3 and image.is_cuda and image.dtype == torch.float32
@@ -80,6 +80,7 @@ def split_forward_views(model, image, size, overlap, xforms=(0,), direction_clas
     for i, g_ in enumerate(geo):
         by_shape.setdefault((g_[3], g_[4], g_[5] * g_[6]), []).append(i)
     for (th, tw, n), idxs in by_shape.items():
+        max_batch = max(1, min(max_batch, (1 << 24) // (th * tw)))      # at most 256 windows of 256 x 256 (64 of 512 x 512) per network batch
         if n <= max_batch:
             per = max(1, max_batch // n)
             per = -(-len(idxs) // -(-len(idxs) // per))    # equal-sized batches (8 views x 25 windows: 4 x 50, not 2 x 64 + ...)
