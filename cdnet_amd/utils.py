@@ -6,6 +6,8 @@
   AverageMeter                                         utils.py:755-774
   adjust_learning_rate                                 utils.py:965-977
 """
+import os
+
 import numpy as np
 import torch
 
@@ -40,7 +42,7 @@ def window_grid(h0, w0, size, overlap):
     return stride, min(size, h), min(size, w), ny, nx
 
 
-def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=256):
+def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=128):
     """Sliding-window forward of one image [3,H,W] (cuda float32) for several TTA views at once.
     Returns a list (one entry per view) of stitched logits (mask [3,hv,wv], point [1,hv,wv], direction [9,hv,wv])."""
     assert image.dim() == 3 and image.is_cuda and image.dtype == torch.float32
@@ -79,6 +81,9 @@ def split_forward_views(model, image, size, overlap, xforms=(0,), direction_clas
     by_shape = {}
     for i, g_ in enumerate(geo):
         by_shape.setdefault((g_[3], g_[4], g_[5] * g_[6]), []).append(i)
+    # (128: two batches of four views for a 1000 x 1000 image.  All eight views in one batch is another 3 % in steady state, but its multi-GB
+    #  tensors make the caching allocator's behaviour - and the time - depend on what the process ran before: 24 to 65 ms per image)
+    max_batch = int(os.environ.get('CDNET_WINDOW_BATCH', max_batch))
     for (th, tw, n), idxs in by_shape.items():
         max_batch = max(1, min(max_batch, (1 << 24) // (th * tw)))      # at most 256 windows of 256 x 256 (64 of 512 x 512) per network batch
         if n <= max_batch:
