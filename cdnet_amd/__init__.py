@@ -18,8 +18,11 @@ _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 def set_precision(p):
     """Arithmetic of the convolution stack: 'bf16' (16-bit NHWC activations, bf16 MFMA operands, fp32 accumulation) or
-    'fp32' (fp32 activations and gradients in HBM, every product as three split-bf16 MFMAs with fp32 accumulation - the
-    reference's precision).  Applies to models / trainers used afterwards; packed weights are rebuilt lazily."""
+    'fp32' = "bf16x3": fp32 activations and gradients in HBM, fp32 accumulation, every product a*b evaluated as three bf16
+    MFMAs over split operands (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with hi = bf16(x), lo = bf16(x - hi): operands carry ~16
+    significand bits, relative error <= 2^-16 per product).  That is the storage and accumulation of the reference's fp32
+    arithmetic and tighter than TF32, but not IEEE-fp32 multiplication (2^-24); kernels agree with fp64 to 4e-5 * sum|a*b|.
+    Applies to models / trainers used afterwards; packed weights are rebuilt lazily."""
     from . import runtime
     runtime.set_precision(p)
 

@@ -39,12 +39,33 @@ def save_checkpoint(state, epoch, is_best, save_dir, branch_value, cp_flag):
     return filename
 
 
+def _numpy_safe_globals():
+    """what unpickling a numpy scalar needs: numpy._core.multiarray.scalar, numpy.dtype and the dtype classes of the scalars
+    the reference writes (float / int AverageMeter values)"""
+    import numpy as np
+    try:
+        from numpy._core.multiarray import scalar
+    except ImportError:                                  # numpy < 2
+        from numpy.core.multiarray import scalar
+    return [scalar, np.dtype] + [type(np.dtype(t)) for t in ('float64', 'float32', 'int64', 'int32', 'bool')]
+
+
 def load_checkpoint(path, model, trainer=None, strict=True, trusted_pickle=False):
     """Load a checkpoint written by the reference or by save_checkpoint.  Returns the checkpoint dict (epoch, best_iou, ...).
     Keys with or without the DataParallel prefix are accepted (test_dam.py:163-165 loads with strict=False).
     The interchange format holds only tensors, numbers, strings and containers of them, so the file is read with
-    `weights_only=True`; `trusted_pickle=True` opts into full unpickling for legacy files from a trusted source."""
-    ck = torch.load(path, map_location='cpu', weights_only=not trusted_pickle)
+    `weights_only=True` - with numpy's scalar / dtype reconstructors allow-listed, because the reference stores
+    `best_iou` / `best_loss` as numpy.float64 (AverageMeter.avg, train.py:390-427), which a bare `weights_only=True`
+    refuses; `trusted_pickle=True` (CDNET_TRUSTED_PICKLE=1, `--trusted-pickle`) opts into full unpickling for legacy files
+    from a trusted source."""
+    if trusted_pickle or os.environ.get('CDNET_TRUSTED_PICKLE', '0') == '1':
+        ck = torch.load(path, map_location='cpu', weights_only=False)
+    else:
+        with torch.serialization.safe_globals(_numpy_safe_globals()):
+            ck = torch.load(path, map_location='cpu', weights_only=True)
+    for k in ('best_iou', 'best_loss'):
+        if k in ck and not isinstance(ck[k], torch.Tensor):
+            ck[k] = float(ck[k])                         # numpy.float64 -> float
     sd = ck['state_dict'] if 'state_dict' in ck else ck
     sd = {(k[len(PREFIX):] if k.startswith(PREFIX) else k): v for k, v in sd.items()}
     model.load_state_dict(sd, strict=strict)

@@ -93,7 +93,9 @@ class DataFolder(torch.utils.data.Dataset):
 class TileBatches:
     """Epoch iterator over a DataFolder for the device train step.  Per item: random crop of `input_size` (zero / 0-weight padded
     when the image is smaller), random horizontal / vertical flip when the transform dict asks for them; per batch: one
-    cdnet_label_encoding launch.  A crop whose label is constant is re-drawn (the DataFolder rule)."""
+    cdnet_label_encoding launch.  A crop whose label is constant is re-drawn (the DataFolder rule).  A transform without crop and
+    flips (the validation transform) yields every image whole and unpadded, in a fixed order with shuffle=False (batch size 1
+    unless the images share one size)."""
 
     SKIPPED = ('random_color', 'random_elastic', 'random_chooseAug', 'random_resize', 'random_affine', 'random_rotation')
 
@@ -125,6 +127,10 @@ class TileBatches:
 
     def _draw(self, img, weight, label):
         H, W = label.shape[:2]
+        if not self.crop and not self.hflip and not self.vflip:
+            # the reference's validation transform {label_encoding, to_tensor, normalize} (options.py:358): the whole image, untouched -
+            # validate() then takes it whole or through split_forward_dam (train_util_dam.py:474)
+            return [np.ascontiguousarray(a) for a in (img, weight, label)]
         s = self.crop or max(H, W)
         for _ in range(50):
             y0 = self.rs.randint(0, max(H - s, 0) + 1)

@@ -92,6 +92,10 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
     if f32:
         # fp32-precision kernels (csrc/conv32.hip): 16-channel chunks, 16x16 tiles (8x8 for the few-pixel layers)
         assert all(c % 16 == 0 for c in src_channels), src_channels
+        assert override is None or (tuple(override)[1] == 16 and tuple(override) in ((16, 16, 64), (16, 16, 32), (8, 16, 64))), \
+            'fp32 precision: configuration override %s is not one of the fp32 kernels' % (override,)
+        if override is not None:
+            return tuple(override)
         small = min(H, W) <= 8 or (min(H, W) <= 16 and N <= 32)
         if small and Cout > 32:
             return (8, 16, 64)

@@ -48,9 +48,7 @@ class GraphedTrainStep:
     def __init__(self, trainer, batch, warmup=3):
         assert trainer.world == 1, 'graph capture covers the single-GPU step (the overlapped all-reduce is launched from Python)'
         self.tr, self.batch = trainer, [t for t in batch]
-        import os
-        self._env = os.environ.get('CDNET_PACKB_STREAM')
-        os.environ['CDNET_PACKB_STREAM'] = '0'       # no cross-stream event from eager code into the captured region
+        trainer._packb_stream = False                 # no cross-stream event from eager code into the captured region (this trainer only)
         for _ in range(warmup):
             trainer.train_step(*self.batch)
         torch.cuda.synchronize()

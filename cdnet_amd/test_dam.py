@@ -74,10 +74,14 @@ def evaluate_labels(pred_labeled, gt_labeled):
 
 
 def main(argv=None):
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
+    trusted = '--trusted-pickle' in argv                    # legacy checkpoints that need full unpickling (trusted source only)
+    argv = [a for a in argv if a != '--trusted-pickle']
     opt = Options(isTrain=False).parse(argv)
     model = utils.chooseModel(opt).cuda()
     if os.path.exists(opt.test['model_path']):
-        checkpoint.load_checkpoint(opt.test['model_path'], model, strict=False)      # DataParallel prefix (test_dam.py:158-167)
+        checkpoint.load_checkpoint(opt.test['model_path'], model, strict=False, trusted_pickle=trusted)      # DataParallel prefix (test_dam.py:158-167)
     elif os.environ.get('CDNET_ALLOW_RANDOM_WEIGHTS') == '1':
         print("=> no checkpoint at '{}': evaluating RANDOM weights (CDNET_ALLOW_RANDOM_WEIGHTS=1)".format(opt.test['model_path']))
     else:

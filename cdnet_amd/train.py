@@ -59,6 +59,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument('--synthetic', type=int, default=0, help='number of synthetic batches per epoch (0 = read the dataset folders)')
     ap.add_argument('--synthetic-val', type=int, default=0, help='synthetic validation batches per epoch (with --synthetic and --validation 1)')
+    ap.add_argument('--trusted-pickle', action='store_true', help='resume from a legacy checkpoint that needs full unpickling (trusted source only)')
     own, rest = ap.parse_known_args(argv)
     opt = Options(isTrain=True).parse(rest)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -83,7 +84,7 @@ def main(argv=None):
     best_iou, best_loss = 0.0, float('inf')
     if opt.train['checkpoint']:                            # train.py:293-306: resume (weights, Adam moments, epoch, best values)
         if os.path.isfile(opt.train['checkpoint']):
-            ck = checkpoint.load_checkpoint(opt.train['checkpoint'], model, trainer)
+            ck = checkpoint.load_checkpoint(opt.train['checkpoint'], model, trainer, trusted_pickle=own.trusted_pickle)
             opt.train['start_epoch'] = ck.get('epoch', 0)
             best_iou, best_loss = ck.get('best_iou', best_iou), ck.get('best_loss', best_loss)
             logger.info("=> loaded checkpoint '{}' (epoch {})".format(opt.train['checkpoint'], opt.train['start_epoch']))
@@ -110,7 +111,9 @@ def main(argv=None):
             vdirs, vfix = _dataset_layout(opt, 'val', logger)
             if all(os.path.isdir(d) for d in vdirs):
                 vset = DataFolder(vdirs, vfix, [3, 1, 3])
-                vt = {k: v for k, v in opt.transform['train'].items() if k in ('random_crop', 'label_encoding', 'to_tensor', 'normalize')}
+                # options.py:358: the validation transform is {label_encoding, to_tensor, normalize} - no crop: every epoch scores the same
+                # whole images (validate() runs them whole or through split_forward_dam with input_size / val_overlap, train_util_dam.py:474)
+                vt = opt.transform.get('val') or {k: v for k, v in opt.transform['train'].items() if k in ('label_encoding', 'to_tensor', 'normalize')}
                 val_loader = TileBatches(vset, vt, 1, dev, seed=opt.train['seed'], shuffle=False, logger=logger)
             else:
                 logger.info('validation = 1 but {} is missing: the training results stand in for the validation results'.format(vdirs[0]))

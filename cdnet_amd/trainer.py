@@ -141,6 +141,7 @@ class Trainer:
         self._cat_cache = {}
         self._wstream, self._events = None, {}
         self._packb_pending = False
+        self._packb_stream = os.environ.get('CDNET_PACKB_STREAM', '1') != '0'      # backward-data re-packs beside the next forward
         self._side_active = False
         self._forwards, self._bn_base = 0, 0                 # training forwards run here / counted in a loaded checkpoint
         if world_size > 1:
@@ -742,7 +743,7 @@ class Trainer:
                 self._pack_jobs.append((arr, len(jobs), table, owners, [True]))
         side = self._side_stream()
         for k, (arr, n, table, owners, first) in enumerate(self._pack_jobs):
-            if k == 1 and side is not None and os.environ.get('CDNET_PACKB_STREAM', '1') != '0':
+            if k == 1 and side is not None and self._packb_stream:
                 # the backward-data packs are not needed before the next backward: pack them beside the next forward
                 ev = self._event('adam')
                 ev.record()

@@ -77,13 +77,16 @@ def test_checkpoint_written_here_loads_in_pytorch_and_back(kind, tmp_path):
     ck = torch.load(path, map_location='cpu', weights_only=False)       # (Adam.load_state_dict shares tensors with the dict it is given)
     opt2 = ot.make_adam(ref)
     opt2.load_state_dict(ck['optimizer'])
-    ref_ck = {'epoch': 9, 'state_dict': torch.nn.DataParallel(ref).state_dict(), 'best_iou': 0.1, 'best_loss': 2.0,
+    # the reference stores numpy.float64 here (AverageMeter.avg through max() / min(), train.py:390-427)
+    import numpy as np
+    ref_ck = {'epoch': 9, 'state_dict': torch.nn.DataParallel(ref).state_dict(), 'best_iou': np.float64(0.1), 'best_loss': np.float64(2.0),
               'optimizer': opt2.state_dict()}
     torch.save(ref_ck, str(tmp_path / 'ref.pth.tar'))
     m2, _ = _pair(kind)
     tr2 = trainer.Trainer(m2)
     got = checkpoint.load_checkpoint(str(tmp_path / 'ref.pth.tar'), m2, tr2)
     assert got['epoch'] == 9 and tr2.flat.step_count == 7 and tr2.lr == 2e-3 and tr2._bn_base == 7
+    assert type(got['best_iou']) is float and got['best_iou'] == 0.1 and type(got['best_loss']) is float and got['best_loss'] == 2.0
     for (n, p), (_, p2) in zip(ref.named_parameters(), m2.named_parameters()):
         assert torch.equal(p.detach(), p2.detach()), n
     if hasattr(m2, '_slots'):

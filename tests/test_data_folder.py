@@ -92,3 +92,21 @@ def test_dataset_layout_follows_the_reference(tmp_path):
     opt.dataset, opt.train['validation'] = 'CPM2017', 1
     dirs, fix = train._dataset_layout(opt, 'val')
     assert dirs == [d + '/images/test', d + '/weight_maps/test', d + '/labels/test_ins'] and fix == ['weight.png', 'label.mat']
+
+
+def test_validation_transform_keeps_the_whole_image(tmp_path):
+    """options.py:358: the validation transform has no crop - every epoch scores the same, whole, unpadded images (a random crop per
+    epoch made val_iou / val_F1, which pick checkpoint_best and drive early stopping, a noisy subset metric)"""
+    from cdnet_amd.data_folder import TileBatches
+    dirs = make_dataset(tmp_path, n=2, size=(70, 90), empty_first=True)
+    ds = DataFolder(dirs, ['weight.png', 'label.png'], [3, 1, 3])
+    tb = TileBatches(ds, {'to_tensor': 1}, 1, 'cpu', seed=3, shuffle=False)
+    assert len(tb) == 2
+    for k in range(2):
+        a, b = tb._draw(*tb.items[k]), tb._draw(*tb.items[k])
+        assert a[0].shape == (70, 90, 3) and a[2].shape[:2] == (70, 90)               # not cropped, not padded to a square
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))                        # the same pixels every epoch
+        assert np.array_equal(a[0], np.asarray(ds.load(k)[0]))
+    # the training transform still crops (and pads what is smaller than the crop)
+    tr = TileBatches(ds, {'random_crop': 64, 'horizontal_flip': True, 'to_tensor': 1}, 1, 'cpu', seed=3)
+    assert tr._draw(*tr.items[1])[0].shape == (64, 64, 3)
