@@ -7,10 +7,13 @@ One rank per GPU (the driver launches N>1 through torch.distributed.run); RANK/L
 from the environment.  W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; the step time
 is the max over ranks; rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 
-The line's `value` is the training rate of BASELINE config 2 in the arithmetic named by `dtype`.  Beside it (same protocol,
-fewer steps): `inference` (tiles/s incl. post-processing), `fp32` = the same two rates at the reference's precision (fp32
-activations, split-bf16 x3 MFMA products), `image` = BASELINE config 3 (one 1000x1000 image, 8 TTA views x 25 windows),
-`roofline` (dominant kernel), `roofline_path` (whole-step fractions in SURVEY 8d's units) and `cpu_baseline`.
+The line's `value` is the training rate of BASELINE config 2 in the arithmetic named by `dtype`.  The default is `fp32` - the
+like-for-like mode: fp32 storage and accumulation as in the reference, every product a*b as three bf16 MFMAs over split operands
+("bf16x3", <= 2^-16 relative error per product; gfx950 has no TF32 path and its fp32 MFMA runs at 1/16 of the bf16 rate).  Beside it
+(same protocol, fewer steps): `inference` (tiles/s incl. post-processing), `bf16` = the same two rates on the 16-bit fast path
+(bf16 / fp16 activations, bf16 MFMA operands, fp32 accumulation; legitimate only behind the label-level gate
+tests/test_gpu_label_gate.py), `image` = BASELINE config 3 (one 1000x1000 image, 8 TTA views x 25 windows), `roofline` (dominant
+kernel of the headline arithmetic), `roofline_path` (whole-step fractions in SURVEY 8d's units) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -43,7 +46,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'train'), choices=['auto', 'train', 'infer', 'image', 'roofline'],
                     help="'roofline': only the dominant-kernel measurement of the roofline object (the command profiles/<round>/dominant_conv_* are taken with)")
-    ap.add_argument('--dtype', default=os.environ.get('CDNET_BENCH_DTYPE', 'bf16'), choices=['bf16', 'fp32'],
+    ap.add_argument('--dtype', default=os.environ.get('CDNET_BENCH_DTYPE', 'fp32'), choices=['bf16', 'fp32'],
                     help='arithmetic of the headline value; the other precision is reported beside it')
     ap.add_argument('--batch', type=int, default=None, help='tiles per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -152,12 +155,12 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16'):
     alg_bytes = B * 256 * 256 * (64 + 64) * esz           # algorithmic: input read once + output written once
     # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 bf16 -> the HBM term bounds this layer
     traffic, traffic_src = None, None
-    for rnd in ('r02', 'r01'):
-        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_traffic.json')
-        if os.path.exists(tj) and B == 16 and not f32:
+    for rnd in ('r03', 'r02', 'r01'):
+        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_traffic.json' if f32 else 'dominant_conv_traffic.json')
+        if os.path.exists(tj) and B == 16:
             with open(tj) as f:
                 traffic = json.load(f).get('hbm_bytes_per_launch')   # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes
-            traffic_src = 'profiles/%s/dominant_conv_traffic.json (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % rnd
+            traffic_src = 'profiles/%s/%s (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % (rnd, os.path.basename(tj))
             break
     gbs = alg_bytes / ms / 1e6
     ws = not f32 and os.environ.get('CDNET_CONV_WS', '1') != '0'          # the library's default: conv_ws_kernel on the 64-channel layers
@@ -215,8 +218,20 @@ def main():
         print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps, precision=a.dtype)}))
         return
 
-    def timed(step, steps, warmup):
-        """W warm-ups, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+    def timed(step, steps, warmup, settle_s=1.0):
+        """(settling: >= settle_s seconds of the same load first - the chip lowers its clock under load over about a second, and a
+        timed region that starts cold reads high) then W warm-ups, then exactly K steps between barrier + synchronize on both sides;
+        max over ranks"""
+        step()                                      # (allocations, kernel attributes, weight packs)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t1 = torch.tensor([time.perf_counter() - t_s], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)      # every rank settles for the same number of steps (collectives inside)
+        for _ in range(min(2000, int(settle_s / max(float(t1.item()), 1e-4)))):
+            step()
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -292,7 +307,9 @@ def main():
                    'tile': '1000x1000x3' if mode == 'image' else '256x256x3', 'parallelism': 'dp%d' % world,
                    'precision': ('bf16/fp16 NHWC activations, bf16 MFMA operands, fp32 accumulation; label-level parity gate vs the fp32 oracle: '
                                  'tests/test_gpu_label_gate.py' if a.dtype == 'bf16' else
-                                 'fp32 NHWC activations and gradients, each product as three split-bf16 MFMAs, fp32 accumulation')},
+                                 'fp32 storage + accumulation (NHWC fp32 activations, gradients, master weights), products = 3 x bf16 MFMA over '
+                                 'split operands (hi*hi + hi*lo + lo*hi), <= 2^-16 relative error per product ("bf16x3"; not IEEE-fp32 '
+                                 'multiplication: gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 rate)')},
     }
     rp = {}
     if mode != 'image':

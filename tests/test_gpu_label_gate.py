@@ -9,7 +9,11 @@ infer_image incl. TTA + sliding windows + device post-processing - and (b) throu
 against each other with the reference's own metrics (stats_utils.get_fast_aji / get_dice_1, test_dam.py:591-669): AJI and
 Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.002.
 
-CDNET_PRECISION selects the arithmetic of the product path: 'fp32' (fp32 activations, split-bf16 x3 MFMA) or 'bf16'."""
+Both arithmetic modes of the product path are gated in one run: every test is parametrised over 'fp32' (fp32 activations,
+split-bf16 x3 MFMA products - the like-for-like mode) and 'bf16' (cdnet_amd.set_precision, restored afterwards).  The gate
+network is trained ONCE, in fp32 mode with a fixed seed and fixed batches, so both gates score the same weights; the CRC of the
+weights is printed with the results (the kernels are deterministic: the CRC only moves when a training kernel changes its
+summation order) so that numbers of different rounds can be told apart from numbers of different networks."""
 import os
 
 import numpy as np
@@ -20,6 +24,7 @@ pytestmark = pytest.mark.gpu
 AJI_MIN = 0.998
 DICE_MIN = 0.998
 ARGMAX_MIN = 0.999
+TILE_FLOOR = 0.995          # bf16 mode, a single 256x256 tile (one nucleus of ~40 merged or split moves a tile's AJI by ~0.003)
 
 
 def _train(precision, steps=300, B=8, seed=0):
@@ -67,12 +72,27 @@ def _score(name, got, want, min_instances):
 
 
 @pytest.fixture(scope='module')
-def trained():
+def gate_net():
+    import zlib
     import cdnet_amd
-    prec = os.environ.get('CDNET_PRECISION', cdnet_amd.get_precision())
-    m = _train(prec)
+    before = cdnet_amd.get_precision()
+    m = _train('fp32')
     m.eval()
-    return m, _oracle_of(m), prec
+    crc = 0
+    for k, v in sorted(m.state_dict().items()):
+        crc = zlib.crc32(v.detach().cpu().contiguous().numpy().tobytes(), crc)
+    print('label gate network: 300 fp32-mode steps, seed 0, weights crc32 %08x' % crc)
+    yield m, _oracle_of(m), crc
+    cdnet_amd.set_precision(before)
+
+
+@pytest.fixture(params=['fp32', 'bf16'])
+def trained(request, gate_net):
+    import cdnet_amd
+    before = cdnet_amd.get_precision()
+    cdnet_amd.set_precision(request.param)
+    yield gate_net[0], gate_net[1], request.param
+    cdnet_amd.set_precision(before)
 
 
 def test_tiles_label_parity(trained):
@@ -94,9 +114,15 @@ def test_tiles_label_parity(trained):
         aji, dice = _score('tile %d' % b, r['final'][b].cpu().numpy(), w['final'], 20)
         report.append((b, agree_m, agree_d, aji, dice, int(w['count']), int(r['counts'][b])))
     print('label gate [%s] tiles: ' % prec + '; '.join('tile %d mask %.5f dir %.5f AJI %.5f Dice %.5f n=%d/%d' % t for t in report))
+    # arg-max agreement per tile; AJI / Dice as the reference reports them - the mean over the images of the set (test_dam.py:693-716
+    # averages per-image metrics; north_star: "AJI/Dice on MoNuSeg within +-0.002") - with a per-tile floor so that no single
+    # tile hides behind the others.  fp32 mode must also hold the bar on every tile.
     for b, am, ad, aji, dice, n_w, n_g in report:
         assert am >= ARGMAX_MIN and ad >= ARGMAX_MIN, (prec, b, am, ad)
-        assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, b, aji, dice)
+        assert aji >= (AJI_MIN if prec == 'fp32' else TILE_FLOOR) and dice >= (DICE_MIN if prec == 'fp32' else TILE_FLOOR), (prec, b, aji, dice)
+    m_aji, m_dice = float(np.mean([t[3] for t in report])), float(np.mean([t[4] for t in report]))
+    print('label gate [%s] tiles: mean AJI %.5f mean Dice %.5f' % (prec, m_aji, m_dice))
+    assert m_aji >= AJI_MIN and m_dice >= DICE_MIN, (prec, m_aji, m_dice)
 
 
 def test_full_image_tta_label_parity(trained):
@@ -115,5 +141,29 @@ def test_full_image_tta_label_parity(trained):
     aji, dice = _score('1000x1000', got, w['final'], 200)
     agree = (r['pred'].cpu().numpy() == w['pred']).mean()
     print('label gate [%s] 1000x1000 TTA: pred agreement %.6f AJI %.5f Dice %.5f instances %d/%d' % (prec, agree, aji, dice, w['count'], r['count']))
+    assert agree >= ARGMAX_MIN, (prec, agree)
+    assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, aji, dice)
+
+
+def test_dense_touching_nuclei_boost(trained):
+    """a tile so densely packed that nuclei touch (400 placement attempts instead of 60): here the direction-difference boost of
+    test_dam.py:490-539 actually decides pixels - the number of arg-max decisions it flipped is reported and must be non-zero on the
+    oracle side too, otherwise the boost arithmetic would go untested at label level"""
+    import torch
+    from cdnet_amd import pipeline, synth
+    from oracle import infer as oinf
+    m, ref, prec = trained
+    x, lab, dirn, point, weight, inst = synth.nuclei_batch(1, 256, 256, 4321, n=400)
+    with torch.no_grad():
+        r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda())
+    w = oinf.infer_image(ref, x[0], tta=False, all_img_test=1)
+    got_pred = r['pred'][0].cpu().numpy()
+    flips_got = int((r['prob'][0].argmax(0).cpu().numpy() != got_pred).sum())
+    flips_want = int((w['probs'][0].argmax(0) != w['pred']).sum())
+    agree = (got_pred == w['pred']).mean()
+    aji, dice = _score('dense tile', r['final'][0].cpu().numpy(), w['final'], 60)
+    print('label gate [%s] dense tile: %d instances (oracle %d), boost flipped %d pixels (oracle %d), pred agreement %.5f AJI %.5f Dice %.5f'
+          % (prec, int(r['counts'][0]), int(w['count']), flips_got, flips_want, agree, aji, dice))
+    assert flips_want > 0, 'the boost changed nothing on the dense tile: not a test of it'
     assert agree >= ARGMAX_MIN, (prec, agree)
     assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, aji, dice)
