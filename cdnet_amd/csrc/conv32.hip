@@ -499,6 +499,10 @@ int conv_forward_f32(const ConvArgs &A, hipStream_t st) {
     for (int i = 0; i < A.nsrc; ++i)
         CDNET_REQUIRE(!A.src[i].pool, "cdnet_conv_forward(f32): pooled sources must be materialised (cdnet_src_materialize)");
     CDNET_REQUIRE(!A.out_f16, "cdnet_conv_forward(f32): out_f16 must be 0");
+    {
+        const int rc = conv_forward_f32_ws(A, st);               // the producer / consumer kernel where it applies
+        if (rc >= 0) return rc;
+    }
     if (A.taps == 9) return dispatch_conv32<9>(A, st);
     if (A.taps == 4) return dispatch_conv32<4>(A, st);
     return dispatch_conv32<1>(A, st);

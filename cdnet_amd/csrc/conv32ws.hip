@@ -1,0 +1,602 @@
+// Wave-specialised, persistent form of the fp32-precision 3x3 convolution (conv32.hip's arithmetic: fp32 NHWC tensors in HBM, every
+// product a*b as three bf16 MFMAs over split operands, a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulation) for the layers that carry
+// the fp32 step: every 3x3 convolution with at least four 16-channel chunks on full 16x16 tiles - forward, backward-data and the
+// space-to-depth backward of the transposed convolutions.
+//
+//   * one 8-wave workgroup per CU, persistent over an XCD-contiguous run of 16x16-pixel tiles, BN output channels per workgroup;
+//   * waves 4..7 (movers) only move data in: the chunk's packed weights (hi image | lo image, 36 KB for 64 output channels) by LDS-DMA
+//     into a two-slot ring - issued first in every interval, from inline assembly, so that they land while the rest of the interval
+//     runs (a DMA the compiler knows about makes it guard every later LDS access of the wave with a wait for it); fp32 halo vectors of
+//     a 16-channel chunk HBM -> registers (two chunks in flight, straight-line code with clamped addresses so that the loads are
+//     counted, not drained) -> source transform (BatchNorm scale / shift, residual, ReLU) -> split into the hi / lo bf16 planes of a
+//     two-slot LDS ring (32 B per pixel and plane, k-halves swizzled by the halo row's parity: conflict-free ds_read_b128);
+//   * waves 0..3 (consumers) read fragments and issue MFMAs: wave w owns rows 4w..4w+3 of the tile (two 32-pixel M blocks) x all
+//     BN/32 N blocks - 8 fragment reads per 12 MFMAs, each issued a whole tap (12 MFMAs) ahead of its use, one per MFMA gap: a
+//     scheduling fence behind every MFMA pins that order (left alone, the scheduler sinks every read to just in front of its first use
+//     and the matrix pipe waits out the LDS latency tap by tap).  Two accumulator sets: while one takes the current tile's MFMAs the
+//     finished tile's epilogue rides in the gaps between them - channel statistics in the first chunk interval, and the tile itself
+//     straight from the accumulators to HBM (bias / folded BatchNorm / ReLU in fp32; the 32 lanes of a half write one 128-byte line of
+//     a pixel), a quarter of it per chunk interval, one 256-byte store every ~7 MFMAs.  No LDS out image, no second pass;
+//   * one barrier per chunk interval (108 MFMAs per consumer wave); 120 KB of LDS.
+// The MFMA sequence per accumulator (chunk, tap, lo*hi, hi*lo, hi*hi) is conv_f32_kernel's, so the outputs are bit-identical
+// (tests/test_gpu_fp32_kernels.py compares the two and both against fp64); the per-tile statistics are summed in conv_ws_kernel's
+// order (blocks (ni, mi), registers ascending, the two lane halves, then the four waves).
+// Measured on the dominant layer (3x3 64->64 @256x256 x16, tools/bench_conv_ws32.py, in a loop of launches): 212-214 us against 255-267 us
+// for conv_f32_kernel; consumers alone 156 us, movers alone 83 us, without the 268 MB of stores 170 us (whoever issues them - movers
+// through an LDS out image, consumers as 16-byte or as 4-byte stores: +40 us each way; the matrix pipe runs at the clock the chip
+// sustains under the combined load).
+//
+// Replaces the same reference lines as conv.hip / conv32.hip: models/dam/model_unet_rev1.py:86-170,244-287 (cuDNN fp32 convolutions).
+#include <type_traits>
+#include "common.h"
+#include "conv_args.h"
+#include <stdlib.h>
+
+using namespace cdnet;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// 8 fp32 values -> hi / lo bf16 vectors (conv32.hip: split8)
+__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 x = {v[2 * k], v[2 * k + 1]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        const f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const bf16x2 l = __builtin_convertvector(x - hf, bf16x2);
+        hi[k] = hb;
+        lo[k] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+// One LDS-DMA piece (64 lanes x 16 bytes = 1 KB): global (uniform base + this lane's byte offset) -> LDS (uniform byte address + lane * 16).
+// Inline assembly on purpose: the compiler does not count it, so (a) it puts no alias guard - s_waitcnt vmcnt(<everything up to the
+// DMA>) - in front of this wave's later LDS accesses, which lets the weight DMA of an interval be issued FIRST and land while the halo
+// chunk is transformed and written, and (b) the wave waits for it itself: conv_ws32_kernel's stream_sync counts the vector-memory
+// operations issued after it.  M0 (the DMA's LDS base) is saved and restored around the piece.
+__device__ __forceinline__ void glds_piece(const void *gbase, unsigned lane_bytes, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_bytes), "s"(gbase), "s"(lds_dst) : "memory");
+}
+
+template <int BN>
+struct Ws32Lds {
+    static constexpr int TH = 16, TW = 16, CK = 16, TAPS = 9;
+    static constexpr int PSTR = 32;                               // bytes per pixel and plane (16 bf16)
+    static constexpr int NPIX = (TH + 2) * (TW + 2);
+    static constexpr int A_PLANE = NPIX * PSTR;
+    static constexpr int A_SLOT = 2 * A_PLANE;                    // hi plane | lo plane
+    static constexpr int B_PLANE = TAPS * CK * BN * 2;            // one image of a chunk's packed weights
+    static constexpr int W_SLOT = 2 * B_PLANE;                    // hi image | lo image: the packed chunk as it lies in memory
+    static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum | sumsq][BN]
+    __host__ __device__ static int bytes(int ctot) { return 2 * A_SLOT + 2 * W_SLOT + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4; }
+};
+
+// XF: source transform decided by the launcher - 0 plain fp32, 1 x * scale + shift -> ReLU (training-mode BatchNorm source), 2 anything
+// (run-time flags: optional scale / shift, residual operand, ReLU).  STATS: per-tile channel sums of the accumulators.
+// The launcher guarantees: taps == 9, npar == 1, ostride == 1, H and W multiples of 16, nchunk >= 4, no pooled source, no fused residual
+// epilogue.
+template <int BN, int XF, bool STATS>
+__global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
+    using L = Ws32Lds<BN>;
+    constexpr int TH = 16, TW = 16, CK = 16, TAPS = 9, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
+    constexpr int NPW = BN / 32, MPW = 2;
+    constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;    // 8-channel vectors per halo pixel / per mover thread and chunk
+    const int NCH = A.nchunk;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_a = smem;
+    unsigned char *lds_w = smem + 2 * L::A_SLOT;
+    float *s_stats = reinterpret_cast<float *>(lds_w + 2 * L::W_SLOT);
+    float *s_xf = reinterpret_cast<float *>(lds_w + 2 * L::W_SLOT + L::STATS_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: tile rows, LDS bases and DMA pieces stay scalar
+    const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
+    const int xfs = (ctot + 7) / 8 * 8;
+    const int cout_tile = blockIdx.y;
+    const int cout0 = cout_tile * BN;
+
+    // this workgroup's contiguous run of tiles; XCD k (workgroups k, k+8, ...) serves the k-th eighth of the tiles (conv_ws_kernel)
+    const int tiles_x = A.W / TW, tiles_y = A.H / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int T = A.N * tiles_img;
+    int t_lo, t_hi;
+    {
+        const int G = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((G & 7) == 0) {
+            const int xcd = b & 7, idx = b >> 3, nw = G >> 3;
+            const long long x0 = (long long)T * xcd / 8, x1 = (long long)T * (xcd + 1) / 8;
+            t_lo = (int)(x0 + (x1 - x0) * idx / nw);
+            t_hi = (int)(x0 + (x1 - x0) * (idx + 1) / nw);
+        } else {
+            t_lo = (int)((long long)T * b / G);
+            t_hi = (int)((long long)T * (b + 1) / G);
+        }
+    }
+    const int ntl = t_hi - t_lo;
+    const int S = ntl * NCH;                                      // chunk intervals of this workgroup
+    if (S == 0) return;
+
+    if (wave >= 4) {
+        // ================================ movers ================================
+        const int ptid = tid - 256, pw = wave - 4;
+        const int slot = ptid % VPP;
+        f32x4 pa[2][NA][2];                      // two chunks of halo vectors in flight (8 channels = two float4 each)
+        unsigned vm[2];                          // bit i: vector i of the chunk lies inside the image / source
+        int eo[2][NA];                           // element offsets (read again for sources with a residual operand)
+        int hyx[NA], doff[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pix = (ptid + i * 256) / VPP;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 16) | hx) : -1;
+            doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
+        }
+        // issue cursor: chunk ik of the tile at (in_, iy0, ix0); saturates on the last chunk of the run
+        int ik = 0, ic = 0, in_, iy0, ix0;
+        {
+            in_ = t_lo / tiles_img;
+            const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
+            iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
+        }
+        int ck = 0;                              // commit cursor: chunk-in-tile index
+        int ge[NA];
+        unsigned gm = 0;
+        const int n0 = A.src[0].C / CK;
+        auto chunk_src = [&](int k, int &si, int &cc0) {
+            if (k < n0) { si = 0; cc0 = k * CK; } else { si = 1; cc0 = (k - n0) * CK; }
+        };
+        auto issue = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            int si, cc0;
+            chunk_src(ik, si, cc0);
+            const ConvSrc &s = A.src[si];
+            if (ik == 0 || ik == n0) {
+                const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
+                const int img = in_ * s.Hs * rs + slot * 8;
+                gm = 0;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int y = iy0 - 1 + (hyx[i] >> 16), x = ix0 - 1 + (hyx[i] & 0xffff);
+                    const int ys = y - s.off_y, xs = x - s.off_x;
+                    const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
+                                    (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
+                    ge[i] = ok ? img + ys * rs + xs * s.C : -1;
+                    gm |= (ok ? 1u : 0u) << i;
+                }
+            }
+            const char *base = reinterpret_cast<const char *>(reinterpret_cast<const float *>(s.x) + cc0);      // uniform
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const unsigned e = ge[i] >= 0 ? (unsigned)ge[i] : 0u;
+                eo[R][i] = (int)e + cc0;
+                const f32x4 *p = reinterpret_cast<const f32x4 *>(base + e * 4u);      // (the launcher keeps every tensor below 2^30 elements)
+                pa[R][i][0] = p[0];
+                pa[R][i][1] = p[1];
+            }
+            vm[R] = gm;
+            if (ic + 1 < S) {
+                ++ic;
+                if (++ik == NCH) {
+                    ik = 0;
+                    ix0 += TW;
+                    if (ix0 >= A.W) { ix0 = 0; iy0 += TH; if (iy0 >= A.H) { iy0 = 0; ++in_; } }
+                }
+            }
+        };
+        // chunk c_ of the run (register set R = c_ & 1) -> halo slot c_ & 1
+        auto commit = [&](auto rc, int c_) {
+            constexpr int R = decltype(rc)::value;
+            int si, cc0;
+            chunk_src(ck, si, cc0);
+            if (c_ + 1 < S) { if (++ck == NCH) ck = 0; }
+            if (A.debug & 2) {                                    // ablation: the loads are waited for, nothing is transformed or written
+                float keep_ = 0.f;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) keep_ += pa[R][i][0][0] + pa[R][i][1][3];
+                if (keep_ == 123.456f) *reinterpret_cast<float *>(lds_a) = keep_;
+                return;
+            }
+            const ConvSrc &s = A.src[si];
+            const float *xf = s_xf + (si ? c0n : 0) + cc0 + slot * 8;
+            float sc[8], sh[8];
+            const bool on = XF == 1 || (XF == 2 && s.scale != nullptr);
+            if (XF != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
+            }
+            const bool relu = XF == 1 || (XF == 2 && s.relu != 0);
+            f32x4 rr[NA][2];
+            const bool has_res = XF == 2 && s.res != nullptr;
+            if (has_res) {
+                const float *rbase = reinterpret_cast<const float *>(s.res);
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const f32x4 *p = reinterpret_cast<const f32x4 *>(rbase + eo[R][i]);
+                    rr[i][0] = p[0];
+                    rr[i][1] = p[1];
+                }
+            }
+            unsigned char *dst0 = lds_a + R * L::A_SLOT;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float v[8] = {pa[R][i][0][0], pa[R][i][0][1], pa[R][i][0][2], pa[R][i][0][3], pa[R][i][1][0], pa[R][i][1][1], pa[R][i][1][2], pa[R][i][1][3]};
+                if (XF != 0 && on) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+                }
+                if (has_res) {
+                    const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += r[j];
+                }
+                if (XF != 0 && relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                const unsigned keep = (vm[R] >> i) & 1u ? 0xffffffffu : 0u;      // outside the image / source: zeros (after the transform)
+                hi &= keep;
+                lo &= keep;
+                if (i < NA - 1 || ptid + i * 256 < NPIX * VPP) {
+                    *reinterpret_cast<u32x4 *>(dst0 + doff[i]) = hi;
+                    *reinterpret_cast<u32x4 *>(dst0 + L::A_PLANE + doff[i]) = lo;
+                }
+            }
+        };
+        // weight chunk wk of the tile -> weight slot (run chunk & 1) by LDS-DMA: the packed chunk (hi image | lo image) is the LDS image
+        int wk = 0;
+        const unsigned lds_w_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_w;
+        auto dma_w = [&](int wslot) {
+            constexpr int NPC = L::W_SLOT / 1024;                 // 1 KB pieces of a chunk; the four mover waves take them in turn
+            static_assert(L::W_SLOT % 1024 == 0, "whole wave-instructions");
+            const char *wsrc = reinterpret_cast<const char *>(A.w) + ((size_t)cout_tile * NCH + wk) * L::W_SLOT;
+            if (++wk == NCH) wk = 0;
+            if (A.debug & 4) return;                              // ablation: no weight DMA
+#pragma unroll
+            for (int i = 0; i < (NPC + 3) / 4; ++i) {
+                const int pc = i * 4 + pw;
+                if (i * 4 + 3 < NPC || pc < NPC) glds_piece(wsrc + pc * 1024, (unsigned)lane * 16u, lds_w_addr + wslot * L::W_SLOT + pc * 1024);
+            }
+        };
+        // the movers' barrier by hand (conv_ws_kernel): this wave's LDS writes done, everything older than its N youngest vector-memory
+        // operations - the weight DMA of this interval - landed, then the barrier; the halo requests issued after the DMA stay in flight
+        auto stream_sync = [](auto n_c) {
+            constexpr int N = decltype(n_c)::value;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        using NHL = std::integral_constant<int, 2 * NA>;          // halo requests of one interval (one chunk: NA vectors of two loads)
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        issue(I0{});
+        issue(I1{});
+        for (int c = ptid; c < ctot; c += 256) {
+            const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
+            const int cc = c < c0n ? c : c - c0n;
+            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+        }
+        __syncthreads();                                         // the scale / shift table
+        dma_w(0);
+        commit(I0{}, 0);
+        issue(I0{});
+        stream_sync(NHL{});                                      // chunk 0 staged, its weights landed
+        // interval k: the consumers work on chunk k (slots k & 1).  Here: the weights of chunk k+1 leave for the other weight slot first
+        // (DMA: they land while the rest of the interval runs), chunk k+1 is transformed, split and written into the other halo slot,
+        // chunk k+3 is requested.  The explicit wait in front of the barrier leaves the 2 NA youngest vector-memory operations - those
+        // halo requests - in flight; the DMA, which is older, has landed.
+        auto interval = [&](auto rc, int k) {
+            constexpr int R = decltype(rc)::value;               // register set / slot of chunk k + 1
+            dma_w(R);
+            commit(rc, k + 1);
+            asm volatile("" ::: "memory");
+            issue(rc);
+            stream_sync(NHL{});
+        };
+        for (int k = 0; k < S; k += 2) {
+            interval(I1{}, k);
+            interval(I0{}, k + 1);                               // (S odd: one more interval than the consumers need; they add a barrier)
+        }
+        __syncthreads();                                         // (the consumers' statistics barrier of the last tile)
+        return;
+    }
+
+    // ================================ consumers ================================
+    __syncthreads();                                             // (the movers' table barrier)
+    const int wm = wave;
+    const int half = lane >> 5, l31 = lane & 31;
+    int abase[MPW][2];                                           // [.][parity of the tap's row offset]
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int m = (wm * MPW + mi) * 32 + l31;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) abase[mi][par] = ((m / TW) * HW_ + m % TW) * PSTR + ((half ^ ((m / TW + par) & 1)) * 16);
+    }
+    auto tpar = [](int t) { return (t / 3) & 1; };
+    auto toff = [](int t) { return ((t / 3) * HW_ + (t % 3)) * PSTR; };
+    const int bbase = half * BN * 16 + l31 * 16;
+    f32x16 accA[MPW][NPW], accB[MPW][NPW];
+    // The finished tile leaves straight from the accumulators, in the gaps between the next tile's MFMAs: register r of block (mi, ni)
+    // is cout ni * 32 + l31 of pixel 4 half + (r & 3) + 8 (r >> 2) of the block's two tile rows - the 32 lanes of a half write one
+    // 128-byte line of a pixel, a wave instruction two of them.  Everything but 4 half pixels + l31 couts is wave-uniform: a scalar base
+    // per store, one per-lane offset register.
+    const unsigned pix_b = (unsigned)A.out_cstride * 4u;
+    const unsigned l_off = (unsigned)(4 * half) * pix_b + (unsigned)l31 * 4u;
+    char *const out_b = reinterpret_cast<char *>(reinterpret_cast<float *>(A.out) + A.out_coff + cout0);
+    int p_n, p_y0, p_x0;                                         // the finished tile (whose epilogue rides in the current one)
+    {
+        p_n = t_lo / tiles_img;
+        const int r = t_lo - p_n * tiles_img, ty = r / tiles_x;
+        p_y0 = ty * TH; p_x0 = (r - ty * tiles_x) * TW;
+    }
+    float e_osc[NPW], e_osh[NPW];
+    bool e_ok[NPW];
+#pragma unroll
+    for (int ni = 0; ni < NPW; ++ni) {
+        const int co = cout0 + ni * 32 + l31;
+        const bool cok = co < A.Cout;
+        e_ok[ni] = cok && !(A.debug & 8);                        // (8: ablation, nothing is stored)
+        e_osc[ni] = (A.oscale && cok) ? A.oscale[co] : 1.f;
+        e_osh[ni] = fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
+    }
+    const bool orelu = A.orelu != 0;
+
+    // epilogue units of a finished accumulator set, four registers each.  Statistics: blocks in the order (ni, mi).  Image: bias / scale /
+    // shift / ReLU in fp32, one ds_write_b32 per value (the 32 lanes of a half write 32 consecutive couts of one pixel).
+    float st_sum = 0.f, st_sq = 0.f;
+    auto stat_unit = [&](const f32x16 (&P)[MPW][NPW], int u, int par) {
+        const int ni = u / (MPW * 4), mi = (u / 4) % MPW, g = u % 4;
+        if (mi == 0 && g == 0) { st_sum = 0.f; st_sq = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float v = P[mi][ni][4 * g + j]; st_sum += v; st_sq = fmaf(v, v, st_sq); }
+        if (mi == MPW - 1 && g == 3) {
+            float *sp = s_stats + par * (4 * 2 * BN);
+            const float a = st_sum + __shfl_xor(st_sum, 32), b2 = st_sq + __shfl_xor(st_sq, 32);
+            if (half == 0) {
+                sp[(wave * 2 + 0) * BN + ni * 32 + l31] = a;
+                sp[(wave * 2 + 1) * BN + ni * 32 + l31] = b2;
+            }
+        }
+    };
+    // store unit u of a finished set: registers 4g .. 4g+3 of block (mi, ni) - bias / scale / shift / ReLU in fp32, four stores
+    auto img_unit = [&](const f32x16 (&P)[MPW][NPW], int u) {
+        const int mi = u / (NPW * 4), ni = (u / 4) % NPW, g = u % 4;
+        const float osc = e_osc[ni], osh = e_osh[ni];
+        // rows 4 wm + 2 mi (+ 1 for g >= 2) of the tile, pixels (g & 1) * 8 + j (+ 4 half) of the row
+        char *ob = out_b + ((size_t)(p_n * A.H + p_y0 + wm * 4 + mi * 2 + (g >> 1)) * A.W + p_x0 + (g & 1) * 8) * pix_b + ni * 128;      // uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = fmaf(P[mi][ni][4 * g + j], osc, osh);
+            if (orelu) v = fmaxf(v, 0.f);
+            if (e_ok[ni]) {
+                if (A.debug & 128) *reinterpret_cast<float *>(ob + j * pix_b + l_off) = v;
+                else __builtin_nontemporal_store(v, reinterpret_cast<float *>(ob + j * pix_b + l_off));
+            }
+        }
+    };
+    constexpr int NSU = STATS ? MPW * NPW * 4 : 0;               // statistics units of a set
+    constexpr int NIU = MPW * NPW * 4;                           // store units of a set: a quarter of them per chunk interval
+
+    int stats_tile = -1, stats_par = 0;
+    auto flush_stats = [&]() {
+        if (STATS && stats_tile >= 0 && tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN;
+            const float *sp = s_stats + stats_par * (4 * 2 * BN);
+            float v = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += sp[(w4 * 2 + which) * BN + col];
+            const int co = cout0 + col;
+            if (co < A.Cout) A.stats[((size_t)stats_tile * 2 + which) * A.Cout + co] = v;
+        }
+        stats_tile = -1;
+    };
+
+    // one chunk interval on accumulator set C (halo / weight slots `sl`): 9 taps x MPW x NPW products of three MFMAs; the fragments of a
+    // tap are requested one tap (12 MFMAs) ahead.  FIRST: the tile's first chunk starts from zero.  EPI 1: the statistics and the first
+    // M block of the finished set P ride behind the MFMAs (every fourth gap one unit), EPI 2: its second M block.
+    auto interval = [&](auto first_c, auto epi_c, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int par, int sl) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int EPI = decltype(epi_c)::value;
+        if (A.debug & 1) return;                                  // ablation (tools/bench_conv_ws32.py): no fragment reads, no MFMAs
+        bf16x8 ah[2][MPW], al[2][MPW], bh[2][NPW], bl[2][NPW];
+        const unsigned char *la = lds_a + sl * L::A_SLOT, *lw = lds_w + sl * L::W_SLOT;
+        // fragment read number i of tap t, in the order tap t's MFMAs use them: al0 bh0 ah0 bl0 | bh1 bl1 | al1 ah1
+        constexpr int NRD = 2 * MPW + 2 * NPW;
+        auto request_one = [&](int t, int i) {
+            const int s2 = t & 1;
+            const int ao = toff(t), bo = bbase + t * 2 * BN * 16;
+            if (i == 0) al[s2][0] = *reinterpret_cast<const bf16x8 *>(la + L::A_PLANE + abase[0][tpar(t)] + ao);
+            else if (i == 1) bh[s2][0] = *reinterpret_cast<const bf16x8 *>(lw + bo);
+            else if (i == 2) ah[s2][0] = *reinterpret_cast<const bf16x8 *>(la + abase[0][tpar(t)] + ao);
+            else if (i == 3) bl[s2][0] = *reinterpret_cast<const bf16x8 *>(lw + L::B_PLANE + bo);
+            else if (NPW == 2 && i == 4) bh[s2][NPW - 1] = *reinterpret_cast<const bf16x8 *>(lw + bo + 512);
+            else if (NPW == 2 && i == 5) bl[s2][NPW - 1] = *reinterpret_cast<const bf16x8 *>(lw + L::B_PLANE + bo + 512);
+            else if (i == NRD - 2) al[s2][1] = *reinterpret_cast<const bf16x8 *>(la + L::A_PLANE + abase[1][tpar(t)] + ao);
+            else if (i == NRD - 1) ah[s2][1] = *reinterpret_cast<const bf16x8 *>(la + abase[1][tpar(t)] + ao);
+        };
+        // after MFMA number g of the interval (program order is issue order: a scheduling fence after every MFMA keeps the next tap's
+        // fragment reads - one per MFMA gap, a whole tap ahead of their use - and the epilogue units where they are written; left to
+        // itself the scheduler sinks every read to just in front of its first use and the matrix pipe waits out the LDS latency tap by tap)
+        auto gap = [&](int t, int m, int g) {
+            if (t + 1 < TAPS && m < NRD && !(A.debug & 16)) request_one(t + 1, m);      // (16: ablation, MFMAs on stale fragments)
+            if (EPI != 0) {
+                // interval EPI of the tile (1..4): a quarter of the finished set's store units, evenly spread over the interval's gaps
+                // (the write path takes 256 bytes every ~24 MFMAs per wave instead of a burst); the statistics ride in the first interval
+                constexpr int GAPS = TAPS * MPW * NPW * 3, QU = NIU / 4, STEP = GAPS / QU;
+                if (EPI == 1 && STATS && (g & 3) == 1 && (g >> 2) < NSU) stat_unit(P, g >> 2, par);
+                if (g % STEP == STEP / 2 && g / STEP < QU) img_unit(P, (EPI - 1) * QU + g / STEP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(4 * NSU + 2 <= TAPS * MPW * NPW * 3, "the deferred statistics fit the MFMA gaps of one interval");
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) request_one(0, i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NPW; ++ni) {
+                    const int m0 = (mi * NPW + ni) * 3, g0 = t * MPW * NPW * 3 + m0;
+                    // small terms first (conv_f32_kernel's order)
+                    if (FIRST && t == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][mi], bh[t & 1][ni], z, 0, 0, 0);
+                    } else {
+                        C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][mi], bh[t & 1][ni], C[mi][ni], 0, 0, 0);
+                    }
+                    gap(t, m0, g0);
+                    C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][mi], bl[t & 1][ni], C[mi][ni], 0, 0, 0);
+                    gap(t, m0 + 1, g0 + 1);
+                    C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][mi], bh[t & 1][ni], C[mi][ni], 0, 0, 0);
+                    gap(t, m0 + 2, g0 + 2);
+                }
+        }
+    };
+    using F_ = std::false_type;
+    using T_ = std::true_type;
+    using E0 = std::integral_constant<int, 0>;
+    using E1 = std::integral_constant<int, 1>;
+    using E2 = std::integral_constant<int, 2>;
+    using E3 = std::integral_constant<int, 3>;
+    using E4 = std::integral_constant<int, 4>;
+    // tile j (run chunks q .. q + NCH - 1) on set C; P = the finished tile j - 1 (at p_*): its statistics ride in chunk interval 0, a quarter
+    // of its stores in each of the intervals 0 .. 3
+    auto tile_step = [&](auto has_prev, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int j, int q) {
+        constexpr bool HP = decltype(has_prev)::value;
+        const int par = (j + 1) & 1;
+        if (HP) interval(T_{}, E1{}, C, P, par, q & 1); else interval(T_{}, E0{}, C, P, par, q & 1);
+        if (HP && STATS) { stats_tile = t_lo + j - 1; stats_par = par; }
+        __syncthreads();
+        flush_stats();
+        if (HP) interval(F_{}, E2{}, C, P, par, (q + 1) & 1); else interval(F_{}, E0{}, C, P, par, (q + 1) & 1);
+        __syncthreads();
+        if (HP) interval(F_{}, E3{}, C, P, par, (q + 2) & 1); else interval(F_{}, E0{}, C, P, par, (q + 2) & 1);
+        __syncthreads();
+        if (HP) interval(F_{}, E4{}, C, P, par, (q + 3) & 1); else interval(F_{}, E0{}, C, P, par, (q + 3) & 1);
+        __syncthreads();
+        for (int i = 4; i < NCH; ++i) {
+            interval(F_{}, E0{}, C, P, par, (q + i) & 1);
+            __syncthreads();
+        }
+        if (HP) {                                                // P has left: the finished tile is now the one just accumulated
+            p_x0 += TW;
+            if (p_x0 >= A.W) { p_x0 = 0; p_y0 += TH; if (p_y0 >= A.H) { p_y0 = 0; ++p_n; } }
+        }
+    };
+    // the last tile of the run: nothing left to hide behind
+    auto serial_epilogue = [&](const f32x16 (&P)[MPW][NPW], int j) {
+        const int par = j & 1;
+        if (STATS) {
+#pragma unroll
+            for (int u = 0; u < NSU; ++u) stat_unit(P, u, par);
+            stats_tile = t_lo + j;
+            stats_par = par;
+        }
+#pragma unroll
+        for (int u = 0; u < NIU; ++u) img_unit(P, u);
+        __syncthreads();                                         // the statistics of the four waves are parked
+        flush_stats();
+    };
+
+    __syncthreads();                                             // chunk 0 is staged
+    tile_step(F_{}, accA, accB, 0, 0);
+    int j = 1, q = NCH;
+    for (; j + 1 < ntl; j += 2, q += 2 * NCH) {
+        tile_step(T_{}, accB, accA, j, q);
+        tile_step(T_{}, accA, accB, j + 1, q + NCH);
+    }
+    const bool tail = j < ntl;
+    if (tail) tile_step(T_{}, accB, accA, j, q);
+    if (S & 1) __syncthreads();                                  // the movers' loop runs whole pairs of intervals
+    if (tail) serial_epilogue(accB, j); else serial_epilogue(accA, ntl - 1);
+}
+
+}  // namespace
+
+namespace cdnet {
+
+// eligibility + launch; returns -1 when the layer must take conv_f32_kernel
+template <int BN>
+static int try_launch_ws32(const ConvArgs &A, hipStream_t st) {
+    using L = Ws32Lds<BN>;
+    int ctot = 0;
+    for (int i = 0; i < A.nsrc; ++i) {
+        if (A.src[i].pool) return -1;
+        ctot += A.src[i].C;
+    }
+    const int smem = L::bytes(ctot);
+    if (smem > 160 * 1024) return -1;
+    const int T = (A.W / 16) * (A.H / 16) * A.N;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return check_launch("hipGetDeviceProperties");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ctiles = cdiv(A.Cout, BN);
+    const int Gmax = n_cu / ctiles > 0 ? n_cu / ctiles : 1;
+    // a persistent workgroup pays a few microseconds of start-up and a serial epilogue for its last tile: worth it from a few tiles'
+    // worth of chunk intervals per workgroup on
+    if (!(A.debug & 64) && (long long)T * A.nchunk < 16LL * Gmax) return -1;
+    bool all_plain = true, all_fast = true;
+    for (int i = 0; i < A.nsrc; ++i) {
+        const ConvSrc &s = A.src[i];
+        all_plain = all_plain && !s.scale && !s.relu && !s.res;
+        all_fast = all_fast && s.scale && s.shift && s.relu == 1 && !s.res;
+    }
+    int G = n_cu / ctiles;
+    G = G > T ? T : G;
+    if (G >= 8) G &= ~7;
+    if ((A.debug >> 8) > 0 && (A.debug >> 8) < G) G = A.debug >> 8;      // tests: few workgroups, long runs of tiles
+    if (G < 1) G = 1;
+    dim3 grid(G, ctiles, 1);
+    auto launch = [&](auto xf_c, auto st_c) -> int {
+        constexpr int XF = decltype(xf_c)::value;
+        constexpr bool STATS = decltype(st_c)::value;
+        auto kern = conv_ws32_kernel<BN, XF, STATS>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(conv_ws32)");
+            attr_done = true;
+        }
+        kern<<<grid, 512, smem, st>>>(A);
+        return check_launch("conv_ws32_kernel");
+    };
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    using X2 = std::integral_constant<int, 2>;
+    const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
+    if (A.stats) return xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
+    return xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
+}
+
+// called by conv_forward_f32 first; -1 = not eligible (the caller falls back to conv_f32_kernel)
+int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st) {
+    static const int use_ws = getenv("CDNET_CONV_WS32") ? atoi(getenv("CDNET_CONV_WS32")) : 1;
+    if ((!use_ws && !(A.debug & 64)) || (A.debug & 32)) return -1;
+    if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || A.eres || A.ws) return -1;
+    if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < 4) return -1;
+    if (A.BN == 64) return try_launch_ws32<64>(A, st);
+    if (A.BN == 32) return try_launch_ws32<32>(A, st);
+    return -1;
+}
+
+}  // namespace cdnet

@@ -162,8 +162,9 @@ typedef struct cdnet_conv_args {
     int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
     int out_f16;            /* 1: store the output as fp16 instead of bf16 */
     int debug;              /* 0 in production.  Kernel-selection switches for the tests: 32 = never take the wave-specialised
-                               persistent kernel (conv_ws_kernel), 64 = take it even for small launches; other bits: ablations of
-                               tools/bench_conv.py */
+                               persistent kernels (conv_ws_kernel; conv_ws32_kernel of the fp32 path), 64 = take them even for
+                               small launches; bits 8..: at most (debug >> 8) persistent workgroups per output-channel tile (long
+                               runs of tiles on small test shapes; conv_ws32_kernel); other bits: ablations of tools/bench_conv.py */
     int ws;                 /* reserved, must be 0 */
     int f32;                /* 1: fp32 precision - x / res / eres / out are fp32 tensors (every source has f16 = 2), `w` is the split
                                pack (mode | CDNET_PACK_SPLIT), each product runs as three bf16 MFMAs over (hi, lo) operand pairs with

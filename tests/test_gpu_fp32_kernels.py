@@ -270,3 +270,129 @@ def test_conv_fp32_full_tile_epilogue_is_bit_identical_to_the_general_one(eres):
     assert torch.equal(outs[0][0], outs[1][0])
     if not eres:
         assert torch.equal(outs[0][1], outs[1][1])
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# conv_ws32_kernel (csrc/conv32ws.hip): the wave-specialised persistent form of the fp32-precision 3x3 convolution.  Same MFMA
+# sequence per accumulator as conv_f32_kernel -> bit-identical outputs; the per-tile statistics are summed in another order (1e-6).
+# Every case runs with few persistent workgroups (debug >> 8), so that a workgroup walks several tiles (odd and even numbers of
+# chunk intervals, the deferred two-half epilogue, the serial epilogue of the last tile), and with the default grid.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def _ws32_case(N, cins, Cout, H, W, xf, stats=False, fold=False, offs=None, res=False, coff=0, cstride=None, seed=0):
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(100 + seed)
+    srcs, parts = [], []
+    for k, c in enumerate(cins):
+        hs, ws = (H, W) if not offs or k == 0 else (H - offs[0] - 1, W - offs[1] - 2)
+        x = torch.randn((N, c, hs, ws), generator=g)
+        sc = sh = r = None
+        t = x
+        if xf >= 1:
+            sc, sh = torch.rand((c,), generator=g) + 0.5, torch.randn((c,), generator=g) * 0.3
+            t = t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        if res and k == len(cins) - 1:
+            r = torch.randn((N, c, hs, ws), generator=g)
+            t = t + r
+        if xf >= 1:
+            t = F.relu(t)
+        off = (0, 0)
+        if offs and k > 0:
+            off = offs
+            t = F.pad(t, (offs[1], W - ws - offs[1], offs[0], H - hs - offs[0]))
+        parts.append(t)
+        srcs.append(engine.Src(_nhwc(x), None if sc is None else sc.cuda(), None if sh is None else sh.cuda(), relu=xf >= 1,
+                               res=None if r is None else _nhwc(r), off=off))
+    cin = sum(cins)
+    w = torch.randn((Cout, cin, 3, 3), generator=g) * (1.5 / (9 * cin) ** 0.5)
+    bias = torch.randn((Cout,), generator=g) * 0.1 if fold else None
+    osc = (torch.rand((Cout,), generator=g) + 0.5) if fold else None
+    osh = torch.randn((Cout,), generator=g) * 0.2 if fold else None
+    want = F.conv2d(torch.cat(parts, 1).double(), w.double(), None if bias is None else bias.double(), padding=1)
+    raw = want
+    if fold:
+        want = F.relu(want * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1))
+    cfg = (16, 16, 64 if Cout > 32 else 32)                 # (choose_cfg would take 8x8 tiles for the few-pixel cases)
+    wp = engine.pack_weights(w.cuda(), cfg, 0, split=True)
+    outs = {}
+    for name, dbg in (('old', 32), ('ws_few', 64 | (3 << 8)), ('ws_five', 64 | (5 << 8)), ('ws', 64)):
+        engine.CONV_DEBUG = dbg
+        try:
+            cs = cstride or Cout
+            out = torch.full((N, H, W, cs), 7.0, dtype=torch.float32, device='cuda')
+            if cs != Cout:
+                # channel slice of a wider tensor: call the ABI with out_cstride / out_coff through a view-less path
+                import ctypes as C
+                from cdnet_amd import _lib
+                a = engine.ConvArgs()
+                for i, s in enumerate(srcs):
+                    s.fill(a.src[i])
+                a.nsrc, a.w = len(srcs), wp.data_ptr()
+                a.out, a.Cout, a.out_cstride, a.out_coff = out.data_ptr(), Cout, cs, coff
+                a.N, a.H, a.W, a.taps, a.npar, a.ostride, a.nchunk = N, H, W, 9, 1, 1, cin // 16
+                a.tile, a.CK, a.BN, a.f32, a.debug = cfg[0], cfg[1], cfg[2], 1, dbg
+                _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
+                st = None
+                got = out[..., coff:coff + Cout]
+                assert float((out[..., :coff] - 7.0).abs().max() if coff else 0.0) == 0.0 and float((out[..., coff + Cout:] - 7.0).abs().max()) == 0.0
+            else:
+                got, st = engine.conv_forward(srcs, wp, Cout, cfg, bias=None if bias is None else bias.cuda(), oscale=None if osc is None else osc.cuda(),
+                                              oshift=None if osh is None else osh.cuda(), orelu=fold, out=out, stats=True if stats else None, H=H, W=W)
+            torch.cuda.synchronize()
+            outs[name] = (got.clone(), None if st is None else st.clone())
+        finally:
+            engine.CONV_DEBUG = 0
+    ref = want.permute(0, 2, 3, 1).contiguous()
+    for name, (got, st) in outs.items():
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 5e-5, (name, err)
+        if name != 'old':
+            assert torch.equal(got, outs['old'][0]), '%s differs from conv_f32_kernel' % name       # the same MFMA sequence per accumulator
+        if stats:
+            T = st.shape[0]
+            rr = raw.permute(0, 2, 3, 1).reshape(N, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 2, 4, 5).reshape(T, 256, Cout)
+            assert float((st[:, 0].double().cpu() - rr.sum(1)).abs().max()) < 2e-4 * float(rr.abs().sum(1).max())
+            assert float((st[:, 1].double().cpu() - (rr * rr).sum(1)).abs().max()) < 2e-4 * float((rr * rr).sum(1).max())
+
+
+@pytest.mark.parametrize('case', [
+    dict(N=2, cins=(64,), Cout=64, H=32, W=48, xf=0),                                   # plain source (stored activations, gradients)
+    dict(N=2, cins=(64,), Cout=64, H=32, W=48, xf=1, stats=True),                       # training: BatchNorm source, raw output + statistics
+    dict(N=1, cins=(64,), Cout=64, H=16, W=16, xf=0),                                   # one tile
+    dict(N=3, cins=(128,), Cout=128, H=32, W=32, xf=1, fold=True),                      # two output-channel tiles, folded BatchNorm + ReLU
+    dict(N=2, cins=(64, 16), Cout=16, H=32, W=32, xf=1, stats=True, offs=(1, 2)),       # decoder: two sources, odd chunk count, pad offsets, 16 couts
+    dict(N=2, cins=(64, 32), Cout=32, H=48, W=32, xf=1, stats=True),                    # six chunks, 32 couts
+    dict(N=1, cins=(256,), Cout=256, H=32, W=32, xf=0),                                 # long channel loop
+    dict(N=2, cins=(64,), Cout=64, H=32, W=32, xf=2, res=True),                         # residual operand (run-time transform flags)
+    dict(N=2, cins=(64,), Cout=32, H=32, W=32, xf=0, coff=16, cstride=64),              # channel slice of a wider output tensor
+])
+def test_conv_ws32_matches_conv_f32_and_fp64(case):
+    _ws32_case(**case)
+
+
+def test_conv_ws32_backward_data_of_transposed_conv_views():
+    """the space-to-depth backward of ConvTranspose2d(k4, s2, p1): two strided view sources (row parities) on conv_ws32_kernel"""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    g = torch.Generator().manual_seed(77)
+    N, Cin, Cout, H, W = 2, 64, 32, 16, 32
+    x = torch.randn((N, Cin, H, W), generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn((Cin, Cout, 4, 4), generator=g) * 0.1
+    dy = torch.randn((N, Cout, 2 * H, 2 * W), generator=g)
+    F.conv_transpose2d(x, w.double(), None, stride=2, padding=1).backward(dy.double())
+    cfg = engine.choose_cfg([2 * Cout, 2 * Cout], Cin, H, W, taps=9, N=N, f32=True)
+    wp = engine.pack_weights(w.cuda(), cfg, 4, split=True)
+    gy = _nhwc(dy)
+    views = [engine.Src(gy, view=(a * 2 * W * Cout, H, W, 2 * Cout, 4 * W * Cout)) for a in (0, 1)]
+    outs = []
+    for dbg in (32, 64 | (2 << 8)):
+        engine.CONV_DEBUG = dbg
+        try:
+            out, _ = engine.conv_forward(views, wp, Cin, cfg, taps=9, H=H, W=W)
+        finally:
+            engine.CONV_DEBUG = 0
+        assert _rel(_nchw(out), x.grad) < 5e-5
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
