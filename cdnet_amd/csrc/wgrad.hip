@@ -12,6 +12,7 @@
 //
 // Replaces the weight-gradient half of loss.backward() (train_util_dam.py:307) for nn.Conv2d / nn.ConvTranspose2d.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "conv_args.h"
 #include "xform.h"
@@ -886,6 +887,259 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Wave-specialised form of the fp32-precision weight gradient (3x3, 64 x 64 channel blocks): wgrad_f32_kernel's four waves stage a
+// tile (transform, hi / lo split, LDS writes: ~450 vector instructions per thread) and then multiply it - the matrix pipe idles a
+// third of the time.  Here waves 0..3 only read fragments and issue MFMAs (one 32 x 32 dW quadrant x 9 taps each), waves 4..7 only
+// move data: fp32 input halo + gradient vectors of two tiles in flight in registers (straight-line code, clamped tile index),
+// source transform, split into hi | lo bf16 planes, the other LDS stage.  Two stages of A_hi | A_lo | G_hi | G_lo only fit the LDS
+// for 4 x 16-pixel tiles (66 KB per stage); a tile is then four k-steps of 27 MFMAs - one barrier per 108 MFMAs per wave, as in
+// conv_ws32_kernel.  The consumers' fragment reads (ds_read_b64_tr_b16 pairs) are issued three taps ahead of their MFMAs, at most one
+// pair per MFMA gap, and pinned there by a scheduling fence behind every MFMA; no fragment ring - 2 waves per SIMD leave 256
+// registers, 144 of them accumulators - so a k-step reads its 9 (hi, lo) input fragments again (40 transposing reads per 27 MFMAs).
+// Same products and the same three-MFMA order per tap as wgrad_f32_kernel; the pixels are summed in another order (other tiles),
+// so the results agree to fp32 rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------------------
+constexpr int TH32 = 4, NPIX_A32 = (TH32 + 2) * HALO_W, NPIX_G32 = TH32 * TW;
+
+template <int XF>      // source transform: 0 plain fp32, 1 x * scale + shift -> ReLU, 2 run-time flags (scale / shift, residual, ReLU)
+__global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
+    constexpr int TAPS = 9, CI = 64, CO = 64, CO_T = 2;
+    constexpr int PA = pstride(CI), PG = pstride(CO);
+    constexpr int A_PLANE = NPIX_A32 * PA, G_PLANE = NPIX_G32 * PG, STAGE = 2 * A_PLANE + 2 * G_PLANE;      // [A_hi][A_lo][G_hi][G_lo]
+    constexpr int VA = CI / 8, VG = CO / 8;
+    constexpr int NA = (NPIX_A32 * VA + 255) / 256, NG = NPIX_G32 * VG / 256;
+    static_assert(NPIX_G32 * VG % 256 == 0, "whole gradient vectors per mover thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef s16x4 __attribute__((address_space(3))) * lptr;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co_blocks = (A.Cout + CO - 1) / CO;
+    const int ci_blocks = (A.src.C + CI - 1) / CI;
+    const int cb = blockIdx.x % co_blocks, ib = blockIdx.x / co_blocks;
+    const int par = blockIdx.y;
+    const int ks = blockIdx.z;
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH32 - 1) / TH32;
+    const int tiles_img = tiles_y * tiles_x;
+    const int ntiles = A.N * tiles_img;
+    const int ntl = ks < ntiles ? (ntiles - ks + A.ksplit - 1) / A.ksplit : 0;      // tiles of this workgroup
+    const int ntl2 = (ntl + 1) & ~1;                                                // barrier steps of both roles (padded to even)
+
+    __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
+    fill_xf<CI>(s_xf, A.src, ib * CI, tid);
+    if (ntl == 0) return;
+    if (wave >= 4) {
+        // ------------------------------- movers -------------------------------
+        const int ptid = tid - 256;
+        const ConvSrc &s = A.src;
+        const float *sx = reinterpret_cast<const float *>(s.x), *sr = reinterpret_cast<const float *>(s.res);
+        const float *gx = reinterpret_cast<const float *>(A.g);
+        const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
+        const int slot_a = ptid % VA, cbase = ib * CI + slot_a * 8;
+        const bool cok_a = cbase < s.C;
+        const int slot_g = ptid % VG, co = cb * CO + slot_g * 8;
+        const bool cok_g = co < A.Cout;
+        const bool on = XF == 1 || (XF == 2 && s.scale != nullptr), relu = XF == 1 || (XF == 2 && s.relu != 0);
+        const bool has_res = XF == 2 && sr != nullptr;
+        float sc[8], sh[8];
+        if (XF != 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = s_xf[slot_a * 8 + j]; sh[j] = s_xf[CI + slot_a * 8 + j]; }
+        }
+        // what depends on the thread only: halo coordinates, element offsets inside a tile and LDS addresses of its vectors
+        int hyx[NA], aoff[NA], adst[NA], gyx[NG], goff[NG], gdst[NG];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = ptid + i * 256, pix = v / VA;
+            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+            hyx[i] = v < NPIX_A32 * VA ? ((hy << 16) | hx) : -1;
+            aoff[i] = hy * rs + hx * s.C;
+            adst[i] = pix * PA + slot_a * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int pix = ptid / VG + i * (256 / VG);
+            const int py = pix / TW, px = pix % TW;
+            gyx[i] = (py << 16) | px;
+            goff[i] = (py * A.W + px) * A.Cout;
+            gdst[i] = 2 * A_PLANE + pix * PG + slot_g * 16;
+        }
+        // tile cursor of the request stream: tile ks + j * ksplit as (image, tile row, tile column), advanced by ksplit without divisions
+        int c_n, c_ty, c_tx, c_j = 0;
+        {
+            c_n = ks / tiles_img;
+            const int rem = ks - c_n * tiles_img;
+            c_ty = rem / tiles_x; c_tx = rem - c_ty * tiles_x;
+        }
+        const int d_n = A.ksplit / tiles_img, d_rem = A.ksplit - d_n * tiles_img, d_ty = d_rem / tiles_x, d_tx = d_rem - d_ty * tiles_x;
+        wg_f32x4 pa_[2][NA][2], pg_[2][NG][2];
+        int ea[2][NA];                       // element offsets of the input vectors (read again for a residual operand), -1 = zero fill
+        unsigned gv[2];
+        auto issue = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            const int y0 = c_ty * TH32, x0 = c_tx * TW;
+            const int abase_e = (c_n * s.Hs + (y0 - 1 - s.off_y)) * rs + (x0 - 1 - s.off_x) * s.C + cbase;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int hy = hyx[i] >> 16, hx = hyx[i] & 0xffff;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool ok = hyx[i] >= 0 && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
+                                (unsigned)(y - s.off_y) < (unsigned)s.Hs && (unsigned)(x - s.off_x) < (unsigned)s.Ws;
+                ea[R][i] = ok ? abase_e + aoff[i] : -1;
+                const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sx + (ok ? ea[R][i] : 0));
+                pa_[R][i][0] = pp[0];
+                pa_[R][i][1] = pp[1];
+            }
+            unsigned gvalid = 0;
+            const int gbase_e = ((c_n * A.H + y0) * A.W + x0) * A.Cout + co;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const bool ok = cok_g && y0 + (gyx[i] >> 16) < A.H && x0 + (gyx[i] & 0xffff) < A.W;
+                const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(gx + (ok ? gbase_e + goff[i] : 0));
+                pg_[R][i][0] = pp[0];
+                pg_[R][i][1] = pp[1];
+                gvalid |= (ok ? 1u : 0u) << i;
+            }
+            gv[R] = gvalid;
+            if (c_j + 1 < ntl) {             // (past the end the last tile is requested and staged again, into the buffer nobody reads)
+                ++c_j;
+                c_tx += d_tx; if (c_tx >= tiles_x) { c_tx -= tiles_x; ++c_ty; }
+                c_ty += d_ty; if (c_ty >= tiles_y) { c_ty -= tiles_y; ++c_n; }
+                c_n += d_n;
+            }
+        };
+        auto commit = [&](auto rc, int bufi) {
+            constexpr int R = decltype(rc)::value;
+            unsigned char *nb = smem + bufi * STAGE;
+            wg_f32x4 rr[NA][2];
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sr + (ea[R][i] >= 0 ? ea[R][i] : 0));
+                    rr[i][0] = pp[0];
+                    rr[i][1] = pp[1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float x[8] = {pa_[R][i][0][0], pa_[R][i][0][1], pa_[R][i][0][2], pa_[R][i][0][3], pa_[R][i][1][0], pa_[R][i][1][1], pa_[R][i][1][2], pa_[R][i][1][3]};
+                if (XF != 0 && on) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], sc[j], sh[j]);
+                }
+                if (has_res) {
+                    const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += r[j];
+                }
+                if (XF != 0 && relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                }
+                u32x4 hi, lo;
+                wg_split8(x, hi, lo);
+                const unsigned keep = ea[R][i] >= 0 ? 0xffffffffu : 0u;      // outside the image / source / channels: zeros
+                hi &= keep;
+                lo &= keep;
+                if (i < NA - 1 || ptid + i * 256 < NPIX_A32 * VA) {
+                    *reinterpret_cast<u32x4 *>(nb + adst[i]) = hi;
+                    *reinterpret_cast<u32x4 *>(nb + A_PLANE + adst[i]) = lo;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const float x[8] = {pg_[R][i][0][0], pg_[R][i][0][1], pg_[R][i][0][2], pg_[R][i][0][3], pg_[R][i][1][0], pg_[R][i][1][1], pg_[R][i][1][2], pg_[R][i][1][3]};
+                u32x4 hi, lo;
+                wg_split8(x, hi, lo);
+                const unsigned keep = (gv[R] >> i) & 1u ? 0xffffffffu : 0u;
+                hi &= keep;
+                lo &= keep;
+                *reinterpret_cast<u32x4 *>(nb + gdst[i]) = hi;
+                *reinterpret_cast<u32x4 *>(nb + G_PLANE + gdst[i]) = lo;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        issue(I0{});                                             // tile 0
+        issue(I1{});                                             // tile 1
+        commit(I0{}, 0);
+        issue(I0{});                                             // tile 2
+        __syncthreads();
+        for (int j = 0; j < ntl2; j += 2) {
+            // consumers are on tile j (stage 0): fill stage 1 with tile j+1, then request tile j+3; then the other way round
+            commit(I1{}, 1);
+            issue(I1{});
+            __syncthreads();
+            commit(I0{}, 0);
+            issue(I0{});
+            __syncthreads();
+        }
+        return;
+    }
+    // ------------------------------- consumers -------------------------------
+    const int quad = wave;
+    const int wci = quad / CO_T, wco = quad % CO_T;
+    const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    const int g_lane = 2 * A_PLANE + (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
+    for (int j = 0; j < ntl2; ++j) {
+        if (j >= ntl) { __syncthreads(); continue; }              // padding step
+        const unsigned char *buf = smem + (j & 1) * STAGE;
+        auto frag = [&](int off, int pstr) -> bf16x8 {
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + off));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + off + 4 * pstr));
+            s16x8 av;
+            av[0] = a0[0]; av[1] = a0[1]; av[2] = a0[2]; av[3] = a0[3];
+            av[4] = a1[0]; av[5] = a1[1]; av[6] = a1[2]; av[7] = a1[3];
+            return __builtin_bit_cast(bf16x8, av);
+        };
+        // tap tau = ky * 9 + t of the tile (36 of them): input fragments of halo row ky + t / 3, column shift t % 3
+        auto a_off = [&](int tau) { return a_lane + ((tau / TAPS + (tau % TAPS) / 3) * HALO_W + (tau % TAPS) % 3) * PA; };
+        constexpr int NTAU = TH32 * TAPS;
+        constexpr int PFD = 3, RING = PFD + 1;                   // fragment pairs requested PFD taps (3 PFD MFMAs) ahead of their use
+        bf16x8 ah[RING], al[RING], gh[2], gl[2];
+        if (!(A.debug & 1)) {
+            gh[0] = frag(g_lane, PG); gl[0] = frag(g_lane + G_PLANE, PG);
+#pragma unroll
+            for (int k = 0; k < PFD; ++k) { ah[k] = frag(a_off(k), PA); al[k] = frag(a_off(k) + A_PLANE, PA); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tau = 0; tau < NTAU; ++tau) {
+                const int ky = tau / TAPS, t = tau % TAPS;
+                // small terms first (wgrad_f32_kernel's order); behind every MFMA a scheduling fence and at most one fragment pair of a
+                // later tap: program order is issue order
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tau % RING], gh[ky & 1], acc[t], 0, 0, 0);
+                if (tau + PFD < NTAU) ah[(tau + PFD) % RING] = frag(a_off(tau + PFD), PA);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tau % RING], gl[ky & 1], acc[t], 0, 0, 0);
+                if (tau + PFD < NTAU) al[(tau + PFD) % RING] = frag(a_off(tau + PFD) + A_PLANE, PA);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tau % RING], gh[ky & 1], acc[t], 0, 0, 0);
+                if (ky + 1 < TH32 && t == 2) gh[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG, PG);
+                if (ky + 1 < TH32 && t == 5) gl[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG + G_PLANE, PG);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
+        }
+}
+
 // sum the split-K slabs in a fixed order and scatter into the PyTorch parameter-gradient layout
 //   mode 0: Conv2d  dW[Cout][Cin][KH][KW]  (taps = KH*KW)
 //   mode 2: ConvTranspose2d k4 s2 p1  dW[Cin][Cout][4][4]   (npar 4 x taps 4)
@@ -980,8 +1234,36 @@ int launch_wgrad_gen(const WgradArgs &A, hipStream_t st) {
     return check_launch("wgrad_kernel");
 }
 
+// the wave-specialised fp32 kernel: 3x3 layers on 64 x 64 channel blocks (ostride 1), tensors below 2^31 elements
+int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
+    constexpr int smem = 2 * (2 * NPIX_A32 * pstride(64) + 2 * NPIX_G32 * pstride(64));
+    const ConvSrc &s = A.src;
+    const bool plain = !s.scale && !s.relu && !s.res, fast = s.scale && s.shift && s.relu == 1 && !s.res;
+    auto go = [&](auto xf_c) -> int {
+        constexpr int XF = decltype(xf_c)::value;
+        auto kern = wgrad_ws32_kernel<XF>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(wgrad_ws32)");
+            attr_done = true;
+        }
+        dim3 grid(cdiv(A.src.C, 64) * cdiv(A.Cout, 64), A.npar, A.ksplit);
+        kern<<<grid, 512, smem, st>>>(A);
+        return check_launch("wgrad_ws32_kernel");
+    };
+    if (plain) return go(std::integral_constant<int, 0>{});
+    if (fast) return go(std::integral_constant<int, 1>{});
+    return go(std::integral_constant<int, 2>{});
+}
+
 template <int CI_T, int CO_T, int TAPS>
 int launch_wgrad_f32(const WgradArgs &A, hipStream_t st) {
+    static const int use_ws32 = getenv("CDNET_WGRAD_WS32") ? atoi(getenv("CDNET_WGRAD_WS32")) : 1;
+    if (CI_T == 2 && CO_T == 2 && TAPS == 9 && use_ws32 && !(A.debug & 8) && A.ostride == 1 && A.npar == 1 && !A.src.pool &&
+        (long long)A.N * A.H * A.W * (A.src.C > A.Cout ? A.src.C : A.Cout) < (1LL << 31) &&
+        (long long)A.N * A.src.Hs * (A.src.row_stride ? A.src.row_stride : A.src.Ws * A.src.C) < (1LL << 31))
+        return launch_wgrad_ws32(A, st);
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int smem = 2 * (NPIX_A * pstride(CI) + NPIX_G * pstride(CO));
     auto kern = wgrad_f32_kernel<CI_T, CO_T, TAPS>;

@@ -1,0 +1,50 @@
+"""Micro-benchmark of the fp32-precision weight gradient (wgrad_ws32_kernel / wgrad_f32_kernel + split-K reduce) on training-step shapes.
+CDNET_WGRAD_WS32=0 selects the older kernel, CDNET_WGRAD_DEBUG=1 drops the MFMA loop.  usage: python tools/bench_wgrad32.py [B] [reps]"""
+import ctypes as C
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cdnet_amd import _lib, engine, trainer
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+lib = _lib.load()
+dev = 'cuda'
+
+
+def run(name, Cin, Cout, H, fused=False, cap=256):
+    N = B
+    x = torch.randn(N, H, H, Cin, device=dev)
+    g = torch.randn(N, H, H, Cout, device=dev)
+    kw = dict(scale=torch.rand(Cin, device=dev) + 0.5, shift=torch.rand(Cin, device=dev) - 0.5, relu=True) if fused else {}
+    s = engine.Src(x, **kw)
+    dw = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    ci_t = trainer._choose_ci_tiles(Cin, Cout)
+    CI, CO = ci_t * 32, (4 // ci_t) * 32
+    other = -(-Cin // CI) * -(-Cout // CO)
+    ntiles = N * (-(-H // 8)) * (-(-H // 16))
+    ks = max(1, min(ntiles, cap // other if other < cap else 1))
+    slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(Cin, Cout, 9, 1, ci_t, ks),), dtype=torch.float32, device=dev)
+    cs = engine.ConvSrc()
+    s.fill(cs)
+    call = lambda: _lib.call('cdnet_conv_backward_weight', C.byref(cs), 0, Cin, Cin, _lib.ptr(g), Cout, N, H, H, 9, 1, 1, ci_t, ks,
+                             _lib.ptr(slab), _lib.ptr(dw), 0, _lib.stream_ptr())
+    for _ in range(20):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / REPS
+    fl = 3 * 2.0 * N * H * H * Cin * Cout * 9
+    print(f'{name:34s} ksplit={ks:4d} {ms*1e3:8.1f} us   {fl / ms / 1e9:7.1f} TFLOP/s of bf16 MFMA work')
+
+
+run('64->64@256 plain', 64, 64, 256)
+run('64->64@256 BN+ReLU source', 64, 64, 256, fused=True)
+run('128->128@128 BN+ReLU source', 128, 128, 128, fused=True)
+run('256->256@64 BN+ReLU source', 256, 256, 64, fused=True)
+run('512->512@32 BN+ReLU source', 512, 512, 32, fused=True)
