@@ -113,11 +113,10 @@ def test_tiles_label_parity(trained):
     x, lab, dirn, point, weight, inst = synth.nuclei_batch(3, 256, 256, 777, n=60)
     with torch.no_grad():
         r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda())
-        want_logits = ref(torch.from_numpy(x))
     got_mask, got_dir = r['prob'].argmax(1).cpu().numpy(), r['dcm'].cpu().numpy().reshape(3, 256, 256)
     report = []
     for b in range(3):
-        w = oinf.infer_image(ref, x[b], tta=False, all_img_test=1)
+        w = _oracle(('tile', b), lambda: oinf.infer_image(ref, x[b], tta=False, all_img_test=1))
         agree_m = (got_mask[b] == w['probs'][0].argmax(0)).mean()
         agree_d = (got_dir[b] == w['dcms'][0, 0]).mean()
         aji, dice = _score('tile %d' % b, r['final'][b].cpu().numpy(), w['final'], 20)
