@@ -1783,7 +1783,8 @@ extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
-    if (A.f32 || !use_ws || (A.debug & 32)) return 0;
+    if (A.f32) return conv_forward_f32_ws(A, nullptr, true) == CDNET_OK ? 1 : 0;
+    if (!use_ws || (A.debug & 32)) return 0;
     if (!(A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32))) return 0;
     const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, nullptr, true) : try_launch_conv_ws<32, 9>(A, nullptr, true);
     return rc == CDNET_OK ? 1 : 0;

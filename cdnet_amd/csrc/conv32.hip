@@ -503,6 +503,8 @@ int conv_forward_f32(const ConvArgs &A, hipStream_t st) {
         const int rc = conv_forward_f32_ws(A, st);               // the producer / consumer kernel where it applies
         if (rc >= 0) return rc;
     }
+    CDNET_REQUIRE(A.ws != 2, "cdnet_conv_forward(f32): the BatchNorm-backward statistics epilogue (ws = 2) needs the producer / consumer kernel "
+                             "(ask cdnet_conv_ws_eligible first)");
     if (A.taps == 9) return dispatch_conv32<9>(A, st);
     if (A.taps == 4) return dispatch_conv32<4>(A, st);
     return dispatch_conv32<1>(A, st);

@@ -78,15 +78,25 @@ struct Ws32Lds {
     static constexpr int B_PLANE = TAPS * CK * BN * 2;            // one image of a chunk's packed weights
     static constexpr int W_SLOT = 2 * B_PLANE;                    // hi image | lo image: the packed chunk as it lies in memory
     static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum | sumsq][BN]
-    __host__ __device__ static int bytes(int ctot) { return 2 * A_SLOT + 2 * W_SLOT + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4; }
+    static constexpr int RAW_Q = 4 * 32 * 32 * 4;                // BNS: a quarter of a tile's raw forward output (one 32 x 32 block per consumer wave)
+    __host__ __device__ static int bytes(int ctot, bool bns = false) { return 2 * A_SLOT + 2 * W_SLOT + STATS_BYTES + 2 * ((ctot + 7) / 8 * 8) * 4 + (bns ? 2 * RAW_Q : 0); }
 };
 
 // XF: source transform decided by the launcher - 0 plain fp32, 1 x * scale + shift -> ReLU (training-mode BatchNorm source), 2 anything
 // (run-time flags: optional scale / shift, residual operand, ReLU).  STATS: per-tile channel sums of the accumulators.
 // The launcher guarantees: taps == 9, npar == 1, ostride == 1, H and W multiples of 16, nchunk >= 4, no pooled source, no fused residual
 // epilogue.
-template <int BN, int XF, bool STATS>
+// BNS (cdnet_conv_args.ws == 2, backward-data launches): the output is the gradient w.r.t. the activated output of a BatchNorm + ReLU
+// layer whose only reader this convolution was.  The first pass of that layer's BatchNorm backward - the channel sums of dz = dY * [act > 0]
+// and of dz * xhat - rides in the consumers' deferred epilogue: the movers bring the layer's raw forward output (eres, fp32
+// [N][H][W][Cout]) for the quarter of the finished tile that leaves in the NEXT interval into a 16 KB LDS buffer by DMA (two buffers;
+// [wave][32 pixels][32 couts], the block (mi, ni) of every consumer wave), the consumers read it back in accumulator layout (ds_read_b32:
+// 32 consecutive couts of a pixel) one element ahead of its use.  oscale | oshift | eres_scale | eres_shift = that layer's BatchNorm
+// scale | shift | mean | invstd (f32 [Cout]); stats = partial rows f32 [4 * gridDim.x][2][Cout] for cdnet_bn_backward_finalize (one row
+// per consumer wave, written once at the end of the run).  No bias / epilogue affine / ReLU in this mode; BN = 64, Cout % 64 == 0.
+template <int BN, int XF, bool STATS, bool BNS = false>
 __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
+    static_assert(!BNS || (BN == 64 && !STATS), "the BatchNorm-backward statistics epilogue serves 64-channel blocks of backward-data launches");
     using L = Ws32Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, TAPS = 9, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NPW = BN / 32, MPW = 2;
@@ -98,6 +108,8 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     unsigned char *lds_w = smem + 2 * L::A_SLOT;
     float *s_stats = reinterpret_cast<float *>(lds_w + 2 * L::W_SLOT);
     float *s_xf = reinterpret_cast<float *>(lds_w + 2 * L::W_SLOT + L::STATS_BYTES);
+    const int xfs_ = ((A.src[0].C + (A.nsrc > 1 ? A.src[1].C : 0)) + 7) / 8 * 8;
+    unsigned char *lds_raw = lds_w + 2 * L::W_SLOT + L::STATS_BYTES + 2 * xfs_ * 4;      // BNS only
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: tile rows, LDS bases and DMA pieces stay scalar
@@ -149,6 +161,10 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
             iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
         }
+        int o_n = in_, o_y0 = iy0, o_x0 = ix0;   // BNS: the tile the consumers are accumulating,
+        int s_n = 0, s_y0 = 0, s_x0 = 0;         //      the finished tile whose epilogue rides in the current one
+        bool s_ok = false;
+        int kt = 0;                              //      chunk-in-tile index of the current interval
         int ck = 0;                              // commit cursor: chunk-in-tile index
         int ge[NA];
         unsigned gm = 0;
@@ -200,13 +216,6 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             int si, cc0;
             chunk_src(ck, si, cc0);
             if (c_ + 1 < S) { if (++ck == NCH) ck = 0; }
-            if (A.debug & 2) {                                    // ablation: the loads are waited for, nothing is transformed or written
-                float keep_ = 0.f;
-#pragma unroll
-                for (int i = 0; i < NA; ++i) keep_ += pa[R][i][0][0] + pa[R][i][1][3];
-                if (keep_ == 123.456f) *reinterpret_cast<float *>(lds_a) = keep_;
-                return;
-            }
             const ConvSrc &s = A.src[si];
             const float *xf = s_xf + (si ? c0n : 0) + cc0 + slot * 8;
             float sc[8], sh[8];
@@ -270,6 +279,18 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
                 if (i * 4 + 3 < NPC || pc < NPC) glds_piece(wsrc + pc * 1024, (unsigned)lane * 16u, lds_w_addr + wslot * L::W_SLOT + pc * 1024);
             }
         };
+        // BNS: quarter q = block (mi = q >> 1, ni = q & 1) of every consumer wave of the tile at (rn, ry0, rx0) -> raw buffer q & 1; this
+        // wave brings the block of consumer wave pw: four 1 KB pieces of 8 pixels x 128 bytes
+        const unsigned lds_raw_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
+        const unsigned raw_lane = (unsigned)((lane >> 3) * A.Cout * 4 + (lane & 7) * 16);
+        auto dma_raw = [&](int q, int rn, int ry0, int rx0) {
+            const int mi = q >> 1, ni = q & 1;
+            const char *rb = reinterpret_cast<const char *>(A.eres) +
+                             (((size_t)(rn * A.H + ry0 + pw * 4 + mi * 2) * A.W + rx0) * A.Cout + cout0 + ni * 32) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                glds_piece(rb + ((size_t)(i >> 1) * A.W + (i & 1) * 8) * A.Cout * 4, raw_lane, lds_raw_addr + (q & 1) * L::RAW_Q + pw * 4096 + i * 1024);
+        };
         // the movers' barrier by hand (conv_ws_kernel): this wave's LDS writes done, everything older than its N youngest vector-memory
         // operations - the weight DMA of this interval - landed, then the barrier; the halo requests issued after the DMA stay in flight
         auto stream_sync = [](auto n_c) {
@@ -302,10 +323,22 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         auto interval = [&](auto rc, int k) {
             constexpr int R = decltype(rc)::value;               // register set / slot of chunk k + 1
             dma_w(R);
+            if (BNS) {
+                // the raw quarter the consumers need in the NEXT interval (all of this is older than the halo requests below: the wait
+                // in front of the barrier covers it whether or not it was issued)
+                if (kt == NCH - 1) dma_raw(0, o_n, o_y0, o_x0);
+                else if (kt < 3 && s_ok) dma_raw(kt + 1, s_n, s_y0, s_x0);
+            }
             commit(rc, k + 1);
             asm volatile("" ::: "memory");
             issue(rc);
             stream_sync(NHL{});
+            if (BNS && ++kt == NCH) {
+                kt = 0;
+                s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
+                o_x0 += TW;
+                if (o_x0 >= A.W) { o_x0 = 0; o_y0 += TH; if (o_y0 >= A.H) { o_y0 = 0; ++o_n; } }
+            }
         };
         for (int k = 0; k < S; k += 2) {
             interval(I1{}, k);
@@ -350,20 +383,43 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         const int co = cout0 + ni * 32 + l31;
         const bool cok = co < A.Cout;
         e_ok[ni] = cok && !(A.debug & 8);                        // (8: ablation, nothing is stored)
-        e_osc[ni] = (A.oscale && cok) ? A.oscale[co] : 1.f;
-        e_osh[ni] = fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
+        e_osc[ni] = (!BNS && A.oscale && cok) ? A.oscale[co] : 1.f;
+        e_osh[ni] = BNS ? 0.f : fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
     }
     const bool orelu = A.orelu != 0;
+    // BNS: the producer layer's BatchNorm scale | shift | mean | invstd of this lane's couts, its running sums, the raw value in flight
+    float b_sc[NPW], b_sh[NPW], b_mu[NPW], b_is[NPW], b_s1[NPW], b_s2[NPW], b_x = 0.f;
+    if (BNS) {
+#pragma unroll
+        for (int ni = 0; ni < NPW; ++ni) {
+            const int co = cout0 + ni * 32 + l31;
+            b_sc[ni] = A.oscale[co]; b_sh[ni] = A.oshift[co]; b_mu[ni] = A.eres_scale[co]; b_is[ni] = A.eres_shift[co];
+            b_s1[ni] = 0.f; b_s2[ni] = 0.f;
+            e_osc[ni] = 1.f; e_osh[ni] = 0.f;
+        }
+    }
+    const unsigned char *raw_w = lds_raw + wave * 4096 + (4 * half) * 128 + l31 * 4;      // this lane inside its wave's raw block
+    // raw value of element i (0..15) of the quarter in buffer `buf`: pixel (r & 3) + 8 (r >> 2) (+ 4 half) of the block, 128 bytes per pixel
+    auto bns_read = [&](int buf, int r) { b_x = *reinterpret_cast<const float *>(raw_w + buf * L::RAW_Q + ((r & 3) + 8 * (r >> 2)) * 128); };
+    auto bns_acc = [&](const f32x16 (&P)[MPW][NPW], int e, float x) {
+        const int b_ = e / 16, r = e % 16, mi = b_ / NPW, ni = b_ % NPW;
+        const float act = fmaf(x, b_sc[ni], b_sh[ni]);
+        const float dz = act > 0.f ? P[mi][ni][r] : 0.f;          // (bn_bwd_flat32_kernel's arithmetic)
+        b_s1[ni] += dz;
+        b_s2[ni] = fmaf(dz, (x - b_mu[ni]) * b_is[ni], b_s2[ni]);
+    };
 
     // epilogue units of a finished accumulator set, four registers each.  Statistics: blocks in the order (ni, mi).  Image: bias / scale /
     // shift / ReLU in fp32, one ds_write_b32 per value (the 32 lanes of a half write 32 consecutive couts of one pixel).
     float st_sum = 0.f, st_sq = 0.f;
-    auto stat_unit = [&](const f32x16 (&P)[MPW][NPW], int u, int par) {
-        const int ni = u / (MPW * 4), mi = (u / 4) % MPW, g = u % 4;
-        if (mi == 0 && g == 0) { st_sum = 0.f; st_sq = 0.f; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float v = P[mi][ni][4 * g + j]; st_sum += v; st_sq = fmaf(v, v, st_sq); }
-        if (mi == MPW - 1 && g == 3) {
+    // statistics of element s of a finished set - blocks in the order (ni, mi), registers ascending; two VALU instructions
+    auto stat_elem = [&](const f32x16 (&P)[MPW][NPW], int s_, int par) {
+        const int ni = s_ / (MPW * 16), mi = (s_ / 16) % MPW, r = s_ % 16;
+        if (mi == 0 && r == 0) { st_sum = 0.f; st_sq = 0.f; }
+        const float v = P[mi][ni][r];
+        st_sum += v;
+        st_sq = fmaf(v, v, st_sq);
+        if (mi == MPW - 1 && r == 15) {
             float *sp = s_stats + par * (4 * 2 * BN);
             const float a = st_sum + __shfl_xor(st_sum, 32), b2 = st_sq + __shfl_xor(st_sq, 32);
             if (half == 0) {
@@ -372,24 +428,31 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             }
         }
     };
-    // store unit u of a finished set: registers 4g .. 4g+3 of block (mi, ni) - bias / scale / shift / ReLU in fp32, four stores
-    auto img_unit = [&](const f32x16 (&P)[MPW][NPW], int u) {
-        const int mi = u / (NPW * 4), ni = (u / 4) % NPW, g = u % 4;
-        const float osc = e_osc[ni], osh = e_osh[ni];
-        // rows 4 wm + 2 mi (+ 1 for g >= 2) of the tile, pixels (g & 1) * 8 + j (+ 4 half) of the row
-        char *ob = out_b + ((size_t)(p_n * A.H + p_y0 + wm * 4 + mi * 2 + (g >> 1)) * A.W + p_x0 + (g & 1) * 8) * pix_b + ni * 128;      // uniform
+    // element e of a finished set leaves: register r of block (mi, ni) (blocks in the order (mi, ni)) = cout ni * 32 + l31 of the pixel in
+    // tile row 4 wm + 2 mi + (r >> 3), column ((r >> 2) & 1) * 8 + (r & 3) + 4 half.  Scalar row base (computed once per tile), one
+    // vector add for the column, bias / scale / shift / ReLU in fp32, one store: four instructions in one MFMA gap.
+    unsigned s_col[8];                                           // column c of a 8-pixel group: c * pix_b (kernel constants, scalar)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = fmaf(P[mi][ni][4 * g + j], osc, osh);
-            if (orelu) v = fmaxf(v, 0.f);
-            if (e_ok[ni]) {
-                if (A.debug & 128) *reinterpret_cast<float *>(ob + j * pix_b + l_off) = v;
-                else __builtin_nontemporal_store(v, reinterpret_cast<float *>(ob + j * pix_b + l_off));
-            }
+    for (int c = 0; c < 8; ++c) s_col[c] = (unsigned)(c & 3) * pix_b + (unsigned)(c >> 2) * 8u * pix_b;
+    char *row_base[4];                                           // rows 4 wm .. 4 wm + 3 of the finished tile, first column
+    auto set_row_bases = [&]() {
+        char *t0 = out_b + ((size_t)(p_n * A.H + p_y0 + wm * 4) * A.W + p_x0) * pix_b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row_base[r] = t0 + (size_t)r * A.W * pix_b;
+    };
+    auto img_elem = [&](const f32x16 (&P)[MPW][NPW], int e) {
+        const int b_ = e / 16, r = e % 16, mi = b_ / NPW, ni = b_ % NPW;
+        float v = fmaf(P[mi][ni][r], e_osc[ni], e_osh[ni]);
+        if (orelu) v = fmaxf(v, 0.f);
+        if (e_ok[ni]) {
+            // (scalar base first, kept opaque: otherwise the 16 column + lane offsets - kernel constants - are hoisted into 16 vector registers)
+            char *sb = row_base[mi * 2 + (r >> 3)] + (s_col[((r >> 2) & 1) * 4 + (r & 3)] + (unsigned)(ni * 128));
+            asm volatile("" : "+s"(sb));
+            // (global_, not flat_: the asm hid the pointer's origin; uniform base + 32-bit lane offset = the store's saddr form)
+            __builtin_nontemporal_store(v, (__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + l_off));
         }
     };
-    constexpr int NSU = STATS ? MPW * NPW * 4 : 0;               // statistics units of a set
-    constexpr int NIU = MPW * NPW * 4;                           // store units of a set: a quarter of them per chunk interval
+    constexpr int NEL = MPW * NPW * 16;                          // elements of a set per lane; a quarter of them leaves per chunk interval
 
     int stats_tile = -1, stats_par = 0;
     auto flush_stats = [&]() {
@@ -432,17 +495,29 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         // fragment reads - one per MFMA gap, a whole tap ahead of their use - and the epilogue units where they are written; left to
         // itself the scheduler sinks every read to just in front of its first use and the matrix pipe waits out the LDS latency tap by tap)
         auto gap = [&](int t, int m, int g) {
-            if (t + 1 < TAPS && m < NRD && !(A.debug & 16)) request_one(t + 1, m);      // (16: ablation, MFMAs on stale fragments)
+            if (t + 1 < TAPS && m < NRD) request_one(t + 1, m);
             if (EPI != 0) {
-                // interval EPI of the tile (1..4): a quarter of the finished set's store units, evenly spread over the interval's gaps
-                // (the write path takes 256 bytes every ~24 MFMAs per wave instead of a burst); the statistics ride in the first interval
-                constexpr int GAPS = TAPS * MPW * NPW * 3, QU = NIU / 4, STEP = GAPS / QU;
-                if (EPI == 1 && STATS && (g & 3) == 1 && (g >> 2) < NSU) stat_unit(P, g >> 2, par);
-                if (g % STEP == STEP / 2 && g / STEP < QU) img_unit(P, (EPI - 1) * QU + g / STEP);
+                // interval EPI of the tile (1..4): a quarter of the finished set's elements leave, one store (4 instructions) every sixth
+                // gap; the statistics ride in the first interval, two elements (4 instructions) in every third gap.  More than ~5 issued
+                // instructions in one gap hold up the next MFMA (a whole 4-store unit with its addresses in one gap cost 17 % of the kernel).
+                constexpr int QEL = NEL / 4;
+                if (EPI == 1 && STATS && g % 3 == 1 && 2 * (g / 3) + 1 < NEL) { stat_elem(P, 2 * (g / 3), par); stat_elem(P, 2 * (g / 3) + 1, par); }
+                if (g % 6 == 3 && g / 6 < QEL) img_elem(P, (EPI - 1) * QEL + g / 6);
+                if (BNS) {
+                    // element i of the quarter (= block EPI - 1 of the finished set; raw buffer (EPI - 1) & 1): read in gap 1 (i = 0) or
+                    // beside the sums of element i - 1, used six gaps later
+                    if (g == 1) bns_read((EPI - 1) & 1, 0);
+                    if (g % 6 == 0 && g >= 6 && g / 6 - 1 < QEL) {
+                        const int i = g / 6 - 1;
+                        const float x = b_x;
+                        if (i + 1 < QEL) bns_read((EPI - 1) & 1, i + 1);
+                        bns_acc(P, (EPI - 1) * QEL + i, x);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        static_assert(4 * NSU + 2 <= TAPS * MPW * NPW * 3, "the deferred statistics fit the MFMA gaps of one interval");
+        static_assert(3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3, "the deferred epilogue fits the MFMA gaps of an interval");
 #pragma unroll
         for (int i = 0; i < NRD; ++i) request_one(0, i);
         __builtin_amdgcn_sched_barrier(0);
@@ -480,6 +555,7 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     auto tile_step = [&](auto has_prev, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int j, int q) {
         constexpr bool HP = decltype(has_prev)::value;
         const int par = (j + 1) & 1;
+        if (HP) set_row_bases();
         if (HP) interval(T_{}, E1{}, C, P, par, q & 1); else interval(T_{}, E0{}, C, P, par, q & 1);
         if (HP && STATS) { stats_tile = t_lo + j - 1; stats_par = par; }
         __syncthreads();
@@ -504,12 +580,33 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         const int par = j & 1;
         if (STATS) {
 #pragma unroll
-            for (int u = 0; u < NSU; ++u) stat_unit(P, u, par);
+            for (int e = 0; e < NEL; ++e) stat_elem(P, e, par);
             stats_tile = t_lo + j;
             stats_par = par;
         }
+        set_row_bases();
 #pragma unroll
-        for (int u = 0; u < NIU; ++u) img_unit(P, u);
+        for (int e = 0; e < NEL; ++e) img_elem(P, e);
+        if (BNS) {
+            // the last tile of the run: its raw values straight from global memory (accumulator layout: 128-byte lines), then this wave's
+            // partial row - the two lane halves hold the same couts
+            const float *rw = reinterpret_cast<const float *>(A.eres) + ((size_t)(p_n * A.H + p_y0 + wm * 4) * A.W + p_x0 + 4 * half) * A.Cout + cout0 + l31;
+#pragma unroll
+            for (int b_ = 0; b_ < NEL / 16; ++b_) {               // (a block at a time: 16 values in flight)
+                const int mi = b_ / NPW, ni = b_ % NPW;
+                float xs[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xs[r] = rw[((size_t)(mi * 2 + (r >> 3)) * A.W + ((r >> 2) & 1) * 8 + (r & 3)) * A.Cout + ni * 32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bns_acc(P, b_ * 16 + r, xs[r]);
+            }
+            float *row = A.stats + (size_t)(blockIdx.x * 4 + wave) * 2 * A.Cout + cout0 + l31;
+#pragma unroll
+            for (int ni = 0; ni < NPW; ++ni) {
+                const float a = b_s1[ni] + __shfl_xor(b_s1[ni], 32), b2 = b_s2[ni] + __shfl_xor(b_s2[ni], 32);
+                if (half == 0) { row[ni * 32] = a; row[A.Cout + ni * 32] = b2; }
+            }
+        }
         __syncthreads();                                         // the statistics of the four waves are parked
         flush_stats();
     };
@@ -533,14 +630,17 @@ namespace cdnet {
 
 // eligibility + launch; returns -1 when the layer must take conv_f32_kernel
 template <int BN>
-static int try_launch_ws32(const ConvArgs &A, hipStream_t st) {
+static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
     using L = Ws32Lds<BN>;
     int ctot = 0;
     for (int i = 0; i < A.nsrc; ++i) {
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
     }
-    const int smem = L::bytes(ctot);
+    const bool bns = A.ws == 2;
+    if (bns && (BN != 64 || A.Cout % 64 != 0 || !A.eres || !A.oscale || !A.oshift || !A.eres_scale || !A.eres_shift || !A.stats || A.bias ||
+                A.orelu || A.out_cstride != A.Cout || A.out_coff)) return -1;
+    const int smem = L::bytes(ctot, bns);
     if (smem > 160 * 1024) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
     static int n_cu = 0;
@@ -584,18 +684,37 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st) {
     using X1 = std::integral_constant<int, 1>;
     using X2 = std::integral_constant<int, 2>;
     const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
+    if (dry_run) return CDNET_OK;
+    if (bns) {
+        if constexpr (BN == 64) {
+            auto launch_bns = [&](auto xf_c) -> int {
+                constexpr int XF = decltype(xf_c)::value;
+                auto kern = conv_ws32_kernel<64, XF, false, true>;
+                static bool attr_done = false;
+                if (!attr_done) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                        return check_launch("hipFuncSetAttribute(conv_ws32 bns)");
+                    attr_done = true;
+                }
+                kern<<<grid, 512, smem, st>>>(A);
+                return check_launch("conv_ws32_kernel(bns)");
+            };
+            return xf == 0 ? launch_bns(X0{}) : (xf == 1 ? launch_bns(X1{}) : launch_bns(X2{}));
+        }
+        return -1;
+    }
     if (A.stats) return xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
     return xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
 }
 
 // called by conv_forward_f32 first; -1 = not eligible (the caller falls back to conv_f32_kernel)
-int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st) {
+int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run) {
     static const int use_ws = getenv("CDNET_CONV_WS32") ? atoi(getenv("CDNET_CONV_WS32")) : 1;
     if ((!use_ws && !(A.debug & 64)) || (A.debug & 32)) return -1;
-    if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || A.eres || A.ws) return -1;
+    if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || (A.eres && A.ws != 2) || (A.ws && A.ws != 2)) return -1;
     if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < 4) return -1;
-    if (A.BN == 64) return try_launch_ws32<64>(A, st);
-    if (A.BN == 32) return try_launch_ws32<32>(A, st);
+    if (A.BN == 64) return try_launch_ws32<64>(A, st, dry_run);
+    if (A.BN == 32) return try_launch_ws32<32>(A, st, dry_run);
     return -1;
 }
 

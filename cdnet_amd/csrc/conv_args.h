@@ -41,6 +41,6 @@ namespace cdnet {
 // conv32.hip: the fp32-storage / split-bf16x3 variant
 int conv_forward_f32(const ConvArgs &A, hipStream_t st);
 // conv32ws.hip: its wave-specialised persistent form (3x3, full 16x16 tiles, >= 4 chunks); -1 = not eligible
-int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st);
+int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false);
 int materialize_f32(const ConvSrc &s, int N, int H, int W, void *out, hipStream_t st);
 }

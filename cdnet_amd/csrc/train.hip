@@ -1693,7 +1693,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
 static bool bn_plain_case(const BnBwdArgs &A) {
     const GradIn &g = A.gin[0];
     return A.ngin == 1 && !g.pooled && g.oy == 0 && g.ox == 0 && g.Hg == A.H && g.Wg == A.W && A.mean && A.scale && A.shift && A.invstd && !A.res &&
-           A.relu == 1 && A.f16 != 2 && (g.cstride == 0 || g.cstride == A.C) && g.coff == 0;
+           A.relu == 1 && (g.cstride == 0 || g.cstride == A.C) && g.coff == 0;
 }
 
 __global__ void bn_ktab_copy_kernel(const float *scale, const float *shift, const float *mean, const float *invstd, int C, float *ktab) {
@@ -1706,7 +1706,7 @@ extern "C" int cdnet_bn_backward_stats(const cdnet_bn_bwd_args *a, const float *
     BnBwdArgs A;
     int rc = fill_bn_args(a, A, "cdnet_bn_backward_stats");
     if (rc) return rc;
-    CDNET_REQUIRE(bn_plain_case(A) && gamma && workspace && ktab, "cdnet_bn_backward_stats: plain case only (one same-size gradient, BatchNorm + ReLU, no residual)");
+    CDNET_REQUIRE(bn_plain_case(A) && A.f16 != 2 && gamma && workspace && ktab, "cdnet_bn_backward_stats: plain 16-bit case only (one same-size gradient, BatchNorm + ReLU, no residual)");
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)A.N * A.H * A.W;
     CDNET_REQUIRE(npix * (size_t)A.C < ((size_t)1 << 32) && npix < ((size_t)1 << 31), "cdnet_bn_backward_stats: tensor too large for 32-bit pixel indexing");
@@ -1747,7 +1747,9 @@ extern "C" int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *a, const float *
     if (rc) return rc;
     CDNET_REQUIRE(bn_plain_case(A) && ktab && draw, "cdnet_bn_backward_apply: plain case only");
     const size_t npix = (size_t)A.N * A.H * A.W;
-    const int ppb = 256 / (A.C / 8);
+    const bool f32 = A.f16 == 2;                                 // fp32 tensors (gradient, raw output, dRaw): the flat32 kernel
+    CDNET_REQUIRE(!f32 || A.C <= 1024, "cdnet_bn_backward_apply(f32): C=%d > 1024", A.C);
+    const int ppb = 256 / (A.C / (f32 ? 4 : 8));
     int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
     if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     if (nb < 1) nb = 1;
@@ -1755,7 +1757,8 @@ extern "C" int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *a, const float *
     A.rev = rev;
     A.draw = draw; A.dz_out = nullptr;
     A.k1 = const_cast<float *>(ktab) + 4 * A.C; A.k2 = const_cast<float *>(ktab) + 5 * A.C; A.k3 = const_cast<float *>(ktab) + 6 * A.C;
-    bn_bwd_apply_flat_kernel<1, false><<<nb, 256, 0, (hipStream_t)stream>>>(A);
+    if (f32) launch_flat32<true>(A, nb, (hipStream_t)stream);
+    else bn_bwd_apply_flat_kernel<1, false><<<nb, 256, 0, (hipStream_t)stream>>>(A);
     return check_launch("cdnet_bn_backward_apply");
 }
 

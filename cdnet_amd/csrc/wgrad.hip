@@ -1147,57 +1147,67 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int ksplit, int npar, int ci_blocks,
                                                            int co_blocks, int TAPS, int CI, int CO, int Csrc_real, int Cin_real,
                                                            int src_coff, int Cout, int mode, float *__restrict__ dw) {
-    // block = 64 consecutive slab elements x 4 interleaved k-lanes (k = kq, kq+4, ...); fixed-order combine in LDS
-    __shared__ float s_part[4][64];
-    const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * TAPS * CI * CO;
+    // block = 256 consecutive slab elements (64 threads x one 16-byte vector) x 4 interleaved k-lanes (k = kq, kq+4, ...); every thread
+    // keeps eight slabs' vectors in flight (the pass is pure streaming: 256 slabs x 147 KB for a 64 x 64 layer; with one 4-byte load per
+    // thread and four in flight it ran at 0.8 TB/s, 49 us per launch on the weight-gradient stream); fixed-order combine
+    typedef float rf4 __attribute__((ext_vector_type(4)));
+    __shared__ rf4 s_part[4][64];
+    const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * TAPS * CI * CO;      // a multiple of 1024 (CI * CO = 4096)
     const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + e;            // per_ks is a multiple of 64 (CO >= 32, CI >= 32)
-    float s = 0.f;
+    const size_t i = ((size_t)blockIdx.x * 64 + e) * 4;
+    rf4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = rf4{0.f, 0.f, 0.f, 0.f};
     if (i < per_ks) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float *p = slab + i;
         int k = kq;
-        for (; k + 12 < ksplit; k += 16) {
-            a0 += slab[(size_t)k * per_ks + i];
-            a1 += slab[(size_t)(k + 4) * per_ks + i];
-            a2 += slab[(size_t)(k + 8) * per_ks + i];
-            a3 += slab[(size_t)(k + 12) * per_ks + i];
+        for (; k + 28 < ksplit; k += 32) {
+            rf4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const rf4 *>(p + (size_t)(k + 4 * u) * per_ks);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += v[u];
         }
-        for (; k < ksplit; k += 4) a0 += slab[(size_t)k * per_ks + i];
-        s = (a0 + a1) + (a2 + a3);
+        for (; k < ksplit; k += 4) a[0] += *reinterpret_cast<const rf4 *>(p + (size_t)k * per_ks);
     }
-    s_part[kq][e] = s;
+    s_part[kq][e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if (kq != 0 || i >= per_ks) return;
-    s = (s_part[0][e] + s_part[1][e]) + (s_part[2][e] + s_part[3][e]);
+    const rf4 sv = (s_part[0][e] + s_part[1][e]) + (s_part[2][e] + s_part[3][e]);
     size_t r = i;
-    const int co_l = r % CO; r /= CO;
+    const int co_l0 = r % CO; r /= CO;                           // four consecutive output channels (CO is a multiple of 32)
     const int ci_l = r % CI; r /= CI;
     const int tap = r % TAPS; r /= TAPS;
     const int cb = r % co_blocks; r /= co_blocks;
     const int ib = r % ci_blocks; r /= ci_blocks;
     const int par = (int)r;
-    const int co = cb * CO + co_l, ci = src_coff + ib * CI + ci_l;
-    if (co >= Cout || ib * CI + ci_l >= Csrc_real) return;
-    size_t o;
-    if (mode == 0) {
-        o = ((size_t)co * Cin_real + ci) * TAPS + tap;
-    } else if (mode == 6) {
-        // stride-2 3x3 conv through the space-to-depth view: GEMM ci = (a, b, c), Cin_real = 4*Ct; dW[co][c][ky][kx] with
-        // ky = 2*(tap/3 - 1) + a + 1 (the other tap / parity combinations multiply structural zeros)
-        const int Ct = Cin_real / 4;
-        const int a = ci / (2 * Ct), b = (ci / Ct) & 1, c = ci % Ct;
-        const int kh = 2 * (tap / 3 - 1) + a + 1, kw = 2 * (tap % 3 - 1) + b + 1;
-        if (kh < 0 || kh > 2 || kw < 0 || kw > 2) return;
-        o = (((size_t)co * Ct + c) * 3 + kh) * 3 + kw;
-    } else if (mode == 2) {
-        const int a = par >> 1, b = par & 1, ty = tap >> 1, tx = tap & 1;
-        const int kh = a == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
-        const int kw = b == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
-        o = (((size_t)ci * Cout + co) * 4 + kh) * 4 + kw;
-    } else {
-        o = (((size_t)ci * Cout + co) * 2 + (par >> 1)) * 2 + (par & 1);
+    const int ci = src_coff + ib * CI + ci_l;
+    if (ib * CI + ci_l >= Csrc_real) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = cb * CO + co_l0 + j;
+        if (co >= Cout) continue;
+        size_t o;
+        if (mode == 0) {
+            o = ((size_t)co * Cin_real + ci) * TAPS + tap;
+        } else if (mode == 6) {
+            // stride-2 3x3 conv through the space-to-depth view: GEMM ci = (a, b, c), Cin_real = 4*Ct; dW[co][c][ky][kx] with
+            // ky = 2*(tap/3 - 1) + a + 1 (the other tap / parity combinations multiply structural zeros)
+            const int Ct = Cin_real / 4;
+            const int a_ = ci / (2 * Ct), b_ = (ci / Ct) & 1, c = ci % Ct;
+            const int kh = 2 * (tap / 3 - 1) + a_ + 1, kw = 2 * (tap % 3 - 1) + b_ + 1;
+            if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+            o = (((size_t)co * Ct + c) * 3 + kh) * 3 + kw;
+        } else if (mode == 2) {
+            const int a_ = par >> 1, b_ = par & 1, ty = tap >> 1, tx = tap & 1;
+            const int kh = a_ == 0 ? (ty == 0 ? 1 : 3) : (ty == 0 ? 0 : 2);
+            const int kw = b_ == 0 ? (tx == 0 ? 1 : 3) : (tx == 0 ? 0 : 2);
+            o = (((size_t)ci * Cout + co) * 4 + kh) * 4 + kw;
+        } else {
+            o = (((size_t)ci * Cout + co) * 2 + (par >> 1)) * 2 + (par & 1);
+        }
+        dw[o] = sv[j];
     }
-    dw[o] = s;
 }
 
 template <int CI_T, int CO_T, int TAPS, bool RES, int XF>
@@ -1342,7 +1352,7 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     const int CI = ci_tiles * 32, CO = (4 / ci_tiles) * 32;
     const int ci_blocks = cdiv(src->C, CI), co_blocks = cdiv(Cout, CO);
     const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * taps * CI * CO;
-    const int blocks = (int)((per_ks + 63) / 64);
+    const int blocks = (int)((per_ks + 255) / 256);
     wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(slab, ksplit, npar, ci_blocks, co_blocks, taps, CI, CO, Csrc_real, Cin_real, src_coff, Cout,
                                                 mode, dw);
     return check_launch("wgrad_reduce_kernel");

@@ -420,7 +420,7 @@ class Trainer:
         a.gin[0].g = g.t.data_ptr()
         a.gin[0].Hg, a.gin[0].Wg, a.gin[0].oy, a.gin[0].ox = g.Hg, g.Wg, 0, 0
         a.gin[0].pooled, a.gin[0].coff, a.gin[0].cstride = 0, 0, Co
-        a.f16 = 1
+        a.f16 = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}[out.dtype]
         a.relu = 1
         a.N, a.H, a.W, a.C = No, Ho, Wo, Co
         ktab = self.buf(('ktab', L.name), (7, Co), torch.float32)
@@ -440,19 +440,23 @@ class Trainer:
         # measured (bench.py, 16 tiles): 11 reduce passes per step disappear (-0.9 ms of kernel time) but the launches that carry the sums
         # cost +16 ... +33 us each (the movers' per-element arithmetic) and the step does not get shorter (1 643-1 659 vs 1 656-1 666
         # tiles/s): off unless CDNET_BN_STATS_FUSE=1
-        if os.environ.get('CDNET_BN_STATS_FUSE', '0') != '1' or runtime.act_dtype() != torch.bfloat16 or getattr(runtime, 'DEBUG_NORELU', False):
+        # fp32 mode (conv_ws32_kernel): the sums ride in the CONSUMERS' deferred epilogue (raw quarters by DMA into LDS) - on by default
+        f32 = runtime.PRECISION == 'fp32'
+        if os.environ.get('CDNET_BN_STATS_FUSE', '1' if f32 else '0') != '1' or getattr(runtime, 'DEBUG_NORELU', False):
             return None
         if L.kind != 'conv3' or L.transposed or len(srcs) != 1:
             return None
         sx = srcs[0]
         if getattr(sx, 'is_input', False) or sx.scale is None or sx.shift is None or sx.relu is not True or sx.res is not None or sx.pool \
-                or tuple(sx.off) != (0, 0) or sx.x.dtype != torch.float16 or hasattr(sx, 'grad_to') or sx.row_stride:
+                or tuple(sx.off) != (0, 0) or sx.x.dtype != runtime.raw_dtype() or hasattr(sx, 'grad_to') or sx.row_stride:
+            return None
+        if f32 and cin_total % 64:
             return None
         P = self._producer.get(id(sx.x))
         if P is None or P.bn is None or getattr(P, 'node_res', None) is not None or getattr(P, 'node_relu', True) is not True \
                 or self._readers.get(id(sx.x), 0) != 1 or tuple(sx.x.shape) != (N, H, W, cin_total):
             return None
-        key = ('statsfusable', L.name, N, H, W)
+        key = ('statsfusable', L.name, N, H, W, runtime.PRECISION)
         hit = self._bufs.get(key)
         if hit is None:
             part = torch.zeros((1024, 2, cin_total), dtype=torch.float32, device=self.dev)

@@ -396,3 +396,47 @@ def test_conv_ws32_backward_data_of_transposed_conv_views():
         assert _rel(_nchw(out), x.grad) < 5e-5
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('case', [dict(N=2, Cin=64, Cout=64, H=32, W=48, G=3), dict(N=1, Cin=128, Cout=128, H=32, W=32, G=0),
+                                  dict(N=3, Cin=64, Cout=64, H=16, W=16, G=2)])
+def test_conv_ws32_bn_backward_statistics_epilogue(case):
+    """cdnet_conv_args.ws = 2 on conv_ws32_kernel: a backward-data launch whose output dY is the gradient w.r.t. the activated output of
+    a BatchNorm + ReLU layer also leaves that layer's first BatchNorm-backward pass - partial rows of sum(dz) and sum(dz * xhat) with
+    dz = dY * [raw * scale + shift > 0] - for cdnet_bn_backward_finalize.  Output bit-identical to the plain launch; the sums against fp64."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, G = [case[k] for k in ('N', 'Cin', 'Cout', 'H', 'W', 'G')]
+    g = torch.Generator().manual_seed(31 + H + Cout)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (1.5 / (9 * Cin) ** 0.5)
+    raw = torch.randn((N, Cout, H, W), generator=g) * 1.5 + 0.3
+    sc, sh = torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.4
+    mu, inv = torch.randn((Cout,), generator=g) * 0.3, torch.rand((Cout,), generator=g) + 0.5
+    cfg = (16, 16, 64)
+    wp = engine.pack_weights(w.cuda(), cfg, 0, split=True)
+    src = engine.Src(_nhwc(x))
+    engine.CONV_DEBUG = 64
+    try:
+        plain, _ = engine.conv_forward([src], wp, Cout, cfg, H=H, W=W)
+        engine.CONV_DEBUG = 64 | (G << 8)
+        part = torch.zeros((1024, 2, Cout), dtype=torch.float32, device='cuda')
+        raw_d = _nhwc(raw)
+        bns = (raw_d, sc.cuda(), sh.cuda(), mu.cuda(), inv.cuda(), part)
+        assert engine.conv_forward([src], wp, Cout, cfg, H=H, W=W, query_ws=True, bns=bns)
+        out, _ = engine.conv_forward([src], wp, Cout, cfg, H=H, W=W, bns=bns)
+        out2, _ = engine.conv_forward([src], wp, Cout, cfg, H=H, W=W, bns=bns)          # (every row is rewritten by every launch)
+    finally:
+        engine.CONV_DEBUG = 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain) and torch.equal(out2, plain)
+    dy = _nchw(out).double()
+    act = raw.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    dz = dy * (act > 0)
+    xhat = (raw.double() - mu.double().view(1, -1, 1, 1)) * inv.double().view(1, -1, 1, 1)
+    want1, want2 = dz.sum((0, 2, 3)), (dz * xhat).sum((0, 2, 3))
+    got = part.double().cpu().sum(0)
+    scale1, scale2 = dz.abs().sum((0, 2, 3)).max(), (dz * xhat).abs().sum((0, 2, 3)).max()
+    assert float((got[0] - want1).abs().max() / scale1) < 1e-5, float((got[0] - want1).abs().max() / scale1)
+    assert float((got[1] - want2).abs().max() / scale2) < 1e-5, float((got[1] - want2).abs().max() / scale2)
