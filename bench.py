@@ -130,7 +130,7 @@ def cpu_baseline_infer(n_tiles=4):
                        'probmaps/DDM/boost/CC chain (1 thread), median of %d repetitions after 2 warm-ups' % (n_tiles, cores, reps))
 
 
-def time_dominant_conv(torch, B, steps=20, precision='bf16'):
+def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5):
     """Average launch duration of the dominant kernel (3x3 conv 64->64 @256x256, the head/stem shape), measured live
     with HIP events on the stream the kernel is launched on (torch's current stream == the ABI stream argument)."""
     from cdnet_amd import engine
@@ -141,8 +141,13 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16'):
     cfg = engine.choose_cfg([64], 64, 256, 256, f32=f32)
     wp = engine.pack_weights(w, cfg, 0, split=f32)
     out = torch.empty((B, 256, 256, 64), dtype=x.dtype, device=dev)
-    for _ in range(3):
+    # settle: the chip lowers its clock under load over about a second; time the launches it would see inside a step, not a cold burst
+    t_s, n_s = time.perf_counter(), 0
+    while n_s < 3 or (time.perf_counter() - t_s < settle_s and n_s < 1500):
         engine.conv_forward([engine.Src(x)], wp, 64, cfg, out=out)
+        n_s += 1
+        if n_s % 16 == 0:
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
@@ -154,20 +159,31 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16'):
     flops = 2.0 * B * 256 * 256 * 64 * 64 * 9             # algorithmic: 2*MACs of this layer (forward hooks)
     alg_bytes = B * 256 * 256 * (64 + 64) * esz           # algorithmic: input read once + output written once
     # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 bf16 -> the HBM term bounds this layer
-    traffic, traffic_src = None, None
+    # HBM traffic, matrix-pipe busy fraction and effective clock of this kernel from the committed PMC summary (separate rocprofv3 --pmc
+    # passes of `bench.py --mode roofline`, tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv[_fp32]_pmc.json); not re-measured here
+    traffic = traffic_src = mfma_busy = clock = None
     for rnd in ('r03', 'r02', 'r01'):
-        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_traffic.json' if f32 else 'dominant_conv_traffic.json')
+        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_pmc.json' if f32 else 'dominant_conv_pmc.json')
+        old = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_traffic.json')
         if os.path.exists(tj) and B == 16:
             with open(tj) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')   # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes
+                pj = json.load(f)
+            traffic, mfma_busy, clock = pj.get('hbm_bytes_per_launch'), pj.get('mfma_busy_frac'), pj.get('clock_mhz')
             traffic_src = 'profiles/%s/%s (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % (rnd, os.path.basename(tj))
+            break
+        if os.path.exists(old) and B == 16 and not f32:
+            with open(old) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
+            traffic_src = 'profiles/%s/dominant_conv_traffic.json (rocprofv3 --pmc passes, not re-measured in this run)' % rnd
             break
     gbs = alg_bytes / ms / 1e6
     ws = not f32 and os.environ.get('CDNET_CONV_WS', '1') != '0'          # the library's default: conv_ws_kernel on the 64-channel layers
-    name = 'conv_f32_kernel' if f32 else ('conv_ws_kernel' if ws else 'conv_fwd_kernel')
+    ws32 = f32 and os.environ.get('CDNET_CONV_WS32', '1') != '0'
+    name = ('conv_ws32_kernel' if ws32 else 'conv_f32_kernel') if f32 else ('conv_ws_kernel' if ws else 'conv_fwd_kernel')
     mfma_peak = DENSE_BF16_PEAK_TFLOPS / 3 if f32 else DENSE_BF16_PEAK_TFLOPS
     return dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, '64,9,0,false' if ws else ','.join(str(c) for c in cfg), B), dtype=precision,
+                kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, '64,9,0,false' if ws else ('64,0,false' if ws32 else ','.join(str(c) for c in cfg)), B), dtype=precision,
+                mfma_busy_frac=mfma_busy, clock_mhz=clock,
                 ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
                 mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / mfma_peak)
 
