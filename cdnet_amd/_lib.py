@@ -23,6 +23,9 @@ SIGNATURES = {
     'cdnet_fuse_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     'cdnet_upsample_bilinear_backward': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_s2d_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_fuse_sum_f32': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    'cdnet_upsample_bilinear_backward_f32': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'cdnet_s2d_to_nhwc_f32': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'cdnet_bn_backward_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'cdnet_bn_backward_apply': (_i, [_vp, _vp, _vp, _vp]),
     'cdnet_bn_backward_finalize': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -465,6 +465,16 @@ __device__ __forceinline__ void bf8_to_f32(uint4 u, float *v) {
 // 8 channels of one term at one source pixel: bf16 / fp16 storage, optional per-channel affine (training mode: the raw
 // convolution output with its BatchNorm scale / shift)
 __device__ __forceinline__ void term8(const FuseTerm &T, const unsigned short *p, int c0, float *v) {
+    if (T.f16 == 2) {                                // fp32 storage: `p` already counts floats (see term_ptr)
+        const float4 *q = reinterpret_cast<const float4 *>(p);
+        const float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if (T.scale) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], T.scale[c0 + j], T.shift[c0 + j]);
+        }
+        return;
+    }
     const uint4 u = *reinterpret_cast<const uint4 *>(p);
     if (T.f16) {
         const unsigned w[4] = {u.x, u.y, u.z, u.w};
@@ -480,7 +490,9 @@ __device__ __forceinline__ void term8(const FuseTerm &T, const unsigned short *p
     }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
+    constexpr int ES = F32 ? 2 : 1;                  // element size in units of unsigned short (the pointer type of the structs)
     const int VPP = A.C / 8;
     const size_t total = (size_t)A.N * A.H * A.W * VPP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -492,10 +504,10 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         for (int k = 0; k < A.nterm; ++k) {
             const FuseTerm &T = A.t[k];
-            const unsigned short *base = T.x + (size_t)n * T.Hs * T.Ws * A.C + slot * 8;
+            const unsigned short *base = T.x + ((size_t)n * T.Hs * T.Ws * A.C + slot * 8) * ES;
             float v[8];
             if (T.Hs == A.H && T.Ws == A.W) {
-                term8(T, base + ((size_t)y * A.W + x) * A.C, slot * 8, v);
+                term8(T, base + ((size_t)y * A.W + x) * A.C * ES, slot * 8, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += v[j];
             } else {
@@ -508,13 +520,21 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
                 const int y1 = y0 + (y0 < T.Hs - 1 ? 1 : 0), x1 = x0 + (x0 < T.Ws - 1 ? 1 : 0);
                 const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
                 float a[8], b[8], c[8], d[8];
-                term8(T, base + ((size_t)y0 * T.Ws + x0) * A.C, slot * 8, a);
-                term8(T, base + ((size_t)y0 * T.Ws + x1) * A.C, slot * 8, b);
-                term8(T, base + ((size_t)y1 * T.Ws + x0) * A.C, slot * 8, c);
-                term8(T, base + ((size_t)y1 * T.Ws + x1) * A.C, slot * 8, d);
+                term8(T, base + ((size_t)y0 * T.Ws + x0) * A.C * ES, slot * 8, a);
+                term8(T, base + ((size_t)y0 * T.Ws + x1) * A.C * ES, slot * 8, b);
+                term8(T, base + ((size_t)y1 * T.Ws + x0) * A.C * ES, slot * 8, c);
+                term8(T, base + ((size_t)y1 * T.Ws + x1) * A.C * ES, slot * 8, d);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += hy * (hx * a[j] + lx * b[j]) + ly * (hx * c[j] + lx * d[j]);
             }
+        }
+        if (F32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = A.relu ? fmaxf(acc[j], 0.f) : acc[j];
+            float4 *o = reinterpret_cast<float4 *>(reinterpret_cast<float *>(A.out) + pix * A.out_cstride + A.out_coff + slot * 8);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            continue;
         }
         unsigned short oh[8];
 #pragma unroll
@@ -529,6 +549,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
 
 // transpose of the bilinear up-sampling inside fuse_sum (gather form, deterministic): din[ys][xs] = sum over the output
 // pixels (y, x) whose interpolation reads (ys, xs) of their weight x dout[y][x].  dout may be a channel slice.
+template <bool F32>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const unsigned short *__restrict__ dout, int N, int H, int W, int C, int cstride,
                                                            int coff, int Hs, int Ws, unsigned short *__restrict__ din) {
     const int VPP = C / 8;
@@ -559,11 +580,23 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const unsigned short 
                 const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
                 if (wx == 0.f) continue;
                 float v[8];
-                bf8_to_f32(*reinterpret_cast<const uint4 *>(dout + (((size_t)n * H + y) * W + x) * cstride + coff + slot * 8), v);
+                if (F32) {
+                    const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(dout) + (((size_t)n * H + y) * W + x) * cstride + coff + slot * 8);
+                    const float4 a = q[0], b = q[1];
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+                    bf8_to_f32(*reinterpret_cast<const uint4 *>(dout + (((size_t)n * H + y) * W + x) * cstride + coff + slot * 8), v);
+                }
                 const float wgt = wy * wx;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(wgt, v[j], acc[j]);
             }
+        }
+        if (F32) {
+            float4 *o = reinterpret_cast<float4 *>(reinterpret_cast<float *>(din) + pix * C + slot * 8);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            continue;
         }
         unsigned short oh[8];
 #pragma unroll
@@ -577,9 +610,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const unsigned short 
 
 // space-to-depth gradient [N][H2][W2][(a, b, c)] -> NHWC [N][2*H2][2*W2][C] (the input gradient of a stride-2 convolution
 // computed through the space-to-depth view)
-__global__ __launch_bounds__(256) void s2d_to_nhwc_kernel(const unsigned short *__restrict__ in, int N, int H2, int W2, int C,
-                                                          unsigned short *__restrict__ out) {
-    const int VPP = C / 8;
+template <typename VT>      // one 16-byte vector per thread: 8 16-bit or 4 fp32 channels
+__global__ __launch_bounds__(256) void s2d_to_nhwc_kernel(const unsigned short *__restrict__ in_, int N, int H2, int W2, int C,
+                                                          unsigned short *__restrict__ out_) {
+    constexpr int EPV = 16 / sizeof(VT);
+    const VT *in = reinterpret_cast<const VT *>(in_);
+    VT *out = reinterpret_cast<VT *>(out_);
+    const int VPP = C / EPV;
     const size_t total = (size_t)N * H2 * W2 * 4 * VPP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int slot = (int)(i % VPP);
@@ -587,8 +624,8 @@ __global__ __launch_bounds__(256) void s2d_to_nhwc_kernel(const unsigned short *
         const int ab = (int)(r & 3); r >>= 2;
         const int x2 = (int)(r % W2), y2 = (int)((r / W2) % H2), n = (int)(r / ((size_t)W2 * H2));
         const int a = ab >> 1, b = ab & 1;
-        const uint4 v = *reinterpret_cast<const uint4 *>(in + (((size_t)n * H2 + y2) * W2 + x2) * 4 * C + (size_t)ab * C + slot * 8);
-        *reinterpret_cast<uint4 *>(out + (((size_t)n * 2 * H2 + 2 * y2 + a) * 2 * W2 + 2 * x2 + b) * C + slot * 8) = v;
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + (((size_t)n * H2 + y2) * W2 + x2) * 4 * C + (size_t)ab * C + slot * EPV);
+        *reinterpret_cast<uint4 *>(out + (((size_t)n * 2 * H2 + 2 * y2 + a) * 2 * W2 + 2 * x2 + b) * C + slot * EPV) = v;
     }
 }
 
@@ -741,39 +778,72 @@ extern "C" int cdnet_window_stitch(const float *tiles, int K, int tile_h, int ti
 }
 
 
-extern "C" int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, uint16_t *out, int out_cstride,
-                              int out_coff, void *stream) {
+static int fuse_sum_impl(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, void *out, int out_cstride, int out_coff,
+                         void *stream, bool f32) {
     CDNET_REQUIRE(terms && out && nterm >= 1 && nterm <= 4, "cdnet_fuse_sum: 1..4 terms");
     CDNET_REQUIRE(N > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0, "cdnet_fuse_sum: bad size (C %% 8)");
     FuseArgs A;
     for (int k = 0; k < 4; ++k) {
         if (k < nterm) {
             CDNET_REQUIRE(terms[k].x && terms[k].Hs > 0 && terms[k].Ws > 0 && terms[k].Hs <= H && terms[k].Ws <= W, "cdnet_fuse_sum: term %d", k);
+            CDNET_REQUIRE((terms[k].f16 == 2) == f32, "cdnet_fuse_sum: term %d storage %d does not match the %s entry point", k, terms[k].f16,
+                          f32 ? "fp32" : "16-bit");
             A.t[k].x = terms[k].x; A.t[k].Hs = terms[k].Hs; A.t[k].Ws = terms[k].Ws;
             A.t[k].scale = terms[k].scale; A.t[k].shift = terms[k].shift; A.t[k].f16 = terms[k].f16;
             CDNET_REQUIRE((terms[k].scale == nullptr) == (terms[k].shift == nullptr), "cdnet_fuse_sum: scale and shift come together");
         } else { A.t[k].x = nullptr; A.t[k].Hs = A.t[k].Ws = 0; A.t[k].scale = A.t[k].shift = nullptr; A.t[k].f16 = 0; }
     }
-    A.nterm = nterm; A.N = N; A.H = H; A.W = W; A.C = C; A.relu = relu; A.out = out;
+    A.nterm = nterm; A.N = N; A.H = H; A.W = W; A.C = C; A.relu = relu; A.out = reinterpret_cast<unsigned short *>(out);
     A.out_cstride = out_cstride ? out_cstride : C; A.out_coff = out_coff;
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && out_coff % 8 == 0 && out_coff + C <= A.out_cstride, "cdnet_fuse_sum: output channel slice");
-    fuse_sum_kernel<<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    if (f32) fuse_sum_kernel<true><<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    else fuse_sum_kernel<false><<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
     return check_launch("cdnet_fuse_sum");
+}
+
+extern "C" int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, uint16_t *out, int out_cstride,
+                              int out_coff, void *stream) {
+    return fuse_sum_impl(terms, nterm, N, H, W, C, relu, out, out_cstride, out_coff, stream, false);
+}
+
+extern "C" int cdnet_fuse_sum_f32(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, float *out, int out_cstride,
+                                  int out_coff, void *stream) {
+    return fuse_sum_impl(terms, nterm, N, H, W, C, relu, out, out_cstride, out_coff, stream, true);
+}
+
+static int upsample_bwd_impl(const void *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws, void *din, void *stream,
+                             bool f32) {
+    CDNET_REQUIRE(dout && din && N > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C % 8 == 0 && C >= 8, "cdnet_upsample_bilinear_backward: bad args");
+    const int cs = dout_cstride ? dout_cstride : C;
+    CDNET_REQUIRE(cs % 8 == 0 && dout_coff % 8 == 0 && dout_coff + C <= cs, "cdnet_upsample_bilinear_backward: channel slice");
+    const unsigned short *d = reinterpret_cast<const unsigned short *>(dout);
+    unsigned short *o = reinterpret_cast<unsigned short *>(din);
+    if (f32) upsample_bwd_kernel<true><<<lin_grid((size_t)N * Hs * Ws * (C / 8)), 256, 0, (hipStream_t)stream>>>(d, N, H, W, C, cs, dout_coff, Hs, Ws, o);
+    else upsample_bwd_kernel<false><<<lin_grid((size_t)N * Hs * Ws * (C / 8)), 256, 0, (hipStream_t)stream>>>(d, N, H, W, C, cs, dout_coff, Hs, Ws, o);
+    return check_launch("cdnet_upsample_bilinear_backward");
 }
 
 extern "C" int cdnet_upsample_bilinear_backward(const uint16_t *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws,
                                                 uint16_t *din, void *stream) {
-    CDNET_REQUIRE(dout && din && N > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C % 8 == 0 && C >= 8, "cdnet_upsample_bilinear_backward: bad args");
-    const int cs = dout_cstride ? dout_cstride : C;
-    CDNET_REQUIRE(cs % 8 == 0 && dout_coff % 8 == 0 && dout_coff + C <= cs, "cdnet_upsample_bilinear_backward: channel slice");
-    upsample_bwd_kernel<<<lin_grid((size_t)N * Hs * Ws * (C / 8)), 256, 0, (hipStream_t)stream>>>(dout, N, H, W, C, cs, dout_coff, Hs, Ws, din);
-    return check_launch("cdnet_upsample_bilinear_backward");
+    return upsample_bwd_impl(dout, N, H, W, C, dout_cstride, dout_coff, Hs, Ws, din, stream, false);
+}
+
+extern "C" int cdnet_upsample_bilinear_backward_f32(const float *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws,
+                                                    float *din, void *stream) {
+    return upsample_bwd_impl(dout, N, H, W, C, dout_cstride, dout_coff, Hs, Ws, din, stream, true);
 }
 
 extern "C" int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int C, uint16_t *out, void *stream) {
     CDNET_REQUIRE(in && out && N > 0 && H2 > 0 && W2 > 0 && C % 8 == 0 && C >= 8, "cdnet_s2d_to_nhwc: bad args");
-    s2d_to_nhwc_kernel<<<lin_grid((size_t)N * H2 * W2 * 4 * (C / 8)), 256, 0, (hipStream_t)stream>>>(in, N, H2, W2, C, out);
+    s2d_to_nhwc_kernel<unsigned short><<<lin_grid((size_t)N * H2 * W2 * 4 * (C / 8)), 256, 0, (hipStream_t)stream>>>(in, N, H2, W2, C, out);
     return check_launch("cdnet_s2d_to_nhwc");
+}
+
+extern "C" int cdnet_s2d_to_nhwc_f32(const float *in, int N, int H2, int W2, int C, float *out, void *stream) {
+    CDNET_REQUIRE(in && out && N > 0 && H2 > 0 && W2 > 0 && C % 4 == 0 && C >= 4, "cdnet_s2d_to_nhwc_f32: bad args");
+    s2d_to_nhwc_kernel<float><<<lin_grid((size_t)N * H2 * W2 * 4 * (C / 4)), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const unsigned short *>(in), N, H2, W2, C, reinterpret_cast<unsigned short *>(out));
+    return check_launch("cdnet_s2d_to_nhwc_f32");
 }
 
 static int grad_sum_impl(const cdnet_grad_term *terms, int nterm, const uint16_t *mask, long long npix, int C, uint16_t *out, void *stream, bool f32);

@@ -1328,7 +1328,6 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     CDNET_REQUIRE(src->C % 8 == 0, "cdnet_conv_backward_weight: source channels %d not a multiple of 8", src->C);
     CDNET_REQUIRE(!(src->res && src->pool), "cdnet_conv_backward_weight: a pooled source with a residual branch is not supported");
     CDNET_REQUIRE(!(src->f16 == 2 && src->pool), "cdnet_conv_backward_weight: fp32 pooled sources must be materialised");
-    CDNET_REQUIRE(!(src->f16 == 2 && mode == 6), "cdnet_conv_backward_weight: stride-2 convolutions have no fp32 path");
     CDNET_REQUIRE(ksplit >= 1 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "cdnet_conv_backward_weight: bad size (Cout %% 8)");
     CDNET_REQUIRE((taps == 9 && npar == 1 && ostride == 1 && mode == 0) || (taps == 1 && npar == 1 && ostride == 1 && mode == 0) ||
                   (taps == 9 && npar == 1 && ostride == 1 && mode == 6) ||

@@ -368,12 +368,9 @@ class HighResolutionNet(nn.Module):
         return self.forward_packed(runtime.input_pack(x.float()))
 
     def forward_packed(self, x16):
-        """forward on packed bf16 NHWC input [N,H,W,16] (3 real channels): what cdnet_input_pack / cdnet_window_pack produce
-        (sliding-window / TTA inference, cdnet_amd.utils.split_forward_views)"""
+        """forward on packed NHWC input [N,H,W,16] (3 real channels; bf16, or fp32 in the fp32 precision mode): what cdnet_input_pack /
+        cdnet_window_pack produce (sliding-window / TTA inference, cdnet_amd.utils.split_forward_views)"""
         training = self.training
-        if runtime.PRECISION != 'bf16':
-            raise NotImplementedError("HRNet18_rev1 runs on the 16-bit kernels only (fuse / up-sampling / stride-2 paths have no fp32-"
-                                      "storage variant): cdnet_amd.set_precision('bf16')")
         self._ensure_runtime()
         rt = self._rt
         x = x16
@@ -401,7 +398,7 @@ class HighResolutionNet(nn.Module):
         # F.upsample + torch.cat (:528-533): every branch written (up-sampled) into its slice of one padded buffer
         N, H, W, _ = ys[0].x.shape
         ctot = sum(w for _, w in self._cat_layout)
-        cat = torch.empty((N, H, W, ctot), dtype=torch.bfloat16, device=x.device)
+        cat = torch.empty((N, H, W, ctot), dtype=runtime.act_dtype(), device=x.device)
         for k, (y, (p0, _)) in enumerate(zip(ys, self._cat_layout)):
             self._node(('cat', k)).forward([y], False, out=cat, out_coff=p0, training=training)
         f1 = rt['ru'][0].forward(Src(cat), training, store=True)

@@ -245,13 +245,17 @@ class FuseNode:
             arr[k].x, arr[k].Hs, arr[k].Ws = t.x.data_ptr(), t.Hs, t.Ws
             arr[k].scale, arr[k].shift = (None if t.scale is None else t.scale.data_ptr()), (None if t.shift is None else t.shift.data_ptr())
             arr[k].f16 = int(t.f16)
+        f32 = terms[0].f32
+        assert all(t.f32 == f32 for t in terms)
         if out is None:
-            o, cs = torch.empty((N, H, W, Cc), dtype=torch.bfloat16, device=terms[0].x.device), Cc
+            o, cs = torch.empty((N, H, W, Cc), dtype=torch.float32 if f32 else torch.bfloat16, device=terms[0].x.device), Cc
         else:
             o, cs = out, out.shape[3]
+        assert (o.dtype == torch.float32) == f32
         if DEBUG_NORELU:
             relu = False
-        _lib.call('cdnet_fuse_sum', C.byref(arr), len(terms), N, H, W, Cc, int(relu), _lib.ptr(o), cs, out_coff, _lib.stream_ptr())
+        _lib.call('cdnet_fuse_sum_f32' if f32 else 'cdnet_fuse_sum', C.byref(arr), len(terms), N, H, W, Cc, int(relu), _lib.ptr(o), cs, out_coff,
+                  _lib.stream_ptr())
         if training:
             self.saved = (list(terms), o, relu, H, W, Cc, out_coff)
             if TAPE is not None:
@@ -271,7 +275,7 @@ class FuseNode:
             if gl is None:
                 return
             if relu or len(gl) > 1 or gl[0].coff or gl[0].cstride not in (0, Cc):
-                d = tr.buf(('dfuse', self.name), o.shape, torch.bfloat16)
+                d = tr.buf(('dfuse', self.name), o.shape, o.dtype)
                 tr.grad_sum(gl, o if relu else None, o.shape[0] * H * W, Cc, d)
             else:
                 d = gl[0].t
@@ -281,8 +285,9 @@ class FuseNode:
             if t.Hs == H and t.Ws == W:
                 add(t.x, tr.G(d, H, W, coff=dco, cstride=dcs))
             else:
-                din = tr.buf(('dup', self.name, k), (N, t.Hs, t.Ws, Cc), torch.bfloat16)
-                _lib.call('cdnet_upsample_bilinear_backward', _lib.ptr(d), N, H, W, Cc, dcs, dco, t.Hs, t.Ws, _lib.ptr(din), _lib.stream_ptr())
+                din = tr.buf(('dup', self.name, k), (N, t.Hs, t.Ws, Cc), d.dtype)
+                _lib.call('cdnet_upsample_bilinear_backward_f32' if d.dtype == torch.float32 else 'cdnet_upsample_bilinear_backward', _lib.ptr(d),
+                          N, H, W, Cc, dcs, dco, t.Hs, t.Ws, _lib.ptr(din), _lib.stream_ptr())
                 add(t.x, tr.G(din, t.Hs, t.Ws))
 
 

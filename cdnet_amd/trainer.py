@@ -620,7 +620,8 @@ class Trainer:
             gs2d = self.buf(('ds2d', L.name), (N, H, W, cin_total), runtime.act_dtype())
             engine.conv_forward([Src(g)], wpb, cin_total, cfgb, taps=9, out=gs2d, H=H, W=W)
             gin = self.buf(('din', L.name), (N, 2 * H, 2 * W, Cp), runtime.act_dtype())
-            _lib.call('cdnet_s2d_to_nhwc', _lib.ptr(gs2d), N, H, W, Cp, _lib.ptr(gin), _lib.stream_ptr())
+            _lib.call('cdnet_s2d_to_nhwc_f32' if gin.dtype == torch.float32 else 'cdnet_s2d_to_nhwc', _lib.ptr(gs2d), N, H, W, Cp, _lib.ptr(gin),
+                      _lib.stream_ptr())
             add(srcs[0].x, _G(gin, 2 * H, 2 * W))
             return
         if not L.transposed:

@@ -468,6 +468,12 @@ int cdnet_fuse_sum(const cdnet_fuse_term *terms, int nterm, int N, int H, int W,
 int cdnet_upsample_bilinear_backward(const uint16_t *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws,
                                      uint16_t *din, void *stream);
 int cdnet_s2d_to_nhwc(const uint16_t *in, int N, int H2, int W2, int C, uint16_t *out, void *stream);
+/* the three entries above for fp32 tensors (fp32 precision mode: every term has f16 = 2; same arithmetic, nothing is rounded to 16 bits) */
+int cdnet_fuse_sum_f32(const cdnet_fuse_term *terms, int nterm, int N, int H, int W, int C, int relu, float *out, int out_cstride,
+                       int out_coff, void *stream);
+int cdnet_upsample_bilinear_backward_f32(const float *dout, int N, int H, int W, int C, int dout_cstride, int dout_coff, int Hs, int Ws,
+                                         float *din, void *stream);
+int cdnet_s2d_to_nhwc_f32(const float *in, int N, int H2, int W2, int C, float *out, void *stream);
 
 /* cdnet_grad_sum: backward of the sums above (autograd's AddBackward + ReluBackward over seg_hrnet_rev1.py:76-92, 256-283 and the
  * torch.cat of :533): out[npix][C] = [mask > 0] * sum of 1..6 gradient contributions, each a bf16 tensor [npix][cstride] read at
