@@ -819,6 +819,9 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
 #ifndef CDNET_CONV_WS
 #define CDNET_CONV_WS 1
 #endif
+#ifndef CDNET_WS_PIN
+#define CDNET_WS_PIN 0      // 1: consumers issue fragment reads pinned two taps ahead with a scheduling fence behind every MFMA - measured 3-7 % SLOWER than the compiler's own order on every streamed layer (the 4 MFMAs of a tap already cover the LDS latency); kept for experiments
+#endif
 
 #ifdef CDNET_WS_STAMPS
 // debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): wall-clock stamps (100 MHz) of one consumer and one mover wave of one
@@ -1106,17 +1109,26 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             }
         };
         auto store_pieces = [&](bool now) {
+            // all transposing reads first, into registers of their own, then the stores: with the pair of reads, the wait for them and
+            // the store piece by piece through one register quad (what the compiler makes of a single loop) every piece paid the LDS
+            // latency - 1.2 us per tile in the movers' second interval, where the consumers then waited 0.9 us (stamp build)
+            ws_s16x4 t1[NP], t2[NP];
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
                 const int o = lg + 4 * kk;
                 const int ni = o >> 2, r0 = 8 * (o & 3);
                 const unsigned char *p = s_img + ((mi * NPW + ni) * 32 + r0) * L::IROW + ch * 32;
-                const ws_s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
-                const ws_s16x4 t2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * L::IROW));
+                t1[pc] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+                t2[pc] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * L::IROW));
+            }
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
+                const int o = lg + 4 * kk;
                 const int y = s_y0 + pw * 4 + mi * 2 + ch, x = s_x0 + li, co = cout0 + 8 * o;
                 if (now && s_ok && co < A.Cout) {
-                    const uint2 a = __builtin_bit_cast(uint2, t1), b2 = __builtin_bit_cast(uint2, t2);
+                    const uint2 a = __builtin_bit_cast(uint2, t1[pc]), b2 = __builtin_bit_cast(uint2, t2[pc]);
                     *reinterpret_cast<uint4 *>(A.out + (((size_t)s_n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = make_uint4(a.x, a.y, b2.x, b2.y);
                     if (BNS) {
                         // the arithmetic of bn_bwd_reduce_flat_kernel<1, false> (train.hip), element for element
@@ -1386,12 +1398,17 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             else if (i == NRD - 1) af[tau % 3][1] = *reinterpret_cast<const bf16x8 *>(la + ch * L::A_BYTES + abase[1][tpar(t)] + toff(t));
             else bfr[tau % 3][i - 1] = *reinterpret_cast<const bf16x8 *>(lw + ch * L::B_CHUNK + bbase + (t * 2) * BN * 16 + (i - 1) * 512);
         };
-        (void)request;
+        (void)request; (void)request_one; (void)NMF;
         request(0);
         request(1);
+#if CDNET_WS_PIN
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int tau = 0; tau < NTAP; ++tau) {
+#if !CDNET_WS_PIN
+            if (tau + 2 < NTAP) request(tau + 2);
+#endif
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
@@ -1407,6 +1424,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                     // waits out the LDS latency tap by tap): the fragment reads of the tap two ahead - one per gap - and, in an epilogue
                     // interval, one unit of the finished tile
                     const int m = mi * NPW + ni;
+#if CDNET_WS_PIN
                     if (tau + 2 < NTAP) {
                         if (m < NRD) request_one(tau + 2, m);
                         if (m == NMF - 1) {
@@ -1420,6 +1438,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                         if (sl >= IMG0 && sl < IMG0 + 2 * NU && ((sl - IMG0) & 1) == 0) img_unit(P, (sl - IMG0) / 2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#else
+                    (void)m;
+                    if (EPI) {
+                        const int sl = (tau * MPW + mi) * NPW + ni;
+                        if (STATS && sl < 2 * NU && (sl & 1) == 0) { __builtin_amdgcn_sched_barrier(0); stat_unit(P, sl / 2, par); __builtin_amdgcn_sched_barrier(0); }
+                        if (sl >= IMG0 && sl < IMG0 + 2 * NU && ((sl - IMG0) & 1) == 0) { __builtin_amdgcn_sched_barrier(0); img_unit(P, (sl - IMG0) / 2); __builtin_amdgcn_sched_barrier(0); }
+                    }
+#endif
                 }
         }
     };
