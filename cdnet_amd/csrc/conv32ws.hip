@@ -34,6 +34,10 @@
 
 using namespace cdnet;
 
+#ifndef CDNET_WS32_PIN
+#define CDNET_WS32_PIN 1      // a scheduling fence behind every MFMA of the consumers (0: the compiler's own order - A/B switch)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -515,7 +519,9 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
                     }
                 }
             }
+#if CDNET_WS32_PIN
             __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         static_assert(3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3, "the deferred epilogue fits the MFMA gaps of an interval");
 #pragma unroll
