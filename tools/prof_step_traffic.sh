@@ -1,8 +1,9 @@
 # HBM bytes of one whole training step from the PMC counters (two separate passes, FETCH_SIZE x 2 on gfx950 - MI355X_MICROARCH.md):
-#   bash tools/prof_step_traffic.sh      (through gpurun)
+#   bash tools/prof_step_traffic.sh [fp32|bf16]     (through gpurun)
+DT=${1:-fp32}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/step_pmc_$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --steps 4 --warmup 2 --no-extras --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/step_pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/step_pmc_$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --dtype $DT --steps 4 --warmup 2 --no-extras --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/step_pmc_$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, os, collections, json

@@ -1,20 +1,46 @@
 #!/bin/bash
 # Re-collect every artifact under profiles/<round>/ on the MI355X box (run through gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r02
-# rocprofv3 runs from /tmp (TMPDIR=/tmp), the program itself follows "--"; PMC passes are separate runs without --stats traces.
-R=${1:-r02}
+#   bash tools/refresh_profiles.sh r03        -> gpurun_out/refresh_r03/<the file names of profiles/r03/>
+# rocprofv3 runs from /tmp (TMPDIR=/tmp), the program itself follows "--"; PMC passes are separate runs without --stats traces
+# (tools/prof_roofline_pmc.sh, tools/prof_step_traffic.sh).
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+export GRAFT_REPO_ROOT=$ROOT
 OUT=$ROOT/gpurun_out/refresh_$R
-mkdir -p $OUT
+RAW=$OUT/raw
+mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_default_line.json 2> $OUT/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o t -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/train_b16_bench_line.json 2> $OUT/train.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train32 -o t -- python3 $ROOT/bench.py --dtype fp32 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $OUT/train_b16_fp32_bench_line.json 2> $OUT/train32.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/infer -o t -- python3 $ROOT/bench.py --mode infer --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $OUT/infer_b64_bench_line.json 2> $OUT/infer.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/infer32 -o t -- python3 $ROOT/bench.py --mode infer --dtype fp32 --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $OUT/infer_b64_fp32_bench_line.json 2> $OUT/infer32.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/image -o t -- python3 $ROOT/bench.py --mode image --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $OUT/image_1000_bench_line.json 2> $OUT/image.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dom -o t -- python3 $ROOT/bench.py --mode roofline > $OUT/dominant_conv_roofline_line.json 2> $OUT/dom.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dom32 -o t -- python3 $ROOT/bench.py --mode roofline --dtype fp32 > $OUT/dominant_conv_fp32_roofline_line.json 2> $OUT/dom32.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- python3 $ROOT/bench.py --mode roofline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- python3 $ROOT/bench.py --mode roofline > $OUT/pmc_write.log 2>&1
-ls -R $OUT | head -80
+python3 $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_default_line.json 2> $RAW/bench_default.err
+prof() {   # prof <name> <bench.py args...>
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/$name -o t -- python3 $ROOT/bench.py "$@" --no-extras --no-cpu-baseline > $OUT/${name}_bench_line.json 2> $RAW/$name.err
+  cp $RAW/$name/t_kernel_stats.csv $OUT/${name}_kernel_stats.csv
+}
+prof train_b16_fp32 --mode train --dtype fp32 --steps 10 --warmup 3
+python3 $ROOT/tools/step_timeline.py $RAW/train_b16_fp32/t_kernel_trace.csv > $OUT/train_b16_fp32_timeline.txt 2>&1
+prof train_b16_bf16 --mode train --dtype bf16 --steps 20 --warmup 5
+python3 $ROOT/tools/step_timeline.py $RAW/train_b16_bf16/t_kernel_trace.csv > $OUT/train_b16_bf16_timeline.txt 2>&1
+prof infer_b64_fp32 --mode infer --dtype fp32 --steps 5 --warmup 2
+prof infer_b64_bf16 --mode infer --dtype bf16 --steps 5 --warmup 2
+prof image_1000_fp32 --mode image --dtype fp32 --steps 3 --warmup 1
+prof image_1000_bf16 --mode image --dtype bf16 --steps 3 --warmup 1
+rm -rf $RAW/*/t_kernel_trace.csv
+# the dominant kernel alone: --stats pass + the PMC passes, folded into dominant_conv_<dtype>_pmc.json
+for DT in fp32 bf16; do
+  bash $ROOT/tools/prof_roofline_pmc.sh $DT $RAW/roofline_$DT > /dev/null 2>&1
+  cp $RAW/roofline_$DT/summary.json $OUT/dominant_conv_${DT}_pmc.json
+  cp $RAW/roofline_$DT/roofline_line.json $OUT/dominant_conv_${DT}_roofline_line.json
+  cp $RAW/roofline_$DT/stats/t_kernel_stats.csv $OUT/dominant_conv_${DT}_kernel_stats.csv
+  rm -rf $RAW/roofline_$DT/pmc*/*kernel_trace.csv $RAW/roofline_$DT/stats/*kernel_trace.csv
+done
+cd /tmp
+for DT in fp32 bf16; do
+  bash $ROOT/tools/prof_step_traffic.sh $DT > $OUT/train_b16_${DT}_step_traffic.txt 2>&1
+done
+rm -rf $ROOT/gpurun_out/step_pmc_*
+bash $ROOT/tools/prof_hrnet_train.sh > $OUT/hrnet_train_b4_512_summary.txt 2>&1
+cp $ROOT/gpurun_out/hrnet_train_prof/t_kernel_stats.csv $OUT/hrnet_train_b4_512_kernel_stats.csv
+rm -rf $ROOT/gpurun_out/hrnet_train_prof
+cd $ROOT
+python3 -m pytest tests/test_gpu_label_gate.py -q -s -m gpu 2>&1 | tail -60 > $OUT/label_gate.log
+du -sh $OUT; ls $OUT
