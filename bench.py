@@ -160,10 +160,10 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5):
     alg_bytes = B * 256 * 256 * (64 + 64) * esz           # algorithmic: input read once + output written once
     # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 bf16 -> the HBM term bounds this layer
     # HBM traffic, matrix-pipe busy fraction and effective clock of this kernel from the committed PMC summary (separate rocprofv3 --pmc
-    # passes of `bench.py --mode roofline`, tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv[_fp32]_pmc.json); not re-measured here
+    # passes of `bench.py --mode roofline`, tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv_<fp32|bf16>_pmc.json); not re-measured here
     traffic = traffic_src = mfma_busy = clock = None
     for rnd in ('r03', 'r02', 'r01'):
-        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_pmc.json' if f32 else 'dominant_conv_pmc.json')
+        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_pmc.json' if f32 else 'dominant_conv_bf16_pmc.json')
         old = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_traffic.json')
         if os.path.exists(tj) and B == 16:
             with open(tj) as f:
@@ -181,7 +181,15 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5):
     ws32 = f32 and os.environ.get('CDNET_CONV_WS32', '1') != '0'
     name = ('conv_ws32_kernel' if ws32 else 'conv_f32_kernel') if f32 else ('conv_ws_kernel' if ws else 'conv_fwd_kernel')
     mfma_peak = DENSE_BF16_PEAK_TFLOPS / 3 if f32 else DENSE_BF16_PEAK_TFLOPS
-    return dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+    # which roof bounds the layer: max(MFMA work / dense bf16 peak, bytes / HBM peak).  bf16: 30.9 us vs 33.6 us -> HBM; fp32 (three bf16
+    # MFMAs per product): 92.8 us vs 67.1 us -> the matrix pipe.  The other fraction stays in hbm_frac / mfma_frac.
+    mfma_work_tflop = flops * (3 if f32 else 1) / 1e12
+    if mfma_work_tflop / DENSE_BF16_PEAK_TFLOPS > alg_bytes / 1e9 / HBM_PEAK_GBS:
+        head = dict(bound='mfma', achieved=mfma_work_tflop / (ms / 1e3), peak=DENSE_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=mfma_work_tflop / (ms / 1e3) / DENSE_BF16_PEAK_TFLOPS)
+    else:
+        head = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
+    return dict(**head, hbm_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                 kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, '64,9,0,false' if ws else ('64,0,false' if ws32 else ','.join(str(c) for c in cfg)), B), dtype=precision,
                 mfma_busy_frac=mfma_busy, clock_mhz=clock,
                 ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,

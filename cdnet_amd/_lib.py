@@ -7,9 +7,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcdnet_hip.so')
+LIB_PATH = os.environ.get('CDNET_LIB_PATH') or os.path.join(_HERE, 'libcdnet_hip.so')      # (the override: A/B builds of tools/build_variant.sh)
 
 _vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+
+class WgradReduceDesc(C.Structure):          # cdnet_wgrad_reduce_desc (include/cdnet_hip.h)
+    _fields_ = [('slab', C.c_void_p), ('dw', C.c_void_p)] + [(n, C.c_int) for n in (
+        'ksplit', 'npar', 'ci_blocks', 'co_blocks', 'taps', 'CI', 'CO', 'Csrc_real', 'Cin_real', 'src_coff', 'Cout', 'mode', 'block0', 'blocks')]
+
 
 # name -> (restype, argtypes); must list every symbol include/cdnet_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
@@ -58,6 +63,8 @@ SIGNATURES = {
     'cdnet_final_conv1x1_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     'cdnet_conv_wgrad_slab_floats': (_sz, [_i] * 6),
     'cdnet_conv_backward_weight': (_i, [_vp, _i, _i, _i, _vp] + [_i] * 9 + [_vp, _vp, _i, _vp]),
+    'cdnet_wgrad_reduce_desc_fill': (_i, [_i] * 9 + [_vp, _vp, _i, _i, _vp]),
+    'cdnet_wgrad_reduce_batch': (_i, [_vp, _i, _i, _vp]),
     'cdnet_bn_backward_workspace_floats': (_sz, [_i]),
     'cdnet_bn_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     'cdnet_dam_head_backward_workspace_floats': (_sz, [_i, _i, _i]),

@@ -34,6 +34,9 @@
 
 using namespace cdnet;
 
+#ifndef CDNET_WS32_MOVER_PRIO
+#define CDNET_WS32_MOVER_PRIO 0   // s_setprio of the mover waves (the younger half of the workgroup loses the VALU arbitration at equal priority)
+#endif
 #ifndef CDNET_WS32_PIN
 #define CDNET_WS32_PIN 1      // a scheduling fence behind every MFMA of the consumers (0: the compiler's own order - A/B switch)
 #endif
@@ -145,6 +148,9 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
 
     if (wave >= 4) {
         // ================================ movers ================================
+#if CDNET_WS32_MOVER_PRIO
+        __builtin_amdgcn_s_setprio(CDNET_WS32_MOVER_PRIO);
+#endif
         const int ptid = tid - 256, pw = wave - 4;
         const int slot = ptid % VPP;
         f32x4 pa[2][NA][2];                      // two chunks of halo vectors in flight (8 channels = two float4 each)

@@ -900,6 +900,9 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
 // Same products and the same three-MFMA order per tap as wgrad_f32_kernel; the pixels are summed in another order (other tiles),
 // so the results agree to fp32 rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------------------
+#ifndef CDNET_WG32_MOVER_PRIO
+#define CDNET_WG32_MOVER_PRIO 0
+#endif
 constexpr int TH32 = 4, NPIX_A32 = (TH32 + 2) * HALO_W, NPIX_G32 = TH32 * TW;
 
 template <int XF>      // source transform: 0 plain fp32, 1 x * scale + shift -> ReLU, 2 run-time flags (scale / shift, residual, ReLU)
@@ -928,9 +931,21 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 
     __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
     fill_xf<CI>(s_xf, A.src, ib * CI, tid);
-    if (ntl == 0) return;
+#ifdef CDNET_WS_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 17 && lane == 0 && (wave == 0 || wave == 4);
+    const int sbase = wave >= 4 ? 1024 : 0;
+    int sn = 0;
+#endif
     if (wave >= 4) {
         // ------------------------------- movers -------------------------------
+        if (ntl == 0) return;                                    // (a slice without tiles: the consumers store a slab of zeros)
+#if CDNET_WG32_MOVER_PRIO
+        __builtin_amdgcn_s_setprio(CDNET_WG32_MOVER_PRIO);
+#endif
+        if (A.debug & 2) {                                       // ablation: consumers alone (whatever the LDS holds)
+            for (int j = -1; j < ntl2; ++j) __syncthreads();
+            return;
+        }
         const int ptid = tid - 256;
         const ConvSrc &s = A.src;
         const float *sx = reinterpret_cast<const float *>(s.x), *sr = reinterpret_cast<const float *>(s.res);
@@ -1038,25 +1053,41 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
                     for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
                 }
                 u32x4 hi, lo;
-                wg_split8(x, hi, lo);
-                const unsigned keep = ea[R][i] >= 0 ? 0xffffffffu : 0u;      // outside the image / source / channels: zeros
-                hi &= keep;
-                lo &= keep;
-                if (i < NA - 1 || ptid + i * 256 < NPIX_A32 * VA) {
+                if (A.debug & 16) {                                          // ablation: no conversion arithmetic
+                    hi = __builtin_bit_cast(u32x4, pa_[R][i][0]);
+                    lo = __builtin_bit_cast(u32x4, pa_[R][i][1]);
+                } else {
+                    wg_split8(x, hi, lo);
+                    const unsigned keep = ea[R][i] >= 0 ? 0xffffffffu : 0u;      // outside the image / source / channels: zeros
+                    hi &= keep;
+                    lo &= keep;
+                }
+                if ((i < NA - 1 || ptid + i * 256 < NPIX_A32 * VA) && !(A.debug & 4)) {      // (4: ablation, no LDS writes)
                     *reinterpret_cast<u32x4 *>(nb + adst[i]) = hi;
                     *reinterpret_cast<u32x4 *>(nb + A_PLANE + adst[i]) = lo;
+                } else if (A.debug & 4) {
+                    asm volatile("" :: "v"(hi), "v"(lo));
                 }
             }
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 const float x[8] = {pg_[R][i][0][0], pg_[R][i][0][1], pg_[R][i][0][2], pg_[R][i][0][3], pg_[R][i][1][0], pg_[R][i][1][1], pg_[R][i][1][2], pg_[R][i][1][3]};
                 u32x4 hi, lo;
-                wg_split8(x, hi, lo);
-                const unsigned keep = (gv[R] >> i) & 1u ? 0xffffffffu : 0u;
-                hi &= keep;
-                lo &= keep;
-                *reinterpret_cast<u32x4 *>(nb + gdst[i]) = hi;
-                *reinterpret_cast<u32x4 *>(nb + G_PLANE + gdst[i]) = lo;
+                if (A.debug & 16) {
+                    hi = __builtin_bit_cast(u32x4, pg_[R][i][0]);
+                    lo = __builtin_bit_cast(u32x4, pg_[R][i][1]);
+                } else {
+                    wg_split8(x, hi, lo);
+                    const unsigned keep = (gv[R] >> i) & 1u ? 0xffffffffu : 0u;
+                    hi &= keep;
+                    lo &= keep;
+                }
+                if (!(A.debug & 4)) {
+                    *reinterpret_cast<u32x4 *>(nb + gdst[i]) = hi;
+                    *reinterpret_cast<u32x4 *>(nb + G_PLANE + gdst[i]) = lo;
+                } else {
+                    asm volatile("" :: "v"(hi), "v"(lo));
+                }
             }
         };
         using I0 = std::integral_constant<int, 0>;
@@ -1068,13 +1099,30 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
         __syncthreads();
         for (int j = 0; j < ntl2; j += 2) {
             // consumers are on tile j (stage 0): fill stage 1 with tile j+1, then request tile j+3; then the other way round
+            WG_STAMP(1);
+#ifdef CDNET_WS_STAMPS
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // (stamped build: the older tile's loads have landed)
+            WG_STAMP(2);
+#endif
             commit(I1{}, 1);
+            WG_STAMP(3);
             issue(I1{});
+            WG_STAMP(4);
             __syncthreads();
+            WG_STAMP(1);
+#ifdef CDNET_WS_STAMPS
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            WG_STAMP(2);
+#endif
             commit(I0{}, 0);
+            WG_STAMP(3);
             issue(I0{});
+            WG_STAMP(4);
             __syncthreads();
         }
+#ifdef CDNET_WS_STAMPS
+        if (stamp_on) g_wg_stamps[sbase + sn] = 0;
+#endif
         return;
     }
     // ------------------------------- consumers -------------------------------
@@ -1088,9 +1136,10 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    __syncthreads();
+    if (ntl) __syncthreads();
     for (int j = 0; j < ntl2; ++j) {
         if (j >= ntl) { __syncthreads(); continue; }              // padding step
+        WG_STAMP(10);
         const unsigned char *buf = smem + (j & 1) * STAGE;
         auto frag = [&](int off, int pstr) -> bf16x8 {
             const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(buf + off));
@@ -1127,8 +1176,13 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        WG_STAMP(11);
         __syncthreads();
     }
+    WG_STAMP(12);
+#ifdef CDNET_WS_STAMPS
+    if (stamp_on) g_wg_stamps[sbase + sn] = 0;
+#endif
     float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -1144,17 +1198,17 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 //   mode 0: Conv2d  dW[Cout][Cin][KH][KW]  (taps = KH*KW)
 //   mode 2: ConvTranspose2d k4 s2 p1  dW[Cin][Cout][4][4]   (npar 4 x taps 4)
 //   mode 3: ConvTranspose2d k2 s2     dW[Cin][Cout][2][2]   (npar 4 x taps 1)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int ksplit, int npar, int ci_blocks,
-                                                           int co_blocks, int TAPS, int CI, int CO, int Csrc_real, int Cin_real,
-                                                           int src_coff, int Cout, int mode, float *__restrict__ dw) {
+typedef float rf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ slab, int ksplit, int npar, int ci_blocks, int co_blocks,
+                                                  int TAPS, int CI, int CO, int Csrc_real, int Cin_real, int src_coff, int Cout,
+                                                  int mode, float *__restrict__ dw, unsigned bidx, rf4 (*s_part)[64]) {
     // block = 256 consecutive slab elements (64 threads x one 16-byte vector) x 4 interleaved k-lanes (k = kq, kq+4, ...); every thread
     // keeps eight slabs' vectors in flight (the pass is pure streaming: 256 slabs x 147 KB for a 64 x 64 layer; with one 4-byte load per
     // thread and four in flight it ran at 0.8 TB/s, 49 us per launch on the weight-gradient stream); fixed-order combine
-    typedef float rf4 __attribute__((ext_vector_type(4)));
-    __shared__ rf4 s_part[4][64];
     const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * TAPS * CI * CO;      // a multiple of 1024 (CI * CO = 4096)
     const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    const size_t i = ((size_t)blockIdx.x * 64 + e) * 4;
+    const size_t i = ((size_t)bidx * 64 + e) * 4;
     rf4 a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = rf4{0.f, 0.f, 0.f, 0.f};
@@ -1208,6 +1262,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         }
         dw[o] = sv[j];
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int ksplit, int npar, int ci_blocks,
+                                                           int co_blocks, int TAPS, int CI, int CO, int Csrc_real, int Cin_real,
+                                                           int src_coff, int Cout, int mode, float *__restrict__ dw) {
+    __shared__ rf4 s_part[4][64];
+    wgrad_reduce_body(slab, ksplit, npar, ci_blocks, co_blocks, TAPS, CI, CO, Csrc_real, Cin_real, src_coff, Cout, mode, dw, blockIdx.x, s_part);
+}
+
+// the reduces of several layers in one launch (cdnet_wgrad_reduce_batch): the descriptors sit in device memory in launch order,
+// `block0` ascending; a workgroup finds its layer by bisection over uniform (scalar) loads and runs the same body
+struct ReduceDesc {
+    const float *slab;
+    float *dw;
+    int ksplit, npar, ci_blocks, co_blocks, taps, CI, CO, Csrc_real, Cin_real, src_coff, Cout, mode;
+    int block0, blocks;
+};
+static_assert(sizeof(ReduceDesc) == sizeof(cdnet_wgrad_reduce_desc), "cdnet_wgrad_reduce_desc layout");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceDesc *__restrict__ tab, int n) {
+    __shared__ rf4 s_part[4][64];
+    const unsigned b = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((unsigned)tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const ReduceDesc d = tab[lo];
+    wgrad_reduce_body(d.slab, d.ksplit, d.npar, d.ci_blocks, d.co_blocks, d.taps, d.CI, d.CO, d.Csrc_real, d.Cin_real, d.src_coff, d.Cout,
+                      d.mode, d.dw, b - (unsigned)d.block0, s_part);
 }
 
 template <int CI_T, int CO_T, int TAPS, bool RES, int XF>
@@ -1329,6 +1413,8 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     CDNET_REQUIRE(!(src->res && src->pool), "cdnet_conv_backward_weight: a pooled source with a residual branch is not supported");
     CDNET_REQUIRE(!(src->f16 == 2 && src->pool), "cdnet_conv_backward_weight: fp32 pooled sources must be materialised");
     CDNET_REQUIRE(ksplit >= 1 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "cdnet_conv_backward_weight: bad size (Cout %% 8)");
+    const bool defer = (mode & CDNET_WGRAD_DEFER_REDUCE) != 0;       // leave the slabs: cdnet_wgrad_reduce_batch sums them later
+    mode &= ~CDNET_WGRAD_DEFER_REDUCE;
     CDNET_REQUIRE((taps == 9 && npar == 1 && ostride == 1 && mode == 0) || (taps == 1 && npar == 1 && ostride == 1 && mode == 0) ||
                   (taps == 9 && npar == 1 && ostride == 1 && mode == 6) ||
                   (taps == 4 && npar == 4 && ostride == 2 && mode == 2) || (taps == 1 && npar == 4 && ostride == 2 && mode == 3),
@@ -1347,7 +1433,7 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     if (taps == 9) rc = dispatch_wgrad<9>(A, ci_tiles, st);
     else if (taps == 4) rc = dispatch_wgrad<4>(A, ci_tiles, st);
     else rc = dispatch_wgrad<1>(A, ci_tiles, st);
-    if (rc != CDNET_OK) return rc;
+    if (rc != CDNET_OK || defer) return rc;
     const int CI = ci_tiles * 32, CO = (4 / ci_tiles) * 32;
     const int ci_blocks = cdiv(src->C, CI), co_blocks = cdiv(Cout, CO);
     const size_t per_ks = (size_t)npar * ci_blocks * co_blocks * taps * CI * CO;
@@ -1355,4 +1441,30 @@ extern "C" int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_cof
     wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(slab, ksplit, npar, ci_blocks, co_blocks, taps, CI, CO, Csrc_real, Cin_real, src_coff, Cout,
                                                 mode, dw);
     return check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int cdnet_wgrad_reduce_desc_fill(int C_src, int src_coff, int Csrc_real, int Cin_real, int Cout, int taps, int npar,
+                                            int ci_tiles, int ksplit, const float *slab, float *dw, int mode, int block0,
+                                            cdnet_wgrad_reduce_desc *out) {
+    CDNET_REQUIRE(out && slab && dw, "cdnet_wgrad_reduce_desc_fill: null pointer");
+    CDNET_REQUIRE(ci_tiles == 1 || ci_tiles == 2 || ci_tiles == 4, "cdnet_wgrad_reduce_desc_fill: ci_tiles=%d", ci_tiles);
+    CDNET_REQUIRE(ksplit >= 1 && C_src > 0 && Cout > 0 && block0 >= 0, "cdnet_wgrad_reduce_desc_fill: bad size");
+    mode &= ~CDNET_WGRAD_DEFER_REDUCE;
+    CDNET_REQUIRE(mode == 0 || mode == 2 || mode == 3 || mode == 6, "cdnet_wgrad_reduce_desc_fill: mode=%d", mode);
+    const int CI = ci_tiles * 32, CO = (4 / ci_tiles) * 32;
+    out->slab = slab; out->dw = dw;
+    out->ksplit = ksplit; out->npar = npar;
+    out->ci_blocks = cdiv(C_src, CI); out->co_blocks = cdiv(Cout, CO);
+    out->taps = taps; out->CI = CI; out->CO = CO;
+    out->Csrc_real = Csrc_real; out->Cin_real = Cin_real; out->src_coff = src_coff; out->Cout = Cout; out->mode = mode;
+    const size_t per_ks = (size_t)npar * out->ci_blocks * out->co_blocks * taps * CI * CO;
+    out->block0 = block0;
+    out->blocks = (int)((per_ks + 255) / 256);
+    return CDNET_OK;
+}
+
+extern "C" int cdnet_wgrad_reduce_batch(const cdnet_wgrad_reduce_desc *table_dev, int n, int total_blocks, void *stream) {
+    CDNET_REQUIRE(table_dev && n >= 1 && total_blocks >= 1, "cdnet_wgrad_reduce_batch: empty table");
+    wgrad_reduce_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const ReduceDesc *>(table_dev), n);
+    return check_launch("wgrad_reduce_batch_kernel");
 }

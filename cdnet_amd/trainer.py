@@ -38,6 +38,7 @@ class BnBwdArgs(C.Structure):
 _WGRAD_WGS_DEEP = int(os.environ.get('CDNET_WGRAD_WGS_DEEP', '128'))
 _WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
 _WGRAD_WGS_F32 = int(os.environ.get('CDNET_WGRAD_WGS_F32', '256'))
+_WGRAD_DEFER = 0x100                       # CDNET_WGRAD_DEFER_REDUCE (include/cdnet_hip.h)
 _WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
 
 
@@ -143,6 +144,10 @@ class Trainer:
         self._packb_pending = False
         self._packb_stream = os.environ.get('CDNET_PACKB_STREAM', '1') != '0'      # backward-data re-packs beside the next forward
         self._side_active = False
+        # split-K sums of the weight gradients: deferred and batched (one cdnet_wgrad_reduce_batch launch per ~CDNET_WGRAD_REDUCE_MB of
+        # slabs instead of one reduce behind every weight-gradient launch; every call keeps its own slab buffer - 1.4 GB for the UNet)
+        self._rd_mb = float(os.environ.get('CDNET_WGRAD_REDUCE_MB', '300'))        # 0: the reduce inside every call (one shared slab)
+        self._rd_pending, self._rd_params, self._rd_bytes, self._rd_tables = [], [], 0, {}
         self._forwards, self._bn_base = 0, 0                 # training forwards run here / counted in a loaded checkpoint
         if world_size > 1:
             self.sync_from_rank0()                           # replicas start identical whatever each rank's RNG / checkpoint did
@@ -328,9 +333,43 @@ class Trainer:
                 L.deferred_layer = None
                 self._layer_backward(('deferred', k), d, grads.pop(id(d.saved[1])), grads, add, side)
         if side is not None:
+            with _on_stream(side):
+                self._flush_reduces()
             ev = self._event(-1)
             ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
+        else:
+            self._flush_reduces()
+
+    def _weights_done(self, params):
+        """the weight-gradient launches of a layer are queued (current stream = the one they run on): sum their slabs now or later, then
+        hand the layer's parameters to the all-reduce"""
+        if not self._rd_pending:
+            self._overlap_done(params)
+            return
+        self._rd_params.append(params)
+        if self._rd_bytes >= self._rd_mb * (1 << 20):
+            self._flush_reduces()
+
+    def _flush_reduces(self):
+        """one cdnet_wgrad_reduce_batch launch over every deferred weight gradient (bit-identical to the per-call reduction).  The
+        descriptor table of a launch is built once per distinct sequence of calls and kept on the device."""
+        if self._rd_pending:
+            key = tuple(self._rd_pending)
+            tab = self._rd_tables.get(key)
+            if tab is None:
+                lib = _lib.load()
+                descs = (_lib.WgradReduceDesc * len(key))()
+                b0 = 0
+                for i, a in enumerate(key):
+                    _lib.call('cdnet_wgrad_reduce_desc_fill', *a, b0, C.byref(descs[i]))
+                    b0 += descs[i].blocks
+                dev_tab = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
+                tab = self._rd_tables[key] = (dev_tab, len(key), b0)
+            _lib.call('cdnet_wgrad_reduce_batch', _lib.ptr(tab[0]), tab[1], tab[2], _lib.stream_ptr())
+        for params in self._rd_params:
+            self._overlap_done(params)
+        self._rd_pending, self._rd_params, self._rd_bytes = [], [], 0
 
     def _layer_backward(self, k, L, gl, grads, add, side):
         """one convolution layer: BatchNorm / residual / ReLU backward of its output, weight gradient (side stream), input gradient"""
@@ -354,7 +393,7 @@ class Trainer:
                 draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
                 _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(draw), _lib.stream_ptr())
                 self._weight_backward(L, srcs, draw, Hl, Wl)
-                self._overlap_done(params)
+                self._weights_done(params)
             self._input_backward(L, srcs, Src(gl[0].t, ktab, ktab, relu=3, res=out), Hl, Wl, add)
             return
         if part is not None:
@@ -365,7 +404,7 @@ class Trainer:
             g = gl[0].t                                     # plain pass-through (conv_1x1 residual branch)
         if side is None:
             self._weight_backward(L, srcs, g, Hl, Wl)
-            self._overlap_done(params)
+            self._weights_done(params)
             self._input_backward(L, srcs, g, Hl, Wl, add)
         else:
             # the weight gradient only feeds the optimiser: it runs on a second stream beside the input-gradient chain.  The chain's
@@ -378,7 +417,7 @@ class Trainer:
             side.wait_event(ev)
             with _on_stream(side):
                 self._weight_backward(L, srcs, g, Hl, Wl)
-                self._overlap_done(params)         # (a bucket released here is ordered after both streams' work so far)
+                self._weights_done(params)         # (a bucket released here is ordered after both streams' work so far)
 
     def _fusable(self, L, srcs, out, gl, H, W):
         """plain BatchNorm + ReLU layer with one same-size gradient source whose backward-data launch runs on the producer / consumer
@@ -586,12 +625,18 @@ class Trainer:
                 cap = _WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW or H * W > 65536 else _WGRAD_WGS_SHALLOW    # (512 x 512 layers of HRNet: 128 again)
             ksplit = max(1, min(ntiles, cap // other if other < cap else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
-            slab = self._slab(nslab)
+            defer = self._rd_mb > 0
+            slab = self.buf(('wslab', L.name, coff), (nslab,), torch.float32) if defer else self._slab(nslab)
             cs = engine.ConvSrc()
             s.fill(cs)
             csrc_real = min(s.C, cin_real - coff) if cin_total != cin_real else s.C
             _lib.call('cdnet_conv_backward_weight', C.byref(cs), coff, csrc_real, cin_real, _lib.ptr(g), Cout, N, H, W, taps,
-                      npar, ostride, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(L.weight.grad), mode, _lib.stream_ptr())
+                      npar, ostride, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(L.weight.grad), mode | (_WGRAD_DEFER if defer else 0),
+                      _lib.stream_ptr())
+            if defer:
+                self._rd_pending.append((s.C, coff, csrc_real, cin_real, Cout, taps, npar, ci_t, ksplit, slab.data_ptr(),
+                                         L.weight.grad.data_ptr(), mode))
+                self._rd_bytes += nslab * 4
             coff += s.C
         if L.bias is not None and L.bn is None:
             # bias of a BN-less conv (ResidualUnit.conv_1x1): sum of its output gradient == dbeta of the unit's bn2

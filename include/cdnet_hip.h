@@ -293,6 +293,23 @@ int cdnet_conv_backward_weight(const cdnet_conv_src *src, int src_coff, int Csrc
                                const uint16_t *grad_out, int Cout, int N, int H, int W, int taps, int npar,
                                int ostride, int ci_tiles, int ksplit, float *slab, float *dw, int mode, void *stream);
 
+/* Deferred split-K reduction: `mode | CDNET_WGRAD_DEFER_REDUCE` makes cdnet_conv_backward_weight stop after the slabs (which then
+ * must stay untouched - one slab buffer per call); cdnet_wgrad_reduce_batch sums the slabs of any number of such calls and scatters
+ * into their dw in ONE launch, bit-identical to the per-call reduction (same fixed order).  The table lives in device memory:
+ * entries filled on the host by cdnet_wgrad_reduce_desc_fill (block0 = sum of the `blocks` of the entries before it), copied by
+ * the caller; total_blocks = block0 + blocks of the last entry.  (The reference has no counterpart: autograd accumulates dW inside
+ * cuDNN's backward-filter call, train_util_dam.py:307.) */
+#define CDNET_WGRAD_DEFER_REDUCE 0x100
+typedef struct cdnet_wgrad_reduce_desc {
+    const float *slab;
+    float *dw;
+    int ksplit, npar, ci_blocks, co_blocks, taps, CI, CO, Csrc_real, Cin_real, src_coff, Cout, mode;
+    int block0, blocks;
+} cdnet_wgrad_reduce_desc;
+int cdnet_wgrad_reduce_desc_fill(int C_src, int src_coff, int Csrc_real, int Cin_real, int Cout, int taps, int npar, int ci_tiles,
+                                 int ksplit, const float *slab, float *dw, int mode, int block0, cdnet_wgrad_reduce_desc *out);
+int cdnet_wgrad_reduce_batch(const cdnet_wgrad_reduce_desc *table_dev, int n, int total_blocks, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Training-only streaming kernels.  Together with cdnet_conv_forward (backward-data packs) and
  * cdnet_conv_backward_weight they replace loss.backward() / optimizer.step() of train_util_dam.py:303-308.

@@ -34,7 +34,7 @@ def _wgrad(srcs, g, weight_shape, kind, H, W, cin_real=None, ksplit=7):
     coff = 0
     for s in srcs:
         ci_t = trainer._choose_ci_tiles(s.C, Cout)
-        slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit),), dtype=torch.float32, device='cuda')
+        slab = torch.full((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit),), float('nan'), dtype=torch.float32, device='cuda')   # (a slice without tiles must still write its slab)
         cs = engine.ConvSrc()
         s.fill(cs)
         assert cs.f16 == 2

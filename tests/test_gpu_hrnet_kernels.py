@@ -53,7 +53,7 @@ def test_stride2_conv_forward_backward():
     for a, s in enumerate(views):
         ci_t = trainer._choose_ci_tiles(s.C, Cout)
         ks = 5
-        slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, 9, 1, ci_t, ks),), dtype=torch.float32, device='cuda')
+        slab = torch.full((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, 9, 1, ci_t, ks),), float('nan'), dtype=torch.float32, device='cuda')
         cs = engine.ConvSrc()
         s.fill(cs)
         _lib.call('cdnet_conv_backward_weight', C.byref(cs), a * 2 * Cp, s.C, 4 * Cp, _lib.ptr(dyd), Cout, N, H // 2, W // 2, 9, 1, 1, ci_t, ks,

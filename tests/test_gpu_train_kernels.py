@@ -24,8 +24,9 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-def _wgrad(srcs, g, weight_shape, kind, H, W, cin_real=None):
-    """run cdnet_conv_backward_weight for every source; returns dW (cpu)"""
+def _wgrad(srcs, g, weight_shape, kind, H, W, cin_real=None, deferred=None):
+    """run cdnet_conv_backward_weight for every source; returns dW (cpu) - or, with a list in `deferred`, leaves the slabs, appends
+    the reduce descriptors' arguments and returns dW on the device (to be filled by _reduce_batch)"""
     import torch
     from cdnet_amd import _lib, engine, trainer
     lib = _lib.load()
@@ -41,13 +42,29 @@ def _wgrad(srcs, g, weight_shape, kind, H, W, cin_real=None):
     for s in srcs:
         ci_t = trainer._choose_ci_tiles(s.C, Cout)
         ksplit = 7
-        slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit),), dtype=torch.float32, device='cuda')
+        slab = torch.full((lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit),), float('nan'), dtype=torch.float32, device='cuda')
         cs = engine.ConvSrc()
         s.fill(cs)
         _lib.call('cdnet_conv_backward_weight', C.byref(cs), coff, min(s.C, cin_real - coff), cin_real, _lib.ptr(g), Cout, N, H, W,
-                  taps, npar, ostride, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(dw), mode, _lib.stream_ptr())
+                  taps, npar, ostride, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(dw), mode | (0x100 if deferred is not None else 0), _lib.stream_ptr())
+        if deferred is not None:
+            deferred.append(((s.C, coff, min(s.C, cin_real - coff), cin_real, Cout, taps, npar, ci_t, ksplit, _lib.ptr(slab), _lib.ptr(dw), mode), slab))
         coff += s.C
-    return dw.cpu()
+    return dw.cpu() if deferred is None else dw
+
+
+def _reduce_batch(deferred):
+    import torch
+    from cdnet_amd import _lib
+    descs = (_lib.WgradReduceDesc * len(deferred))()
+    b0 = 0
+    for i, (a, _) in enumerate(deferred):
+        _lib.call('cdnet_wgrad_reduce_desc_fill', *a, b0, C.byref(descs[i]))
+        assert descs[i].block0 == b0 and descs[i].blocks > 0
+        b0 += descs[i].blocks
+    tab = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).cuda()
+    _lib.call('cdnet_wgrad_reduce_batch', _lib.ptr(tab), len(deferred), b0, _lib.stream_ptr())
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 24, 40), (1, 32, 128, 16, 16), (2, 128, 32, 9, 21), (1, 16, 64, 32, 32),
@@ -117,6 +134,33 @@ def test_wgrad_conv1x1_and_transposed():
     F.conv_transpose2d(x, w, None, stride=2).backward(dy)
     got = _wgrad([engine.Src(_nhwc(x))], _nhwc(dy), (64, 32, 2, 2), 'convT2', 12, 20)
     assert _rel(got, w.grad) < 2e-3
+
+
+@pytest.mark.parametrize('f32', [False, True])
+def test_wgrad_deferred_batch_reduce_is_bit_identical(f32):
+    """CDNET_WGRAD_DEFER_REDUCE + one cdnet_wgrad_reduce_batch launch over the slabs of six calls (3x3 with two concat sources and a
+    zero-padded stem, 1x1, both transposed forms; 16-bit and fp32 tensors) == the reduce inside every call, bit for bit; the
+    untouched dW elements of a call stay untouched"""
+    import torch
+    from cdnet_amd import engine
+    gen = torch.Generator().manual_seed(11)
+    cast = (lambda t: t.float().cuda().contiguous()) if f32 else (lambda t: t)
+    nh = lambda t: cast(_nhwc(_bf(t)))
+    jobs = []
+    a, b = torch.randn((2, 32, 20, 28), generator=gen), torch.randn((2, 64, 20, 28), generator=gen)
+    jobs.append(([engine.Src(nh(a)), engine.Src(nh(b))], nh(torch.randn((2, 64, 20, 28), generator=gen)), (64, 96, 3, 3), 'conv3', 20, 28, None))
+    x16 = torch.zeros((2, 16, 32, 32)); x16[:, :3] = torch.rand((2, 3, 32, 32), generator=gen)
+    jobs.append(([engine.Src(nh(x16))], nh(torch.randn((2, 64, 32, 32), generator=gen)), (64, 3, 3, 3), 'conv3', 32, 32, 3))
+    jobs.append(([engine.Src(nh(torch.randn((2, 64, 24, 16), generator=gen)))], nh(torch.randn((2, 64, 24, 16), generator=gen)), (64, 64, 1, 1), 'conv1', 24, 16, None))
+    jobs.append(([engine.Src(nh(torch.randn((2, 64, 8, 8), generator=gen)))], nh(torch.randn((2, 32, 16, 16), generator=gen)), (64, 32, 4, 4), 'convT4', 8, 8, None))
+    jobs.append(([engine.Src(nh(torch.randn((2, 64, 12, 20), generator=gen)))], nh(torch.randn((2, 32, 24, 40), generator=gen)), (64, 32, 2, 2), 'convT2', 12, 20, None))
+    want = [_wgrad(srcs, g, shape, kind, H, W, cin_real=cr) for srcs, g, shape, kind, H, W, cr in jobs]
+    deferred = []
+    dws = [_wgrad(srcs, g, shape, kind, H, W, cin_real=cr, deferred=deferred) for srcs, g, shape, kind, H, W, cr in jobs]
+    assert len(deferred) == 6 and all(float(d.abs().sum()) == 0.0 for d in dws)        # nothing summed yet
+    _reduce_batch(deferred)
+    for w, d in zip(want, dws):
+        assert float(w.abs().sum()) > 0 and torch.equal(w, d.cpu())
 
 
 def test_backward_data_of_transposed_conv_via_space_to_depth():

@@ -195,6 +195,32 @@ def test_fused_batchnorm_backward_source_is_bit_identical(monkeypatch):
         assert torch.equal(grads[0][n], grads[1][n]), n
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_deferred_batched_split_k_reduce_is_bit_identical(monkeypatch, precision):
+    """weight gradients with their split-K sums deferred into a few cdnet_wgrad_reduce_batch launches (one slab buffer per call; the
+    default) == the reduce behind every weight-gradient launch (CDNET_WGRAD_REDUCE_MB=0), bit for bit on every parameter gradient;
+    a small threshold forces several flushes inside backward, a huge one leaves a single launch at its end"""
+    import torch
+    import cdnet_amd
+    before = cdnet_amd.get_precision()
+    cdnet_amd.set_precision(precision)
+    try:
+        grads = []
+        for mb in ('0', '1', '1000000'):
+            monkeypatch.setenv('CDNET_WGRAD_REDUCE_MB', mb)
+            m, ref, x, t = _setup(B=2, S=64)
+            tr, g = _hip_grads(m, x, t)
+            ntab = len(tr._rd_tables)
+            assert (ntab == 0) if mb == '0' else (ntab == 1 if mb == '1000000' else ntab >= 3), (mb, ntab)
+            assert not tr._rd_pending and not tr._rd_params
+            grads.append(g)
+        for g in grads[1:]:
+            for n in grads[0]:
+                assert torch.equal(grads[0][n], g[n]), n
+    finally:
+        cdnet_amd.set_precision(before)
+
+
 def test_channel_sums_from_the_backward_data_launch_match_the_separate_pass(monkeypatch):
     """first BatchNorm-backward pass (sum dz, sum dz * xhat) accumulated by the movers of the backward-data launch that produced the
     gradient (cdnet_conv_args.ws = 2 + cdnet_bn_backward_finalize) against the separate reduce pass: same arithmetic per element,

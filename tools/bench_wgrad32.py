@@ -44,6 +44,30 @@ def run(name, Cin, Cout, H, fused=False, cap=256):
 
 
 run('64->64@256 plain', 64, 64, 256)
+if os.environ.get('WG_STAMPS'):
+    # stamped build (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): per-interval timeline of one consumer and one mover wave of workgroup 17
+    import ctypes, numpy as np, collections
+    buf = np.zeros(2048, dtype=np.uint64)
+    f = lib.cdnet_debug_wgrad_stamps
+    f.argtypes = [ctypes.c_void_p]
+    assert f(buf.ctypes.data) == 0
+    for role, off in (('consumer', 0), ('mover', 1024)):
+        v = buf[off:off + 1024]
+        n = int(np.argmax(v == 0))
+        ids = (v[:n] & np.uint64(255)).astype(int)
+        ts = (v[:n] >> np.uint64(8)).astype(np.int64)
+        ts = (ts - ts[0]) / 100.0
+        print(role, n, 'stamps, span %.1f us' % ts[-1])
+        d = collections.defaultdict(list)
+        for i in range(1, n):
+            d[(ids[i - 1], ids[i])].append(ts[i] - ts[i - 1])
+        for k in sorted(d):
+            a = np.array(d[k])
+            print('  %2d -> %2d : n %3d  mean %6.2f  med %6.2f  min %6.2f  max %6.2f  total %7.1f' % (k[0], k[1], len(a), a.mean(), np.median(a), a.min(), a.max(), a.sum()))
+        print('  first 24:', ' '.join('%d@%.2f' % (ids[i], ts[i]) for i in range(min(n, 24))))
+    sys.exit(0)
+if os.environ.get('WG32_ONLY') == '1':
+    sys.exit(0)
 run('64->64@256 BN+ReLU source', 64, 64, 256, fused=True)
 run('128->128@128 BN+ReLU source', 128, 128, 128, fused=True)
 run('256->256@64 BN+ReLU source', 256, 256, 64, fused=True)
