@@ -34,6 +34,9 @@
 
 using namespace cdnet;
 
+#ifndef CDNET_WS32_SCALAR_SUB
+#define CDNET_WS32_SCALAR_SUB 1
+#endif
 #ifndef CDNET_WS32_MOVER_PRIO
 #define CDNET_WS32_MOVER_PRIO 0   // s_setprio of the mover waves (the younger half of the workgroup loses the VALU arbitration at equal priority)
 #endif
@@ -57,8 +60,18 @@ __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
         const f32x2 x = {v[2 * k], v[2 * k + 1]};
         const bf16x2 h = __builtin_convertvector(x, bf16x2);
         const unsigned hb = __builtin_bit_cast(unsigned, h);
+#if CDNET_WS32_SCALAR_SUB
+        // two plain subtractions instead of the v_pk_add_f32 the compiler would make of them: a packed fp32 instruction of a mover wave
+        // is expensive beside the consumers' MFMA stream (measured on wgrad_ws32_kernel, wgrad.hip: wg_split8)
+        float d0, d1;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x[0]), "v"(__builtin_bit_cast(float, hb << 16)));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x[1]), "v"(__builtin_bit_cast(float, hb & 0xffff0000u)));
+        const f32x2 df = {d0, d1};
+        const bf16x2 l = __builtin_convertvector(df, bf16x2);
+#else
         const f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
         const bf16x2 l = __builtin_convertvector(x - hf, bf16x2);
+#endif
         hi[k] = hb;
         lo[k] = __builtin_bit_cast(unsigned, l);
     }

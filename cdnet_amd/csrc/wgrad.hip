@@ -637,15 +637,21 @@ typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float wg_f32x2;
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
 
+// hi = bf16(x) (RNE), lo = bf16(x - hi) for eight values.  The two subtractions of a pair are kept scalar (inline assembly): left to
+// the compiler they become one v_pk_add_f32, and a packed fp32 instruction costs a mover wave far more than two plain ones beside
+// the consumers' MFMA stream (wgrad_ws32_kernel: 257 -> 241 us on the 64 -> 64 layer at 256 x 256 x 16).
 __device__ __forceinline__ void wg_split8(const float *v, u32x4 &hi, u32x4 &lo) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const wg_f32x2 x = {v[2 * k], v[2 * k + 1]};
         const wg_bf16x2 h = __builtin_convertvector(x, wg_bf16x2);
         const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const wg_f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        float d0, d1;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(x[0]), "v"(__builtin_bit_cast(float, hb << 16)));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x[1]), "v"(__builtin_bit_cast(float, hb & 0xffff0000u)));
+        const wg_f32x2 d = {d0, d1};
         hi[k] = hb;
-        lo[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, wg_bf16x2));
+        lo[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, wg_bf16x2));
     }
 }
 
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
     __shared__ __attribute__((aligned(16))) float s_xf[2 * CI];
     fill_xf<CI>(s_xf, A.src, ib * CI, tid);
 #ifdef CDNET_WS_STAMPS
-    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 17 && lane == 0 && (wave == 0 || wave == 4);
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == (A.debug >> 8 ? A.debug >> 8 : 17) && lane == 0 && (wave == 0 || wave == 4);
     const int sbase = wave >= 4 ? 1024 : 0;
     int sn = 0;
 #endif
@@ -962,24 +968,47 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sc[j] = s_xf[slot_a * 8 + j]; sh[j] = s_xf[CI + slot_a * 8 + j]; }
         }
-        // what depends on the thread only: halo coordinates, element offsets inside a tile and LDS addresses of its vectors
-        int hyx[NA], aoff[NA], adst[NA], gyx[NG], goff[NG], gdst[NG];
+        // Requests go through buffer descriptors: a vector outside the image / source window / channels gets the byte offset ~0, the
+        // range check returns zeros for it - no test, no select and no 64-bit address arithmetic per vector (a vector instruction of a
+        // mover wave costs ~10 ns beside the consumers' MFMA stream, stamped: the movers, not the matrix pipe, bounded this kernel).
+        // Validity of a tile's halo rows / columns = two scalar bit masks per tile; per vector: two shifts, or, bit extract.
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, (int)((unsigned)A.N * s.Hs * rs * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sr ? sr : sx), 0, (int)((unsigned)A.N * s.Hs * rs * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gx), 0, (int)((unsigned)A.N * A.H * A.W * A.Cout * 4u), 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff) -> wg_f32x4 {
+            return __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+        };
+        // what depends on the thread only: halo coordinates (31 = a vector that never exists: the masks' bit 31 is always set), byte
+        // offsets inside a tile and LDS addresses of its vectors
+        int ahy[NA], ahx[NA], adst[NA], gpy[NG], gpx[NG], gdst[NG];
+        unsigned aoffb[NA], goffb[NG];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int v = ptid + i * 256, pix = v / VA;
             const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-            hyx[i] = v < NPIX_A32 * VA ? ((hy << 16) | hx) : -1;
-            aoff[i] = hy * rs + hx * s.C;
+            const bool exists = v < NPIX_A32 * VA && cok_a;
+            ahy[i] = exists ? hy : 31;
+            ahx[i] = exists ? hx : 31;
+            aoffb[i] = (unsigned)(hy * rs + hx * s.C + slot_a * 8) * 4u;
             adst[i] = pix * PA + slot_a * 16;
         }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int pix = ptid / VG + i * (256 / VG);
             const int py = pix / TW, px = pix % TW;
-            gyx[i] = (py << 16) | px;
-            goff[i] = (py * A.W + px) * A.Cout;
+            gpy[i] = cok_g ? py : 31;
+            gpx[i] = cok_g ? px : 31;
+            goffb[i] = (unsigned)((py * A.W + px) * A.Cout + slot_g * 8) * 4u;
             gdst[i] = 2 * A_PLANE + pix * PG + slot_g * 16;
         }
+        const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;       // valid rows / columns of
+        const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;       // the input: image and source window
+        // bits [lo, hi) clear, everything else set (lo, hi clamped to [0, 31])
+        auto bad_mask = [](int lo, int hi) -> unsigned {
+            lo = lo < 0 ? 0 : (lo > 31 ? 31 : lo);
+            hi = hi < lo ? lo : (hi > 31 ? 31 : hi);
+            return ~(((1u << hi) - 1u) & ~((1u << lo) - 1u));
+        };
         // tile cursor of the request stream: tile ks + j * ksplit as (image, tile row, tile column), advanced by ksplit without divisions
         int c_n, c_ty, c_tx, c_j = 0;
         {
@@ -989,34 +1018,30 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
         }
         const int d_n = A.ksplit / tiles_img, d_rem = A.ksplit - d_n * tiles_img, d_ty = d_rem / tiles_x, d_tx = d_rem - d_ty * tiles_x;
         wg_f32x4 pa_[2][NA][2], pg_[2][NG][2];
-        int ea[2][NA];                       // element offsets of the input vectors (read again for a residual operand), -1 = zero fill
-        unsigned gv[2];
+        unsigned av[2][NA];                  // byte offsets of the input vectors (read again for a residual operand), ~0 = zero fill
         auto issue = [&](auto rc) {
             constexpr int R = decltype(rc)::value;
             const int y0 = c_ty * TH32, x0 = c_tx * TW;
-            const int abase_e = (c_n * s.Hs + (y0 - 1 - s.off_y)) * rs + (x0 - 1 - s.off_x) * s.C + cbase;
+            // halo row r <-> y = y0 - 1 + r, halo column c <-> x = x0 - 1 + c
+            const unsigned rowbad = bad_mask(ylo - (y0 - 1), yhi - (y0 - 1)), colbad = bad_mask(xlo - (x0 - 1), xhi - (x0 - 1));
+            const unsigned abase_b = (unsigned)((c_n * s.Hs + (y0 - 1 - s.off_y)) * rs + (x0 - 1 - s.off_x) * s.C + ib * CI) * 4u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int hy = hyx[i] >> 16, hx = hyx[i] & 0xffff;
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                const bool ok = hyx[i] >= 0 && cok_a && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
-                                (unsigned)(y - s.off_y) < (unsigned)s.Hs && (unsigned)(x - s.off_x) < (unsigned)s.Ws;
-                ea[R][i] = ok ? abase_e + aoff[i] : -1;
-                const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sx + (ok ? ea[R][i] : 0));
-                pa_[R][i][0] = pp[0];
-                pa_[R][i][1] = pp[1];
+                const unsigned t = (rowbad >> ahy[i]) | (colbad >> ahx[i]);
+                const unsigned voff = (abase_b + aoffb[i]) | (unsigned)(-(int)(t & 1u));
+                av[R][i] = voff;
+                pa_[R][i][0] = bload(rs_a, voff);
+                pa_[R][i][1] = bload(rs_a, voff | 16u);          // (| 16: the ~0 of a zero-fill vector stays out of range)
             }
-            unsigned gvalid = 0;
-            const int gbase_e = ((c_n * A.H + y0) * A.W + x0) * A.Cout + co;
+            const unsigned growbad = bad_mask(0, A.H - y0), gcolbad = bad_mask(0, A.W - x0);
+            const unsigned gbase_b = (unsigned)(((c_n * A.H + y0) * A.W + x0) * A.Cout + cb * CO) * 4u;
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
-                const bool ok = cok_g && y0 + (gyx[i] >> 16) < A.H && x0 + (gyx[i] & 0xffff) < A.W;
-                const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(gx + (ok ? gbase_e + goff[i] : 0));
-                pg_[R][i][0] = pp[0];
-                pg_[R][i][1] = pp[1];
-                gvalid |= (ok ? 1u : 0u) << i;
+                const unsigned t = (growbad >> gpy[i]) | (gcolbad >> gpx[i]);
+                const unsigned voff = (gbase_b + goffb[i]) | (unsigned)(-(int)(t & 1u));
+                pg_[R][i][0] = bload(rs_g, voff);
+                pg_[R][i][1] = bload(rs_g, voff | 16u);
             }
-            gv[R] = gvalid;
             if (c_j + 1 < ntl) {             // (past the end the last tile is requested and staged again, into the buffer nobody reads)
                 ++c_j;
                 c_tx += d_tx; if (c_tx >= tiles_x) { c_tx -= tiles_x; ++c_ty; }
@@ -1031,63 +1056,53 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
             if (has_res) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const wg_f32x4 *pp = reinterpret_cast<const wg_f32x4 *>(sr + (ea[R][i] >= 0 ? ea[R][i] : 0));
-                    rr[i][0] = pp[0];
-                    rr[i][1] = pp[1];
+                    rr[i][0] = bload(rs_r, av[R][i]);
+                    rr[i][1] = bload(rs_r, av[R][i] | 16u);
                 }
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 float x[8] = {pa_[R][i][0][0], pa_[R][i][0][1], pa_[R][i][0][2], pa_[R][i][0][3], pa_[R][i][1][0], pa_[R][i][1][1], pa_[R][i][1][2], pa_[R][i][1][3]};
-                if (XF != 0 && on) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], sc[j], sh[j]);
-                }
-                if (has_res) {
-                    const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] += r[j];
-                }
-                if (XF != 0 && relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
-                }
                 u32x4 hi, lo;
-                if (A.debug & 16) {                                          // ablation: no conversion arithmetic
-                    hi = __builtin_bit_cast(u32x4, pa_[R][i][0]);
-                    lo = __builtin_bit_cast(u32x4, pa_[R][i][1]);
-                } else {
+                if (XF == 1) {
+                    // BatchNorm + ReLU with the zero fill folded into the clamp: med3(v, 0, lim) = max(v, 0) for lim = +inf, 0 for lim = 0
+                    const float lim = __builtin_bit_cast(float, av[R][i] == ~0u ? 0u : 0x7f800000u);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaf(x[j], sc[j], sh[j]), 0.f, lim);
                     wg_split8(x, hi, lo);
-                    const unsigned keep = ea[R][i] >= 0 ? 0xffffffffu : 0u;      // outside the image / source / channels: zeros
-                    hi &= keep;
-                    lo &= keep;
+                } else {
+                    if (XF != 0 && on) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = fmaf(x[j], sc[j], sh[j]);
+                    }
+                    if (has_res) {
+                        const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] += r[j];
+                    }
+                    if (XF != 0 && relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                    }
+                    wg_split8(x, hi, lo);
+                    if (XF != 0) {                                           // (plain sources: the zero fill arrived as zeros)
+                        const unsigned keep = av[R][i] == ~0u ? 0u : 0xffffffffu;
+                        hi &= keep;
+                        lo &= keep;
+                    }
                 }
-                if ((i < NA - 1 || ptid + i * 256 < NPIX_A32 * VA) && !(A.debug & 4)) {      // (4: ablation, no LDS writes)
+                if (i < NA - 1 || ptid + i * 256 < NPIX_A32 * VA) {
                     *reinterpret_cast<u32x4 *>(nb + adst[i]) = hi;
                     *reinterpret_cast<u32x4 *>(nb + A_PLANE + adst[i]) = lo;
-                } else if (A.debug & 4) {
-                    asm volatile("" :: "v"(hi), "v"(lo));
                 }
             }
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 const float x[8] = {pg_[R][i][0][0], pg_[R][i][0][1], pg_[R][i][0][2], pg_[R][i][0][3], pg_[R][i][1][0], pg_[R][i][1][1], pg_[R][i][1][2], pg_[R][i][1][3]};
                 u32x4 hi, lo;
-                if (A.debug & 16) {
-                    hi = __builtin_bit_cast(u32x4, pg_[R][i][0]);
-                    lo = __builtin_bit_cast(u32x4, pg_[R][i][1]);
-                } else {
-                    wg_split8(x, hi, lo);
-                    const unsigned keep = (gv[R] >> i) & 1u ? 0xffffffffu : 0u;
-                    hi &= keep;
-                    lo &= keep;
-                }
-                if (!(A.debug & 4)) {
-                    *reinterpret_cast<u32x4 *>(nb + gdst[i]) = hi;
-                    *reinterpret_cast<u32x4 *>(nb + G_PLANE + gdst[i]) = lo;
-                } else {
-                    asm volatile("" :: "v"(hi), "v"(lo));
-                }
+                wg_split8(x, hi, lo);                                        // (no mask: the range check zero-filled it)
+                *reinterpret_cast<u32x4 *>(nb + gdst[i]) = hi;
+                *reinterpret_cast<u32x4 *>(nb + G_PLANE + gdst[i]) = lo;
             }
         };
         using I0 = std::integral_constant<int, 0>;
@@ -1328,7 +1343,7 @@ int launch_wgrad_gen(const WgradArgs &A, hipStream_t st) {
     return check_launch("wgrad_kernel");
 }
 
-// the wave-specialised fp32 kernel: 3x3 layers on 64 x 64 channel blocks (ostride 1), tensors below 2^31 elements
+// the wave-specialised fp32 kernel: 3x3 layers on 64 x 64 channel blocks (ostride 1), tensors below 4 GB (32-bit byte offsets)
 int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
     constexpr int smem = 2 * (2 * NPIX_A32 * pstride(64) + 2 * NPIX_G32 * pstride(64));
     const ConvSrc &s = A.src;
@@ -1355,8 +1370,8 @@ template <int CI_T, int CO_T, int TAPS>
 int launch_wgrad_f32(const WgradArgs &A, hipStream_t st) {
     static const int use_ws32 = getenv("CDNET_WGRAD_WS32") ? atoi(getenv("CDNET_WGRAD_WS32")) : 1;
     if (CI_T == 2 && CO_T == 2 && TAPS == 9 && use_ws32 && !(A.debug & 8) && A.ostride == 1 && A.npar == 1 && !A.src.pool &&
-        (long long)A.N * A.H * A.W * (A.src.C > A.Cout ? A.src.C : A.Cout) < (1LL << 31) &&
-        (long long)A.N * A.src.Hs * (A.src.row_stride ? A.src.row_stride : A.src.Ws * A.src.C) < (1LL << 31))
+        (long long)A.N * A.H * A.W * (A.src.C > A.Cout ? A.src.C : A.Cout) < (1LL << 30) &&
+        (long long)A.N * A.src.Hs * (A.src.row_stride ? A.src.row_stride : A.src.Ws * A.src.C) < (1LL << 30))
         return launch_wgrad_ws32(A, st);
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int smem = 2 * (NPIX_A * pstride(CI) + NPIX_G * pstride(CO));
