@@ -509,6 +509,116 @@ static void launch_flat32(const BnBwdArgs &A, int nb, hipStream_t st) {
     }
 }
 
+// fp32 variant of the window kernels (one 2x2 max-pool consumer + NF same-size un-shifted ones: the encoder's conv1_2 ... conv5_3):
+// one pooling window x 4 channels per thread, the four raw vectors, their flat gradients and the pooled gradient requested back to back,
+// plain fp32 arithmetic, the pooled gradient to the first maximum of relu(bn(raw)) (nn.MaxPool2d backward) - bit-identical to the
+// generic per-pixel path (bn_bwd_reduce_kernel / bn_bwd_apply_kernel<true>), which reads a window's raw vectors once per pixel.
+template <int NF, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_window32_kernel(BnBwdArgs A, int kp) {
+    __shared__ float s_red[APPLY ? 1 : 256][9];
+    const int VPP = A.C / 4;
+    const int tid = threadIdx.x;
+    const int slot = tid % VPP, c0 = slot * 4;
+    float sc[4], sh[4], mu[4], is[4], k1[4], k2[4], k3[4], s1[4], s2[4];
+    load4(A.scale, c0, sc, 1.f); load4(A.shift, c0, sh, 0.f); load4(A.mean, c0, mu, 0.f); load4(A.invstd, c0, is, 1.f);
+    if (APPLY) { load4(A.k1, c0, k1, 1.f); load4(A.k2, c0, k2, 0.f); load4(A.k3, c0, k3, 0.f); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const unsigned H = A.H, W = A.W, Hp = (H + 1) / 2, Wp = (W + 1) / 2, nwin = (unsigned)A.N * Hp * Wp;
+    const unsigned ppb = 256 / VPP;
+    const bool relu = A.relu != 0;
+    const GradIn gp = A.gin[kp];
+    const float *gpool_p = reinterpret_cast<const float *>(gp.g);
+    const float *raw = reinterpret_cast<const float *>(A.raw);
+    float *draw = reinterpret_cast<float *>(A.draw);
+    const float *gf[NF > 0 ? NF : 1];
+    int gcs[NF > 0 ? NF : 1], gco[NF > 0 ? NF : 1];
+    {
+        int m = 0;
+        for (int k = 0; k < A.ngin && m < NF; ++k)
+            if (k != kp) { gf[m] = reinterpret_cast<const float *>(A.gin[k].g); gcs[m] = A.gin[k].cstride; gco[m] = A.gin[k].coff; ++m; }
+    }
+    for (unsigned w0 = first_pixel(ppb, VPP); w0 < nwin; w0 += gridDim.x * ppb) {
+        const unsigned w = (APPLY && A.rev) ? nwin - 1 - w0 : w0;
+        const unsigned n = w / (Hp * Wp), r = w - n * Hp * Wp;
+        const unsigned py = r / Wp, px = r - py * Wp;
+        bn_f32x4 x[4], g[4][NF > 0 ? NF : 1], gv;
+        unsigned pix[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned yy = 2 * py + (q >> 1), xx = 2 * px + (q & 1);
+            ok[q] = yy < H && xx < W;
+            yy = yy < H ? yy : H - 1;
+            xx = xx < W ? xx : W - 1;
+            pix[q] = (n * H + yy) * W + xx;
+            x[q] = *reinterpret_cast<const bn_f32x4 *>(raw + (size_t)pix[q] * A.C + c0);
+#pragma unroll
+            for (int m = 0; m < NF; ++m)
+                g[q][m] = *reinterpret_cast<const bn_f32x4 *>(gf[m] + (size_t)pix[q] * gcs[m] + gco[m] + c0);
+        }
+        const bool pok = py < (unsigned)gp.Hg && px < (unsigned)gp.Wg;
+        {
+            const unsigned cy = pok ? py : 0, cx = pok ? px : 0;
+            gv = *reinterpret_cast<const bn_f32x4 *>(gpool_p + (((size_t)n * gp.Hg + cy) * gp.Wg + cx) * gp.cstride + gp.coff + c0);
+        }
+        bn_f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = fmaf(x[q][j], sc[j], sh[j]);
+                a[q] = relu ? fmaxf(v, 0.f) : v;
+            }
+            int bi = 0;
+            float best = a[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (ok[q] && a[q] > best) { best = a[q]; bi = q; }
+            const float gpool = pok ? gv[j] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // the generic path's order: 0 + the sources in argument order (kp = the pooled one's position)
+                const float pt = (bi == q) ? gpool : 0.f;
+                float gsum;
+                if (NF == 0) gsum = 0.f + pt;
+                else if (NF == 1) gsum = (0.f + (kp == 0 ? pt : g[q][0][j])) + (kp == 0 ? g[q][0][j] : pt);
+                else gsum = ((0.f + (kp == 0 ? pt : g[q][0][j])) + (kp == 0 ? g[q][0][j] : (kp == 1 ? pt : g[q][NF - 1][j]))) +
+                            (kp == 2 ? pt : g[q][NF - 1][j]);
+                const float dz = (!ok[q] || (relu && !(a[q] > 0.f))) ? 0.f : gsum;
+                const float xh = (x[q][j] - mu[j]) * is[j];
+                if (APPLY) o[q][j] = k1[j] * (dz - k2[j] - xh * k3[j]);
+                else { s1[j] += dz; s2[j] = fmaf(dz, xh, s2[j]); }
+            }
+        }
+        if (APPLY) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) *reinterpret_cast<bn_f32x4 *>(draw + (size_t)pix[q] * A.C + c0) = o[q];
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s_red[tid][j] = s1[j]; s_red[tid][4 + j] = s2[j]; }
+        __syncthreads();
+        for (int q = tid; q < 8 * VPP; q += 256) {
+            const int sl = q % VPP, j = q / VPP;
+            float t = 0.f;
+            for (int k = sl; k < 256; k += VPP) t += s_red[k][j];
+            float *op = A.partial + (size_t)blockIdx.x * 2 * A.C;
+            op[(j >> 2) * A.C + sl * 4 + (j & 3)] = t;
+        }
+    }
+}
+
+template <bool APPLY>
+static void launch_window32(const BnBwdArgs &A, int nflat, int kp, int nb, hipStream_t st) {
+    if (nflat == 0) bn_bwd_window32_kernel<0, APPLY><<<nb, 256, 0, st>>>(A, kp);
+    else if (nflat == 1) bn_bwd_window32_kernel<1, APPLY><<<nb, 256, 0, st>>>(A, kp);
+    else bn_bwd_window32_kernel<2, APPLY><<<nb, 256, 0, st>>>(A, kp);
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs A) {
     __shared__ float s_red[256][17];
@@ -1634,6 +1744,14 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     CDNET_REQUIRE(A.relu != 2 || (flat && A.res), "cdnet_bn_backward: relu = 2 (mask from the stored output) needs same-size gradient sources and res");
     const bool f32 = A.f16 == 2;                      // fp32 tensors: flat32 kernels (same-size sources) or the generic ones (pool / pad routing)
     const bool flat32 = f32 && flat && A.C <= 1024;
+    static const int use_w32 = getenv("CDNET_BN_WINDOW32") ? atoi(getenv("CDNET_BN_WINDOW32")) : 1;
+    const bool window32 = f32 && window && use_w32 && A.C % 4 == 0 && A.C <= 1024 && A.shift && A.invstd;
+    if (window32) {
+        const int ppb4 = 256 / (A.C / 4);
+        const size_t nwin = (size_t)A.N * ((A.H + 1) / 2) * ((A.W + 1) / 2);
+        nb = (int)((nwin + ppb4 - 1) / ppb4);
+        if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
+    }
     if (f32) { window = false; flat = false; }
     if (flat32) {
         const int ppb4 = 256 / (A.C / 4);
@@ -1660,7 +1778,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
                 case 6: bn_bwd_reduce_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
                 default: bn_bwd_reduce_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
             }
-        } else if (flat32) launch_flat32<false>(A, nb, st);
+        } else if (window32) launch_window32<false>(A, nflat, kp, nb, st);
+        else if (flat32) launch_flat32<false>(A, nb, st);
         else if (f32) bn_bwd_reduce_kernel<true><<<nb, 256, 0, st>>>(A);
         else bn_bwd_reduce_kernel<false><<<nb, 256, 0, st>>>(A);
         bn_bwd_finalize_kernel<<<A.C, 256, 0, st>>>(A.partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, k,
@@ -1680,7 +1799,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
             case 6: bn_bwd_apply_flat_kernel<3, false><<<nb, 256, 0, st>>>(A); break;
             default: bn_bwd_apply_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
         }
-    } else if (flat32) launch_flat32<true>(A, nb, st);
+    } else if (window32) launch_window32<true>(A, nflat, kp, nb, st);
+    else if (flat32) launch_flat32<true>(A, nb, st);
     else if (f32) bn_bwd_apply_kernel<true><<<nb, 256, 0, st>>>(A);
     else bn_bwd_apply_kernel<false><<<nb, 256, 0, st>>>(A);
     return check_launch("cdnet_bn_backward");

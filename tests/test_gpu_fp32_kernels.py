@@ -129,12 +129,12 @@ def test_backward_data_fp32():
         assert _rel(_nchw(out), x.grad) < 5e-5, (k, _rel(_nchw(out), x.grad))
 
 
-def _bn_case(pooled, with_res, two_grads, seed, outmask=False):
+def _bn_case(pooled, with_res, two_grads, seed, outmask=False, skip=0, size=(12, 20), pool_first=True):
     import torch
     import torch.nn.functional as F
     from cdnet_amd import _lib, trainer
     g = torch.Generator().manual_seed(seed)
-    N, Cc, H, W = 2, 32, 12, 20
+    N, Cc, (H, W) = 2, 32, size
     raw = torch.randn((N, Cc, H, W), generator=g).requires_grad_(True)
     res = torch.randn((N, Cc, H, W), generator=g).requires_grad_(True) if with_res else None
     gamma = (torch.rand((Cc,), generator=g) + 0.5).requires_grad_(True)
@@ -153,7 +153,14 @@ def _bn_case(pooled, with_res, two_grads, seed, outmask=False):
         gp = torch.randn(p.shape, generator=g)
         total = total + (p * gp).sum()
         gins.append(trainer._G(_nhwc(gp), p.shape[2], p.shape[3], pooled=1))
-    if two_grads or not pooled:
+    for _ in range(skip):
+        # a same-size consumer that reads the activation as a channel slice of a wider tensor (the decoder's torch.cat with the skip)
+        gwide = torch.randn((N, Cc + 16, H, W), generator=g)
+        total = total + (a * gwide[:, 16:16 + Cc]).sum()
+        gins.append(trainer._G(_nhwc(gwide), H, W, coff=16, cstride=Cc + 16))
+    if not pool_first:
+        gins = gins[1:] + gins[:1]
+    if (two_grads or not pooled) and not skip:
         if outmask:
             gfull = torch.randn((N, Cc, H, W), generator=g)
             total = total + (a * gfull).sum()
@@ -197,6 +204,14 @@ def _bn_case(pooled, with_res, two_grads, seed, outmask=False):
                                  (True, True, True)])
 def test_bn_backward_fp32(cfg):
     _bn_case(*cfg, seed=11)
+
+
+@pytest.mark.parametrize('cfg', [(1, (12, 20), True), (1, (13, 21), False), (2, (10, 18), False), (0, (9, 7), True)])
+def test_bn_backward_fp32_pool_window(cfg):
+    """the encoder's layers in front of a max-pool (one pooled consumer + the decoder's skip slice): bn_bwd_window32_kernel, odd sizes
+    (a last window row / column without a pooled gradient), the pooled source first or last in the argument order"""
+    skip, size, pool_first = cfg
+    _bn_case(True, False, False, seed=13, skip=skip, size=size, pool_first=pool_first)
 
 
 def test_bn_backward_fp32_mask_from_stored_output():
