@@ -167,16 +167,34 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         const int ptid = tid - 256, pw = wave - 4;
         const int slot = ptid % VPP;
         f32x4 pa[2][NA][2];                      // two chunks of halo vectors in flight (8 channels = two float4 each)
-        unsigned vm[2];                          // bit i: vector i of the chunk lies inside the image / source
-        int eo[2][NA];                           // element offsets (read again for sources with a residual operand)
+        unsigned eo[2][NA];                      // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
         int hyx[NA], doff[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int pix = (ptid + i * 256) / VPP;
             const int hy = pix / HW_, hx = pix - hy * HW_;
-            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 16) | hx) : -1;
+            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 8) | hx) : 0x1f1f;      // (31 = a vector that never exists: bit 31 of the masks is always set)
             doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
         }
+        // Requests go through buffer descriptors (one per source, tensors below 2 GB): a vector outside the image / the source window
+        // carries bit 31 in its byte offset, the range check returns zeros for it - no select, no 64-bit address arithmetic and, for plain
+        // sources, no mask per vector (every vector instruction of a mover wave costs the consumers' MFMA stream issue time).  Validity of a
+        // tile's halo rows / columns = two scalar bit masks per tile and source.
+        const unsigned src_bytes0 = (unsigned)A.N * A.src[0].Hs * (A.src[0].row_stride ? A.src[0].row_stride : A.src[0].Ws * A.src[0].C) * 4u;
+        const unsigned src_bytes1 = A.nsrc > 1 ? (unsigned)A.N * A.src[1].Hs * (A.src[1].row_stride ? A.src[1].row_stride : A.src[1].Ws * A.src[1].C) * 4u : 0u;
+        const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].x), 0, (int)src_bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.nsrc > 1 ? A.src[1].x : A.src[0].x), 0, (int)src_bytes1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].res ? A.src[0].res : A.src[0].x), 0, (int)src_bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.nsrc > 1 && A.src[1].res ? A.src[1].res : A.src[0].x), 0, (int)src_bytes1, 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff) -> f32x4 {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+        };
+        // bits [lo, hi) clear, everything else set (lo, hi clamped to [0, 31])
+        auto bad_mask = [](int lo, int hi) -> unsigned {
+            lo = lo < 0 ? 0 : (lo > 31 ? 31 : lo);
+            hi = hi < lo ? lo : (hi > 31 ? 31 : hi);
+            return ~(((1u << hi) - 1u) & ~((1u << lo) - 1u));
+        };
         // issue cursor: chunk ik of the tile at (in_, iy0, ix0); saturates on the last chunk of the run
         int ik = 0, ic = 0, in_, iy0, ix0;
         {
@@ -189,8 +207,7 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         bool s_ok = false;
         int kt = 0;                              //      chunk-in-tile index of the current interval
         int ck = 0;                              // commit cursor: chunk-in-tile index
-        int ge[NA];
-        unsigned gm = 0;
+        unsigned ge[NA];                         // byte offset of channel 0 of the tile's vectors in the current source, bit 31 = zero fill
         const int n0 = A.src[0].C / CK;
         auto chunk_src = [&](int k, int &si, int &cc0) {
             if (k < n0) { si = 0; cc0 = k * CK; } else { si = 1; cc0 = (k - n0) * CK; }
@@ -202,28 +219,28 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             const ConvSrc &s = A.src[si];
             if (ik == 0 || ik == n0) {
                 const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
-                const int img = in_ * s.Hs * rs + slot * 8;
-                gm = 0;
+                // halo row r <-> y = iy0 - 1 + r, halo column c <-> x = ix0 - 1 + c; valid = inside the image and the source window
+                const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
+                const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;
+                const unsigned rowbad = bad_mask(ylo - (iy0 - 1), yhi - (iy0 - 1)), colbad = bad_mask(xlo - (ix0 - 1), xhi - (ix0 - 1));
+                const unsigned img_b = (unsigned)((in_ * s.Hs + (iy0 - 1 - s.off_y)) * rs + (ix0 - 1 - s.off_x) * s.C) * 4u;
+                const unsigned rs_b = (unsigned)rs * 4u, c_b = (unsigned)s.C * 4u;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const int y = iy0 - 1 + (hyx[i] >> 16), x = ix0 - 1 + (hyx[i] & 0xffff);
-                    const int ys = y - s.off_y, xs = x - s.off_x;
-                    const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
-                                    (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
-                    ge[i] = ok ? img + ys * rs + xs * s.C : -1;
-                    gm |= (ok ? 1u : 0u) << i;
+                    const unsigned hy = (unsigned)hyx[i] >> 8, hx = (unsigned)hyx[i] & 0xffu;
+                    const unsigned t = (rowbad >> hy) | (colbad >> hx);
+                    ge[i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 32u) & 0x7fffffffu) | (t << 31);
                 }
             }
-            const char *base = reinterpret_cast<const char *>(reinterpret_cast<const float *>(s.x) + cc0);      // uniform
+            const __amdgpu_buffer_rsrc_t rsx = si ? rsx1 : rsx0;
+            const unsigned cc0_b = (unsigned)cc0 * 4u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const unsigned e = ge[i] >= 0 ? (unsigned)ge[i] : 0u;
-                eo[R][i] = (int)e + cc0;
-                const f32x4 *p = reinterpret_cast<const f32x4 *>(base + e * 4u);      // (the launcher keeps every tensor below 2^30 elements)
-                pa[R][i][0] = p[0];
-                pa[R][i][1] = p[1];
+                const unsigned voff = ge[i] + cc0_b;                   // (a zero-fill vector keeps bit 31: beyond every tensor the launcher admits)
+                eo[R][i] = voff;
+                pa[R][i][0] = bload(rsx, voff);
+                pa[R][i][1] = bload(rsx, voff + 16u);
             }
-            vm[R] = gm;
             if (ic + 1 < S) {
                 ++ic;
                 if (++ik == NCH) {
@@ -251,36 +268,45 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             f32x4 rr[NA][2];
             const bool has_res = XF == 2 && s.res != nullptr;
             if (has_res) {
-                const float *rbase = reinterpret_cast<const float *>(s.res);
+                const __amdgpu_buffer_rsrc_t rsr = si ? rsr1 : rsr0;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const f32x4 *p = reinterpret_cast<const f32x4 *>(rbase + eo[R][i]);
-                    rr[i][0] = p[0];
-                    rr[i][1] = p[1];
+                    rr[i][0] = bload(rsr, eo[R][i]);
+                    rr[i][1] = bload(rsr, eo[R][i] + 16u);
                 }
             }
             unsigned char *dst0 = lds_a + R * L::A_SLOT;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 float v[8] = {pa[R][i][0][0], pa[R][i][0][1], pa[R][i][0][2], pa[R][i][0][3], pa[R][i][1][0], pa[R][i][1][1], pa[R][i][1][2], pa[R][i][1][3]};
-                if (XF != 0 && on) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
-                }
-                if (has_res) {
-                    const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += r[j];
-                }
-                if (XF != 0 && relu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
                 u32x4 hi, lo;
-                split8(v, hi, lo);
-                const unsigned keep = (vm[R] >> i) & 1u ? 0xffffffffu : 0u;      // outside the image / source: zeros (after the transform)
-                hi &= keep;
-                lo &= keep;
+                if (XF == 1) {
+                    // BatchNorm + ReLU with the zero fill folded into the clamp: med3(v, 0, lim) = max(v, 0) for lim = +inf, 0 for lim = 0
+                    const float lim = __builtin_bit_cast(float, (int)eo[R][i] < 0 ? 0u : 0x7f800000u);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaf(v[j], sc[j], sh[j]), 0.f, lim);
+                    split8(v, hi, lo);
+                } else {
+                    if (XF != 0 && on) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+                    }
+                    if (has_res) {
+                        const float r[8] = {rr[i][0][0], rr[i][0][1], rr[i][0][2], rr[i][0][3], rr[i][1][0], rr[i][1][1], rr[i][1][2], rr[i][1][3]};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += r[j];
+                    }
+                    if (XF != 0 && relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    split8(v, hi, lo);
+                    if (XF != 0) {                                       // (plain sources: the zero fill arrived as zeros)
+                        const unsigned keep = (int)eo[R][i] < 0 ? 0u : 0xffffffffu;      // outside the image / source: zeros (after the transform)
+                        hi &= keep;
+                        lo &= keep;
+                    }
+                }
                 if (i < NA - 1 || ptid + i * 256 < NPIX * VPP) {
                     *reinterpret_cast<u32x4 *>(dst0 + doff[i]) = hi;
                     *reinterpret_cast<u32x4 *>(dst0 + L::A_PLANE + doff[i]) = lo;
@@ -661,6 +687,9 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
     for (int i = 0; i < A.nsrc; ++i) {
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
+        // the movers' requests: 31-bit byte offsets from the source's base (bit 31 marks a zero-fill vector)
+        const long long rs = A.src[i].row_stride ? A.src[i].row_stride : (long long)A.src[i].Ws * A.src[i].C;
+        if ((long long)A.N * A.src[i].Hs * rs * 4 >= (1LL << 31)) return -1;
     }
     const bool bns = A.ws == 2;
     if (bns && (BN != 64 || A.Cout % 64 != 0 || !A.eres || !A.oscale || !A.oshift || !A.eres_scale || !A.eres_shift || !A.stats || A.bias ||
