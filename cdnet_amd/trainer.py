@@ -38,6 +38,7 @@ class BnBwdArgs(C.Structure):
 _WGRAD_WGS_DEEP = int(os.environ.get('CDNET_WGRAD_WGS_DEEP', '128'))
 _WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
 _WGRAD_WGS_F32 = int(os.environ.get('CDNET_WGRAD_WGS_F32', '256'))
+_RU_1X1_SIDE = os.environ.get('CDNET_RU_1X1_SIDE', '1') != '0'      # residual units' 1x1 backward-data beside the chain
 _WGRAD_DEFER = 0x100                       # CDNET_WGRAD_DEFER_REDUCE (include/cdnet_hip.h)
 _WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
 
@@ -61,10 +62,11 @@ class _on_stream:
 
 class _G:
     """a gradient contribution for a stored tensor"""
-    __slots__ = ('t', 'Hg', 'Wg', 'oy', 'ox', 'pooled', 'coff', 'cstride')
+    __slots__ = ('t', 'Hg', 'Wg', 'oy', 'ox', 'pooled', 'coff', 'cstride', 'event')
 
     def __init__(self, t, Hg, Wg, oy=0, ox=0, pooled=0, coff=0, cstride=0):
         self.t, self.Hg, self.Wg, self.oy, self.ox, self.pooled, self.coff, self.cstride = t, Hg, Wg, oy, ox, pooled, coff, cstride
+        self.event = None                    # produced on another stream: the consumer's stream waits for this event first
 
 
 class FlatState:
@@ -373,6 +375,10 @@ class Trainer:
 
     def _layer_backward(self, k, L, gl, grads, add, side):
         """one convolution layer: BatchNorm / residual / ReLU backward of its output, weight gradient (side stream), input gradient"""
+        for g_ in gl:
+            if g_.event is not None:         # a contribution computed beside the chain (_RU_1X1_SIDE)
+                torch.cuda.current_stream().wait_event(g_.event)
+                g_.event = None
         srcs, out, Hl, Wl = L.saved
         No, Ho, Wo, Co = out.shape
         params = (L.weight, L.bias, None if L.bn is None else L.bn.weight, None if L.bn is None else L.bn.bias)
@@ -413,9 +419,21 @@ class Trainer:
             # keeps its lead either way)
             ev = self._event(k)
             ev.record()             # (recorded after backward-data instead, the weight gradient overlaps the HBM-bound BatchNorm passes of
-            self._input_backward(L, srcs, g, Hl, Wl, add)      # the next layer rather than the convolution: -2 %)
+            beside = _RU_1X1_SIDE and L.kind == 'conv1' and isinstance(k, tuple) and getattr(L, 'needs_input_grad', True)
+            if not beside:
+                self._input_backward(L, srcs, g, Hl, Wl, add)      # the next layer rather than the convolution: -2 %)
             side.wait_event(ev)
             with _on_stream(side):
+                if beside:
+                    # the 1x1 branch of a residual unit: its input gradient is first needed by the BatchNorm backward of the PREVIOUS unit,
+                    # three convolutions down the chain - it runs beside the chain, in front of the weight gradients queued from here on
+                    ev2 = self._event(('beside', k))
+
+                    def add_beside(tgt, g_):
+                        g_.event = ev2
+                        add(tgt, g_)
+                    self._input_backward(L, srcs, g, Hl, Wl, add_beside)
+                    ev2.record()
                 self._weight_backward(L, srcs, g, Hl, Wl)
                 self._weights_done(params)         # (a bucket released here is ordered after both streams' work so far)
 

@@ -221,6 +221,28 @@ def test_deferred_batched_split_k_reduce_is_bit_identical(monkeypatch, precision
         cdnet_amd.set_precision(before)
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_residual_1x1_backward_beside_the_chain_is_bit_identical(monkeypatch, precision):
+    """the input gradient of a residual unit's 1x1 branch computed on the weight-gradient stream (its consumer, the BatchNorm backward of
+    the previous unit, waits for an event) == computed on the chain, bit for bit on every parameter gradient"""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import trainer
+    before = cdnet_amd.get_precision()
+    cdnet_amd.set_precision(precision)
+    try:
+        grads = []
+        for beside in (False, True):
+            monkeypatch.setattr(trainer, '_RU_1X1_SIDE', beside)
+            m, ref, x, t = _setup(B=2, S=64)
+            tr, g = _hip_grads(m, x, t)
+            grads.append(g)
+        for n in grads[0]:
+            assert torch.equal(grads[0][n], grads[1][n]), n
+    finally:
+        cdnet_amd.set_precision(before)
+
+
 def test_channel_sums_from_the_backward_data_launch_match_the_separate_pass(monkeypatch):
     """first BatchNorm-backward pass (sum dz, sum dz * xhat) accumulated by the movers of the backward-data launch that produced the
     gradient (cdnet_conv_args.ws = 2 + cdnet_bn_backward_finalize) against the separate reduce pass: same arithmetic per element,
