@@ -104,7 +104,7 @@ struct Ws32Lds {
 
 // XF: source transform decided by the launcher - 0 plain fp32, 1 x * scale + shift -> ReLU (training-mode BatchNorm source), 2 anything
 // (run-time flags: optional scale / shift, residual operand, ReLU).  STATS: per-tile channel sums of the accumulators.
-// The launcher guarantees: taps == 9, npar == 1, ostride == 1, H and W multiples of 16, nchunk >= 4, no pooled source, no fused residual
+// The launcher guarantees: taps == 9, npar == 1, ostride == 1, H and W multiples of 16, nchunk >= 1 (>= 4 with BNS), no pooled source, no fused residual
 // epilogue.
 // BNS (cdnet_conv_args.ws == 2, backward-data launches): the output is the gradient w.r.t. the activated output of a BatchNorm + ReLU
 // layer whose only reader this convolution was.  The first pass of that layer's BatchNorm backward - the channel sums of dz = dY * [act > 0]
@@ -114,7 +114,8 @@ struct Ws32Lds {
 // 32 consecutive couts of a pixel) one element ahead of its use.  oscale | oshift | eres_scale | eres_shift = that layer's BatchNorm
 // scale | shift | mean | invstd (f32 [Cout]); stats = partial rows f32 [4 * gridDim.x][2][Cout] for cdnet_bn_backward_finalize (one row
 // per consumer wave, written once at the end of the run).  No bias / epilogue affine / ReLU in this mode; BN = 64, Cout % 64 == 0.
-template <int BN, int XF, bool STATS, bool BNS = false>
+// NCS: chunks per tile known to the compiler - 0: four or more (the epilogue of a tile leaves over four intervals), 1: one, 2: two or three
+template <int BN, int XF, bool STATS, bool BNS = false, int NCS = 0>
 __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     static_assert(!BNS || (BN == 64 && !STATS), "the BatchNorm-backward statistics epilogue serves 64-channel blocks of backward-data launches");
     using L = Ws32Lds<BN>;
@@ -549,10 +550,15 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
                 // interval EPI of the tile (1..4): a quarter of the finished set's elements leave, one store (4 instructions) every sixth
                 // gap; the statistics ride in the first interval, two elements (4 instructions) in every third gap.  More than ~5 issued
                 // instructions in one gap hold up the next MFMA (a whole 4-store unit with its addresses in one gap cost 17 % of the kernel).
+                // Tiles of fewer than four chunks (the 16- / 32- / 48-channel layers: HBM-bound, the matrix pipe has the slack): EPI 5 = the
+                // whole finished tile in ONE interval (statistics as in EPI 1, a store in each of the other two gaps of three), EPI 6 / 7 =
+                // half of it each (a store in every third gap).
                 constexpr int QEL = NEL / 4;
-                if (EPI == 1 && STATS && g % 3 == 1 && 2 * (g / 3) + 1 < NEL) { stat_elem(P, 2 * (g / 3), par); stat_elem(P, 2 * (g / 3) + 1, par); }
-                if (g % 6 == 3 && g / 6 < QEL) img_elem(P, (EPI - 1) * QEL + g / 6);
-                if (BNS) {
+                if ((EPI == 1 || EPI == 5 || EPI == 6) && STATS && g % 3 == 1 && 2 * (g / 3) + 1 < NEL) { stat_elem(P, 2 * (g / 3), par); stat_elem(P, 2 * (g / 3) + 1, par); }
+                if (EPI <= 4 && g % 6 == 3 && g / 6 < QEL) img_elem(P, (EPI - 1) * QEL + g / 6);
+                if (EPI == 5 && g % 3 != 1 && 2 * (g / 3) + (g % 3 == 2 ? 1 : 0) < NEL) img_elem(P, 2 * (g / 3) + (g % 3 == 2 ? 1 : 0));
+                if ((EPI == 6 || EPI == 7) && g % 3 == 0 && g / 3 < NEL / 2) img_elem(P, (EPI - 6) * (NEL / 2) + g / 3);
+                if (BNS && EPI <= 4) {
                     // element i of the quarter (= block EPI - 1 of the finished set; raw buffer (EPI - 1) & 1): read in gap 1 (i = 0) or
                     // beside the sums of element i - 1, used six gaps later
                     if (g == 1) bns_read((EPI - 1) & 1, 0);
@@ -568,7 +574,8 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             __builtin_amdgcn_sched_barrier(0);
 #endif
         };
-        static_assert(3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3, "the deferred epilogue fits the MFMA gaps of an interval");
+        static_assert(3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3 && 2 * (TAPS * MPW * NPW) >= NEL,
+                      "the deferred epilogue fits the MFMA gaps of an interval");
 #pragma unroll
         for (int i = 0; i < NRD; ++i) request_one(0, i);
         __builtin_amdgcn_sched_barrier(0);
@@ -601,25 +608,45 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     using E2 = std::integral_constant<int, 2>;
     using E3 = std::integral_constant<int, 3>;
     using E4 = std::integral_constant<int, 4>;
+    using E5 = std::integral_constant<int, 5>;
+    using E6 = std::integral_constant<int, 6>;
+    using E7 = std::integral_constant<int, 7>;
     // tile j (run chunks q .. q + NCH - 1) on set C; P = the finished tile j - 1 (at p_*): its statistics ride in chunk interval 0, a quarter
     // of its stores in each of the intervals 0 .. 3
     auto tile_step = [&](auto has_prev, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int j, int q) {
         constexpr bool HP = decltype(has_prev)::value;
         const int par = (j + 1) & 1;
         if (HP) set_row_bases();
-        if (HP) interval(T_{}, E1{}, C, P, par, q & 1); else interval(T_{}, E0{}, C, P, par, q & 1);
-        if (HP && STATS) { stats_tile = t_lo + j - 1; stats_par = par; }
-        __syncthreads();
-        flush_stats();
-        if (HP) interval(F_{}, E2{}, C, P, par, (q + 1) & 1); else interval(F_{}, E0{}, C, P, par, (q + 1) & 1);
-        __syncthreads();
-        if (HP) interval(F_{}, E3{}, C, P, par, (q + 2) & 1); else interval(F_{}, E0{}, C, P, par, (q + 2) & 1);
-        __syncthreads();
-        if (HP) interval(F_{}, E4{}, C, P, par, (q + 3) & 1); else interval(F_{}, E0{}, C, P, par, (q + 3) & 1);
-        __syncthreads();
-        for (int i = 4; i < NCH; ++i) {
-            interval(F_{}, E0{}, C, P, par, (q + i) & 1);
+        if constexpr (NCS != 0) {
+            // one to three chunks per tile: the finished tile leaves in the first interval (one chunk) or the first two
+            if constexpr (NCS == 1) { if (HP) interval(T_{}, E5{}, C, P, par, q & 1); else interval(T_{}, E0{}, C, P, par, q & 1); }
+            else { if (HP) interval(T_{}, E6{}, C, P, par, q & 1); else interval(T_{}, E0{}, C, P, par, q & 1); }
+            if (HP && STATS) { stats_tile = t_lo + j - 1; stats_par = par; }
             __syncthreads();
+            flush_stats();
+            if constexpr (NCS == 2) {
+                if (HP) interval(F_{}, E7{}, C, P, par, (q + 1) & 1); else interval(F_{}, E0{}, C, P, par, (q + 1) & 1);
+                __syncthreads();
+                if (NCH == 3) {
+                    interval(F_{}, E0{}, C, P, par, (q + 2) & 1);
+                    __syncthreads();
+                }
+            }
+        } else {
+            if (HP) interval(T_{}, E1{}, C, P, par, q & 1); else interval(T_{}, E0{}, C, P, par, q & 1);
+            if (HP && STATS) { stats_tile = t_lo + j - 1; stats_par = par; }
+            __syncthreads();
+            flush_stats();
+            if (HP) interval(F_{}, E2{}, C, P, par, (q + 1) & 1); else interval(F_{}, E0{}, C, P, par, (q + 1) & 1);
+            __syncthreads();
+            if (HP) interval(F_{}, E3{}, C, P, par, (q + 2) & 1); else interval(F_{}, E0{}, C, P, par, (q + 2) & 1);
+            __syncthreads();
+            if (HP) interval(F_{}, E4{}, C, P, par, (q + 3) & 1); else interval(F_{}, E0{}, C, P, par, (q + 3) & 1);
+            __syncthreads();
+            for (int i = 4; i < NCH; ++i) {
+                interval(F_{}, E0{}, C, P, par, (q + i) & 1);
+                __syncthreads();
+            }
         }
         if (HP) {                                                // P has left: the finished tile is now the one just accumulated
             p_x0 += TW;
@@ -721,10 +748,11 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
     if ((A.debug >> 8) > 0 && (A.debug >> 8) < G) G = A.debug >> 8;      // tests: few workgroups, long runs of tiles
     if (G < 1) G = 1;
     dim3 grid(G, ctiles, 1);
-    auto launch = [&](auto xf_c, auto st_c) -> int {
+    auto launch_n = [&](auto xf_c, auto st_c, auto ncs_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
         constexpr bool STATS = decltype(st_c)::value;
-        auto kern = conv_ws32_kernel<BN, XF, STATS>;
+        constexpr int NCS = decltype(ncs_c)::value;
+        auto kern = conv_ws32_kernel<BN, XF, STATS, false, NCS>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -734,10 +762,22 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
         kern<<<grid, 512, smem, st>>>(A);
         return check_launch("conv_ws32_kernel");
     };
+    auto launch = [&](auto xf_c, auto st_c) -> int {
+        // tiles of one / two or three chunks (16- to 48-channel inputs): their own instantiations, and only for the source forms that
+        // occur there (plain or BatchNorm + ReLU) with 64 output channels per workgroup
+        constexpr int XF = decltype(xf_c)::value;
+        if (A.nchunk >= 4) return launch_n(xf_c, st_c, std::integral_constant<int, 0>{});
+        if constexpr (BN == 64 && XF != 2) {
+            if (A.nchunk == 1) return launch_n(xf_c, st_c, std::integral_constant<int, 1>{});
+            return launch_n(xf_c, st_c, std::integral_constant<int, 2>{});
+        }
+        return -1;
+    };
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
     using X2 = std::integral_constant<int, 2>;
     const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
+    if (A.nchunk < 4 && (BN != 64 || xf == 2)) return -1;          // (no small-tile instantiation for these)
     if (dry_run) return CDNET_OK;
     if (bns) {
         if constexpr (BN == 64) {
@@ -766,7 +806,8 @@ int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run) {
     static const int use_ws = getenv("CDNET_CONV_WS32") ? atoi(getenv("CDNET_CONV_WS32")) : 1;
     if ((!use_ws && !(A.debug & 64)) || (A.debug & 32)) return -1;
     if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || (A.eres && A.ws != 2) || (A.ws && A.ws != 2)) return -1;
-    if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < 4) return -1;
+    static const int min_chunks = getenv("CDNET_WS32_MIN_CHUNKS") ? atoi(getenv("CDNET_WS32_MIN_CHUNKS")) : 1;      // (4: round 3's first version)
+    if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < (A.ws == 2 ? 4 : (min_chunks < 1 ? 1 : min_chunks))) return -1;
     if (A.BN == 64) return try_launch_ws32<64>(A, st, dry_run);
     if (A.BN == 32) return try_launch_ws32<32>(A, st, dry_run);
     return -1;

@@ -381,6 +381,12 @@ def _ws32_case(N, cins, Cout, H, W, xf, stats=False, fold=False, offs=None, res=
     dict(N=1, cins=(256,), Cout=256, H=32, W=32, xf=0),                                 # long channel loop
     dict(N=2, cins=(64,), Cout=64, H=32, W=32, xf=2, res=True),                         # residual operand (run-time transform flags)
     dict(N=2, cins=(64,), Cout=32, H=32, W=32, xf=0, coff=16, cstride=64),              # channel slice of a wider output tensor
+    dict(N=2, cins=(16,), Cout=64, H=32, W=48, xf=0, stats=True),                       # ONE chunk per tile (the stem): the whole epilogue in one interval
+    dict(N=3, cins=(16,), Cout=64, H=32, W=32, xf=1, stats=True),                       # one chunk, BatchNorm source
+    dict(N=2, cins=(16,), Cout=80, H=32, W=32, xf=0),                                   # one chunk, two output-channel tiles, ragged couts (backward of 80 -> 16)
+    dict(N=2, cins=(32,), Cout=64, H=32, W=32, xf=1, stats=True),                       # two chunks
+    dict(N=2, cins=(32, 16), Cout=64, H=32, W=48, xf=1, fold=True, offs=(1, 2)),        # three chunks, two sources
+    dict(N=1, cins=(48,), Cout=128, H=16, W=32, xf=0),                                  # three chunks, one source
 ])
 def test_conv_ws32_matches_conv_f32_and_fp64(case):
     _ws32_case(**case)
