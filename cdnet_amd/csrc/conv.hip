@@ -943,17 +943,34 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int slot = ptid % VPP;
         u32x4v pa[PF][NA];
         u32x4v pr[XF == 3 ? PF : 1][NA];         // XF 3: the raw forward output beside the gradient
-        unsigned vm[PF];                         // bit i: vector i of the chunk is inside the image / source
-        int eo[PF][NA];                          // element offsets (only read for sources with a residual operand)
+        unsigned eo[PF][NA];                     // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
         // per-thread constants: halo coordinates and LDS offsets of its NA vectors
         int hyx[NA], doff[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int pix = (ptid + i * 256) / VPP;
             const int hy = pix / HW_, hx = pix - hy * HW_;
-            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 16) | hx) : -1;
+            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 8) | hx) : 0x1f1f;      // (31 = a vector that never exists: bit 31 of the masks is always set)
             doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
         }
+        // Requests through buffer descriptors (conv_ws32_kernel's recipe, round 3): a vector outside the image / the source window carries
+        // bit 31 in its byte offset and reads as zeros (the launcher admits tensors below 2 GB) - no select, no 64-bit address arithmetic and,
+        // for plain sources, no mask per vector: every vector instruction of a mover wave costs the consumers' MFMA stream issue time.
+        const unsigned src_bytes0 = (unsigned)(A.N * A.npar) * A.src[0].Hs * (A.src[0].row_stride ? A.src[0].row_stride : A.src[0].Ws * A.src[0].C) * 2u;
+        const unsigned src_bytes1 = A.nsrc > 1 ? (unsigned)(A.N * A.npar) * A.src[1].Hs * (A.src[1].row_stride ? A.src[1].row_stride : A.src[1].Ws * A.src[1].C) * 2u : 0u;
+        const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].x), 0, (int)src_bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.nsrc > 1 ? A.src[1].x : A.src[0].x), 0, (int)src_bytes1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].res ? A.src[0].res : A.src[0].x), 0, (int)src_bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.nsrc > 1 && A.src[1].res ? A.src[1].res : A.src[0].x), 0, (int)src_bytes1, 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff) -> u32x4v {
+            return __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+        };
+        // bits [lo, hi) clear, everything else set (lo, hi clamped to [0, 31])
+        auto bad_mask = [](int lo, int hi) -> unsigned {
+            lo = lo < 0 ? 0 : (lo > 31 ? 31 : lo);
+            hi = hi < lo ? lo : (hi > 31 ? 31 : hi);
+            return ~(((1u << hi) - 1u) & ~((1u << lo) - 1u));
+        };
         // cursors (no integer division per chunk): the issue cursor walks chunks 0, 1, 2, ... of the run and stops on the last
         // one; the commit cursor only needs the chunk-in-tile index
         int ik = 0, ic = 0, in_, iy0, ix0;
@@ -968,8 +985,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         int ck = 0;
         // staging geometry of the current tile and source (the chunks of one source share it): element offset of each vector
         // without the chunk's channel offset, validity mask
-        int ge[NA];
-        unsigned gm = 0;
+        unsigned ge[NA];                         // byte offset of channel 0 of the tile's vectors in the current source, bit 31 = zero fill
         const int n0 = A.src[0].C / CK;
         auto issue = [&](auto rc) {
             constexpr int R = decltype(rc)::value;
@@ -978,27 +994,28 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
             const ConvSrc &s = A.src[si];
             if (ik == 0 || ik == n0) {
                 const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
-                const int img = in_ * s.Hs * rs + slot * 8;
-                gm = 0;
+                // halo row r <-> y = iy0 - 1 + r, halo column c <-> x = ix0 - 1 + c; valid = inside the image and the source window
+                const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
+                const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;
+                const unsigned rowbad = bad_mask(ylo - (iy0 - 1), yhi - (iy0 - 1)), colbad = bad_mask(xlo - (ix0 - 1), xhi - (ix0 - 1));
+                const unsigned img_b = (unsigned)((in_ * s.Hs + (iy0 - 1 - s.off_y)) * rs + (ix0 - 1 - s.off_x) * s.C) * 2u;
+                const unsigned rs_b = (unsigned)rs * 2u, c_b = (unsigned)s.C * 2u;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const int y = iy0 - 1 + (hyx[i] >> 16), x = ix0 - 1 + (hyx[i] & 0xffff);
-                    const int ys = y - s.off_y, xs = x - s.off_x;
-                    const bool ok = hyx[i] >= 0 && (unsigned)y < (unsigned)A.H && (unsigned)x < (unsigned)A.W &&
-                                    (unsigned)ys < (unsigned)s.Hs && (unsigned)xs < (unsigned)s.Ws;
-                    ge[i] = ok ? img + ys * rs + xs * s.C : -1;
-                    gm |= (ok ? 1u : 0u) << i;
+                    const unsigned hy = (unsigned)hyx[i] >> 8, hx = (unsigned)hyx[i] & 0xffu;
+                    const unsigned t = (rowbad >> hy) | (colbad >> hx);
+                    ge[i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 16u) & 0x7fffffffu) | (t << 31);
                 }
             }
-            const unsigned short *base = s.x + cc0;
+            const __amdgpu_buffer_rsrc_t rsx = si ? rsx1 : rsx0;
+            const unsigned cc0_b = (unsigned)cc0 * 2u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int e = ge[i] >= 0 ? ge[i] : 0;
-                eo[R][i] = e + cc0;
-                pa[R][i] = *reinterpret_cast<const u32x4v *>(base + e);
-                if (XF == 3) pr[XF == 3 ? R : 0][i] = *reinterpret_cast<const u32x4v *>(s.res + cc0 + e);
+                const unsigned voff = ge[i] + cc0_b;                   // (a zero-fill vector keeps bit 31: beyond every tensor the launcher admits)
+                eo[R][i] = voff;
+                pa[R][i] = bload(rsx, voff);
+                if (XF == 3) pr[XF == 3 ? R : 0][i] = bload(si ? rsr1 : rsr0, voff);
             }
-            vm[R] = gm;
             // advance (saturating at the last chunk of the run)
             if (ic + 1 < S) {
                 ++ic;
@@ -1057,13 +1074,15 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                     raw.u = __builtin_bit_cast(uint4, pa[R][i]);
                     const bool relu = s.relu != 0, f16 = s.f16 != 0;
                     if (s.res) {
-                        rr.u = *reinterpret_cast<const uint4 *>(s.res + eo[R][i]);
+                        rr.u = __builtin_bit_cast(uint4, bload(si ? rsr1 : rsr0, eo[R][i]));
                         val = __builtin_bit_cast(u32x4v, xform8(raw, &rr, t, relu, f16).u);
                     } else if (!t.on && !relu && !f16) val = pa[R][i];
                     else val = __builtin_bit_cast(u32x4v, xform8(raw, nullptr, t, relu, f16).u);
                 }
-                const unsigned keep = (vm[R] >> i) & 1u ? 0xffffffffu : 0u;
-                val &= keep;
+                if (XF != 0) {                                   // (plain sources: the zero fill arrived as zeros)
+                    const unsigned keep = (int)eo[R][i] < 0 ? 0u : 0xffffffffu;
+                    val &= keep;
+                }
 #ifdef CDNET_WS_STAMPS
                 if (A.debug & 1024) { if (val[0] == 0x12345678u) *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val; continue; }
 #endif
@@ -1528,6 +1547,9 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) 
         if (A.src[i].pool) return -1;
         ctot += A.src[i].C;
         bnb = bnb || A.src[i].relu == 3;
+        // the movers' requests: 31-bit byte offsets from the source's base (bit 31 marks a zero-fill vector)
+        const long long rs_ = A.src[i].row_stride ? A.src[i].row_stride : (long long)A.src[i].Ws * A.src[i].C;
+        if ((long long)A.N * A.npar * A.src[i].Hs * rs_ * 2 >= (1LL << 31)) return -1;
     }
     if (bnb && (A.nsrc != 1 || !A.src[0].res || !A.src[0].scale || A.src[0].f16 != 0)) return -1;
 #ifdef CDNET_WS_STAMPS
