@@ -357,7 +357,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(BnBwdArgs A) {
                 const float dz = (!valid || (relu && !(bf2f(f2bf(v)) > 0.f))) ? 0.f : gs;
                 s1[j] += dz;
                 s2[j] = fmaf(dz, (x - mu[j]) * is[j], s2[j]);
+                if (RES) res[u].h[j] = f2bf(dz);                             // (the register is free: dz for the store below)
             }
+            // a residual unit's bn2: dz is the 1x1 branch's gradient and is stored anyway - by this pass, so that the second pass reads
+            // one tensor instead of the NG gradient sources and the mask again (cdnet_bn_backward; it then sees dz rounded to bf16)
+            if (RES && A.dz_out && valid) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)(p0 + u * step) * A.C + c0) = res[u].u;
         }
     }
 #pragma unroll
@@ -1739,6 +1743,8 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
         if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     }
     A.draw = draw; A.dz_out = dz_out;
+    static const bool dz_reuse = !(getenv("CDNET_BN_DZ_REUSE") && atoi(getenv("CDNET_BN_DZ_REUSE")) == 0);
+    if (!dz_reuse) A.dz_out = nullptr;                // (the sums pass stores dz only when the second pass is going to read it)
     // The apply pass re-reads what the reduce pass just streamed (raw + gradients, up to 2 x 134 MB against 256 MB of
     // Infinity Cache): walking it back to front meets the most recently cached lines first instead of chasing the LRU tail.
     static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
@@ -1789,10 +1795,18 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
                                                               k + A.C, k + 2 * A.C);
         A.k1 = k; A.k2 = k + A.C; A.k3 = k + 2 * A.C;
     }
+    A.dz_out = dz_out;
     if (window) {
         if (nflat == 0) bn_bwd_window_kernel<0, true><<<nb, 256, 0, st>>>(A, kp);
         else if (nflat == 1) bn_bwd_window_kernel<1, true><<<nb, 256, 0, st>>>(A, kp);
         else bn_bwd_window_kernel<2, true><<<nb, 256, 0, st>>>(A, kp);
+    } else if (flat && dz_reuse && A.mean && A.res && dz_out) {
+        BnBwdArgs B = A;
+        B.ngin = 1;
+        B.gin[0].g = dz_out; B.gin[0].Hg = A.H; B.gin[0].Wg = A.W; B.gin[0].oy = 0; B.gin[0].ox = 0; B.gin[0].pooled = 0;
+        B.gin[0].coff = 0; B.gin[0].cstride = A.C;
+        B.res = nullptr; B.relu = 0; B.dz_out = nullptr;
+        bn_bwd_apply_flat_kernel<1, false><<<nb, 256, 0, st>>>(B);
     } else if (flat) {
         switch (A.ngin * 2 + (A.res ? 1 : 0)) {
             case 2: bn_bwd_apply_flat_kernel<1, false><<<nb, 256, 0, st>>>(A); break;
@@ -1803,7 +1817,7 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
             default: bn_bwd_apply_flat_kernel<3, true><<<nb, 256, 0, st>>>(A); break;
         }
     } else if (window32) launch_window32<true>(A, nflat, kp, nb, st);
-    else if (flat32 && A.mean && A.res && dz_out && !(getenv("CDNET_BN_DZ_REUSE") && atoi(getenv("CDNET_BN_DZ_REUSE")) == 0)) {
+    else if (flat32 && A.mean && A.res && dz_out && dz_reuse) {
         // (the sums pass stored dz: one plain source, no mask, no second dz store - bit-identical, 9 instead of 12 tensor passes)
         BnBwdArgs B = A;
         B.ngin = 1;
