@@ -37,7 +37,7 @@ class BnBwdArgs(C.Structure):
 # layers of up to 128 x 128 pixels / larger ones
 _WGRAD_WGS_DEEP = int(os.environ.get('CDNET_WGRAD_WGS_DEEP', '128'))
 _WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
-_WGRAD_WGS_F32 = int(os.environ.get('CDNET_WGRAD_WGS_F32', '256'))
+_WGRAD_WGS_F32 = int(os.environ.get('CDNET_WGRAD_WGS_F32', '160'))      # (128 / 160 / 256: 989 / 994 / 987 tiles/s, three runs each on one box)
 _RU_1X1_SIDE = os.environ.get('CDNET_RU_1X1_SIDE', '1') != '0'      # residual units' 1x1 backward-data beside the chain
 _WGRAD_DEFER = 0x100                       # CDNET_WGRAD_DEFER_REDUCE (include/cdnet_hip.h)
 _WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
@@ -633,8 +633,8 @@ class Trainer:
             ntiles = N * (-(-H // 8)) * (-(-W // 16))
             # beside the input-gradient chain the weight-gradient kernels take fewer workgroups than there are CUs: a full grid of
             # them holds every CU's LDS, and the chain's producer / consumer convolutions (one 157 KB workgroup per CU) then queue
-            # behind it - measured 1 663 -> 1 745 / 1 730 -> 1 813 tiles/s (two boxes).  fp32 mode keeps the full grid: its
-            # weight-gradient stream is nearly as long as the chain (-1.7 % with the caps).
+            # behind it - measured 1 663 -> 1 745 / 1 730 -> 1 813 tiles/s (two boxes).  fp32 mode: 160 workgroups since the
+            # end of round 3 (+0.7 %; with round 2's kernels the caps cost 1.7 %).
             if not self._side_active or not getattr(L, 'needs_input_grad', True):
                 cap = 256                                   # (the first layer's weight gradient runs after the chain has ended: whole chip)
             elif runtime.PRECISION == 'fp32':
