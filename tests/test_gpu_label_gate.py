@@ -7,7 +7,10 @@ actually segments nuclei; the SAME weights then run (a) through the product path
 infer_image incl. TTA + sliding windows + device post-processing - and (b) through the fp32 CPU oracle
 (oracle.models.Unet + oracle.infer + oracle.postproc, each pinned to the reference).  The two instance-label maps are scored
 against each other with the reference's own metrics (stats_utils.get_fast_aji / get_dice_1, test_dam.py:591-669): AJI and
-Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.002.
+Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.002.  fp32 mode holds that mutual bar on every case
+(its label maps are identical); bf16 mode is held to north_star's literal bar - AJI / Dice of BOTH sides against the ground truth (the
+rendered instance map) within 0.002 - plus a mutual floor of 0.997 (mean) / 0.995 (single tile): one merged nucleus of ~40 moves a tile's
+mutual AJI by 0.003 without moving its ground-truth score.
 
 Both arithmetic modes of the product path are gated in one run: every test is parametrised over 'fp32' (fp32 activations,
 split-bf16 x3 MFMA products - the like-for-like mode) and 'bf16' (cdnet_amd.set_precision, restored afterwards).  The gate
@@ -25,6 +28,9 @@ AJI_MIN = 0.998
 DICE_MIN = 0.998
 ARGMAX_MIN = 0.999
 TILE_FLOOR = 0.995          # bf16 mode, a single 256x256 tile (one nucleus of ~40 merged or split moves a tile's AJI by ~0.003)
+BF16_MEAN_MIN = 0.997       # bf16 mode, mean over the tiles of the MUTUAL score (two gate networks of this round: 0.99830 and 0.99910);
+                            # the bar north_star states - ground-truth AJI / Dice of both sides within 0.002 - is asserted beside it
+GT_DELTA_MAX = 0.002
 
 
 def _train(precision, steps=300, B=8, seed=0):
@@ -114,13 +120,16 @@ def test_tiles_label_parity(trained):
     with torch.no_grad():
         r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda())
     got_mask, got_dir = r['prob'].argmax(1).cpu().numpy(), r['dcm'].cpu().numpy().reshape(3, 256, 256)
-    report = []
+    report, gt_scores = [], []
     for b in range(3):
         w = _oracle(('tile', b), lambda: oinf.infer_image(ref, x[b], tta=False, all_img_test=1))
         agree_m = (got_mask[b] == w['probs'][0].argmax(0)).mean()
         agree_d = (got_dir[b] == w['dcms'][0, 0]).mean()
         aji, dice = _score('tile %d' % b, r['final'][b].cpu().numpy(), w['final'], 20)
         report.append((b, agree_m, agree_d, aji, dice, int(w['count']), int(r['counts'][b])))
+        # north_star's literal bar: the scores of both sides against the ground truth (the rendered instance map)
+        gt_scores.append((_score('tile %d vs truth (HIP)' % b, r['final'][b].cpu().numpy(), inst[b], 20),
+                          _score('tile %d vs truth (oracle)' % b, w['final'], inst[b], 20)))
     print('label gate [%s] tiles: ' % prec + '; '.join('tile %d mask %.5f dir %.5f AJI %.5f Dice %.5f n=%d/%d' % t for t in report))
     # arg-max agreement per tile; AJI / Dice as the reference reports them - the mean over the images of the set (test_dam.py:693-716
     # averages per-image metrics; north_star: "AJI/Dice on MoNuSeg within +-0.002") - with a per-tile floor so that no single
@@ -130,7 +139,13 @@ def test_tiles_label_parity(trained):
         assert aji >= (AJI_MIN if prec == 'fp32' else TILE_FLOOR) and dice >= (DICE_MIN if prec == 'fp32' else TILE_FLOOR), (prec, b, aji, dice)
     m_aji, m_dice = float(np.mean([t[3] for t in report])), float(np.mean([t[4] for t in report]))
     print('label gate [%s] tiles: mean AJI %.5f mean Dice %.5f' % (prec, m_aji, m_dice))
-    assert m_aji >= AJI_MIN and m_dice >= DICE_MIN, (prec, m_aji, m_dice)
+    floor = AJI_MIN if prec == 'fp32' else BF16_MEAN_MIN
+    assert m_aji >= floor and m_dice >= floor, (prec, m_aji, m_dice)
+    g = np.array(gt_scores)                                   # [tile][side][AJI, Dice]
+    d_aji, d_dice = float(g[:, 0, 0].mean() - g[:, 1, 0].mean()), float(g[:, 0, 1].mean() - g[:, 1, 1].mean())
+    print('label gate [%s] tiles vs ground truth: AJI %.5f (oracle %.5f), Dice %.5f (oracle %.5f)'
+          % (prec, g[:, 0, 0].mean(), g[:, 1, 0].mean(), g[:, 0, 1].mean(), g[:, 1, 1].mean()))
+    assert abs(d_aji) <= GT_DELTA_MAX and abs(d_dice) <= GT_DELTA_MAX, (prec, d_aji, d_dice)
 
 
 def test_full_image_tta_label_parity(trained):
@@ -150,7 +165,12 @@ def test_full_image_tta_label_parity(trained):
     agree = (r['pred'].cpu().numpy() == w['pred']).mean()
     print('label gate [%s] 1000x1000 TTA: pred agreement %.6f AJI %.5f Dice %.5f instances %d/%d' % (prec, agree, aji, dice, w['count'], r['count']))
     assert agree >= ARGMAX_MIN, (prec, agree)
-    assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, aji, dice)
+    floor = AJI_MIN if prec == 'fp32' else BF16_MEAN_MIN
+    assert aji >= floor and dice >= floor, (prec, aji, dice)
+    # north_star's literal bar: both sides against the ground truth
+    (ga, gd), (wa, wd) = _score('1000x1000 vs truth (HIP)', got, inst, 200), _score('1000x1000 vs truth (oracle)', w['final'], inst, 200)
+    print('label gate [%s] 1000x1000 vs ground truth: AJI %.5f (oracle %.5f), Dice %.5f (oracle %.5f)' % (prec, ga, wa, gd, wd))
+    assert abs(ga - wa) <= GT_DELTA_MAX and abs(gd - wd) <= GT_DELTA_MAX, (prec, ga, wa, gd, wd)
 
 
 def test_dense_touching_nuclei_boost(trained):
@@ -174,4 +194,8 @@ def test_dense_touching_nuclei_boost(trained):
           % (prec, int(r['counts'][0]), int(w['count']), flips_got, flips_want, agree, aji, dice))
     assert flips_want > 0, 'the boost changed nothing on the dense tile: not a test of it'
     assert agree >= ARGMAX_MIN, (prec, agree)
-    assert aji >= AJI_MIN and dice >= DICE_MIN, (prec, aji, dice)
+    floor = AJI_MIN if prec == 'fp32' else BF16_MEAN_MIN
+    assert aji >= floor and dice >= floor, (prec, aji, dice)
+    (ga, gd), (wa, wd) = _score('dense vs truth (HIP)', r['final'][0].cpu().numpy(), inst[0], 60), _score('dense vs truth (oracle)', w['final'], inst[0], 60)
+    print('label gate [%s] dense tile vs ground truth: AJI %.5f (oracle %.5f), Dice %.5f (oracle %.5f)' % (prec, ga, wa, gd, wd))
+    assert abs(ga - wa) <= GT_DELTA_MAX and abs(gd - wd) <= GT_DELTA_MAX, (prec, ga, wa, gd, wd)
