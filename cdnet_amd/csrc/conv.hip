@@ -853,7 +853,7 @@ struct WsLds {
     static constexpr int IBLK = 32 * IROW;                        // one block: 32 couts x 32 pixels
     static constexpr int OUT_WAVE = 2 * (BN / 32) * IBLK;         // a consumer wave's 64 pixels x BN couts
     static constexpr int STATS_BYTES = 2 * 4 * 2 * BN * 4;        // double-buffered [wave][sum|sumsq][BN]
-    __host__ __device__ static int bytes(int nchunk, int ctot, int xf_rows = 2) {
+    __host__ __device__ static int bytes(int nchunk, int ctot, int xf_rows = 2) {      // (xf_rows: scale | shift)
         return nchunk * B_CHUNK + NSLOT * A_BYTES + 4 * OUT_WAVE + STATS_BYTES + xf_rows * ((ctot + 7) / 8 * 8) * 4;
     }
 };
@@ -862,21 +862,15 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));      // register st
 typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
 
 // XF: input transform of every source, decided by the launcher - 0 plain bf16, 1 fp16 raw x scale + shift -> ReLU (training-mode
-// BatchNorm source, packed math), 2 anything (run-time flags), 3 BatchNorm-backward source (ConvSrc.relu == 3: x = the bf16
-// gradient w.r.t. the activated output, res = the fp16 raw forward output, scale = a [7][C] table scale | shift | mean | invstd |
-// k1 | k2 | k3 - the movers apply the second BatchNorm-backward pass, k1 * (dz - k2 - xhat * k3) with dz = the ReLU-masked
-// gradient, while they stage: backward-data without the stored dRaw tensor on its critical path).
+// BatchNorm source, packed math), 2 anything (run-time flags).
 // STATS: per-tile channel sums of the unrounded accumulators.
 // STREAM: more than four chunks per tile (128+ input channels, two-source layers) - the weight tile no longer fits the LDS; its
 // chunks then stream through a four-slot ring by LDS-DMA, two chunks ahead of the consumers, beside the halo ring.
 // The launcher guarantees nchunk % 4 == 0 (== 4 without STREAM) and full tiles (H, W multiples of 16).
-// BNS (cdnet_conv_args.ws == 2, backward-data launches): the output is the gradient w.r.t. the activated output of a BatchNorm + ReLU
-// layer whose only consumer this convolution was - the movers, who hold every finished output vector in registers on its way to
-// global memory, also fetch the matching vector of that layer's raw forward output and accumulate the first BatchNorm-backward
-// pass (sum of dz, sum of dz * xhat per channel): eres = raw fp16 [N][H][W][Cout], oscale | oshift | eres_scale | eres_shift = that
-// layer's BatchNorm scale | shift | mean | invstd (f32 [Cout] each), stats = f32 partial rows [4 * gridDim.x][2][Cout] for the
-// finalize pass (cdnet_bn_backward_finalize).
-template <int BN, int TAPS, int XF, bool STATS, bool STREAM, bool BNS = false>
+// (Round 2's mover-side BatchNorm-backward experiments - the second pass applied while staging, XF 3, and the channel sums beside the
+// stores, cdnet_conv_args.ws = 2 - were correct and not faster: a vector instruction of a mover wave costs the matrix pipe issue time.
+// They were removed in round 3; the fp32 kernel carries the sums in the consumers' gaps instead, conv32ws.hip.)
+template <int BN, int TAPS, int XF, bool STATS, bool STREAM>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     using L = WsLds<BN, TAPS>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
@@ -900,7 +894,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     const int cout_tile = blockIdx.y;
     const int cout0 = cout_tile * BN;
 #ifdef CDNET_WS_STAMPS
-    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NWS, ctot, XF == 3 ? 7 : 2)) + (wave >= 4 ? 384 : 0);
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(smem + L::bytes(NWS, ctot, 2)) + (wave >= 4 ? 384 : 0);
     const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
     int sn = 0;
 #endif
@@ -942,7 +936,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int ptid = tid - 256;
         const int slot = ptid % VPP;
         u32x4v pa[PF][NA];
-        u32x4v pr[XF == 3 ? PF : 1][NA];         // XF 3: the raw forward output beside the gradient
         unsigned eo[PF][NA];                     // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
         // per-thread constants: halo coordinates and LDS offsets of its NA vectors
         int hyx[NA], doff[NA];
@@ -1014,7 +1007,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 const unsigned voff = ge[i] + cc0_b;                   // (a zero-fill vector keeps bit 31: beyond every tensor the launcher admits)
                 eo[R][i] = voff;
                 pa[R][i] = bload(rsx, voff);
-                if (XF == 3) pr[XF == 3 ? R : 0][i] = bload(si ? rsr1 : rsr0, voff);
             }
             // advance (saturating at the last chunk of the run)
             if (ic + 1 < S) {
@@ -1039,33 +1031,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            float bmu[8], bis[8], bk1[8], bk2[8], bk3[8];
-            if (XF == 3) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    bmu[j] = xf[2 * xfs + j]; bis[j] = xf[3 * xfs + j]; bk1[j] = xf[4 * xfs + j]; bk2[j] = xf[5 * xfs + j]; bk3[j] = xf[6 * xfs + j];
-                }
-            }
             unsigned char *dst0 = lds_a + R * L::A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
                 if (XF == 0) val = pa[R][i];
                 else if (XF == 1) val = xf_bnrelu_f16<false>(pa[R][i], pa[R][i], sc, sh);
-                else if (XF == 3) {
-                    // the arithmetic of bn_bwd_apply_flat_kernel<1, false> (train.hip), element for element
-                    V16 g8, r8, o8;
-                    g8.u = __builtin_bit_cast(uint4, pa[R][i]);
-                    r8.u = __builtin_bit_cast(uint4, pr[XF == 3 ? R : 0][i]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = h2f(r8.h[j]);
-                        const float v = fmaf(x, sc[j], sh[j]);
-                        const float dz = !(bf2f(f2bf(v)) > 0.f) ? 0.f : bf2f(g8.h[j]);
-                        o8.h[j] = f2bf(bk1[j] * (dz - bk2[j] - (x - bmu[j]) * bis[j] * bk3[j]));
-                    }
-                    val = __builtin_bit_cast(u32x4v, o8.u);
-                } else {
+                else {
                     ChanXf t;
                     t.on = s.scale != nullptr;
 #pragma unroll
@@ -1098,35 +1070,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const int pw = wave - 4;
         const int lg = lane >> 4, li = lane & 15;
         const unsigned char *s_img = lds_o + pw * L::OUT_WAVE + (li >> 2) * L::IROW + (li & 3) * 8;
-        // BNS: the raw forward vectors of the finished tile (requested one interval before they are used) and this lane's running sums
-        // for its KO cout octets
-        u32x4v rawv[BNS ? NP : 1];
-        float bs1[BNS ? KO : 1][8], bs2[BNS ? KO : 1][8], bsc[BNS ? KO : 1][8], bsh[BNS ? KO : 1][8], bmu_[BNS ? KO : 1][8], bis_[BNS ? KO : 1][8];
-        if (BNS) {
-#pragma unroll
-            for (int kk = 0; kk < KO; ++kk)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = cout0 + 8 * (lg + 4 * kk) + j;
-                    const bool cok = c < A.Cout;
-                    bs1[kk][j] = 0.f; bs2[kk][j] = 0.f;
-                    bsc[kk][j] = cok ? A.oscale[c] : 1.f;
-                    bsh[kk][j] = cok ? A.oshift[c] : 0.f;
-                    bmu_[kk][j] = cok ? A.eres_scale[c] : 0.f;
-                    bis_[kk][j] = cok ? A.eres_shift[c] : 0.f;
-                }
-        }
-        auto request_raw = [&](int rn, int ry0, int rx0) {
-            if (!BNS) return;
-#pragma unroll
-            for (int pc = 0; pc < NP; ++pc) {
-                const int mi = pc / (2 * KO), ch = (pc / KO) % 2, kk = pc % KO;
-                const int o = lg + 4 * kk;
-                const int y = ry0 + pw * 4 + mi * 2 + ch, x = rx0 + li, co = cout0 + 8 * o;
-                const size_t e = co < A.Cout ? (((size_t)rn * A.H + y) * A.W + x) * A.Cout + co : 0;
-                rawv[BNS ? pc : 0] = *reinterpret_cast<const u32x4v *>(A.eres + e);
-            }
-        };
         auto store_pieces = [&](bool now) {
             // all transposing reads first, into registers of their own, then the stores: with the pair of reads, the wait for them and
             // the store piece by piece through one register quad (what the compiler makes of a single loop) every piece paid the LDS
@@ -1149,20 +1092,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 if (now && s_ok && co < A.Cout) {
                     const uint2 a = __builtin_bit_cast(uint2, t1[pc]), b2 = __builtin_bit_cast(uint2, t2[pc]);
                     *reinterpret_cast<uint4 *>(A.out + (((size_t)s_n * A.H + y) * A.W + x) * A.out_cstride + A.out_coff + co) = make_uint4(a.x, a.y, b2.x, b2.y);
-                    if (BNS) {
-                        // the arithmetic of bn_bwd_reduce_flat_kernel<1, false> (train.hip), element for element
-                        V16 g8, r8;
-                        g8.u = make_uint4(a.x, a.y, b2.x, b2.y);
-                        r8.u = __builtin_bit_cast(uint4, rawv[BNS ? pc : 0]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float xr = h2f(r8.h[j]);
-                            const float v = fmaf(xr, bsc[BNS ? kk : 0][j], bsh[BNS ? kk : 0][j]);
-                            const float dz = !(bf2f(f2bf(v)) > 0.f) ? 0.f : bf2f(g8.h[j]);
-                            bs1[BNS ? kk : 0][j] += dz;
-                            bs2[BNS ? kk : 0][j] = fmaf(dz, (xr - bmu_[BNS ? kk : 0][j]) * bis_[BNS ? kk : 0][j], bs2[BNS ? kk : 0][j]);
-                        }
-                    }
                 }
             }
         };
@@ -1212,13 +1141,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         for (int c = ptid; c < ctot; c += 256) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
             const int cc = c < c0n ? c : c - c0n;
-            if (XF == 3) {
-#pragma unroll
-                for (int r = 0; r < 7; ++r) s_xf[r * xfs + c] = Sx.scale[r * Sx.C + cc];
-            } else {
-                s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
-                s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
-            }
+            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
         }
         __syncthreads();                                         // table + weights
         commit(I0{}, 0);
@@ -1235,7 +1159,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         // of tile j+1 and the out image of tile j-1 leaves for global memory.
         if (!STREAM) {
             for (int q0 = 0; q0 < S; q0 += 4) {
-                WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); request_raw(s_n, s_y0, s_x0); WS_STAMP(3); __syncthreads();
+                WS_STAMP(1); commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); WS_STAMP(3); __syncthreads();
                 WS_STAMP(1); commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); WS_STAMP(2); store_pieces(true); WS_STAMP(3); __syncthreads();
                 s_n = o_n; s_y0 = o_y0; s_x0 = o_x0; s_ok = true;
                 o_x0 += TW;
@@ -1252,12 +1176,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 commit(I2{}, q0 + 2); commit(I3{}, q0 + 3);
                 dma_w(); dma_w();
                 issue(I2{}); issue(I3{});
-                if (BNS && it == 0) {
-                    request_raw(s_n, s_y0, s_x0);
-                    stream_sync(std::integral_constant<int, 2 * NA + (BNS ? NP : 0)>{});      // the raw requests are younger than the halo requests
-                } else {
-                    stream_sync(NHL{});
-                }
+                stream_sync(NHL{});
                 store_pieces(it == 0);
                 commit(I0{}, q0 + 4); commit(I1{}, q0 + 5);
                 dma_w(); dma_w();
@@ -1271,23 +1190,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 }
             }
         }
-        request_raw(s_n, s_y0, s_x0);
         __syncthreads();                                         // the consumers have parked the last tile's out image
         store_pieces(true);
-        if (BNS) {
-            // one partial row per mover wave: the 16 lanes of a group hold the same cout octets for 16 different pixels
-            float *row = A.stats + (size_t)(blockIdx.x * 4 + pw) * 2 * A.Cout;
-#pragma unroll
-            for (int kk = 0; kk < KO; ++kk)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float a = bs1[BNS ? kk : 0][j], b2 = bs2[BNS ? kk : 0][j];
-#pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
-                    const int c = cout0 + 8 * (lg + 4 * kk) + j;
-                    if (li == 0 && c < A.Cout) { row[c] = a; row[A.Cout + c] = b2; }
-                }
-        }
 #ifdef CDNET_WS_STAMPS
         if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws_stamps[1024 + i] = s_stamp[i]; g_ws_stamps[1024 + sn] = 0; }
 #endif
@@ -1331,8 +1235,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
     for (int ni = 0; ni < NPW; ++ni) {
         const int co = cout0 + ni * 32 + l31;
         const bool cok = co < A.Cout;
-        e_osc[ni] = (!BNS && A.oscale && cok) ? A.oscale[co] : 1.f;
-        e_osh[ni] = BNS ? 0.f : fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
+        e_osc[ni] = (A.oscale && cok) ? A.oscale[co] : 1.f;
+        e_osh[ni] = fmaf((A.bias && cok) ? A.bias[co] : 0.f, e_osc[ni], (A.oshift && cok) ? A.oshift[co] : 0.f);
     }
     const bool f16out = A.out_f16 != 0;
     const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
@@ -1535,27 +1439,22 @@ template <int BN, int TAPS>
 int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) {
     using L = WsLds<BN, TAPS>;
     int ctot = 0;
-    const bool bns = A.ws == 2;                                  // BatchNorm-backward statistics of the output beside the stores (eres = raw)
-    if (A.eres && !bns) return -1;                               // fused residual epilogues stay on conv_fwd_kernel
-    if (bns && (!A.eres || !A.oscale || !A.oshift || !A.eres_scale || !A.eres_shift || !A.stats || A.bias || A.orelu || A.out_f16 ||
-                A.out_cstride != A.Cout || A.out_coff)) return -1;
+    if (A.ws == 2) return -1;                                    // (BatchNorm-backward sums beside the stores: the fp32 kernel only, conv32ws.hip)
+    if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
     if (A.nchunk < 4 || A.nchunk % 4 != 0) return -1;            // whole pairs of barrier intervals (two chunks each) per tile
     const bool stream = A.nchunk != 4;                           // 128+ input channels / two sources: the weight chunks stream through the LDS
     if (A.H % 16 != 0 || A.W % 16 != 0) return -1;               // full tiles only
-    bool bnb = false;
     for (int i = 0; i < A.nsrc; ++i) {
-        if (A.src[i].pool) return -1;
+        if (A.src[i].pool || A.src[i].relu == 3) return -1;
         ctot += A.src[i].C;
-        bnb = bnb || A.src[i].relu == 3;
         // the movers' requests: 31-bit byte offsets from the source's base (bit 31 marks a zero-fill vector)
         const long long rs_ = A.src[i].row_stride ? A.src[i].row_stride : (long long)A.src[i].Ws * A.src[i].C;
         if ((long long)A.N * A.npar * A.src[i].Hs * rs_ * 2 >= (1LL << 31)) return -1;
     }
-    if (bnb && (A.nsrc != 1 || !A.src[0].res || !A.src[0].scale || A.src[0].f16 != 0)) return -1;
 #ifdef CDNET_WS_STAMPS
-    const int smem = L::bytes(4, ctot, bnb ? 7 : 2) + 2 * 384 * 8;
+    const int smem = L::bytes(4, ctot, 2) + 2 * 384 * 8;
 #else
-    const int smem = L::bytes(4, ctot, bnb ? 7 : 2);
+    const int smem = L::bytes(4, ctot, 2);
 #endif
     if (smem > 160 * 1024) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
@@ -1602,27 +1501,13 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) 
     auto launch = [&](auto xf_c, auto st_c) -> int {
         return stream ? launch2(xf_c, st_c, std::true_type{}) : launch2(xf_c, st_c, std::false_type{});
     };
-    const int xf = bnb ? 3 : (all_plain ? 0 : (all_fast ? 1 : 2));
-    if (bns && xf != 0) return -1;
+    const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
     if (dry_run) return CDNET_OK;
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
     using X2 = std::integral_constant<int, 2>;
-    using X3 = std::integral_constant<int, 3>;
     int rc;
-    if (bns) {
-        auto kern = stream ? conv_ws_kernel<BN, TAPS, 0, false, true, true> : conv_ws_kernel<BN, TAPS, 0, false, false, true>;
-        static bool attr_done[2] = {false, false};
-        if (!attr_done[stream]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return check_launch("hipFuncSetAttribute(conv_ws)");
-            attr_done[stream] = true;
-        }
-        kern<<<grid, 512, smem, st>>>(A);
-        return check_launch("conv_ws_kernel");
-    }
-    if (xf == 3) rc = A.stats ? -1 : launch(X3{}, std::false_type{});
-    else if (A.stats) rc = xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
+    if (A.stats) rc = xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
     else rc = xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
     if (rc != CDNET_OK) return rc;
     return check_launch("conv_ws_kernel");
@@ -1815,9 +1700,8 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         if (rc >= 0) return rc;
     }
     for (int i = 0; i < A.nsrc; ++i)
-        CDNET_REQUIRE(A.src[i].relu != 3, "cdnet_conv_forward: a BatchNorm-backward source (relu = 3) needs the producer / consumer kernel "
-                                          "(ask cdnet_conv_ws_eligible first)");
-    CDNET_REQUIRE(A.ws != 2, "cdnet_conv_forward: the BatchNorm-backward statistics epilogue (ws = 2) needs the producer / consumer kernel "
+        CDNET_REQUIRE(A.src[i].relu >= 0 && A.src[i].relu <= 2, "cdnet_conv_forward: source %d: relu = %d (the BatchNorm-backward source of round 2, relu = 3, was removed)", i, A.src[i].relu);
+    CDNET_REQUIRE(A.ws != 2, "cdnet_conv_forward: the BatchNorm-backward statistics epilogue (ws = 2) exists in fp32 mode on conv_ws32_kernel only "
                              "(ask cdnet_conv_ws_eligible first)");
     if (dbg) { ConvArgs B = A; B.debug = dbg; if (B.taps == 9) return dispatch_conv<9>(B, st); }
     if (A.debug & 32) { ConvArgs B = A; B.debug = 0; if (B.taps == 9) return dispatch_conv<9>(B, st); if (B.taps == 4) return dispatch_conv<4>(B, st); return dispatch_conv<1>(B, st); }
@@ -1826,7 +1710,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     return dispatch_conv<1>(A, st);
 }
 
-/* 1 when cdnet_conv_forward would run these arguments on conv_ws_kernel (the only kernel that takes BatchNorm-backward sources) */
+/* 1 when cdnet_conv_forward would run these arguments on the producer / consumer kernel (conv_ws_kernel / conv_ws32_kernel) */
 extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);

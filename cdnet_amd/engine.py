@@ -36,9 +36,8 @@ class Src:
 
     def __init__(self, x, scale=None, shift=None, relu=False, pool=False, res=None, off=(0, 0), view=None):
         assert x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.is_contiguous()
-        # relu = 3: BatchNorm-backward source (x = bf16 gradient, res = the layer's fp16 raw forward output, scale = the [7][C] table
-        # of cdnet_bn_backward_stats); every other source keeps its residual branch in the storage type of x
-        assert res is None or res.dtype == x.dtype or (relu == 3 and x.dtype == torch.bfloat16 and res.dtype == torch.float16)
+        # a source keeps its residual branch in the storage type of x
+        assert res is None or res.dtype == x.dtype
         self.x, self.scale, self.shift, self.relu, self.pool, self.res, self.off = x, scale, shift, relu, pool, res, off
         if view is None:
             assert x.dim() == 4

@@ -388,20 +388,6 @@ class Trainer:
             a, ktab = self._bn_backward_stats(L, out, gl[0], partial=part)
             g = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
             _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(g), _lib.stream_ptr())
-        elif side is not None and self._fusable(L, srcs, out, gl, Hl, Wl):
-            # the second BatchNorm-backward pass leaves the critical chain: statistics here, backward-data applies the pass while it
-            # stages (cdnet_conv_src.relu = 3), the stored dRaw is produced beside it on the side stream for the weight gradient alone
-            a, ktab = self._bn_backward_stats(L, out, gl[0])
-            ev = self._event(k)
-            ev.record()
-            side.wait_event(ev)
-            with _on_stream(side):
-                draw = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
-                _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(draw), _lib.stream_ptr())
-                self._weight_backward(L, srcs, draw, Hl, Wl)
-                self._weights_done(params)
-            self._input_backward(L, srcs, Src(gl[0].t, ktab, ktab, relu=3, res=out), Hl, Wl, add)
-            return
         if part is not None:
             pass
         elif L.bn is not None or len(gl) > 1 or gl[0].pooled or gl[0].coff or (gl[0].cstride not in (0, Co)):
@@ -437,36 +423,9 @@ class Trainer:
                 self._weight_backward(L, srcs, g, Hl, Wl)
                 self._weights_done(params)         # (a bucket released here is ordered after both streams' work so far)
 
-    def _fusable(self, L, srcs, out, gl, H, W):
-        """plain BatchNorm + ReLU layer with one same-size gradient source whose backward-data launch runs on the producer / consumer
-        kernel (bf16 mode, 3x3, <= 256 output channels): see _layer_backward"""
-        # measured (bench.py, 16 tiles): the fused launch costs +45 us (the movers' per-element arithmetic makes them the slower half of the
-        # kernel) against the 30 us apply pass it takes off the chain, and the apply pass then competes with the chain from the side stream:
-        # 1 646 vs 1 683 tiles/s - off unless CDNET_BN_FUSE=1 (bit-identical either way: tests/test_gpu_train_step.py)
-        if os.environ.get('CDNET_BN_FUSE', '0') != '1' or runtime.act_dtype() != torch.bfloat16:
-            return False
-        No, Ho, Wo, Co = out.shape
-        if L.bn is None or len(gl) != 1 or getattr(L, 'node_res', None) is not None or not getattr(L, 'node_relu', True):
-            return False
-        g = gl[0]
-        if g.pooled or g.oy or g.ox or g.coff or (g.cstride not in (0, Co)) or (g.Hg, g.Wg) != (Ho, Wo):
-            return False
-        if L.kind != 'conv3' or L.transposed or not getattr(L, 'needs_input_grad', True) or Co > 256 or Co % 64:
-            return False
-        if out.dtype != torch.float16 or g.t.dtype != torch.bfloat16 or getattr(runtime, 'DEBUG_NORELU', False):
-            return False
-        key = ('fusable', L.name, No, H, W)
-        hit = self._bufs.get(key)
-        if hit is None:
-            cin_total = sum(s.C for s in srcs)
-            wpb, cfgb = L.backward_pack(cin_total, H, W)
-            ktab = self.buf(('ktab', L.name), (7, Co), torch.float32)
-            gin = self.buf(('din', L.name), (No, H, W, cin_total), runtime.act_dtype())
-            hit = engine.conv_forward([Src(g.t, ktab, ktab, relu=3, res=out)], wpb, cin_total, cfgb, taps=L.taps, out=gin, H=H, W=W, query_ws=True)
-            self._bufs[key] = hit
-        return hit
-
-    def _bn_backward_stats(self, L, out, g, partial=None):
+    def _bn_backward_stats(self, L, out, g, partial):
+        """finalize pass over the partial channel sums a backward-data launch left (cdnet_conv_args.ws = 2, fp32 mode): dgamma, dbeta and
+        the [7][C] table the second pass reads"""
         a = BnBwdArgs()
         No, Ho, Wo, Co = out.shape
         a.raw = out.data_ptr()
@@ -482,24 +441,18 @@ class Trainer:
         a.N, a.H, a.W, a.C = No, Ho, Wo, Co
         ktab = self.buf(('ktab', L.name), (7, Co), torch.float32)
         bn = L.bn
-        if partial is not None:
-            _lib.call('cdnet_bn_backward_finalize', C.byref(a), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.weight.grad), _lib.ptr(bn.bias.grad),
-                      _lib.ptr(partial), partial.shape[0], _lib.ptr(ktab), _lib.stream_ptr())
-            return a, ktab
-        ws = self._bn_ws(Co)
-        _lib.call('cdnet_bn_backward_stats', C.byref(a), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.weight.grad), _lib.ptr(bn.bias.grad),
-                  _lib.ptr(ws), ws.numel(), _lib.ptr(ktab), _lib.stream_ptr())
+        _lib.call('cdnet_bn_backward_finalize', C.byref(a), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.weight.grad), _lib.ptr(bn.bias.grad),
+                  _lib.ptr(partial), partial.shape[0], _lib.ptr(ktab), _lib.stream_ptr())
         return a, ktab
 
     def _stats_fusable(self, L, srcs, H, W, N, wpb, cfgb, cin_total):
         """the single lazily transformed BatchNorm + ReLU source of a 3x3 convolution that is its only reader, and a backward-data
         launch that runs on the producer / consumer kernel: returns (producer layer, partial-row buffer) or None"""
-        # measured (bench.py, 16 tiles): 11 reduce passes per step disappear (-0.9 ms of kernel time) but the launches that carry the sums
-        # cost +16 ... +33 us each (the movers' per-element arithmetic) and the step does not get shorter (1 643-1 659 vs 1 656-1 666
-        # tiles/s): off unless CDNET_BN_STATS_FUSE=1
-        # fp32 mode (conv_ws32_kernel): the sums ride in the CONSUMERS' deferred epilogue (raw quarters by DMA into LDS) - on by default
+        # fp32 mode only (conv_ws32_kernel): the sums ride in the CONSUMERS' deferred epilogue (raw quarters by DMA into LDS).  Round 2's
+        # 16-bit form - the sums accumulated by the movers of conv_ws_kernel - saved 11 reduce passes and was not faster (the movers'
+        # per-element arithmetic costs the matrix pipe issue time); it was removed in round 3.
         f32 = runtime.PRECISION == 'fp32'
-        if os.environ.get('CDNET_BN_STATS_FUSE', '1' if f32 else '0') != '1' or getattr(runtime, 'DEBUG_NORELU', False):
+        if not f32 or os.environ.get('CDNET_BN_STATS_FUSE', '1') != '1' or getattr(runtime, 'DEBUG_NORELU', False):
             return None
         if L.kind != 'conv3' or L.transposed or len(srcs) != 1:
             return None

@@ -269,9 +269,9 @@ int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const
  * nn.MaxPool2d(2, 2[, ceil_mode]) (model_unet_rev1.py:268-287 backbone 'M' layers, unet.py:19), F.pad offset - written out
  * as a plain bf16 NHWC tensor out[N][H][W][C]: bit-identical to what cdnet_conv_forward stages on the fly for the same
  * source (H, W = the logical size after the pool).  Consumers of a max-pooled training-mode activation read this copy. */
-/* 1 when cdnet_conv_forward runs these arguments on the producer / consumer kernel (conv_ws_kernel) - the only one that takes a
- * BatchNorm-backward source: cdnet_conv_src.relu = 3 with x = bf16 gradient w.r.t. the activated output, res = the fp16 raw forward
- * output of the layer, scale = the [7][C] table of cdnet_bn_backward_stats (single source, C <= 256). */
+/* 1 when cdnet_conv_forward runs these arguments on the producer / consumer kernel (conv_ws_kernel, fp32 mode: conv_ws32_kernel) - the
+ * only one that takes cdnet_conv_args.ws = 2 (fp32 mode: the BatchNorm-backward sums of the layer the output feeds, beside the stores).
+ * (Round 2's 16-bit BatchNorm-backward source, cdnet_conv_src.relu = 3, was removed in round 3: correct, not faster.) */
 int cdnet_conv_ws_eligible(const cdnet_conv_args *args);
 
 int cdnet_src_materialize(const cdnet_conv_src *src, int N, int H, int W, uint16_t *out, void *stream);
@@ -341,10 +341,10 @@ typedef struct cdnet_bn_bwd_args {
  * branch.  workspace: cdnet_bn_backward_workspace_floats(C) floats. */
 size_t cdnet_bn_backward_workspace_floats(int C);
 /* The two passes of cdnet_bn_backward as separate calls for the plain case (one same-size gradient source, BatchNorm + ReLU, no
- * residual branch, 16-bit tensors).  cdnet_bn_backward_stats = reduce + finalize; it also writes ktab f32 [7][C] =
- * scale | shift | mean | invstd | k1 | k2 | k3, the table cdnet_bn_backward_apply (the second pass alone: draw = k1 * (dz - k2 -
- * xhat * k3)) and a fused convolution source (cdnet_conv_src.relu = 3) read.  With them the second pass leaves the critical chain of
- * loss.backward() (train_util_dam.py:307): backward-data applies it while staging, the stored dRaw only feeds the weight gradient. */
+ * residual branch).  cdnet_bn_backward_stats (16-bit tensors) = reduce + finalize; it also writes ktab f32 [7][C] =
+ * scale | shift | mean | invstd | k1 | k2 | k3, the table cdnet_bn_backward_apply reads (the second pass alone: draw = k1 * (dz - k2 -
+ * xhat * k3); 16-bit and fp32 tensors).  The trainer uses finalize + apply behind a backward-data launch that carried the sums
+ * (cdnet_conv_args.ws = 2, fp32 mode). */
 int cdnet_bn_backward_stats(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, float *workspace,
                             size_t workspace_floats, float *ktab, void *stream);
 int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *args, const float *ktab, uint16_t *draw, void *stream);
