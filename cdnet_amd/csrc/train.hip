@@ -1871,7 +1871,8 @@ extern "C" int cdnet_bn_backward_stats(const cdnet_bn_bwd_args *a, const float *
 }
 
 /* finalize pass alone over partial rows f32 [nb][2][C] that somebody else produced (the backward-data kernel with
- * cdnet_conv_args.ws = 2): dgamma, dbeta and rows 4..6 (k1 | k2 | k3) of ktab; rows 0..3 are copied from the arguments */
+ * cdnet_conv_args.ws = 2): dgamma, dbeta and rows 4..6 (k1 | k2 | k3) of ktab - all cdnet_bn_backward_apply reads; rows 0..3 are left
+ * alone (their only reader, round 2's fused convolution source, is gone: nine copy launches per training step less) */
 extern "C" int cdnet_bn_backward_finalize(const cdnet_bn_bwd_args *a, const float *gamma, float *dgamma, float *dbeta, const float *partial,
                                           int nb, float *ktab, void *stream) {
     BnBwdArgs A;
@@ -1880,7 +1881,6 @@ extern "C" int cdnet_bn_backward_finalize(const cdnet_bn_bwd_args *a, const floa
     CDNET_REQUIRE(bn_plain_case(A) && gamma && partial && ktab && nb >= 1, "cdnet_bn_backward_finalize: plain case only");
     hipStream_t st = (hipStream_t)stream;
     const size_t npix = (size_t)A.N * A.H * A.W;
-    bn_ktab_copy_kernel<<<cdiv(A.C, 256), 256, 0, st>>>(A.scale, A.shift, A.mean, A.invstd, A.C, ktab);
     bn_bwd_finalize_kernel<<<A.C, 256, 0, st>>>(partial, nb, A.C, (float)npix, gamma, A.invstd, dgamma, dbeta, ktab + 4 * A.C, ktab + 5 * A.C,
                                                  ktab + 6 * A.C);
     return check_launch("cdnet_bn_backward_finalize");

@@ -351,7 +351,9 @@ int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *args, const float *ktab, ui
 /* The finalize pass alone, over partial rows f32 [nb][2][C] produced by the backward-data launch that computed this layer's output
  * gradient: cdnet_conv_args.ws = 2 with eres = the layer's raw fp16 forward output [N][H][W][Cout], oscale / oshift / eres_scale /
  * eres_shift = its BatchNorm scale / shift / batch mean / invstd (f32 [Cout]), stats = the partial rows (4 per workgroup of the
- * producer / consumer kernel, at most 1024: zero-fill the buffer once and pass nb = 1024).  The first BatchNorm-backward pass then costs no pass of its own over the two tensors. */
+ * producer / consumer kernel, at most 1024: zero-fill the buffer once and pass nb = 1024).  The first BatchNorm-backward pass then costs no pass of
+ * its own over the two tensors.  Writes dgamma, dbeta and rows 4..6 (k1 | k2 | k3) of ktab - what cdnet_bn_backward_apply reads; rows 0..3 are not touched
+ * (fp32 mode: eres = the raw fp32 output, conv_ws32_kernel). */
 int cdnet_bn_backward_finalize(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, const float *partial,
                                int nb, float *ktab, void *stream);
 int cdnet_bn_backward(const cdnet_bn_bwd_args *args, const float *gamma, float *dgamma, float *dbeta, float *workspace,
