@@ -34,6 +34,9 @@
 
 using namespace cdnet;
 
+#ifndef CDNET_WS32_NT_STORES
+#define CDNET_WS32_NT_STORES 1
+#endif
 #ifndef CDNET_WS32_SCALAR_SUB
 #define CDNET_WS32_SCALAR_SUB 1
 #endif
@@ -499,7 +502,11 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             char *sb = row_base[mi * 2 + (r >> 3)] + (s_col[((r >> 2) & 1) * 4 + (r & 3)] + (unsigned)(ni * 128));
             asm volatile("" : "+s"(sb));
             // (global_, not flat_: the asm hid the pointer's origin; uniform base + 32-bit lane offset = the store's saddr form)
+#if CDNET_WS32_NT_STORES
             __builtin_nontemporal_store(v, (__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + l_off));
+#else
+            *(__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + l_off) = v;
+#endif
         }
     };
     constexpr int NEL = MPW * NPW * 16;                          // elements of a set per lane; a quarter of them leaves per chunk interval
