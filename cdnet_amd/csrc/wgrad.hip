@@ -911,9 +911,13 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
 #endif
 constexpr int TH32 = 4, NPIX_A32 = (TH32 + 2) * HALO_W, NPIX_G32 = TH32 * TW;
 
-template <int XF>      // source transform: 0 plain fp32, 1 x * scale + shift -> ReLU, 2 run-time flags (scale / shift, residual, ReLU)
+// XF: source transform: 0 plain fp32, 1 x * scale + shift -> ReLU, 2 run-time flags (scale / shift, residual, ReLU).  TAPS: 9 (3x3), or 1
+// (the residual units' 1x1 convolutions: the same pipeline on the tile's inner 4 x 16 pixels - the halo vectors are never requested;
+// wgrad_f32_kernel took 250-470 us per launch for this HBM-bound product, one 4-wave workgroup per CU waiting out every load)
+template <int XF, int TAPS = 9>
 __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
-    constexpr int TAPS = 9, CI = 64, CO = 64, CO_T = 2;
+    constexpr int CI = 64, CO = 64, CO_T = 2;
+    static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     constexpr int PA = pstride(CI), PG = pstride(CO);
     constexpr int A_PLANE = NPIX_A32 * PA, G_PLANE = NPIX_G32 * PG, STAGE = 2 * A_PLANE + 2 * G_PLANE;      // [A_hi][A_lo][G_hi][G_lo]
     constexpr int VA = CI / 8, VG = CO / 8;
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
         for (int i = 0; i < NA; ++i) {
             const int v = ptid + i * 256, pix = v / VA;
             const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-            const bool exists = v < NPIX_A32 * VA && cok_a;
+            const bool exists = v < NPIX_A32 * VA && cok_a && (TAPS == 9 || (hy >= 1 && hy <= TH32 && hx >= 1 && hx <= TW));
             ahy[i] = exists ? hy : 31;
             ahx[i] = exists ? hx : 31;
             aoffb[i] = (unsigned)(hy * rs + hx * s.C + slot_a * 8) * 4u;
@@ -1165,14 +1169,17 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
             return __builtin_bit_cast(bf16x8, av);
         };
         // tap tau = ky * 9 + t of the tile (36 of them): input fragments of halo row ky + t / 3, column shift t % 3
-        auto a_off = [&](int tau) { return a_lane + ((tau / TAPS + (tau % TAPS) / 3) * HALO_W + (tau % TAPS) % 3) * PA; };
+        auto a_off = [&](int tau) {
+            return TAPS == 1 ? a_lane + ((tau + 1) * HALO_W + 1) * PA                      // 1x1: the pixel itself
+                             : a_lane + ((tau / TAPS + (tau % TAPS) / 3) * HALO_W + (tau % TAPS) % 3) * PA;
+        };
         constexpr int NTAU = TH32 * TAPS;
         constexpr int PFD = 3, RING = PFD + 1;                   // fragment pairs requested PFD taps (3 PFD MFMAs) ahead of their use
         bf16x8 ah[RING], al[RING], gh[2], gl[2];
         if (!(A.debug & 1)) {
             gh[0] = frag(g_lane, PG); gl[0] = frag(g_lane + G_PLANE, PG);
 #pragma unroll
-            for (int k = 0; k < PFD; ++k) { ah[k] = frag(a_off(k), PA); al[k] = frag(a_off(k) + A_PLANE, PA); }
+            for (int k = 0; k < PFD && k < NTAU; ++k) { ah[k] = frag(a_off(k), PA); al[k] = frag(a_off(k) + A_PLANE, PA); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tau = 0; tau < NTAU; ++tau) {
@@ -1186,8 +1193,8 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
                 if (tau + PFD < NTAU) al[(tau + PFD) % RING] = frag(a_off(tau + PFD) + A_PLANE, PA);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tau % RING], gh[ky & 1], acc[t], 0, 0, 0);
-                if (ky + 1 < TH32 && t == 2) gh[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG, PG);
-                if (ky + 1 < TH32 && t == 5) gl[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG + G_PLANE, PG);
+                if (ky + 1 < TH32 && t == (TAPS == 1 ? 0 : 2)) gh[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG, PG);
+                if (ky + 1 < TH32 && t == (TAPS == 1 ? 0 : 5)) gl[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG + G_PLANE, PG);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1344,13 +1351,14 @@ int launch_wgrad_gen(const WgradArgs &A, hipStream_t st) {
 }
 
 // the wave-specialised fp32 kernel: 3x3 layers on 64 x 64 channel blocks (ostride 1), tensors below 4 GB (32-bit byte offsets)
+template <int TAPS>
 int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
     constexpr int smem = 2 * (2 * NPIX_A32 * pstride(64) + 2 * NPIX_G32 * pstride(64));
     const ConvSrc &s = A.src;
     const bool plain = !s.scale && !s.relu && !s.res, fast = s.scale && s.shift && s.relu == 1 && !s.res;
     auto go = [&](auto xf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
-        auto kern = wgrad_ws32_kernel<XF>;
+        auto kern = wgrad_ws32_kernel<XF, TAPS>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1369,10 +1377,10 @@ int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
 template <int CI_T, int CO_T, int TAPS>
 int launch_wgrad_f32(const WgradArgs &A, hipStream_t st) {
     static const int use_ws32 = getenv("CDNET_WGRAD_WS32") ? atoi(getenv("CDNET_WGRAD_WS32")) : 1;
-    if (CI_T == 2 && CO_T == 2 && TAPS == 9 && use_ws32 && !(A.debug & 8) && A.ostride == 1 && A.npar == 1 && !A.src.pool &&
+    if (CI_T == 2 && CO_T == 2 && (TAPS == 9 || TAPS == 1) && use_ws32 && !(A.debug & 8) && A.ostride == 1 && A.npar == 1 && !A.src.pool &&
         (long long)A.N * A.H * A.W * (A.src.C > A.Cout ? A.src.C : A.Cout) < (1LL << 30) &&
         (long long)A.N * A.src.Hs * (A.src.row_stride ? A.src.row_stride : A.src.Ws * A.src.C) < (1LL << 30))
-        return launch_wgrad_ws32(A, st);
+        return launch_wgrad_ws32<(TAPS == 1 ? 1 : 9)>(A, st);
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int smem = 2 * (NPIX_A * pstride(CI) + NPIX_G * pstride(CO));
     auto kern = wgrad_f32_kernel<CI_T, CO_T, TAPS>;

@@ -58,6 +58,28 @@ def test_wgrad_fp32_conv3x3(case):
     assert _rel(got, want) < 5e-5, _rel(got, want)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 64, 24, 16, False), (3, 64, 64, 10, 20, True), (1, 128, 64, 7, 33, True), (2, 64, 128, 16, 48, False)])
+def test_wgrad_fp32_conv1x1_ws32(case):
+    """1x1 weight gradient on wgrad_ws32_kernel<XF, 1> (64 x 64 channel blocks): plain and BatchNorm + ReLU sources, ragged sizes (tiles
+    of 4 x 16 pixels cut by the image), several channel blocks, more slices than tiles"""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, fused = case
+    g = torch.Generator().manual_seed(17 + H)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    dy = torch.randn((N, Cout, H, W), generator=g)
+    if fused:
+        sc, sh = torch.rand((Cin,), generator=g) + 0.5, torch.randn((Cin,), generator=g) * 0.3
+        t = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        src = engine.Src(_nhwc(x), sc.cuda(), sh.cuda(), relu=True)
+    else:
+        t, src = x, engine.Src(_nhwc(x))
+    want = torch.nn.grad.conv2d_weight(t.double(), (Cout, Cin, 1, 1), dy.double())
+    got = _wgrad([src], _nhwc(dy), (Cout, Cin, 1, 1), 'conv1', H, W)
+    assert _rel(got, want) < 5e-5, _rel(got, want)
+
+
 def test_wgrad_fp32_transformed_sources_1x1_and_transposed():
     import torch
     import torch.nn.functional as F
