@@ -97,6 +97,11 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
             return tuple(override)
         small = min(H, W) <= 8 or (min(H, W) <= 16 and N <= 32)
         if small and Cout > 32:
+            # 16 x 16-pixel layers with long channel loops (the 512-channel bottleneck): 32-cout tiles give the persistent producer /
+            # consumer kernel one workgroup per CU (16 tiles x 16 cout tiles at 16 images) instead of 8 x 8 tiles on the one-tile kernel
+            if os.environ.get('CDNET_F32_WS16', '1') == '1' and taps == 9 and not transposed and H == 16 and W == 16 and \
+                    sum(src_channels) >= 256 and Cout >= 256 and 8 <= N <= 32:
+                return (16, 16, 32)
             return (8, 16, 64)
         return (16, 16, 64 if Cout > 32 else 32)
     if override is not None:
