@@ -130,7 +130,98 @@ def cpu_baseline_infer(n_tiles=4):
                        'probmaps/DDM/boost/CC chain (1 thread), median of %d repetitions after 2 warm-ups' % (n_tiles, cores, reps))
 
 
-def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5):
+def dominant_roofline(ms, B, precision, traffic=None, traffic_src=None, mfma_busy=None, clock=None, kernel=None):
+    """The `roofline` object of the dominant layer (3x3 conv 64->64 @256x256 x B tiles) from its measured launch duration `ms` (pure
+    arithmetic - tests/test_bench_contract.py calls it on the CPU).  `frac` is the ALGORITHMIC fraction of SURVEY 8d:
+    max(algorithmic flops / dense bf16 MFMA peak, algorithmic bytes / HBM peak) / measured time - 2*MACs of the layer and one read of
+    its input + one write of its output, whatever the kernel does internally.  The fp32 mode's three bf16 MFMAs per product are the
+    strategy's own overhead, not useful work: that view (3 x flops against the same peak) stays under `mfma_work_frac`."""
+    f32 = precision == 'fp32'
+    esz = 4 if f32 else 2
+    flops = 2.0 * B * 256 * 256 * 64 * 64 * 9             # algorithmic: 2*MACs of this layer (SURVEY 8d, forward hooks)
+    alg_bytes = B * 256 * 256 * (64 + 64) * esz           # algorithmic: input read once + output written once (SURVEY 8d)
+    t_mfma = flops / 1e12 / DENSE_BF16_PEAK_TFLOPS * 1e3  # ms at the dense bf16 peak
+    t_hbm = alg_bytes / 1e9 / HBM_PEAK_GBS * 1e3          # ms at the HBM peak
+    gbs = alg_bytes / ms / 1e6
+    tfl = flops / ms / 1e9
+    # bf16: 30.9 us of MFMA vs 33.6 us of HBM; fp32: 30.9 us vs 67.1 us -> the HBM term bounds this layer in both modes
+    if t_mfma > t_hbm:
+        head = dict(bound='mfma', achieved=tfl, peak=DENSE_BF16_PEAK_TFLOPS, unit='TFLOP/s', frac=t_mfma / ms)
+    else:
+        head = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=t_hbm / ms)
+    work = 3 if f32 else 1                                # bf16 MFMAs issued per algorithmic product
+    return dict(**head, hbm_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, kernel=kernel, dtype=precision,
+                mfma_busy_frac=mfma_busy, clock_mhz=clock, ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
+                mfma_tflops=tfl, mfma_frac=tfl / DENSE_BF16_PEAK_TFLOPS,
+                mfma_work_frac=work * tfl / DENSE_BF16_PEAK_TFLOPS, mfma_work_per_product=work,
+                vs_fp32_mfma_peak=(tfl / FP32_MATRIX_PEAK_TFLOPS if f32 else None))
+
+
+def committed_pmc(precision, B=16):
+    """(traffic bytes per launch, source note, matrix-pipe busy fraction, clock MHz) of the dominant kernel from the newest committed PMC
+    summary (tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv_<dtype>_pmc.json)"""
+    f32 = precision == 'fp32'
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
+        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_pmc.json' if f32 else 'dominant_conv_bf16_pmc.json')
+        if os.path.exists(tj) and B == 16:
+            with open(tj) as f:
+                pj = json.load(f)
+            return (pj.get('hbm_bytes_per_launch'),
+                    'profiles/%s/%s (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % (rnd, os.path.basename(tj)),
+                    pj.get('mfma_busy_frac'), pj.get('clock_mhz'))
+    return None, None, None, None
+
+
+def live_pmc_traffic(precision, kernel_names, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel measured IN THIS RUN when rocprofv3 is on the box: two child processes
+    `rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --mode roofline` (separate passes, the program right
+    after `--`, from /tmp: MI355X_MICROARCH.md's HBM / rocprofv3 section), FETCH_SIZE x 2 on gfx950 (a 16-B/lane read stream counts
+    half), both in KiB.  Returns (bytes, note) or (None, reason).  Children, not exec: this process keeps the GPU."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get('CDNET_BENCH_LIVE_PMC', '1') == '0':
+        return None, 'disabled (CDNET_BENCH_LIVE_PMC=0)'
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not on the box'
+    if any('rocprof' in (os.environ.get(k) or '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'ROCPROFILER_REGISTER_ROOT')):
+        return None, 'this process already runs under a profiler'
+    env = dict(os.environ)
+    env['TMPDIR'] = '/tmp'
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    vals = {}
+    out = tempfile.mkdtemp(prefix='cdnet_pmc_', dir='/tmp')
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(out, ctr)
+            cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 't', '--',
+                   sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'roofline', '--dtype', precision, '--steps', '20']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, 'rocprofv3 --pmc %s failed (rc %d)' % (ctr, r.returncode)
+            per = {}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get('Counter_Name') == ctr and any(w in row.get('Kernel_Name', '') for w in kernel_names):
+                            per[row['Dispatch_Id']] = per.get(row['Dispatch_Id'], 0.0) + float(row['Counter_Value'])
+            if len(per) < 10:
+                return None, 'no %s rows for the dominant kernel' % ctr
+            vals[ctr] = sum(per.values()) / len(per)
+        traffic = vals['FETCH_SIZE'] * 1024 * 2 + vals['WRITE_SIZE'] * 1024
+        return traffic, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of `bench.py --mode roofline '
+                         '--dtype %s`), per-launch mean, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB units' % precision)
+    except Exception as e:                               # (timeouts, parse errors: the committed summary is the fallback)
+        return None, 'live PMC pass failed: %r' % (e,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5, live_pmc=False):
     """Average launch duration of the dominant kernel (3x3 conv 64->64 @256x256, the head/stem shape), measured live
     with HIP events on the stream the kernel is launched on (torch's current stream == the ABI stream argument)."""
     from cdnet_amd import engine
@@ -155,63 +246,40 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    esz = 4 if f32 else 2
-    flops = 2.0 * B * 256 * 256 * 64 * 64 * 9             # algorithmic: 2*MACs of this layer (forward hooks)
-    alg_bytes = B * 256 * 256 * (64 + 64) * esz           # algorithmic: input read once + output written once
-    # roofline time = max(flops / MFMA peak, bytes / HBM peak): 30.9 us vs 33.6 us at B=16 bf16 -> the HBM term bounds this layer
-    # HBM traffic, matrix-pipe busy fraction and effective clock of this kernel from the committed PMC summary (separate rocprofv3 --pmc
-    # passes of `bench.py --mode roofline`, tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv_<fp32|bf16>_pmc.json); not re-measured here
-    traffic = traffic_src = mfma_busy = clock = None
-    for rnd in ('r03', 'r02', 'r01'):
-        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_pmc.json' if f32 else 'dominant_conv_bf16_pmc.json')
-        old = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_traffic.json')
-        if os.path.exists(tj) and B == 16:
-            with open(tj) as f:
-                pj = json.load(f)
-            traffic, mfma_busy, clock = pj.get('hbm_bytes_per_launch'), pj.get('mfma_busy_frac'), pj.get('clock_mhz')
-            traffic_src = 'profiles/%s/%s (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % (rnd, os.path.basename(tj))
-            break
-        if os.path.exists(old) and B == 16 and not f32:
-            with open(old) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
-            traffic_src = 'profiles/%s/dominant_conv_traffic.json (rocprofv3 --pmc passes, not re-measured in this run)' % rnd
-            break
-    gbs = alg_bytes / ms / 1e6
-    ws = not f32 and os.environ.get('CDNET_CONV_WS', '1') != '0'          # the library's default: conv_ws_kernel on the 64-channel layers
-    ws32 = f32 and os.environ.get('CDNET_CONV_WS32', '1') != '0'
-    name = ('conv_ws32_kernel' if ws32 else 'conv_f32_kernel') if f32 else ('conv_ws_kernel' if ws else 'conv_fwd_kernel')
-    mfma_peak = DENSE_BF16_PEAK_TFLOPS / 3 if f32 else DENSE_BF16_PEAK_TFLOPS
-    # which roof bounds the layer: max(MFMA work / dense bf16 peak, bytes / HBM peak).  bf16: 30.9 us vs 33.6 us -> HBM; fp32 (three bf16
-    # MFMAs per product): 92.8 us vs 67.1 us -> the matrix pipe.  The other fraction stays in hbm_frac / mfma_frac.
-    mfma_work_tflop = flops * (3 if f32 else 1) / 1e12
-    if mfma_work_tflop / DENSE_BF16_PEAK_TFLOPS > alg_bytes / 1e9 / HBM_PEAK_GBS:
-        head = dict(bound='mfma', achieved=mfma_work_tflop / (ms / 1e3), peak=DENSE_BF16_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=mfma_work_tflop / (ms / 1e3) / DENSE_BF16_PEAK_TFLOPS)
-    else:
-        head = dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS)
-    return dict(**head, hbm_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                kernel='%s<%s> 3x3 64->64 @256x256 x%d tiles' % (name, '64,9,0,false' if ws else ('64,0,false' if ws32 else ','.join(str(c) for c in cfg)), B), dtype=precision,
-                mfma_busy_frac=mfma_busy, clock_mhz=clock,
-                ms_per_launch=ms, algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
-                mfma_tflops=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / mfma_peak)
+    name = engine.dominant_kernel_name(precision)
+    # HBM traffic of this kernel: measured in this run by PMC child passes when asked and possible, else quoted from the committed
+    # summary; matrix-pipe busy fraction and clock always from the committed summary (six more passes: tools/prof_roofline_pmc.sh)
+    traffic, traffic_src, mfma_busy, clock = committed_pmc(precision, B)
+    if live_pmc and B == 16:
+        del x, out
+        torch.cuda.synchronize()
+        live, note = live_pmc_traffic(precision, (name.split('<')[0],))
+        if live is not None:
+            traffic, traffic_src = live, note
+        elif traffic_src is not None:
+            traffic_src += '; live pass: ' + note
+    return dominant_roofline(ms, B, precision, traffic, traffic_src, mfma_busy, clock,
+                             kernel='%s 3x3 64->64 @256x256 x%d tiles' % (name, B))
 
 
 def path_roofline(kind, precision, tiles_per_step, ms_per_step):
-    """Whole-step fraction of roofline in SURVEY 8d's units: roofline_time = max(FLOPs / peak_MFMA(dtype), bytes / peak_HBM) with
-    the algorithmic per-tile figures (every convolution reads its input once and writes its output once)."""
+    """Whole-step fraction of roofline in SURVEY 8d's units: roofline_time = max(FLOPs / peak_MFMA, bytes / peak_HBM) with the
+    algorithmic per-tile figures (every convolution reads its input once and writes its output once; 2*MACs) against the dense bf16
+    MFMA peak in BOTH modes.  `mfma_work_frac`: the matrix work the fp32 mode actually issues (three bf16 MFMAs per product)."""
     if kind == 'train':
         gflop = TRAIN_GFLOP_PER_TILE * tiles_per_step
         mb = TRAIN_MB_PER_TILE[precision] * tiles_per_step + OPT_MB_PER_STEP
     else:
         gflop = INFER_GFLOP_PER_TILE * tiles_per_step
         mb = (INFER_MB_PER_TILE[precision] + POSTPROC_MB_PER_TILE) * tiles_per_step + WEIGHT_MB[precision]
-    # fp32 mode: one product = three bf16 MFMAs, so its matrix roof is a third of the bf16 peak (5.3x gfx950's fp32 MFMA peak)
-    peak_tf = DENSE_BF16_PEAK_TFLOPS / 3 if precision == 'fp32' else DENSE_BF16_PEAK_TFLOPS
+    peak_tf = DENSE_BF16_PEAK_TFLOPS
     t_flop = gflop / peak_tf                      # ms  (GFLOP / (TFLOP/s) = ms)
     t_hbm = mb / HBM_PEAK_GBS                     # ms  (MB / (GB/s) = ms)
     t_roof = max(t_flop, t_hbm)
+    work = 3 if precision == 'fp32' else 1
     out = dict(frac=t_roof / ms_per_step, bound='mfma' if t_flop > t_hbm else 'hbm', roofline_ms=t_roof, hbm_ms=t_hbm, mfma_ms=t_flop,
-               hbm_frac=t_hbm / ms_per_step, mfma_frac=t_flop / ms_per_step, achieved_GBs=mb / ms_per_step, achieved_TFLOPs=gflop / ms_per_step,
+               hbm_frac=t_hbm / ms_per_step, mfma_frac=t_flop / ms_per_step, mfma_work_frac=work * t_flop / ms_per_step,
+               achieved_GBs=mb / ms_per_step, achieved_TFLOPs=gflop / ms_per_step,
                algorithmic_MB_per_step=mb, algorithmic_GFLOP_per_step=gflop, peak_GBs=HBM_PEAK_GBS, peak_TFLOPs=peak_tf)
     if precision == 'fp32':
         out['vs_fp32_mfma_peak'] = gflop / ms_per_step / FP32_MATRIX_PEAK_TFLOPS
@@ -335,6 +403,7 @@ def main():
                                  'split operands (hi*hi + hi*lo + lo*hi), <= 2^-16 relative error per product ("bf16x3"; not IEEE-fp32 '
                                  'multiplication: gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 rate)')},
     }
+    line['config']['process_group'] = ('%s, %d rank(s)' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else None
     rp = {}
     if mode != 'image':
         rp[kind + '_' + a.dtype] = path_roofline(kind, a.dtype, B, head['ms_per_step'])
@@ -362,7 +431,7 @@ def main():
         line['roofline_path'] = rp
     if rank == 0:
         cdnet_amd.set_precision(a.dtype)
-        line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype)
+        line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype, live_pmc=(world == 1 and extras))
         if extras and world == 1:
             line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)
         if not a.no_cpu_baseline and world == 1:

@@ -751,6 +751,7 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
     }
     int G = n_cu / ctiles;
     G = G > T ? T : G;
+    if (bns && G > 256) G = 256;                                  // ws == 2 writes 4 * G partial rows into the caller's CDNET_BNS_PARTIAL_ROWS = 1024
     if (G >= 8) G &= ~7;
     if ((A.debug >> 8) > 0 && (A.debug >> 8) < G) G = A.debug >> 8;      // tests: few workgroups, long runs of tiles
     if (G < 1) G = 1;

@@ -132,6 +132,14 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
     return (16, ck, bn)
 
 
+def dominant_kernel_name(precision):
+    """the kernel cdnet_conv_forward runs the dominant layer (3x3 64 -> 64 on full 16x16 tiles) on - what bench.py's `roofline` object and
+    the profile filters name"""
+    if precision == 'fp32':
+        return 'conv_ws32_kernel<64,0,false>' if os.environ.get('CDNET_CONV_WS32', '1') != '0' else 'conv_f32_kernel<16,16,64,4,1,9>'
+    return 'conv_ws_kernel<64,9,0,false,false>' if os.environ.get('CDNET_CONV_WS', '1') != '0' else 'conv_fwd_kernel<16,16,16,64,4,1,9>'
+
+
 def packed_elems(Cout, nchunk, taps, CK, BN, npar):
     return _lib.load().cdnet_conv_packed_weight_elems(Cout, nchunk, taps, CK, BN, npar)
 

@@ -271,7 +271,7 @@ class FuseNode:
             if d is None:
                 return
         else:
-            gl = grads.pop(id(o), None)
+            gl = tr.take(grads, id(o))
             if gl is None:
                 return
             if relu or len(gl) > 1 or gl[0].coff or gl[0].cstride not in (0, Cc):

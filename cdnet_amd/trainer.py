@@ -216,11 +216,23 @@ class Trainer:
         entry = 'cdnet_grad_sum_f32' if out.dtype == torch.float32 else 'cdnet_grad_sum'
         _lib.call(entry, C.byref(arr), len(gl), None if mask is None else _lib.ptr(mask), npix, Cc, _lib.ptr(out), _lib.stream_ptr())
 
+    def take(self, grads, key):
+        """pop the gradient contributions of a stored tensor for a consumer on the CURRENT stream: a contribution computed beside the chain
+        (_RU_1X1_SIDE: the residual units' 1x1 backward-data on the weight-gradient stream) carries an event the consumer's stream must
+        wait for first - wherever the list is consumed (a layer's BatchNorm backward, cat_grad, FuseNode.backward)"""
+        gl = grads.pop(key, None)
+        if gl is not None:
+            for g_ in gl:
+                if g_.event is not None:
+                    torch.cuda.current_stream().wait_event(g_.event)
+                    g_.event = None
+        return gl
+
     def cat_grad(self, o, grads):
         """gradient of a concatenation buffer (several consumers, several writers): summed once per backward"""
         key = id(o)
         if key not in self._cat_cache:
-            gl = grads.pop(key, None)
+            gl = self.take(grads, key)
             if gl is None:
                 d = None
             elif len(gl) == 1 and not gl[0].coff and gl[0].cstride in (0, o.shape[3]):
@@ -299,6 +311,10 @@ class Trainer:
         """walk the forward tape backwards: BatchNorm(+ReLU, residual, pool/pad/concat routing) backward, then the
         weight and input gradients of every convolution that received a gradient"""
         self._cat_cache = {}
+        # (a backward that raised midway - CDNET_REQUIRE failure, OOM - must not leave its deferred split-K descriptors to this one)
+        self._rd_pending, self._rd_params, self._rd_bytes = [], [], 0
+        if len(self._rd_tables) > 16:
+            self._rd_tables.clear()                 # (one small device table per distinct call sequence: batch-size changes add entries)
         # who reads what: a BatchNorm layer whose raw output has exactly one reader - a 3x3 convolution - gets the first pass of its
         # backward (the channel sums) from that reader's backward-data launch (_input_backward), see _stats_fusable
         self._readers, self._producer, self._bn_partials = {}, {}, {}
@@ -319,7 +335,7 @@ class Trainer:
             if isinstance(L, runtime.FuseNode):
                 L.backward(self, grads, add)
                 continue
-            gl = grads.pop(id(L.saved[1]), None)
+            gl = self.take(grads, id(L.saved[1]))
             if gl is None:
                 continue
             owner = getattr(L, 'fused_res_of', None)
@@ -333,7 +349,7 @@ class Trainer:
             d = getattr(L, 'deferred_layer', None)
             if d is not None:
                 L.deferred_layer = None
-                self._layer_backward(('deferred', k), d, grads.pop(id(d.saved[1])), grads, add, side)
+                self._layer_backward(('deferred', k), d, self.take(grads, id(d.saved[1])), grads, add, side)
         if side is not None:
             with _on_stream(side):
                 self._flush_reduces()
@@ -385,6 +401,7 @@ class Trainer:
         part = self._bn_partials.pop(id(out), None)
         if part is not None:
             # the reader's backward-data launch left the channel sums: finalize + second pass only
+            assert len(gl) == 1, (L.name, len(gl))
             a, ktab = self._bn_backward_stats(L, out, gl[0], partial=part)
             g = self.buf(('draw', L.name), (No, Ho, Wo, Co), runtime.act_dtype())
             _lib.call('cdnet_bn_backward_apply', C.byref(a), _lib.ptr(ktab), _lib.ptr(g), _lib.stream_ptr())

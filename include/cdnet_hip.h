@@ -165,7 +165,10 @@ typedef struct cdnet_conv_args {
                                persistent kernels (conv_ws_kernel; conv_ws32_kernel of the fp32 path), 64 = take them even for
                                small launches; bits 8..: at most (debug >> 8) persistent workgroups per output-channel tile (long
                                runs of tiles on small test shapes; conv_ws32_kernel); other bits: ablations of tools/bench_conv.py */
-    int ws;                 /* reserved, must be 0 */
+    int ws;                 /* 0, or 2 (fp32 mode, conv_ws32_kernel only - ask cdnet_conv_ws_eligible): the launch also leaves the first
+                               BatchNorm-backward pass of the layer its output feeds; eres / oscale / oshift / eres_scale / eres_shift /
+                               stats then carry that layer's raw output, scale, shift, mean, invstd and the partial rows f32
+                               [1024][2][Cout] (at most 4 x 256 workgroups write rows; see cdnet_bn_backward_finalize) */
     int f32;                /* 1: fp32 precision - x / res / eres / out are fp32 tensors (every source has f16 = 2), `w` is the split
                                pack (mode | CDNET_PACK_SPLIT), each product runs as three bf16 MFMAs over (hi, lo) operand pairs with
                                fp32 accumulation; CK = 16, no pooled sources (materialise them).  0: the 16-bit path. */

@@ -315,7 +315,7 @@ def test_conv_fp32_full_tile_epilogue_is_bit_identical_to_the_general_one(eres):
 # Every case runs with few persistent workgroups (debug >> 8), so that a workgroup walks several tiles (odd and even numbers of
 # chunk intervals, the deferred two-half epilogue, the serial epilogue of the last tile), and with the default grid.
 # ----------------------------------------------------------------------------------------------------------------------------------
-def _ws32_case(N, cins, Cout, H, W, xf, stats=False, fold=False, offs=None, res=False, coff=0, cstride=None, seed=0):
+def _ws32_case(N, cins, Cout, H, W, xf, stats=False, fold=False, offs=None, res=False, coff=0, cstride=None, seed=0, bn=None):
     import torch
     import torch.nn.functional as F
     from cdnet_amd import engine
@@ -350,7 +350,7 @@ def _ws32_case(N, cins, Cout, H, W, xf, stats=False, fold=False, offs=None, res=
     raw = want
     if fold:
         want = F.relu(want * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1))
-    cfg = (16, 16, 64 if Cout > 32 else 32)                 # (choose_cfg would take 8x8 tiles for the few-pixel cases)
+    cfg = (16, 16, bn or (64 if Cout > 32 else 32))         # (choose_cfg would take 8x8 tiles for the few-pixel cases)
     wp = engine.pack_weights(w.cuda(), cfg, 0, split=True)
     outs = {}
     for name, dbg in (('old', 32), ('ws_few', 64 | (3 << 8)), ('ws_five', 64 | (5 << 8)), ('ws', 64)):
@@ -409,6 +409,12 @@ def _ws32_case(N, cins, Cout, H, W, xf, stats=False, fold=False, offs=None, res=
     dict(N=2, cins=(32,), Cout=64, H=32, W=32, xf=1, stats=True),                       # two chunks
     dict(N=2, cins=(32, 16), Cout=64, H=32, W=48, xf=1, fold=True, offs=(1, 2)),        # three chunks, two sources
     dict(N=1, cins=(48,), Cout=128, H=16, W=32, xf=0),                                  # three chunks, one source
+    # the route of the timed workload's bottleneck (engine.choose_cfg, CDNET_F32_WS16: 16 x 16-pixel layers with >= 256 channels at
+    # 8 <= N <= 32 take 32-cout tiles on conv_ws32_kernel): the 768 -> 256 decoder convolution (model_unet_rev1.py:119-143; two sources,
+    # a 48-chunk loop) and a 512 -> 512 encoder layer (32 chunks), one image tile per image
+    dict(N=16, cins=(256, 512), Cout=256, H=16, W=16, xf=1, stats=True, bn=32),
+    dict(N=16, cins=(512,), Cout=512, H=16, W=16, xf=1, stats=True, bn=32),
+    dict(N=8, cins=(512,), Cout=512, H=16, W=16, xf=0, bn=32),                          # its backward-data form (plain gradient source)
 ])
 def test_conv_ws32_matches_conv_f32_and_fp64(case):
     _ws32_case(**case)

@@ -284,3 +284,28 @@ def test_fp32_mode_two_steps_follow_the_reference_train_loop(golden, fp32_mode):
         np.testing.assert_allclose(got[:5], z['results'][it][:5], rtol=2e-4 if it == 0 else 5e-2, err_msg='iteration %d' % it)
     sd = m.state_dict()
     np.testing.assert_allclose(sd['bn1.running_mean'].cpu().numpy(), z['rm_bn1.running_mean'], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_residual_1x1_backward_beside_the_chain_is_bit_identical_on_hrnet(monkeypatch, precision):
+    """HRNet's first residual unit reads the concatenation of the four branches: the input gradient of its 1x1 branch - computed on the
+    weight-gradient stream (trainer._RU_1X1_SIDE) - is consumed by FuseNode.backward / Trainer.cat_grad, not by a convolution layer's
+    BatchNorm backward.  Every consumer of a gradient list waits for the producing stream's event (Trainer.take): beside == on the chain,
+    bit for bit on every parameter gradient (a missed wait reads a half-written buffer and shows up here)."""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import trainer
+    before = cdnet_amd.get_precision()
+    cdnet_amd.set_precision(precision)
+    try:
+        grads = []
+        for beside in (False, True, True):
+            monkeypatch.setattr(trainer, '_RU_1X1_SIDE', beside)
+            m, ref, x, t = _setup(B=2, S=128)
+            _, g = _hip_grads(m, x, t)
+            grads.append(g)
+        for g in grads[1:]:
+            for n in grads[0]:
+                assert torch.equal(grads[0][n], g[n]), n
+    finally:
+        cdnet_amd.set_precision(before)

@@ -176,6 +176,78 @@ def test_full_size_step_is_deterministic_and_learns():
     assert (l1[:, 6:] >= 0).all() and (l1[:, 6:] <= 1).all()          # the pixel-level metrics are ratios
 
 
+def test_full_size_fp32_step_is_deterministic_learns_and_matches_the_one_tile_kernels(monkeypatch):
+    """The timed workload of bench.py in the arithmetic of its headline: 16 tiles of 256x256, fp32 mode (train_util_dam.py:303-308;
+    the 768 -> 256 @16x16 decoder convolution of model_unet_rev1.py:119-143 and the 512-channel bottleneck take engine.choose_cfg's
+    CDNET_F32_WS16 route only at this size).  Two runs from the same state are bit-identical, the loss falls; then the first step's
+    loss and gradients against the same step with (a) CDNET_F32_WS16=0 (8x8 tiles on conv_f32_kernel for those layers: other tile
+    partition of the BatchNorm statistics), (b) CDNET_BN_STATS_FUSE=0 (the separate reduce pass: other summation order) and (c)
+    engine.CONV_DEBUG = 32 (one-tile kernels only, the fp64-checked baseline of tests/test_gpu_fp32_kernels.py).  The convolution
+    outputs of all routes are bit-identical; what differs is the order in which per-tile channel sums are added, so the forward
+    agrees to 1e-6 and the gradients within the conditioning of a randomly initialised ReLU network."""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import engine, trainer
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    dev = torch.device('cuda:0')
+    batch = trainer.synthetic_batch(16, dev, seed=11)
+    before = cdnet_amd.get_precision()
+    cdnet_amd.set_precision('fp32')
+
+    def fresh():
+        torch.manual_seed(3)
+        return Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).to(dev)
+
+    def run(steps):
+        m = fresh()
+        tr = trainer.Trainer(m)
+        losses = [tr.train_step(*batch).clone() for _ in range(steps)]
+        torch.cuda.synchronize()
+        return tr, tr.flat.P.clone(), torch.stack(losses).cpu().numpy()
+
+    def first_step():
+        m = fresh()
+        tr = trainer.Trainer(m)
+        out = tr.forward(batch[0])
+        g = tr.loss_and_grads(out[0], out[1], out[2], *batch[1:])
+        tr.backward(*g)
+        torch.cuda.synchronize()
+        return tr, float(tr.losses[0]), tr.flat.G[:tr.flat.n_used].clone()
+
+    try:
+        tr1, p1, l1 = run(3)
+        # the routes under test were really taken at this size
+        cfgs = {L.name: L.cfg for L in tr1.tape if hasattr(L, 'cfg')}
+        assert cfgs['upsample_blocks.0.conv2'] == (16, 16, 32) and cfgs['backbone.37'] == (16, 16, 32), cfgs
+        fused = [k for k, v in tr1._bufs.items() if isinstance(k, tuple) and k and k[0] == 'statsfusable' and v is not False]
+        assert len(fused) >= 6, fused
+        _, p2, l2 = run(3)
+        assert np.isfinite(l1).all() and torch.equal(p1, p2) and np.array_equal(l1, l2)
+        assert l1[-1, 0] < l1[0, 0]
+        _, loss0, g0 = first_step()
+        variants = {}
+        monkeypatch.setenv('CDNET_F32_WS16', '0')
+        trv, variants['ws16=0'], gv = first_step()
+        assert {L.name: L.cfg for L in trv.tape if hasattr(L, 'cfg')}['backbone.37'] == (8, 16, 64)
+        grads = {'ws16=0': gv}
+        monkeypatch.delenv('CDNET_F32_WS16')
+        monkeypatch.setenv('CDNET_BN_STATS_FUSE', '0')
+        _, variants['bnfuse=0'], grads['bnfuse=0'] = first_step()
+        monkeypatch.delenv('CDNET_BN_STATS_FUSE')
+        monkeypatch.setattr(engine, 'CONV_DEBUG', 32)
+        _, variants['one-tile'], grads['one-tile'] = first_step()
+        monkeypatch.setattr(engine, 'CONV_DEBUG', 0)
+        for name, lv in variants.items():
+            assert abs(lv - loss0) <= 2e-6 * abs(loss0), (name, lv, loss0)
+            rel = float((grads[name] - g0).norm() / g0.norm())
+            assert rel <= 5e-2, (name, rel)                   # (flat gradient vector; per-tensor spread as in the test below)
+            nh = tr1.flat.n_head
+            relh = float((grads[name][:nh] - g0[:nh]).norm() / g0[:nh].norm())
+            assert relh <= 1e-4, (name, relh)                 # the head block sits above every ReLU decision that can flip
+    finally:
+        cdnet_amd.set_precision(before)
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])
 def test_deferred_batched_split_k_reduce_is_bit_identical(monkeypatch, precision):
     """weight gradients with their split-K sums deferred into a few cdnet_wgrad_reduce_batch launches (one slab buffer per call; the
