@@ -46,6 +46,7 @@ SIGNATURES = {
     'cdnet_cc_chain': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_conv_packed_weight_elems': (_sz, [_i] * 6),
     'cdnet_pack_conv_weights': (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    'cdnet_pack_conv_weights_scaled': (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp]),
     'cdnet_pack_batch_table_bytes': (_sz, [_i]),
     'cdnet_pack_conv_weights_batch': (_i, [_vp, _i, _vp, _sz, _i, _vp]),
     'cdnet_conv_forward': (_i, [_vp, _vp]),

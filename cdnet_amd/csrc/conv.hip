@@ -19,34 +19,17 @@
 #include "common.h"
 #include "conv_args.h"
 #include "xform.h"
+#include "stage16.h"
 #include <stdlib.h>
 
 using namespace cdnet;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
 __device__ int g_dbg_dummy;
-
-__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
-__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
-__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
-// storage formats: 0 = bf16 (activated tensors, gradients: MFMA operands), 1 = fp16 (raw pre-BatchNorm outputs and
-// residual branches: the consumer's affine must see more than bf16's 8 significant bits when |mean| >> std)
-__device__ __forceinline__ float ld16(unsigned short u, bool f16) { return f16 ? h2f(u) : bf2f(u); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    __bf16 b = (__bf16)f;
-    return __builtin_bit_cast(unsigned short, b);
-}
-
-union V16 {
-    uint4 u;
-    unsigned short h[8];
-    bf16x8 v;
-};
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing: fp32 master weights -> bf16 MFMA B-fragment order
@@ -65,6 +48,7 @@ struct PackDesc {            // one (layer, sub-pixel parity) packing job
     int Cout, Cin, KH, KW, CK, BN, nchunk, ntile, TAPS, mode, parity;
     unsigned block0, nblocks; // its slice of the batched launch
     int split;                // 1: fp32-precision pack - per chunk the bf16(w) image followed by the bf16(w - bf16(w)) image
+    const float *scale;       // optional per-output-channel multiplier applied in fp32 before the rounding (eval-mode BatchNorm fold; mode 0)
 };
 
 __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size_t stride) {
@@ -138,6 +122,7 @@ __device__ __forceinline__ void pack_range(const PackDesc &d, size_t first, size
                 }
             }
         }
+        if (d.scale && co < Cout) v *= d.scale[co];
         const unsigned short hi = f2bf(v);
         o8[j] = hl ? f2bf(v - bf2f(hi)) : hi;
         }
@@ -167,35 +152,6 @@ __global__ void pack_weights_batch_kernel(const PackDesc *__restrict__ table, in
 // ------------------------------------------------------------------------------------------------------
 // input staging
 // ------------------------------------------------------------------------------------------------------
-struct ChanXf {           // per-thread channel transform for its 8 channels of the current chunk
-    float sc[8], sh[8];
-    bool on;
-};
-
-__device__ __forceinline__ V16 xform8(V16 raw, const V16 *res, const ChanXf &t, bool relu, bool f16) {
-    V16 o;
-    if (f16 && !t.on && relu && res) {           // eval-mode residual unit: relu(raw + res), packed math
-        o.u = __builtin_bit_cast(uint4, xf_addrelu_f16(__builtin_bit_cast(xf_u32x4, raw.u), __builtin_bit_cast(xf_u32x4, res->u)));
-        return o;
-    }
-    if (f16 && t.on && relu) {                   // the training-mode combination: packed math (xform.h)
-        const xf_u32x4 r = __builtin_bit_cast(xf_u32x4, raw.u);
-        const xf_u32x4 v = res ? xf_bnrelu_f16<true>(r, __builtin_bit_cast(xf_u32x4, res->u), t.sc, t.sh)
-                               : xf_bnrelu_f16<false>(r, r, t.sc, t.sh);
-        o.u = __builtin_bit_cast(uint4, v);
-        return o;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = ld16(raw.h[j], f16);
-        if (t.on) v = fmaf(v, t.sc[j], t.sh[j]);
-        if (res) v += ld16(res->h[j], f16);
-        if (relu) v = fmaxf(v, 0.f);
-        o.h[j] = f2bf(v);
-    }
-    return o;
-}
-
 __device__ __forceinline__ V16 max8(V16 a, V16 b, bool nonneg) {
     V16 o;
     if (nonneg) {                                // post-ReLU values: integer order == float order
@@ -1602,6 +1558,7 @@ static int fill_pack_desc(PackDesc &d, const float *w, void *packed, int Cout, i
     const int nchunk = Cin / CK, ntile = cdiv(Cout, BN);
     const size_t per = (size_t)ntile * nchunk * taps * CK * BN * (split ? 2 : 1);
     d.split = split;
+    d.scale = nullptr;
     d.w = w; d.out = (unsigned short *)packed + (size_t)p * per;
     d.Cout = Cout; d.Cin = Cin; d.KH = KH; d.KW = KW; d.CK = CK; d.BN = BN; d.nchunk = nchunk; d.ntile = ntile; d.TAPS = taps; d.mode = mode;
     d.parity = p;
@@ -1621,6 +1578,17 @@ extern "C" int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, i
         pack_weights_kernel<<<d.nblocks, 256, 0, (hipStream_t)stream>>>(d);
     }
     return check_launch("cdnet_pack_conv_weights");
+}
+
+extern "C" int cdnet_pack_conv_weights_scaled(const float *w, const float *cout_scale, void *packed, int Cout, int Cin, int KH, int KW, int CK,
+                                              int BN, int mode, void *stream) {
+    CDNET_REQUIRE(cout_scale && (mode & 15) == 0, "cdnet_pack_conv_weights_scaled: forward Conv2d packs (mode 0) with a scale vector");
+    PackDesc d;
+    int rc = fill_pack_desc(d, w, packed, Cout, Cin, KH, KW, CK, BN, mode, 0, "cdnet_pack_conv_weights_scaled");
+    if (rc) return rc;
+    d.scale = cout_scale;
+    pack_weights_kernel<<<d.nblocks, 256, 0, (hipStream_t)stream>>>(d);
+    return check_launch("cdnet_pack_conv_weights_scaled");
 }
 
 extern "C" size_t cdnet_pack_batch_table_bytes(int n_jobs) { return (size_t)n_jobs * 4 * sizeof(PackDesc); }
@@ -1693,6 +1661,12 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (A.f32) return conv_forward_f32(A, st);
+    CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps || (A.taps1 == 1 && A.taps == 9 && A.nsrc == 2), "cdnet_conv_forward: taps1 = %d (0, taps, or 1 beside a nine-tap first source)", A.taps1);
+    {
+        const int rc = conv_forward_ws16(A, st);
+        if (rc >= 0) return rc;
+        CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps, "cdnet_conv_forward: a one-tap second source runs on conv_ws16_kernel only (ask cdnet_conv_ws_eligible)");
+    }
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
     if ((use_ws || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
@@ -1710,12 +1684,15 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     return dispatch_conv<1>(A, st);
 }
 
-/* 1 when cdnet_conv_forward would run these arguments on the producer / consumer kernel (conv_ws_kernel / conv_ws32_kernel) */
+/* non-zero when cdnet_conv_forward would run these arguments on a producer / consumer kernel: 2 = conv_ws16_kernel, 1 = conv_ws_kernel /
+ * conv_ws32_kernel */
 extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
     if (A.f32) return conv_forward_f32_ws(A, nullptr, true) == CDNET_OK ? 1 : 0;
+    if (conv_forward_ws16(A, nullptr, true) == CDNET_OK) return 2;
+    if (A.taps1 != 0 && A.taps1 != A.taps) return 0;
     if (!use_ws || (A.debug & 32)) return 0;
     if (!(A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32))) return 0;
     const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, nullptr, true) : try_launch_conv_ws<32, 9>(A, nullptr, true);

@@ -1,0 +1,600 @@
+// Wave-specialised, persistent 3x3 convolution of the 16-bit path for every launch that carries no BatchNorm statistics: the eval-mode
+// forward (inference tiles, sliding windows), every backward-data pass of training, the space-to-depth backward of the transposed
+// convolutions.  Round 4: the recipe of conv_ws32_kernel (conv32ws.hip) for bf16 operands -
+//
+//   * OPERAND ROLES SWAPPED against conv_fwd_kernel / conv_ws_kernel: the packed weights are the MFMA's A operand (M = 32 output channels),
+//     the halo pixels its B operand (N = 32 pixels).  An accumulator block then holds, per lane, ONE pixel x 16 output channels, and with
+//     the weight rows read through the permutation sigma (bits 2 and 3 of the row swapped) registers 8s..8s+7 of a lane are 8 CONSECUTIVE
+//     output channels: the finished tile leaves straight from the accumulators as 16-byte NHWC stores (the two lane halves of a pixel
+//     write 32 contiguous bytes) - no LDS out image, no transposing read-back, no store burst by the movers.  The packed weights in
+//     memory are the ones every other kernel reads (the permutation is in the fragment address);
+//   * bias + folded BatchNorm shift enter as the accumulators' initial value (the first MFMA of a tile takes them as its C operand):
+//     the epilogue is convert, ReLU on the packed 16-bit patterns, store - 10 instructions per 8 outputs, spread over the MFMA gaps of
+//     the next tile (the eval-mode BatchNorm scale is folded into the packed weights by the host, runtime.ConvLayer.eval_pack);
+//   * any number of 16-channel chunks from one up (the stem 16 -> 64, the decoder's 80 -> 16 and 160 -> 32, the 512-channel loops):
+//     one barrier per TWO chunks of the workgroup's run of chunks, wherever tile boundaries fall; weights resident in LDS when the tile's
+//     chunks fit (<= 96 KB), else streamed through a four-slot ring by LDS-DMA two chunks ahead (conv_ws_kernel's scheme);
+//   * a second source may carry ONE tap per chunk instead of nine (cdnet_conv_args.taps1 = 1): the 1x1 branch of a residual unit then is
+//     four more K steps of its second 3x3 convolution - relu(bn2(conv2(h)) + conv_1x1(x)) in one launch, eval mode
+//     (model_unet_rev1.py:161-170), no stored conv2 output, no separate 1x1 pass;
+//   * waves 4..7 (movers) are conv_ws_kernel's: four halo chunks in flight in registers, requests through buffer descriptors (zero fill by
+//     the range check), generic source transform, four-slot halo ring.
+// Accumulation order per output (chunk, tap, k) is conv_fwd_kernel's; without bias the outputs are bit-identical to it
+// (tests/test_gpu_conv16ws.py); with bias the sum starts from the bias instead of ending with it (one rounding moved).
+//
+// Replaces the same reference lines as conv.hip: models/dam/model_unet_rev1.py:86-170, 244-287.
+#include <type_traits>
+#include "common.h"
+#include "conv_args.h"
+#include "xform.h"
+#include "stage16.h"
+#include <stdlib.h>
+
+using namespace cdnet;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int BN>
+struct W16Lds {
+    static constexpr int TH = 16, TW = 16, CK = 16;
+    static constexpr int PSTR = 32;                               // bytes per halo pixel (16 bf16), k-halves swizzled by the halo row's parity
+    static constexpr int NPIX = (TH + 2) * (TW + 2);
+    static constexpr int A_BYTES = NPIX * PSTR;
+    static constexpr int NSLOT = 4;
+    static constexpr int WCH9 = 9 * CK * BN * 2;                  // packed weights of a nine-tap chunk
+    static constexpr int WCH1 = CK * BN * 2;                      // ... of a one-tap chunk
+    static constexpr int RES_MAX = 96 * 1024;                     // resident weights up to this many bytes, else the ring
+    __host__ __device__ static int wbytes(int n9, int n1) { return n9 * WCH9 + n1 * WCH1; }
+    __host__ __device__ static int bytes(int wb, int ctot) { return NSLOT * A_BYTES + wb + 2 * ((ctot + 7) / 8 * 8) * 4; }
+};
+
+// sigma: the weight row lane m of an A fragment reads (an involution: bits 2 and 3 swapped).  D row m = (r & 3) + 8 (r >> 2) + 4 half then
+// holds output channel 16 (r >> 3) + 8 half + (r & 7) of the block: 8 consecutive channels per 8 registers, the two halves adjacent.
+__device__ __forceinline__ int sigma32(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+
+// XF: 0 every source plain bf16, 2 anything (run-time flags: fp16 storage, scale / shift, residual, ReLU)
+// STREAM: the weight chunks stream through a four-slot ring (even chunk count); else all of a tile's chunks are resident
+// MIX: the second source's chunks carry one tap (the centre) instead of nine
+// NCS: chunks per tile known to the compiler - 1: one, 2: two or three, 0: four or more (how the finished tile's epilogue is spread)
+template <int BN, int XF, bool STREAM, bool MIX, int NCS>
+__global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
+    using L = W16Lds<BN>;
+    constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
+    constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
+    constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
+    constexpr int PF = 4;
+    static_assert(!(STREAM && MIX), "one-tap chunks only with resident weights");
+    const int NCH = A.nchunk;
+    const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_a = smem;
+    unsigned char *lds_w = smem + L::NSLOT * L::A_BYTES;
+    const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
+    const int xfs = (ctot + 7) / 8 * 8;
+    const int n1 = NCH - n0;
+    const int wres_bytes = STREAM ? 4 * L::WCH9 : (MIX ? L::wbytes(n0, n1) : L::wbytes(NCH, 0));
+    float *s_xf = reinterpret_cast<float *>(lds_w + wres_bytes);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cout_tile = blockIdx.y;
+    const int cout0 = cout_tile * BN;
+
+    // this workgroup's contiguous run of tiles; XCD k (workgroups k, k+8, ...) serves the k-th eighth of the tiles (conv_ws_kernel)
+    const int tiles_x = A.W / TW, tiles_y = A.H / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int T = A.N * tiles_img;
+    int t_lo, t_hi;
+    {
+        const int G = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((G & 7) == 0) {
+            const int xcd = b & 7, idx = b >> 3, nw = G >> 3;
+            const long long x0 = (long long)T * xcd / 8, x1 = (long long)T * (xcd + 1) / 8;
+            t_lo = (int)(x0 + (x1 - x0) * idx / nw);
+            t_hi = (int)(x0 + (x1 - x0) * (idx + 1) / nw);
+        } else {
+            t_lo = (int)((long long)T * b / G);
+            t_hi = (int)((long long)T * (b + 1) / G);
+        }
+    }
+    const int ntl = t_hi - t_lo;
+    const int S = ntl * NCH;                                      // chunks of this workgroup's run
+    if (S == 0) return;
+    const int NI = (S + 1) >> 1;                                  // barrier intervals: two run chunks each
+
+    if (wave >= 4) {
+        // ================================ movers (conv_ws_kernel's, without the out path) ================================
+        const int ptid = tid - 256, pw = wave - 4;
+        const int slot = ptid % VPP;
+        if (A.debug & 16) __builtin_amdgcn_s_setprio(2);         // (experiment: the younger half of the workgroup loses the issue arbitration at equal priority)
+        u32x4v pa[PF][NA];
+        unsigned eo[PF][NA];                     // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
+        int hyx[NA], doff[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int pix = (ptid + i * 256) / VPP;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 8) | hx) : 0x1f1f;
+            doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
+        }
+        const unsigned src_bytes0 = (unsigned)A.N * A.src[0].Hs * (A.src[0].row_stride ? A.src[0].row_stride : A.src[0].Ws * A.src[0].C) * 2u;
+        const unsigned src_bytes1 = A.nsrc > 1 ? (unsigned)A.N * A.src[1].Hs * (A.src[1].row_stride ? A.src[1].row_stride : A.src[1].Ws * A.src[1].C) * 2u : 0u;
+        const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].x), 0, (int)src_bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.nsrc > 1 ? A.src[1].x : A.src[0].x), 0, (int)src_bytes1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].res ? A.src[0].res : A.src[0].x), 0, (int)src_bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.nsrc > 1 && A.src[1].res ? A.src[1].res : A.src[0].x), 0, (int)src_bytes1, 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff) -> u32x4v {
+            return __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+        };
+        auto bad_mask = [](int lo, int hi) -> unsigned {
+            lo = lo < 0 ? 0 : (lo > 31 ? 31 : lo);
+            hi = hi < lo ? lo : (hi > 31 ? 31 : hi);
+            return ~(((1u << hi) - 1u) & ~((1u << lo) - 1u));
+        };
+        int ik = 0, ic = 0, in_, iy0, ix0;
+        {
+            in_ = t_lo / tiles_img;
+            const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
+            iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
+        }
+        int ck = 0;
+        unsigned ge[NA];
+        auto chunk_src = [&](int k, int &si, int &cc0) {
+            if (k < n0) { si = 0; cc0 = k * CK; } else { si = 1; cc0 = (k - n0) * CK; }
+        };
+        auto issue = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            int si, cc0;
+            chunk_src(ik, si, cc0);
+            const ConvSrc &s = A.src[si];
+            if (ik == 0 || ik == n0) {
+                const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
+                const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
+                const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;
+                const unsigned rowbad = bad_mask(ylo - (iy0 - 1), yhi - (iy0 - 1)), colbad = bad_mask(xlo - (ix0 - 1), xhi - (ix0 - 1));
+                const unsigned img_b = (unsigned)((in_ * s.Hs + (iy0 - 1 - s.off_y)) * rs + (ix0 - 1 - s.off_x) * s.C) * 2u;
+                const unsigned rs_b = (unsigned)rs * 2u, c_b = (unsigned)s.C * 2u;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const unsigned hy = (unsigned)hyx[i] >> 8, hx = (unsigned)hyx[i] & 0xffu;
+                    const unsigned t = (rowbad >> hy) | (colbad >> hx);
+                    ge[i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 16u) & 0x7fffffffu) | (t << 31);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rsx = si ? rsx1 : rsx0;
+            const unsigned cc0_b = (unsigned)cc0 * 2u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const unsigned voff = ge[i] + cc0_b;
+                eo[R][i] = voff;
+                if (!(A.debug & 2)) pa[R][i] = bload(rsx, voff);     // (2: ablation - no halo requests)
+            }
+            if (ic + 1 < S) {
+                ++ic;
+                if (++ik == NCH) {
+                    ik = 0;
+                    ix0 += TW;
+                    if (ix0 >= A.W) { ix0 = 0; iy0 += TH; if (iy0 >= A.H) { iy0 = 0; ++in_; } }
+                }
+            }
+        };
+        // run chunk c_ (register set R = c_ % 4) -> ring slot c_ % 4
+        auto commit = [&](auto rc, int c_) {
+            constexpr int R = decltype(rc)::value;
+            int si, cc0;
+            chunk_src(ck, si, cc0);
+            if (c_ + 1 < S) { if (++ck == NCH) ck = 0; }
+            const ConvSrc &s = A.src[si];
+            const float *xf = s_xf + (si ? c0n : 0) + cc0 + slot * 8;
+            float sc[8], sh[8];
+            if (XF != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
+            }
+            unsigned char *dst0 = lds_a + R * L::A_BYTES;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                u32x4v val;
+                if (XF == 0) val = pa[R][i];
+                else {
+                    ChanXf t;
+                    t.on = s.scale != nullptr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { t.sc[j] = sc[j]; t.sh[j] = sh[j]; }
+                    V16 raw, rr;
+                    raw.u = __builtin_bit_cast(uint4, pa[R][i]);
+                    const bool relu = s.relu != 0, f16 = s.f16 != 0;
+                    if (s.res) {
+                        rr.u = __builtin_bit_cast(uint4, bload(si ? rsr1 : rsr0, eo[R][i]));
+                        val = __builtin_bit_cast(u32x4v, xform8(raw, &rr, t, relu, f16).u);
+                    } else if (!t.on && !relu && !f16) val = pa[R][i];
+                    else val = __builtin_bit_cast(u32x4v, xform8(raw, nullptr, t, relu, f16).u);
+                    const unsigned keep = (int)eo[R][i] < 0 ? 0u : 0xffffffffu;      // outside the image / source: zeros (after the transform)
+                    val &= keep;
+                }
+                if (i < NA - 1 || ptid + i * 256 < NPIX * VPP)
+                    *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val;
+            }
+        };
+        // STREAM: weight chunk wk of the tile -> weight slot (run chunk & 3) by LDS-DMA (the packed chunk is the LDS image)
+        int wk = 0, wq = 0;
+        auto dma_w = [&]() {
+            constexpr int NVEC = L::WCH9 / 16;
+            static_assert(NVEC % 64 == 0, "whole wave-instructions");
+            const unsigned short *wsrc = A.w + ((size_t)cout_tile * NCH + wk) * (L::WCH9 / 2);
+            unsigned char *wdst = lds_w + (wq & 3) * L::WCH9;
+#pragma unroll
+            for (int i = 0; i < (NVEC / 64 + 3) / 4; ++i) {
+                const int v0 = (i * 4 + pw) * 64;
+                if (v0 < NVEC)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)(v0 + lane) * 8),
+                                                     (__attribute__((address_space(3))) void *)(wdst + v0 * 16), 16, 0, 0);
+            }
+            if (++wk == NCH) wk = 0;
+            ++wq;
+        };
+        auto wait_vm = [](auto n_c) {
+            constexpr int N = decltype(n_c)::value;
+            __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+        };
+        using NHL = std::integral_constant<int, 2 * NA>;          // halo requests of one interval (two chunks)
+        // the movers' barrier of the streaming loop by hand (conv_ws_kernel): this wave's LDS writes done, its weight DMA landed (everything
+        // older than the N youngest vector-memory operations), then the barrier; the halo requests issued after the DMA stay in flight
+        auto stream_sync = [](auto n_c) {
+            constexpr int N = decltype(n_c)::value;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        issue(I0{});
+        issue(I1{});
+        issue(I2{});
+        issue(I3{});
+        for (int c = ptid; c < ctot; c += 256) {
+            const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
+            const int cc = c < c0n ? c : c - c0n;
+            s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+            s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+        }
+        __syncthreads();                                         // B0: table (+ resident weights)
+        commit(I0{}, 0);
+        commit(I1{}, 1);
+        if (STREAM) { dma_w(); dma_w(); }
+        issue(I0{});
+        issue(I1{});
+        if (STREAM) wait_vm(NHL{});
+        __syncthreads();                                         // B1: run chunks 0, 1 staged
+        // interval i: the consumers work on run chunks 2i, 2i+1 (slots 2i & 3, ...); here the two chunks after them are staged
+        if (!STREAM) {
+            for (int i = 0; i < NI; i += 2) {
+                const int q0 = 2 * i;
+                commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); __syncthreads();
+                commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); __syncthreads();
+            }
+        } else {
+            for (int i = 0; i < NI; i += 2) {
+                const int q0 = 2 * i;
+                commit(I2{}, q0 + 2); commit(I3{}, q0 + 3);
+                dma_w(); dma_w();
+                issue(I2{}); issue(I3{});
+                stream_sync(NHL{});
+                commit(I0{}, q0 + 4); commit(I1{}, q0 + 5);
+                dma_w(); dma_w();
+                issue(I0{}); issue(I1{});
+                stream_sync(NHL{});
+            }
+        }
+        return;
+    }
+
+    // ================================ consumers ================================
+    if (!STREAM) {
+        // the resident weights of this output-channel tile: one contiguous block of the pack
+        const u32x4v *src = reinterpret_cast<const u32x4v *>(reinterpret_cast<const unsigned char *>(A.w) + (size_t)cout_tile * wres_bytes);
+        u32x4v *dst = reinterpret_cast<u32x4v *>(lds_w);
+        const int nv = wres_bytes / 16;
+        for (int v0 = 0; v0 < nv; v0 += 256 * 8) {
+            u32x4v wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = src[v0 + tid + i * 256 < nv ? v0 + tid + i * 256 : 0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (v0 + tid + i * 256 < nv) dst[v0 + tid + i * 256] = wv[i];
+        }
+    }
+    __syncthreads();                                             // B0
+    const int wm = wave;
+    const int half = lane >> 5, l31 = lane & 31;
+    int pbase[NPI][2];                                           // pixel fragment (B operand) of block pi; [.][parity of the tap's row offset]
+#pragma unroll
+    for (int pi = 0; pi < NPI; ++pi) {
+        const int m = (wm * NPI + pi) * 32 + l31;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) pbase[pi][par] = ((m / TW) * HW_ + m % TW) * PSTR + ((half ^ ((m / TW + par) & 1)) * 16);
+    }
+    const int wbase = half * BN * 16 + sigma32(l31) * 16;         // weight fragment (A operand): packed column sigma(l31) of block ci (+ ci * 512)
+    f32x16 accA[NCI][NPI], accB[NCI][NPI];
+    // initial value of every accumulator block ci: bias + epilogue shift of this lane's 16 output channels
+    f32x16 binit[NCI];
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cout0 + ci * 32 + 16 * (r >> 3) + 8 * half + (r & 7);
+            float b = 0.f;
+            if (co < A.Cout) b = (A.bias ? A.bias[co] : 0.f) + (A.oshift ? A.oshift[co] : 0.f);
+            binit[ci][r] = b;
+        }
+    const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
+    // the finished tile's stores: pixel (row 4 wm + 2 pi + (l31 >> 4), column l31 & 15) of the tile, channels 32 ci + 16 s + 8 half .. + 8
+    const unsigned pix_b = (unsigned)A.out_cstride * 2u;
+    const unsigned l_off = ((unsigned)(l31 >> 4) * (unsigned)A.W + (unsigned)(l31 & 15)) * pix_b + (unsigned)half * 16u;
+    char *const out_b = reinterpret_cast<char *>(A.out + A.out_coff + cout0);
+    int p_n, p_y0, p_x0;                                         // the finished tile (whose epilogue rides in the current one)
+    {
+        p_n = t_lo / tiles_img;
+        const int r = t_lo - p_n * tiles_img, ty = r / tiles_x;
+        p_y0 = ty * TH; p_x0 = (r - ty * tiles_x) * TW;
+    }
+    char *row_base[NPI];
+    auto set_row_bases = [&]() {
+#pragma unroll
+        for (int pi = 0; pi < NPI; ++pi)
+            row_base[pi] = out_b + ((size_t)(p_n * A.H + p_y0 + wm * 4 + pi * 2) * A.W + p_x0) * pix_b;
+    };
+    // epilogue micro-operations of a finished set, a pixel block (group) at a time: for each of its UG = 2 NCI units (ci, s) - 8 consecutive
+    // output channels of this lane's pixel - convert 2 x 2 and ReLU (three micro-operations), then the group's UG stores one after the
+    // other: together they complete the 128-byte lines of the block's 32 pixels while those are still in the L2 (spread over a tile, the
+    // partial lines of a launch larger than the caches were evicted and written to HBM piecemeal: 398 us against 354 at 64 tiles)
+    constexpr int UG = NCI * 2, NMO = NPI * UG * 4;
+    unsigned dd[UG][4];
+    auto cvt2 = [&](float a, float b) -> unsigned {              // (bf16 outputs only: the launcher sends fp16 outputs to the older kernels)
+        const xf_f32x2 p = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(p, xf_bf16x2));
+    };
+    auto relu2 = [&](unsigned v) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(xf_s16x2, v), lo_clamp));
+    };
+    auto micro = [&](const f32x16 (&P)[NCI][NPI], int e) {
+        const int pi = e / (4 * UG), j = e % (4 * UG);
+        if (j < 3 * UG) {
+            const int u = j / 3, k = j % 3, ci = u >> 1, s = u & 1;
+            const f32x16 &v = P[ci][pi];
+            if (k == 0) { dd[u][0] = cvt2(v[8 * s + 0], v[8 * s + 1]); dd[u][1] = cvt2(v[8 * s + 2], v[8 * s + 3]); }
+            else if (k == 1) { dd[u][2] = cvt2(v[8 * s + 4], v[8 * s + 5]); dd[u][3] = cvt2(v[8 * s + 6], v[8 * s + 7]); }
+            else { dd[u][0] = relu2(dd[u][0]); dd[u][1] = relu2(dd[u][1]); dd[u][2] = relu2(dd[u][2]); dd[u][3] = relu2(dd[u][3]); }
+        } else {
+            const int u = j - 3 * UG, ci = u >> 1, s = u & 1;
+            if (cout0 + ci * 32 + s * 16 < A.Cout && !(A.debug & 8)) {
+                char *sb = row_base[pi] + (ci * 64 + s * 32);
+                asm volatile("" : "+s"(sb));                    // (scalar base kept opaque: uniform base + one per-lane offset register = the store's saddr form)
+                const u32x4v val = {dd[u][0], dd[u][1], dd[u][2], dd[u][3]};
+                *(__attribute__((address_space(1))) u32x4v *)((__attribute__((address_space(1))) char *)sb + l_off) = val;
+            }
+        }
+    };
+
+    // one chunk step on accumulator set C: NT taps x NCI x NPI MFMAs; the fragments of a tap are requested two taps ahead (three sets).
+    // FIRST: the tile's first chunk starts from the bias.  EP of NP (NP > 0): this step carries that share of the finished set P's epilogue
+    // micro-operations, one or two per MFMA gap, evenly spread.
+    auto chunk_step = [&](auto nt_c, auto first_c, auto ep_c, auto np_c, f32x16 (&C)[NCI][NPI], const f32x16 (&P)[NCI][NPI],
+                          const unsigned char *la, const unsigned char *lw) {
+        constexpr int NT = decltype(nt_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int EP = decltype(ep_c)::value, NP = decltype(np_c)::value;
+        if (A.debug & 1) return;                                  // ablation: no fragment reads, no MFMAs
+        bf16x8 wf[3][NCI], pf[3][NPI];
+        auto request = [&](int t) {
+            const int tr = NT == 9 ? t / 3 : 1, tc = NT == 9 ? t % 3 : 1;
+            const int po = (tr * HW_ + tc) * PSTR, par = tr & 1;
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci) wf[t % 3][ci] = *reinterpret_cast<const bf16x8 *>(lw + wbase + t * 2 * BN * 16 + ci * 512);
+#pragma unroll
+            for (int pi = 0; pi < NPI; ++pi) pf[t % 3][pi] = *reinterpret_cast<const bf16x8 *>(la + pbase[pi][par] + po);
+        };
+        constexpr int NG = NT * NCI * NPI;                        // MFMA gaps of the step
+        constexpr int NPD = NP > 0 ? NP : 1;
+        constexpr int E0 = NP > 0 ? EP * NMO / NPD : 0, E1 = NP > 0 ? (EP + 1) * NMO / NPD : 0, CNT = E1 - E0, CNTD = CNT > 0 ? CNT : 1;
+        request(0);
+        if (NT > 1) request(1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 2 < NT) request(t + 2);
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                for (int pi = 0; pi < NPI; ++pi) {
+                    if (FIRST && t == 0) C[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t % 3][ci], pf[t % 3][pi], binit[ci], 0, 0, 0);
+                    else C[ci][pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t % 3][ci], pf[t % 3][pi], C[ci][pi], 0, 0, 0);
+                    if (CNT > 0) {
+                        const int g = (t * NCI + ci) * NPI + pi;
+                        // micro-operation i of this step rides in gap (i * NG) / CNT
+                        bool any = false;
+#pragma unroll
+                        for (int i = 0; i < CNT; ++i)
+                            if ((i * NG) / CNTD == g) {
+                                if (!any) __builtin_amdgcn_sched_barrier(0);
+                                any = true;
+                                micro(P, E0 + i);
+                            }
+                        if (any) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
+    };
+    using F_ = std::false_type;
+    using T_ = std::true_type;
+    using N9 = std::integral_constant<int, 9>;
+    using N1 = std::integral_constant<int, 1>;
+    using Z0 = std::integral_constant<int, 0>;
+    using Z1 = std::integral_constant<int, 1>;
+    using Z2 = std::integral_constant<int, 2>;
+    using Z3 = std::integral_constant<int, 3>;
+    using Z4 = std::integral_constant<int, 4>;
+    int q = 0;                                                   // run chunk counter
+    auto slot_a = [&]() -> const unsigned char * { return lds_a + (q & 3) * L::A_BYTES; };
+    auto slot_w = [&](int k) -> const unsigned char * {
+        if (STREAM) return lds_w + (q & 3) * L::WCH9;
+        if (MIX && k >= n0) return lds_w + n0 * L::WCH9 + (k - n0) * L::WCH1;
+        return lds_w + k * L::WCH9;
+    };
+    auto after_chunk = [&]() {
+        ++q;
+        if ((q & 1) == 0) __syncthreads();
+    };
+    // tile j on set C; P = the finished tile j - 1: its epilogue rides in the first chunk steps
+    auto tile_step = [&](auto has_prev, f32x16 (&C)[NCI][NPI], const f32x16 (&P)[NCI][NPI]) {
+        constexpr bool HP = decltype(has_prev)::value;
+        if (HP) set_row_bases();
+        if constexpr (NCS == 1) {
+            if (HP) chunk_step(N9{}, T_{}, Z0{}, Z1{}, C, P, slot_a(), slot_w(0)); else chunk_step(N9{}, T_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(0));
+            after_chunk();
+        } else if constexpr (NCS == 2) {
+            if (HP) chunk_step(N9{}, T_{}, Z0{}, Z2{}, C, P, slot_a(), slot_w(0)); else chunk_step(N9{}, T_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(0));
+            after_chunk();
+            if (HP) chunk_step(N9{}, F_{}, Z1{}, Z2{}, C, P, slot_a(), slot_w(1)); else chunk_step(N9{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(1));
+            after_chunk();
+            if (NCH == 3) {
+                chunk_step(N9{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(2));
+                after_chunk();
+            }
+        } else {
+            if (HP) chunk_step(N9{}, T_{}, Z0{}, Z4{}, C, P, slot_a(), slot_w(0)); else chunk_step(N9{}, T_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(0));
+            after_chunk();
+            if (HP) chunk_step(N9{}, F_{}, Z1{}, Z4{}, C, P, slot_a(), slot_w(1)); else chunk_step(N9{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(1));
+            after_chunk();
+            if (HP) chunk_step(N9{}, F_{}, Z2{}, Z4{}, C, P, slot_a(), slot_w(2)); else chunk_step(N9{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(2));
+            after_chunk();
+            if (HP) chunk_step(N9{}, F_{}, Z3{}, Z4{}, C, P, slot_a(), slot_w(3)); else chunk_step(N9{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(3));
+            after_chunk();
+            for (int k = 4; k < NCH; ++k) {
+                if (MIX && k >= n0) chunk_step(N1{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(k));
+                else chunk_step(N9{}, F_{}, Z0{}, Z0{}, C, P, slot_a(), slot_w(k));
+                after_chunk();
+            }
+        }
+        if (HP) {                                                // P has left: the finished tile is now the one just accumulated
+            p_x0 += TW;
+            if (p_x0 >= A.W) { p_x0 = 0; p_y0 += TH; if (p_y0 >= A.H) { p_y0 = 0; ++p_n; } }
+        }
+    };
+    // the last tile of the run: nothing left to hide behind
+    auto serial_epilogue = [&](const f32x16 (&P)[NCI][NPI]) {
+        set_row_bases();
+#pragma unroll
+        for (int e = 0; e < NMO; ++e) micro(P, e);
+    };
+
+    __syncthreads();                                             // B1: run chunks 0, 1 are staged
+    tile_step(F_{}, accA, accB);
+    int j = 1;
+    for (; j + 1 < ntl; j += 2) {
+        tile_step(T_{}, accB, accA);
+        tile_step(T_{}, accA, accB);
+    }
+    const bool tail = j < ntl;
+    if (tail) tile_step(T_{}, accB, accA);
+    if (q & 1) __syncthreads();                                  // the last, half-filled interval
+    if (NI & 1) __syncthreads();                                 // the movers' loop runs whole pairs of intervals
+    if (tail) serial_epilogue(accB); else serial_epilogue(accA);
+}
+
+}  // namespace
+
+namespace cdnet {
+
+// eligibility + launch; returns -1 when the launch must take the older kernels
+template <int BN>
+static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
+    using L = W16Lds<BN>;
+    int ctot = 0;
+    bool all_plain = true;
+    for (int i = 0; i < A.nsrc; ++i) {
+        const ConvSrc &s = A.src[i];
+        if (s.pool || s.relu < 0 || s.relu > 2) return -1;
+        ctot += s.C;
+        const long long rs = s.row_stride ? s.row_stride : (long long)s.Ws * s.C;
+        if ((long long)A.N * s.Hs * rs * 2 >= (1LL << 31)) return -1;      // the movers' requests: 31-bit byte offsets
+        all_plain = all_plain && !s.scale && !s.relu && !s.res && !s.f16;
+    }
+    const bool mix = A.taps1 == 1 && A.nsrc == 2;
+    if (A.taps1 != 0 && !mix && A.taps1 != 9) return -1;
+    const int n0 = A.src[0].C / 16, nch = A.nchunk, n1 = nch - n0;
+    if (mix && n0 < 4) return -1;                                 // (the epilogue rides in the first four nine-tap steps)
+    const int wres = mix ? L::wbytes(n0, n1) : L::wbytes(nch, 0);
+    const bool stream = wres > L::RES_MAX;
+    if (stream && (mix || (nch & 1))) return -1;
+    const int smem = L::bytes(stream ? 4 * L::WCH9 : wres, ctot);
+    if (smem > 160 * 1024) return -1;
+    const int T = (A.W / 16) * (A.H / 16) * A.N;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return check_launch("hipGetDeviceProperties");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ctiles = cdiv(A.Cout, BN);
+    const int Gmax = n_cu / ctiles > 0 ? n_cu / ctiles : 1;
+    // a persistent workgroup pays a few microseconds of start-up and a serial epilogue for its last tile
+    if (!(A.debug & 64) && ((long long)T * nch < 16LL * Gmax || (T < Gmax && nch < 16))) return -1;
+    int G = n_cu / ctiles;
+    G = G > T ? T : G;
+    if (G >= 8) G &= ~7;
+    if ((A.debug >> 8) > 0 && (A.debug >> 8) < G) G = A.debug >> 8;      // tests: few workgroups, long runs of tiles
+    if (G < 1) G = 1;
+    if (dry_run) return CDNET_OK;
+    dim3 grid(G, ctiles, 1);
+    auto go = [&](auto xf_c, auto sm_c, auto mx_c, auto ncs_c) -> int {
+        constexpr int XF = decltype(xf_c)::value;
+        constexpr bool STREAM = decltype(sm_c)::value;
+        constexpr bool MIX = decltype(mx_c)::value;
+        constexpr int NCS = decltype(ncs_c)::value;
+        auto kern = conv_ws16_kernel<BN, XF, STREAM, MIX, NCS>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(conv_ws16)");
+            attr_done = true;
+        }
+        kern<<<grid, 512, smem, st>>>(A);
+        return check_launch("conv_ws16_kernel");
+    };
+    using X0 = std::integral_constant<int, 0>;
+    using X2 = std::integral_constant<int, 2>;
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using F_ = std::false_type;
+    using T_ = std::true_type;
+    auto by_xf = [&](auto sm_c, auto mx_c, auto ncs_c) -> int {
+        return all_plain ? go(X0{}, sm_c, mx_c, ncs_c) : go(X2{}, sm_c, mx_c, ncs_c);
+    };
+    if (stream) return by_xf(T_{}, F_{}, C0{});                  // (an even chunk count >= 6)
+    if (mix) return by_xf(F_{}, T_{}, C0{});
+    if (nch == 1) return by_xf(F_{}, F_{}, C1{});
+    if (nch <= 3) return by_xf(F_{}, F_{}, C2{});
+    return by_xf(F_{}, F_{}, C0{});
+}
+
+// called by cdnet_conv_forward first (16-bit path); -1 = not eligible
+int conv_forward_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
+    static const int use = getenv("CDNET_CONV_WS16") ? atoi(getenv("CDNET_CONV_WS16")) : 1;
+    if ((!use && !(A.debug & 64)) || (A.debug & 32) || (A.debug & 128)) return -1;      // (128: tests - the older persistent kernel instead)
+    if (A.f32 || A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || A.eres || A.ws || A.stats || A.oscale || A.out_f16) return -1;
+    if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < 1 || A.Cout % 16 != 0) return -1;
+    if (A.BN == 64) return try_launch_ws16<64>(A, st, dry_run);
+    if (A.BN == 32) return try_launch_ws16<32>(A, st, dry_run);
+    return -1;
+}
+
+}  // namespace cdnet

@@ -32,6 +32,7 @@ struct ConvArgs {
     const unsigned short *eres;
     const float *eres_scale, *eres_shift;
     int eres_f16, eres_relu;
+    int taps1, pad_;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");
@@ -42,5 +43,7 @@ namespace cdnet {
 int conv_forward_f32(const ConvArgs &A, hipStream_t st);
 // conv32ws.hip: its wave-specialised persistent form (3x3, full 16x16 tiles, >= 4 chunks); -1 = not eligible
 int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false);
+// conv16ws.hip: the 16-bit path's persistent kernel for launches without statistics (any chunk count, direct stores); -1 = not eligible
+int conv_forward_ws16(const ConvArgs &A, hipStream_t st, bool dry_run = false);
 int materialize_f32(const ConvSrc &s, int N, int H, int W, void *out, hipStream_t st);
 }

@@ -22,7 +22,8 @@ class ConvArgs(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('taps', C.c_int), ('npar', C.c_int),
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
                 ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('f32', C.c_int),
-                ('eres', C.c_void_p), ('eres_scale', C.c_void_p), ('eres_shift', C.c_void_p), ('eres_f16', C.c_int), ('eres_relu', C.c_int)]
+                ('eres', C.c_void_p), ('eres_scale', C.c_void_p), ('eres_shift', C.c_void_p), ('eres_f16', C.c_int), ('eres_relu', C.c_int),
+                ('taps1', C.c_int), ('pad_', C.c_int)]
 
 
 def _dp(t):
@@ -182,7 +183,7 @@ def pack_job(w, cfg, mode, out, split=False):
 PACK_SPLIT = 16       # CDNET_PACK_SPLIT
 
 
-def pack_weights(w, cfg, mode, Cin_pad=None, out=None, split=False):
+def pack_weights(w, cfg, mode, Cin_pad=None, out=None, split=False, cout_scale=None):
     """w: fp32 cuda tensor. mode 0 Conv2d fwd [Cout,Cin,KH,KW]; 1 Conv2d bwd-data; 2 ConvT k4s2p1; 3 ConvT k2s2.
     Cin_pad: Cin rounded up to the chunk grid (e.g. 3 -> 16 for the RGB input).  Returns a bf16-bits int16 tensor."""
     assert w.dtype == torch.float32 and w.is_cuda and w.is_contiguous()
@@ -199,6 +200,11 @@ def pack_weights(w, cfg, mode, Cin_pad=None, out=None, split=False):
     n = packed_elems(Cout, Cin // CK, taps, CK, BN, npar) * (2 if split else 1)
     if out is None or out.numel() != n:
         out = torch.empty((n,), dtype=torch.int16, device=w.device)
+    if cout_scale is not None:           # eval-mode BatchNorm scale folded into the weights (mode 0): w[cout] * cout_scale[cout], then rounded
+        assert mode == 0 and cout_scale.dtype == torch.float32 and cout_scale.numel() == Cout
+        _lib.call('cdnet_pack_conv_weights_scaled', _lib.ptr(w), _lib.ptr(cout_scale), _lib.ptr(out), Cout, Cin, KH, KW, CK, BN,
+                  mode | (PACK_SPLIT if split else 0), _lib.stream_ptr())
+        return out
     _lib.call('cdnet_pack_conv_weights', _lib.ptr(w), _lib.ptr(out), Cout, Cin, KH, KW, CK, BN, mode | (PACK_SPLIT if split else 0),
               _lib.stream_ptr())
     return out
@@ -208,7 +214,7 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -244,6 +250,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out.dtype == torch.float16)
     a.ws = 0
+    a.taps1 = taps1
     a.debug = CONV_DEBUG
     a.f32 = int(f32)
     assert (out.dtype == torch.float32) == f32
@@ -257,7 +264,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
         assert eres is None and stats is None and bias is None and oscale is None and oshift is None and tuple(raw.shape) == tuple(out.shape)
         a.ws = 2
         a.eres, a.oscale, a.oshift, a.eres_scale, a.eres_shift, a.stats = raw.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), partial.data_ptr()
-    if query_ws:                         # would this launch run on the producer / consumer kernel? (nothing is launched)
-        return bool(_lib.load().cdnet_conv_ws_eligible(C.byref(a)))
+    if query_ws:                         # would this launch run on a producer / consumer kernel? 2 = conv_ws16_kernel, 1 = conv_ws_kernel / conv_ws32_kernel (nothing is launched)
+        return int(_lib.load().cdnet_conv_ws_eligible(C.byref(a)))
     _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
     return out, stats

@@ -81,6 +81,10 @@ class _RU:
 
     def forward(self, x, training, store=False):
         relu2 = not runtime.DEBUG_NORELU
+        if not training:
+            f = runtime.residual_unit_eval(self.c1, self.c2, self.cr, x, relu2)      # eval, 16-bit path: conv2 + 1x1 branch in one launch
+            if f is not None:
+                return f
         if runtime.RU_FUSE:
             # out = relu2(bn2(conv2(relu1(bn1(conv1(x))))) + conv_1x1(x))   (:161-170).  conv_1x1 runs LAST, with the other
             # branch in its epilogue (cdnet_conv_args.eres): the unit's output leaves as one stored bf16 tensor - no separate

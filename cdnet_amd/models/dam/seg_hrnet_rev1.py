@@ -183,7 +183,9 @@ class HighResolutionNet(nn.Module):
                 bnp.train(bn.training)
         bias = None if conv.bias is None else self._compute_param(conv.bias, (cout_p,))
         kind = 'conv1' if k == 1 else ('conv3s2' if stride == 2 else 'conv3')
-        return ConvLayer(name, kind, w, bias, bnp)
+        L = ConvLayer(name, kind, w, bias, bnp)
+        L.fold_eval = False      # eval-mode BatchNorm stays an epilogue affine here: the golden tolerances of tests/test_gpu_hrnet.py were set on it
+        return L
 
     def _build_runtime(self):
         self._slots, self._pmap, self._nodes = [], {}, {}
@@ -238,6 +240,9 @@ class HighResolutionNet(nn.Module):
                                                                     bias=mf.conv_1x1.bias))
         rt['ru'] = [_RU('mask_feature', shim), _RU('direction_feature', self.direction_feature),
                     _RU('point_feature', self.point_feature)]
+        for ru in rt['ru']:
+            for L in ru.layers():
+                L.fold_eval = False
         self._rt = rt
         self.rebind_views()
         self._rt_ver = self._param_version()

@@ -160,6 +160,20 @@ class ConvLayer:
             self.fold_version = ver
         return self.fold
 
+    def eval_pack(self, src_channels):
+        """eval mode, 16-bit path, 3x3 / 1x1 Conv2d + BatchNorm: the packed weights with the BatchNorm scale folded in
+        (bf16(w[cout] * scale[cout])) and the shift that is left for the epilogue - what conv_ws16_kernel takes as the accumulators'
+        initial value (csrc/conv16ws.hip).  Returns (packed, shift) or None when the layer keeps the epilogue affine (transposed and
+        stride-2 layers, the RGB stem's zero-extended pack, fp32 mode)."""
+        if not EVAL_FOLD_WEIGHTS or not getattr(self, 'fold_eval', True) or PRECISION != 'bf16' or self.kind not in ('conv3', 'conv1') or self.bn is None or sum(src_channels) != self.Cin:
+            return None
+        sc, sh = self.eval_fold()
+        ver = (self.weight._version, self.fold_version, WEIGHTS_EPOCH[0], tuple(self.cfg))
+        if getattr(self, 'wpe', None) is None or self.wpe_version != ver:
+            self.wpe = engine.pack_weights(self.weight.detach(), self.cfg, 0, out=getattr(self, 'wpe', None), cout_scale=sc)
+            self.wpe_version = ver
+        return self.wpe, sh
+
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=None, eres=None):
         """Returns the output as a Src (lazy transform attached in train mode).  Raw (pre-BatchNorm) outputs of the
@@ -186,6 +200,11 @@ class ConvLayer:
                     TAPE.append(self)
             return Src(out)
         if not training:
+            ep = self.eval_pack([s.C for s in srcs])
+            if ep is not None:
+                out, _ = engine.conv_forward(srcs, ep[0], self.Cout, self.cfg, self.taps, self.transposed, oshift=ep[1],
+                                             orelu=relu and eres is None, H=H, W=W, out_dtype=out_dtype, eres=eres)
+                return Src(out)
             sc, sh = self.eval_fold()
             out, _ = engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, oscale=sc,
                                          oshift=sh, orelu=relu and eres is None, H=H, W=W, out_dtype=out_dtype, eres=eres)
@@ -305,6 +324,52 @@ def input_pack(x):
 POOL_MATERIALIZE = _os.environ.get('CDNET_POOL_MATERIALIZE', '1') != '0'
 RU_MATERIALIZE = _os.environ.get('CDNET_RU_MATERIALIZE', '1') != '0'
 RU_FUSE = _os.environ.get('CDNET_RU_FUSE', '1') != '0'       # ResidualUnit: add + ReLU in the epilogue of its conv_1x1
+# eval mode, 16-bit path: BatchNorm scale folded into the packed weights (ConvLayer.eval_pack), and a residual unit's 1x1 branch as extra K
+# steps of its second 3x3 convolution (cdnet_conv_args.taps1 = 1, conv_ws16_kernel)
+EVAL_FOLD_WEIGHTS = _os.environ.get('CDNET_EVAL_FOLD', '1') != '0'
+RU_EVAL_ONE_LAUNCH = _os.environ.get('CDNET_RU_EVAL_FUSE', '1') != '0'
+
+
+def residual_unit_eval(c1, c2, cr, x, relu2=True):
+    """relu2(bn2(conv2(relu1(bn1(conv1(x))))) + conv_1x1(x)) (model_unet_rev1.py:161-170) in eval mode on the 16-bit path with TWO launches:
+    conv1 (BatchNorm folded, ReLU), then conv2 with the 1x1 branch as one-tap chunks of a second source - no stored conv2 output, no
+    separate 1x1 pass.  Returns the unit's output as a plain Src, or None when the shape is not conv_ws16_kernel's (the caller then takes
+    the three-launch form)."""
+    if not (RU_EVAL_ONE_LAUNCH and EVAL_FOLD_WEIGHTS and PRECISION == 'bf16') or x.pool or x.C % 16 or c2.Cout % 16:
+        return None
+    H, W = x.logical_hw()
+    if H % 16 or W % 16 or x.C != cr.Cin:
+        return None
+    c2.prepare([c2.Cin], H, W, x.N)
+    if tuple(c2.cfg[:2]) != (16, 16):
+        return None
+    h = c1.forward([x], False, relu=True)
+    cr.prepare([x.C], H, W, x.N)
+    if tuple(c2.cfg[:2]) != (16, 16):
+        return None
+    if tuple(cr.cfg) != tuple(c2.cfg):
+        cr.cfg, cr.wp = tuple(c2.cfg), None              # (one configuration for both packs: they lie end to end)
+        cr.prepare([x.C], H, W, x.N)
+    ep = c2.eval_pack([h.C])
+    if ep is None:
+        return None
+    ver = (c2.wpe_version, cr.wp_version, None if cr.bias is None else cr.bias._version)
+    if getattr(c2, 'ru_pack', None) is None or c2.ru_pack_version != ver:
+        BN = c2.cfg[2]
+        ntile = -(-c2.Cout // BN)
+        a, b = ep[0].view(ntile, -1), cr.wp.view(ntile, -1)      # per output-channel tile: the nine-tap chunks, then the one-tap chunks
+        c2.ru_pack = torch.cat([a, b], 1).contiguous().view(-1)
+        c2.ru_shift = ep[1] if cr.bias is None else ep[1] + cr.bias.detach()
+        c2.ru_pack_version = ver
+    keep = engine.CONV_DEBUG
+    engine.CONV_DEBUG = keep | 64                        # (the persistent kernel also on small launches: nothing else computes this form)
+    try:
+        if keep & 32 or engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1, query_ws=True) != 2:
+            return None
+        out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1)
+    finally:
+        engine.CONV_DEBUG = keep
+    return Src(out)
 
 
 def materialize(s, H=None, W=None):

@@ -182,6 +182,13 @@ typedef struct cdnet_conv_args {
     const uint16_t *eres;
     const float *eres_scale, *eres_shift;
     int eres_f16, eres_relu;
+    /* taps of the chunks of the SECOND source: 0 = `taps` (the usual concatenation).  1 with taps = 9 (16-bit path, conv_ws16_kernel
+     * only - ask cdnet_conv_ws_eligible): the second source contributes through a 1x1 convolution, its chunks carry the centre tap
+     * alone.  `w` then holds, per output-channel tile, the nine-tap chunks of source 0 followed by the one-tap chunks of source 1
+     * (two cdnet_pack_conv_weights packs laid end to end).  One launch computes relu(bn2(conv2(h)) + conv_1x1(x)) of a residual unit
+     * in eval mode (model_unet_rev1.py:161-170) with the BatchNorm scale folded into conv2's weights and shift + bias in `oshift`. */
+    int taps1;
+    int pad_;
 } cdnet_conv_args;
 
 /* packed element count for a weight tensor; nchunk = Cin/CK over all sources */
@@ -199,6 +206,11 @@ size_t cdnet_conv_packed_weight_elems(int Cout, int nchunk, int taps, int CK, in
                                 bf16(w - bf16(w)) image; twice cdnet_conv_packed_weight_elems elements */
 int cdnet_pack_conv_weights(const float *w, void *packed, int Cout, int Cin, int KH, int KW, int CK, int BN, int mode,
                             void *stream);
+/* mode 0 (optionally | CDNET_PACK_SPLIT) with every output channel's weights multiplied by cout_scale[cout] in fp32 before the rounding:
+ * the eval-mode BatchNorm scale folded into the convolution (nn.BatchNorm2d in eval mode after nn.Conv2d, model_unet_rev1.py:40-41,
+ * 112-114, 146-170), so that the epilogue is shift + ReLU only - what conv_ws16_kernel takes as the accumulators' initial value. */
+int cdnet_pack_conv_weights_scaled(const float *w, const float *cout_scale, void *packed, int Cout, int Cin, int KH, int KW, int CK,
+                                   int BN, int mode, void *stream);
 /* The same packing for many tensors in one launch (the training step re-packs every layer's forward and backward-data
  * weights after each optimizer update - train_util_dam.py:308 optimizer.step()).  `table` is device scratch of
  * cdnet_pack_batch_table_bytes(n_jobs) bytes; upload = 1 copies the job table there (first call, or whenever the jobs
@@ -272,9 +284,10 @@ int cdnet_final_conv1x1_backward(const cdnet_head_feat *f, const float *w, const
  * nn.MaxPool2d(2, 2[, ceil_mode]) (model_unet_rev1.py:268-287 backbone 'M' layers, unet.py:19), F.pad offset - written out
  * as a plain bf16 NHWC tensor out[N][H][W][C]: bit-identical to what cdnet_conv_forward stages on the fly for the same
  * source (H, W = the logical size after the pool).  Consumers of a max-pooled training-mode activation read this copy. */
-/* 1 when cdnet_conv_forward runs these arguments on the producer / consumer kernel (conv_ws_kernel, fp32 mode: conv_ws32_kernel) - the
- * only one that takes cdnet_conv_args.ws = 2 (fp32 mode: the BatchNorm-backward sums of the layer the output feeds, beside the stores).
- * (Round 2's 16-bit BatchNorm-backward source, cdnet_conv_src.relu = 3, was removed in round 3: correct, not faster.) */
+/* Non-zero when cdnet_conv_forward runs these arguments on a producer / consumer kernel: 2 = conv_ws16_kernel (16-bit path, launches
+ * without statistics: the only one that takes cdnet_conv_args.taps1 = 1), 1 = conv_ws_kernel, or in fp32 mode conv_ws32_kernel - the
+ * only one that takes cdnet_conv_args.ws = 2 (the BatchNorm-backward sums of the layer the output feeds, beside the stores).
+ * Nothing is launched. */
 int cdnet_conv_ws_eligible(const cdnet_conv_args *args);
 
 int cdnet_src_materialize(const cdnet_conv_src *src, int N, int H, int W, uint16_t *out, void *stream);
