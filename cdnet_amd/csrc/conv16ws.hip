@@ -42,13 +42,17 @@ struct W16Lds {
     static constexpr int TH = 16, TW = 16, CK = 16;
     static constexpr int PSTR = 32;                               // bytes per halo pixel (16 bf16), k-halves swizzled by the halo row's parity
     static constexpr int NPIX = (TH + 2) * (TW + 2);
-    static constexpr int A_BYTES = NPIX * PSTR;
-    static constexpr int NSLOT = 4;
+    static constexpr int A_BYTES = 11 * 1024;                     // a ring slot: the halo image of a chunk (10 368 B) in whole 1 KB DMA pieces
+    static constexpr int NPIECE = 11;
+    static constexpr int OROW = BN * 2 + 16;                      // out image: bytes per pixel (padded: conflict-free 16-byte writes of 8 consecutive pixels)
+    static constexpr int OBLK = 32 * OROW;                        // a consumer wave's 32-pixel block
+    static constexpr int OHALF = 4 * OBLK;                        // pixel block pi of the four consumer waves
+    static constexpr int OUT_BYTES = 2 * OHALF;
     static constexpr int WCH9 = 9 * CK * BN * 2;                  // packed weights of a nine-tap chunk
     static constexpr int WCH1 = CK * BN * 2;                      // ... of a one-tap chunk
-    static constexpr int RES_MAX = 96 * 1024;                     // resident weights up to this many bytes, else the ring
+    static constexpr int RES_MAX = 82 * 1024;                     // resident weights up to this many bytes, else the ring
     __host__ __device__ static int wbytes(int n9, int n1) { return n9 * WCH9 + n1 * WCH1; }
-    __host__ __device__ static int bytes(int wb, int ctot) { return NSLOT * A_BYTES + wb + 2 * ((ctot + 7) / 8 * 8) * 4; }
+    __host__ __device__ static int bytes(int ns, int wb, int ctot, bool out = false) { return ns * A_BYTES + wb + 2 * ((ctot + 7) / 8 * 8) * 4 + (out ? OUT_BYTES : 0); }
 };
 
 // sigma: the weight row lane m of an A fragment reads (an involution: bits 2 and 3 swapped).  D row m = (r & 3) + 8 (r >> 2) + 4 half then
@@ -59,25 +63,49 @@ __device__ __forceinline__ int sigma32(int m) { return (m & ~12) | ((m & 4) << 1
 // STREAM: the weight chunks stream through a four-slot ring (even chunk count); else all of a tile's chunks are resident
 // MIX: the second source's chunks carry one tap (the centre) instead of nine
 // NCS: chunks per tile known to the compiler - 1: one, 2: two or three, 0: four or more (how the finished tile's epilogue is spread)
-template <int BN, int XF, bool STREAM, bool MIX, int NCS>
+// NS: halo ring slots.  XF 0 (plain bf16 sources): the movers only ISSUE - every halo chunk goes HBM -> LDS by DMA (buffer_load ... lds, 1 KB
+// pieces; zero fill by the descriptor's range check), NS - 2 chunks ahead of the consumers; no staging registers, no ds_write bursts in front
+// of the consumers' fragment reads.  XF 2: four chunks in flight in registers, transformed and written by the movers (NS = 4).
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+// one LDS-DMA piece through a buffer descriptor: 64 lanes x 16 bytes, global (descriptor base + this lane's byte offset; out of range -> zeros)
+// -> LDS (uniform byte address + lane * 16).  Inline assembly: the compiler does not count it - the mover waits by hand (conv32ws.hip).
+__device__ __forceinline__ void blds_piece(i32x4s rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_piece16(const void *gbase, unsigned lane_bytes, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_bytes), "s"(gbase), "s"(lds_dst) : "memory");
+}
+
+// PFD: 0 = the DMA movers; 4 / 8 / 12 = the register movers with that many halo chunks in flight per thread (NS = 4)
+// OUT: the finished tile leaves through an LDS out image and the MOVERS store it (register movers, an even chunk count >= 4): a store issued by
+// a consumer wave between MFMAs waits for the memory pipeline behind the movers' requests, and the matrix pipe waits with it
+template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT>
 __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using L = W16Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
-    constexpr int PF = 4;
+    constexpr int PF = PFD > 0 ? PFD : 4;
+    constexpr int IPG = PFD > 0 ? PF / 2 : 2;                     // barrier intervals per iteration of the movers' loop
     static_assert(!(STREAM && MIX), "one-tap chunks only with resident weights");
+    static_assert(!OUT || (PFD > 0 && NCS == 0 && !MIX), "LDS out image: register movers, tiles of an even number (>= 4) of nine-tap chunks");
+    static_assert(PFD == 0 ? XF == 0 : (NS == 4 && PF % 4 == 0), "DMA movers: plain sources; register movers: a four-slot ring, sets = slots mod 4");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_a = smem;
-    unsigned char *lds_w = smem + L::NSLOT * L::A_BYTES;
+    unsigned char *lds_w = smem + NS * L::A_BYTES;
     const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
     const int xfs = (ctot + 7) / 8 * 8;
     const int n1 = NCH - n0;
     const int wres_bytes = STREAM ? 4 * L::WCH9 : (MIX ? L::wbytes(n0, n1) : L::wbytes(NCH, 0));
     float *s_xf = reinterpret_cast<float *>(lds_w + wres_bytes);
+    unsigned char *lds_o = lds_w + wres_bytes + 2 * xfs * 4;      // OUT only
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,10 +137,127 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     if (wave >= 4) {
         // ================================ movers (conv_ws_kernel's, without the out path) ================================
         const int ptid = tid - 256, pw = wave - 4;
-        const int slot = ptid % VPP;
         if (A.debug & 16) __builtin_amdgcn_s_setprio(2);         // (experiment: the younger half of the workgroup loses the issue arbitration at equal priority)
+        if constexpr (PFD == 0) {
+            // ---- DMA movers.  Piece p of a chunk's halo image = LDS bytes [1024 p, 1024 p + 1024) = 32 halo pixels x 32 B; lane l of the piece
+            // ---- brings the 16 bytes at pixel 32 p + l / 2, position l & 1 - the channel half (l & 1) ^ (halo row & 1) (the consumers'
+            // ---- swizzle, in the SOURCE address).  Wave pw issues pieces pw, pw + 4, pw + 8 (< 11) of every chunk.
+            constexpr int PD = NS - 2;                           // run chunks issued ahead of the consumers' interval
+            constexpr int NJ = 3;
+            int hyx[NJ];
+            unsigned cb[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int pc = pw + 4 * j, pix = 32 * pc + (lane >> 1);
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                const bool ok = pc < L::NPIECE && pix < NPIX;
+                hyx[j] = ok ? ((hy << 8) | hx) : 0x1f1f;       // (31 = a vector that never exists: bit 31 of the masks is always set)
+                cb[j] = (unsigned)(((lane & 1) ^ (hy & 1)) * 16);
+            }
+            auto mkdesc = [](const void *base, unsigned nbytes) -> i32x4s {
+                const unsigned long long b = (unsigned long long)(size_t)base;
+                const i32x4s d = {(int)__builtin_amdgcn_readfirstlane((int)(unsigned)b), (int)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)),
+                                  (int)__builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000};
+                return d;
+            };
+            const unsigned sb0 = (unsigned)A.N * A.src[0].Hs * (A.src[0].row_stride ? A.src[0].row_stride : A.src[0].Ws * A.src[0].C) * 2u;
+            const unsigned sb1 = A.nsrc > 1 ? (unsigned)A.N * A.src[1].Hs * (A.src[1].row_stride ? A.src[1].row_stride : A.src[1].Ws * A.src[1].C) * 2u : 0u;
+            const i32x4s rs0 = mkdesc(A.src[0].x, sb0), rs1 = mkdesc(A.nsrc > 1 ? A.src[1].x : A.src[0].x, sb1);
+            auto bad_mask = [](int lo, int hi) -> unsigned {
+                lo = lo < 0 ? 0 : (lo > 31 ? 31 : lo);
+                hi = hi < lo ? lo : (hi > 31 ? 31 : hi);
+                return ~(((1u << hi) - 1u) & ~((1u << lo) - 1u));
+            };
+            int ik = 0, ic = 0, in_, iy0, ix0, isl = 0;
+            {
+                in_ = t_lo / tiles_img;
+                const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
+                iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
+            }
+            unsigned ge[NJ];
+            const unsigned lds_a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_a;
+            auto issue = [&]() {
+                const int si = ik < n0 ? 0 : 1, cc0 = (ik < n0 ? ik : ik - n0) * CK;
+                const ConvSrc &s = A.src[si];
+                if (ik == 0 || ik == n0) {
+                    const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
+                    const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
+                    const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;
+                    const unsigned rowbad = bad_mask(ylo - (iy0 - 1), yhi - (iy0 - 1)), colbad = bad_mask(xlo - (ix0 - 1), xhi - (ix0 - 1));
+                    const unsigned img_b = (unsigned)((in_ * s.Hs + (iy0 - 1 - s.off_y)) * rs + (ix0 - 1 - s.off_x) * s.C) * 2u;
+                    const unsigned rs_b = (unsigned)rs * 2u, c_b = (unsigned)s.C * 2u;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const unsigned hy = (unsigned)hyx[j] >> 8, hx = (unsigned)hyx[j] & 0xffu;
+                        const unsigned t = (rowbad >> hy) | (colbad >> hx);
+                        ge[j] = ((img_b + hy * rs_b + hx * c_b + cb[j]) & 0x7fffffffu) | (t << 31);
+                    }
+                }
+                const i32x4s rsx = si ? rs1 : rs0;
+                const unsigned cc0_b = (unsigned)cc0 * 2u;
+                const unsigned dst = lds_a_addr + (unsigned)isl * L::A_BYTES + (unsigned)pw * 1024u;
+                if (!(A.debug & 2)) {                            // (2: ablation - no halo requests)
+                    blds_piece(rsx, ge[0] + cc0_b, dst);
+                    blds_piece(rsx, ge[1] + cc0_b, dst + 4096u);
+                    if (pw < 3) blds_piece(rsx, ge[2] + cc0_b, dst + 8192u);
+                }
+                isl = isl + 1 == NS ? 0 : isl + 1;
+                if (ic + 1 < S) {
+                    ++ic;
+                    if (++ik == NCH) {
+                        ik = 0;
+                        ix0 += TW;
+                        if (ix0 >= A.W) { ix0 = 0; iy0 += TH; if (iy0 >= A.H) { iy0 = 0; ++in_; } }
+                    }
+                }
+            };
+            // STREAM: weight chunk wk of the tile -> weight slot (run chunk & 3): 18 / 9 pieces, the four waves in turn
+            int wk = 0, wq = 0;
+            const unsigned lds_w_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_w;
+            auto dma_w = [&]() {
+                constexpr int NPC = L::WCH9 / 1024;
+                const char *wsrc = reinterpret_cast<const char *>(A.w) + ((size_t)cout_tile * NCH + wk) * L::WCH9;
+                const unsigned wdst = lds_w_addr + (unsigned)(wq & 3) * L::WCH9;
+#pragma unroll
+                for (int i = 0; i < (NPC + 3) / 4; ++i) {
+                    const int pc = i * 4 + pw;
+                    if (i * 4 + 3 < NPC || pc < NPC) glds_piece16(wsrc + pc * 1024, (unsigned)lane * 16u, wdst + pc * 1024);
+                }
+                if (++wk == NCH) wk = 0;
+                ++wq;
+            };
+            // everything older than this wave's N youngest vector-memory operations has landed
+            auto wait_keep = [&](auto n3_c, auto n2_c) {
+                constexpr int N3 = decltype(n3_c)::value, N2 = decltype(n2_c)::value;
+                if (pw < 3) __builtin_amdgcn_s_waitcnt((N3 & 15) | (7 << 4) | (15 << 8) | ((N3 >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt((N2 & 15) | (7 << 4) | (15 << 8) | ((N2 >> 4) << 14));
+            };
+            // resident weights: the halo pieces of PD - 2 chunks may stay in flight across a barrier; streamed weights: the weight DMA of an
+            // interval is issued first and must have landed at its end - only that interval's two halo chunks stay in flight
+            using K3 = std::integral_constant<int, STREAM ? 2 * 3 : (PD - 2) * 3>;
+            using K2 = std::integral_constant<int, STREAM ? 2 * 2 : (PD - 2) * 2>;
+            __syncthreads();                                     // B0 (the consumers' resident weights)
+            if (STREAM) { dma_w(); dma_w(); }
+#pragma unroll
+            for (int c = 0; c < PD; ++c) issue();
+            if (STREAM) wait_keep(std::integral_constant<int, (PD - 2) * 3>{}, std::integral_constant<int, (PD - 2) * 2>{});
+            else wait_keep(K3{}, K2{});
+            __builtin_amdgcn_s_barrier();                        // B1: run chunks 0, 1 (and their weights) are in the LDS
+            for (int i = 0; i < NI; i += 2) {
+                if (STREAM) { dma_w(); dma_w(); }
+                issue(); issue();
+                wait_keep(K3{}, K2{});
+                __builtin_amdgcn_s_barrier();
+                if (STREAM) { dma_w(); dma_w(); }
+                issue(); issue();
+                wait_keep(K3{}, K2{});
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+        const int slot = ptid % VPP;
         u32x4v pa[PF][NA];
-        unsigned eo[PF][NA];                     // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
+        unsigned eo[XF != 0 ? PF : 1][NA];       // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
         int hyx[NA], doff[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -170,7 +315,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const unsigned voff = ge[i] + cc0_b;
-                eo[R][i] = voff;
+                if (XF != 0) eo[R][i] = voff;
                 if (!(A.debug & 2)) pa[R][i] = bload(rsx, voff);     // (2: ablation - no halo requests)
             }
             if (ic + 1 < S) {
@@ -195,7 +340,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            unsigned char *dst0 = lds_a + R * L::A_BYTES;
+            unsigned char *dst0 = lds_a + (R & 3) * L::A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -251,14 +396,67 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        using I3 = std::integral_constant<int, 3>;
-        issue(I0{});
-        issue(I1{});
-        issue(I2{});
-        issue(I3{});
+        // OUT: the half (pixel block pi of the four consumer waves) of a finished tile the consumers parked in the PREVIOUS interval leaves
+        // here: wave pw stores the block of consumer wave pw - 8 lanes per pixel, one 128-byte line each (BN = 64)
+        const int NIT = NCH >> 1;                                // intervals per tile (OUT: even chunk counts)
+        int st_jt = 0, st_it = 0;                                // tile / interval-in-tile of the interval the consumers work on
+        int h_n[2], h_y0[2], h_x0[2];                            // coordinates of tiles jt - 1, jt - 2
+        int c_n = in_, c_y0 = iy0, c_x0 = ix0;                   // ... of tile jt
+        h_n[0] = h_n[1] = c_n; h_y0[0] = h_y0[1] = c_y0; h_x0[0] = h_x0[1] = c_x0;
+        auto store_half = [&](int hf, int tn, int ty0, int tx0) {
+            constexpr int SPP = BN / 8;                          // 16-byte segments per pixel
+            constexpr int PPR = 64 / SPP, NR = 32 / PPR;         // pixels per wave-instruction, instructions per block
+            const int seg = lane % SPP, lp = lane / SPP;
+            const unsigned char *blk = lds_o + hf * L::OHALF + pw * L::OBLK + seg * 16;
+            u32x4v v[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r] = *reinterpret_cast<const u32x4v *>(blk + (r * PPR + lp) * L::OROW);
+            const bool ok = cout0 + seg * 8 < A.Cout && !(A.debug & 8);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int px = r * PPR + lp;
+                unsigned short *dstp = A.out + (((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)) * A.out_cstride + A.out_coff + cout0 + seg * 8;
+                if (ok) *reinterpret_cast<u32x4v *>(dstp) = v[r];
+            }
+        };
+        // called once per mover interval iv (the consumers' interval); stores what the consumers parked in interval iv - 1
+        auto store_prev = [&](int iv) -> bool {
+            bool stored = false;
+            if (OUT) {
+                const int pv = iv - 1;
+                if (pv >= 0 && pv < NI) {
+                    // interval pv = (tile pj, interval pit)
+                    int pj = st_jt, pit = st_it - 1;
+                    if (pit < 0) { pj -= 1; pit = NIT - 1; }
+                    if (pj >= 1 && pit <= 1) {
+                        const int k = st_jt - (pj - 1) - 1;           // tile pj - 1 = history slot (st_jt - 1 - (pj - 1)) ... 0: jt - 1, 1: jt - 2
+                        store_half(pit, h_n[k], h_y0[k], h_x0[k]);
+                        stored = true;
+                    }
+                }
+                // advance to the next interval
+                if (++st_it == NIT) {
+                    st_it = 0; ++st_jt;
+                    h_n[1] = h_n[0]; h_y0[1] = h_y0[0]; h_x0[1] = h_x0[0];
+                    h_n[0] = c_n; h_y0[0] = c_y0; h_x0[0] = c_x0;
+                    c_x0 += TW;
+                    if (c_x0 >= A.W) { c_x0 = 0; c_y0 += TH; if (c_y0 >= A.H) { c_y0 = 0; ++c_n; } }
+                }
+            }
+            return stored;
+        };
+        // lgkmcnt(0) + barrier, no wait for vector memory (the stores of the out image stay in flight)
+        auto lds_sync = []() {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // register set of run chunk c = c mod PF (compile-time inside the unrolled loop body), ring slot = c mod 4
+        auto for_sets = [&](auto f) {                            // f(integral_constant<int, k>) for k = 0 .. PF - 1
+            [&]<int... K>(std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }(std::make_integer_sequence<int, PF>{});
+        };
+        for_sets([&](auto k) { issue(k); });
         for (int c = ptid; c < ctot; c += 256) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
             const int cc = c < c0n ? c : c - c0n;
@@ -266,6 +464,8 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
         }
         __syncthreads();                                         // B0: table (+ resident weights)
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
         commit(I0{}, 0);
         commit(I1{}, 1);
         if (STREAM) { dma_w(); dma_w(); }
@@ -273,26 +473,36 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         issue(I1{});
         if (STREAM) wait_vm(NHL{});
         __syncthreads();                                         // B1: run chunks 0, 1 staged
-        // interval i: the consumers work on run chunks 2i, 2i+1 (slots 2i & 3, ...); here the two chunks after them are staged
-        if (!STREAM) {
-            for (int i = 0; i < NI; i += 2) {
-                const int q0 = 2 * i;
-                commit(I2{}, q0 + 2); issue(I2{}); commit(I3{}, q0 + 3); issue(I3{}); __syncthreads();
-                commit(I0{}, q0 + 4); issue(I0{}); commit(I1{}, q0 + 5); issue(I1{}); __syncthreads();
-            }
-        } else {
-            for (int i = 0; i < NI; i += 2) {
-                const int q0 = 2 * i;
-                commit(I2{}, q0 + 2); commit(I3{}, q0 + 3);
-                dma_w(); dma_w();
-                issue(I2{}); issue(I3{});
-                stream_sync(NHL{});
-                commit(I0{}, q0 + 4); commit(I1{}, q0 + 5);
-                dma_w(); dma_w();
-                issue(I0{}); issue(I1{});
-                stream_sync(NHL{});
-            }
+        // interval i: the consumers work on run chunks 2i, 2i+1; here the two chunks after them are staged (their register sets are
+        // refilled with the chunks PF further on).  One loop iteration = PF / 2 intervals, so that every set index is a constant.
+        for (int i0 = 0; i0 < NI; i0 += IPG) {
+            [&]<int... M>(std::integer_sequence<int, M...>) {
+                ([&] {
+                    constexpr int RA = (2 * M + 2) % PF, RB = (2 * M + 3) % PF;
+                    const int qa = 2 * (i0 + M) + 2;
+                    using SA = std::integral_constant<int, RA>;
+                    using SB = std::integral_constant<int, RB>;
+                    if (!STREAM) {
+                        commit(SA{}, qa); issue(SA{}); commit(SB{}, qa + 1); issue(SB{});
+                        store_prev(i0 + M);
+                        if (OUT) lds_sync(); else __syncthreads();
+                    } else {
+                        commit(SA{}, qa); commit(SB{}, qa + 1);
+                        dma_w(); dma_w();
+                        if (OUT) {
+                            // (the stores sit between the weight DMA and the halo requests: the wait leaves them in flight too)
+                            const bool stored = store_prev(i0 + M);
+                            issue(SA{}); issue(SB{});
+                            if (stored) stream_sync(std::integral_constant<int, 2 * NA + 32 / (64 / (BN / 8))>{}); else stream_sync(NHL{});
+                        } else {
+                            issue(SA{}); issue(SB{});
+                            stream_sync(NHL{});
+                        }
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, IPG>{});
         }
+        if (OUT) store_prev((NI + IPG - 1) / IPG * IPG);         // what the consumers parked in the very last interval
         return;
     }
 
@@ -351,11 +561,12 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         for (int pi = 0; pi < NPI; ++pi)
             row_base[pi] = out_b + ((size_t)(p_n * A.H + p_y0 + wm * 4 + pi * 2) * A.W + p_x0) * pix_b;
     };
-    // epilogue micro-operations of a finished set, a pixel block (group) at a time: for each of its UG = 2 NCI units (ci, s) - 8 consecutive
-    // output channels of this lane's pixel - convert 2 x 2 and ReLU (three micro-operations), then the group's UG stores one after the
-    // other: together they complete the 128-byte lines of the block's 32 pixels while those are still in the L2 (spread over a tile, the
-    // partial lines of a launch larger than the caches were evicted and written to HBM piecemeal: 398 us against 354 at 64 tiles)
-    constexpr int UG = NCI * 2, NMO = NPI * UG * 4;
+    // epilogue micro-operations of a finished set, one (pixel block, output-channel block) group at a time: for its two units s = 0, 1 - 8
+    // consecutive output channels of this lane's pixel each - convert 2 x 2 and ReLU (three micro-operations per unit), then the group's two
+    // stores one after the other (64 contiguous bytes per pixel); the groups of a pixel block follow each other, so the 128-byte lines of
+    // its 32 pixels are completed while they are still in the L2 (with a tile's stores spread over the whole next tile, the partial lines of
+    // a launch larger than the caches were evicted and written to HBM piecemeal: 398 us against 354 at 64 tiles)
+    constexpr int UG = 2, NMO = NPI * NCI * UG * 4;
     unsigned dd[UG][4];
     auto cvt2 = [&](float a, float b) -> unsigned {              // (bf16 outputs only: the launcher sends fp16 outputs to the older kernels)
         const xf_f32x2 p = {a, b};
@@ -364,20 +575,25 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     auto relu2 = [&](unsigned v) -> unsigned {
         return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(xf_s16x2, v), lo_clamp));
     };
-    auto micro = [&](const f32x16 (&P)[NCI][NPI], int e) {
-        const int pi = e / (4 * UG), j = e % (4 * UG);
+    unsigned char *const o_lane = lds_o + wave * L::OBLK + l31 * L::OROW + half * 16;      // OUT: this lane's pixel in its wave's block
+    auto micro = [&](const f32x16 (&P)[NCI][NPI], int e, bool direct) {
+        const int gi = e / (4 * UG), j = e % (4 * UG);
+        const int pi = gi / NCI, ci = gi % NCI;
+        const f32x16 &v = P[ci][pi];
         if (j < 3 * UG) {
-            const int u = j / 3, k = j % 3, ci = u >> 1, s = u & 1;
-            const f32x16 &v = P[ci][pi];
-            if (k == 0) { dd[u][0] = cvt2(v[8 * s + 0], v[8 * s + 1]); dd[u][1] = cvt2(v[8 * s + 2], v[8 * s + 3]); }
-            else if (k == 1) { dd[u][2] = cvt2(v[8 * s + 4], v[8 * s + 5]); dd[u][3] = cvt2(v[8 * s + 6], v[8 * s + 7]); }
-            else { dd[u][0] = relu2(dd[u][0]); dd[u][1] = relu2(dd[u][1]); dd[u][2] = relu2(dd[u][2]); dd[u][3] = relu2(dd[u][3]); }
+            const int s = j / 3, k = j % 3;
+            if (k == 0) { dd[s][0] = cvt2(v[8 * s + 0], v[8 * s + 1]); dd[s][1] = cvt2(v[8 * s + 2], v[8 * s + 3]); }
+            else if (k == 1) { dd[s][2] = cvt2(v[8 * s + 4], v[8 * s + 5]); dd[s][3] = cvt2(v[8 * s + 6], v[8 * s + 7]); }
+            else { dd[s][0] = relu2(dd[s][0]); dd[s][1] = relu2(dd[s][1]); dd[s][2] = relu2(dd[s][2]); dd[s][3] = relu2(dd[s][3]); }
         } else {
-            const int u = j - 3 * UG, ci = u >> 1, s = u & 1;
-            if (cout0 + ci * 32 + s * 16 < A.Cout && !(A.debug & 8)) {
+            const int s = j - 3 * UG;
+            if (OUT && !direct) {
+                const u32x4v val = {dd[s][0], dd[s][1], dd[s][2], dd[s][3]};
+                *reinterpret_cast<u32x4v *>(o_lane + pi * L::OHALF + ci * 64 + s * 32) = val;
+            } else if (cout0 + ci * 32 + s * 16 < A.Cout && !(A.debug & 8)) {
                 char *sb = row_base[pi] + (ci * 64 + s * 32);
                 asm volatile("" : "+s"(sb));                    // (scalar base kept opaque: uniform base + one per-lane offset register = the store's saddr form)
-                const u32x4v val = {dd[u][0], dd[u][1], dd[u][2], dd[u][3]};
+                const u32x4v val = {dd[s][0], dd[s][1], dd[s][2], dd[s][3]};
                 *(__attribute__((address_space(1))) u32x4v *)((__attribute__((address_space(1))) char *)sb + l_off) = val;
             }
         }
@@ -424,7 +640,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                             if ((i * NG) / CNTD == g) {
                                 if (!any) __builtin_amdgcn_sched_barrier(0);
                                 any = true;
-                                micro(P, E0 + i);
+                                micro(P, E0 + i, false);
                             }
                         if (any) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -440,8 +656,8 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using Z2 = std::integral_constant<int, 2>;
     using Z3 = std::integral_constant<int, 3>;
     using Z4 = std::integral_constant<int, 4>;
-    int q = 0;                                                   // run chunk counter
-    auto slot_a = [&]() -> const unsigned char * { return lds_a + (q & 3) * L::A_BYTES; };
+    int q = 0, qs = 0;                                           // run chunk counter; its halo ring slot (q mod NS)
+    auto slot_a = [&]() -> const unsigned char * { return lds_a + qs * L::A_BYTES; };
     auto slot_w = [&](int k) -> const unsigned char * {
         if (STREAM) return lds_w + (q & 3) * L::WCH9;
         if (MIX && k >= n0) return lds_w + n0 * L::WCH9 + (k - n0) * L::WCH1;
@@ -449,6 +665,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     };
     auto after_chunk = [&]() {
         ++q;
+        qs = qs + 1 == NS ? 0 : qs + 1;
         if ((q & 1) == 0) __syncthreads();
     };
     // tile j on set C; P = the finished tile j - 1: its epilogue rides in the first chunk steps
@@ -491,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     auto serial_epilogue = [&](const f32x16 (&P)[NCI][NPI]) {
         set_row_bases();
 #pragma unroll
-        for (int e = 0; e < NMO; ++e) micro(P, e);
+        for (int e = 0; e < NMO; ++e) micro(P, e, true);
     };
 
     __syncthreads();                                             // B1: run chunks 0, 1 are staged
@@ -504,7 +721,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     const bool tail = j < ntl;
     if (tail) tile_step(T_{}, accB, accA);
     if (q & 1) __syncthreads();                                  // the last, half-filled interval
-    if (NI & 1) __syncthreads();                                 // the movers' loop runs whole pairs of intervals
+    for (int i = NI; i % IPG != 0; ++i) __syncthreads();         // the movers' loop runs whole groups of IPG intervals
     if (tail) serial_epilogue(accB); else serial_epilogue(accA);
 }
 
@@ -533,7 +750,18 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     const int wres = mix ? L::wbytes(n0, n1) : L::wbytes(nch, 0);
     const bool stream = wres > L::RES_MAX;
     if (stream && (mix || (nch & 1))) return -1;
-    const int smem = L::bytes(stream ? 4 * L::WCH9 : wres, ctot);
+    // halo ring: four slots under the register movers; under the DMA movers (plain sources) seven - five chunks ahead of the consumers -
+    // or six beside the one-tap chunks' extra weights
+    // plain sources: CDNET_WS16_PF=0 selects the DMA movers (halo chunks HBM -> LDS by buffer_load ... lds, a seven-slot ring, direct stores by
+    // the consumers) instead of the register movers + LDS out image.  Measured on the dominant layer (tools/bench_ws16_pf.py, 16 / 64 tiles):
+    // DMA 73 / 347 us, register movers with 4 / 8 / 12 chunks in flight and direct stores 74-77 / 353-388 us (depth does not help: the launch
+    // is not latency-bound), register movers + out image stored by the movers 74-76 / 319 us (conv_ws_kernel: 82 / 360 us)
+    static const int pfd_env = getenv("CDNET_WS16_PF") ? atoi(getenv("CDNET_WS16_PF")) : 4;
+    const int pfd = !all_plain ? 4 : (pfd_env == 0 ? 0 : 4);
+    const int ns = pfd != 0 ? 4 : (mix ? 6 : 7);
+    static const int out_env = getenv("CDNET_WS16_OUT") ? atoi(getenv("CDNET_WS16_OUT")) : 1;
+    const bool out = out_env && pfd != 0 && !mix && nch >= 4 && !(nch & 1) && L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
+    const int smem = L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, out);
     if (smem > 160 * 1024) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
     static int n_cu = 0;
@@ -554,12 +782,29 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     if (G < 1) G = 1;
     if (dry_run) return CDNET_OK;
     dim3 grid(G, ctiles, 1);
-    auto go = [&](auto xf_c, auto sm_c, auto mx_c, auto ncs_c) -> int {
+    auto go = [&](auto xf_c, auto sm_c, auto mx_c, auto ncs_c, auto pf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
+        constexpr bool OUTOK = decltype(pf_c)::value > 0 && decltype(ncs_c)::value == 0 && !decltype(mx_c)::value;
+        if constexpr (OUTOK) {
+            if (out) {
+                constexpr bool STREAM_ = decltype(sm_c)::value;
+                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, false, 0, 4, decltype(pf_c)::value, true>;
+                static bool attr_o = false;
+                if (!attr_o) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_o), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                        return check_launch("hipFuncSetAttribute(conv_ws16 out)");
+                    attr_o = true;
+                }
+                kern_o<<<grid, 512, smem, st>>>(A);
+                return check_launch("conv_ws16_kernel(out)");
+            }
+        }
         constexpr bool STREAM = decltype(sm_c)::value;
         constexpr bool MIX = decltype(mx_c)::value;
         constexpr int NCS = decltype(ncs_c)::value;
-        auto kern = conv_ws16_kernel<BN, XF, STREAM, MIX, NCS>;
+        constexpr int PFD = decltype(pf_c)::value;
+        constexpr int NS = PFD != 0 ? 4 : (MIX ? 6 : 7);
+        auto kern = conv_ws16_kernel<BN, XF, STREAM, MIX, NCS, NS, PFD, false>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -577,7 +822,9 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     using F_ = std::false_type;
     using T_ = std::true_type;
     auto by_xf = [&](auto sm_c, auto mx_c, auto ncs_c) -> int {
-        return all_plain ? go(X0{}, sm_c, mx_c, ncs_c) : go(X2{}, sm_c, mx_c, ncs_c);
+        if (!all_plain) return go(X2{}, sm_c, mx_c, ncs_c, std::integral_constant<int, 4>{});
+        if (pfd == 0) return go(X0{}, sm_c, mx_c, ncs_c, std::integral_constant<int, 0>{});
+        return go(X0{}, sm_c, mx_c, ncs_c, std::integral_constant<int, 4>{});
     };
     if (stream) return by_xf(T_{}, F_{}, C0{});                  // (an even chunk count >= 6)
     if (mix) return by_xf(F_{}, T_{}, C0{});
