@@ -42,7 +42,9 @@ struct W16Lds {
     static constexpr int TH = 16, TW = 16, CK = 16;
     static constexpr int PSTR = 32;                               // bytes per halo pixel (16 bf16), k-halves swizzled by the halo row's parity
     static constexpr int NPIX = (TH + 2) * (TW + 2);
-    static constexpr int A_BYTES = 11 * 1024;                     // a ring slot: the halo image of a chunk (10 368 B) in whole 1 KB DMA pieces
+    static constexpr int A_IMG = NPIX * PSTR;                     // the halo image of a chunk: 10 368 B
+    static constexpr int A_DMA = 11 * 1024;                       // ... as a ring slot of the DMA movers: whole 1 KB pieces
+    __host__ __device__ static constexpr int a_bytes(bool dma) { return dma ? A_DMA : A_IMG; }
     static constexpr int NPIECE = 11;
     static constexpr int OROW = BN * 2 + 16;                      // out image: bytes per pixel (padded: conflict-free 16-byte writes of 8 consecutive pixels)
     static constexpr int OBLK = 32 * OROW;                        // a consumer wave's 32-pixel block
@@ -52,7 +54,7 @@ struct W16Lds {
     static constexpr int WCH1 = CK * BN * 2;                      // ... of a one-tap chunk
     static constexpr int RES_MAX = 82 * 1024;                     // resident weights up to this many bytes, else the ring
     __host__ __device__ static int wbytes(int n9, int n1) { return n9 * WCH9 + n1 * WCH1; }
-    __host__ __device__ static int bytes(int ns, int wb, int ctot, bool out = false) { return ns * A_BYTES + wb + 2 * ((ctot + 7) / 8 * 8) * 4 + (out ? OUT_BYTES : 0); }
+    __host__ __device__ static int bytes(int ns, bool dma, int wb, int ctot, bool out = false) { return ns * a_bytes(dma) + wb + 2 * ((ctot + 7) / 8 * 8) * 4 + (out ? OUT_BYTES : 0); }
 };
 
 // sigma: the weight row lane m of an A fragment reads (an involution: bits 2 and 3 swapped).  D row m = (r & 3) + 8 (r >> 2) + 4 half then
@@ -90,16 +92,17 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
     constexpr int PF = PFD > 0 ? PFD : 4;
+    constexpr int A_BYTES = L::a_bytes(PFD == 0);                 // halo ring slot stride
     constexpr int IPG = PFD > 0 ? PF / 2 : 2;                     // barrier intervals per iteration of the movers' loop
     static_assert(!(STREAM && MIX), "one-tap chunks only with resident weights");
-    static_assert(!OUT || (PFD > 0 && NCS == 0 && !MIX), "LDS out image: register movers, tiles of an even number (>= 4) of nine-tap chunks");
+    static_assert(!OUT || (PFD > 0 && NCS == 0), "LDS out image: register movers, tiles of an even number (>= 4) of chunks");
     static_assert(PFD == 0 ? XF == 0 : (NS == 4 && PF % 4 == 0), "DMA movers: plain sources; register movers: a four-slot ring, sets = slots mod 4");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_a = smem;
-    unsigned char *lds_w = smem + NS * L::A_BYTES;
+    unsigned char *lds_w = smem + NS * A_BYTES;
     const int c0n = A.src[0].C, ctot = c0n + (A.nsrc > 1 ? A.src[1].C : 0);
     const int xfs = (ctot + 7) / 8 * 8;
     const int n1 = NCH - n0;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 }
                 const i32x4s rsx = si ? rs1 : rs0;
                 const unsigned cc0_b = (unsigned)cc0 * 2u;
-                const unsigned dst = lds_a_addr + (unsigned)isl * L::A_BYTES + (unsigned)pw * 1024u;
+                const unsigned dst = lds_a_addr + (unsigned)isl * A_BYTES + (unsigned)pw * 1024u;
                 if (!(A.debug & 2)) {                            // (2: ablation - no halo requests)
                     blds_piece(rsx, ge[0] + cc0_b, dst);
                     blds_piece(rsx, ge[1] + cc0_b, dst + 4096u);
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            unsigned char *dst0 = lds_a + (R & 3) * L::A_BYTES;
+            unsigned char *dst0 = lds_a + (R & 3) * A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using Z3 = std::integral_constant<int, 3>;
     using Z4 = std::integral_constant<int, 4>;
     int q = 0, qs = 0;                                           // run chunk counter; its halo ring slot (q mod NS)
-    auto slot_a = [&]() -> const unsigned char * { return lds_a + qs * L::A_BYTES; };
+    auto slot_a = [&]() -> const unsigned char * { return lds_a + qs * A_BYTES; };
     auto slot_w = [&](int k) -> const unsigned char * {
         if (STREAM) return lds_w + (q & 3) * L::WCH9;
         if (MIX && k >= n0) return lds_w + n0 * L::WCH9 + (k - n0) * L::WCH1;
@@ -760,8 +763,8 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     const int pfd = !all_plain ? 4 : (pfd_env == 0 ? 0 : 4);
     const int ns = pfd != 0 ? 4 : (mix ? 6 : 7);
     static const int out_env = getenv("CDNET_WS16_OUT") ? atoi(getenv("CDNET_WS16_OUT")) : 1;
-    const bool out = out_env && pfd != 0 && !mix && nch >= 4 && !(nch & 1) && L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
-    const int smem = L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, out);
+    const bool out = out_env && pfd != 0 && nch >= 4 && !(nch & 1) && L::bytes(ns, false, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
+    const int smem = L::bytes(ns, pfd == 0, stream ? 4 * L::WCH9 : wres, ctot, out);
     if (smem > 160 * 1024) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
     static int n_cu = 0;
@@ -784,11 +787,11 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     dim3 grid(G, ctiles, 1);
     auto go = [&](auto xf_c, auto sm_c, auto mx_c, auto ncs_c, auto pf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
-        constexpr bool OUTOK = decltype(pf_c)::value > 0 && decltype(ncs_c)::value == 0 && !decltype(mx_c)::value;
+        constexpr bool OUTOK = decltype(pf_c)::value > 0 && decltype(ncs_c)::value == 0;
         if constexpr (OUTOK) {
             if (out) {
                 constexpr bool STREAM_ = decltype(sm_c)::value;
-                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, false, 0, 4, decltype(pf_c)::value, true>;
+                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, decltype(mx_c)::value, 0, 4, decltype(pf_c)::value, true>;
                 static bool attr_o = false;
                 if (!attr_o) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_o), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

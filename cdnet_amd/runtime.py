@@ -165,14 +165,17 @@ class ConvLayer:
         (bf16(w[cout] * scale[cout])) and the shift that is left for the epilogue - what conv_ws16_kernel takes as the accumulators'
         initial value (csrc/conv16ws.hip).  Returns (packed, shift) or None when the layer keeps the epilogue affine (transposed and
         stride-2 layers, the RGB stem's zero-extended pack, fp32 mode)."""
-        if not EVAL_FOLD_WEIGHTS or not getattr(self, 'fold_eval', True) or PRECISION != 'bf16' or self.kind not in ('conv3', 'conv1') or self.bn is None:
+        if not EVAL_FOLD_WEIGHTS or not getattr(self, 'fold_eval', True) or self.kind not in ('conv3', 'conv1') or self.bn is None:
             return None
+        if PRECISION != 'bf16':
+            return None                                      # (fp32 mode keeps the epilogue affine: conv_ws32_kernel applies it per lane at no cost)
+        f32 = False
         cin_total = sum(src_channels)
         pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16 zero-extended reduction channels
         sc, sh = self.eval_fold()
-        ver = (self.weight._version, self.fold_version, WEIGHTS_EPOCH[0], tuple(self.cfg))
+        ver = (self.weight._version, self.fold_version, WEIGHTS_EPOCH[0], tuple(self.cfg), f32)
         if getattr(self, 'wpe', None) is None or self.wpe_version != ver:
-            self.wpe = engine.pack_weights(self.weight.detach(), self.cfg, 0, Cin_pad=pad, out=getattr(self, 'wpe', None), cout_scale=sc)
+            self.wpe = engine.pack_weights(self.weight.detach(), self.cfg, 0, Cin_pad=pad, out=getattr(self, 'wpe', None), cout_scale=sc, split=f32)
             self.wpe_version = ver
         return self.wpe, sh
 
