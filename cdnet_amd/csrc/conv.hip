@@ -1660,8 +1660,8 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
                   "cdnet_conv_forward: taps=%d npar=%d ostride=%d", A.taps, A.npar, A.ostride);
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (A.f32) return conv_forward_f32(A, st);
     CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps || (A.taps1 == 1 && A.taps == 9 && A.nsrc == 2), "cdnet_conv_forward: taps1 = %d (0, taps, or 1 beside a nine-tap first source)", A.taps1);
+    if (A.f32) return conv_forward_f32(A, st);
     {
         const int rc = conv_forward_ws16(A, st);
         if (rc >= 0) return rc;

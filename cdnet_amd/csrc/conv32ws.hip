@@ -118,14 +118,20 @@ struct Ws32Lds {
 // scale | shift | mean | invstd (f32 [Cout]); stats = partial rows f32 [4 * gridDim.x][2][Cout] for cdnet_bn_backward_finalize (one row
 // per consumer wave, written once at the end of the run).  No bias / epilogue affine / ReLU in this mode; BN = 64, Cout % 64 == 0.
 // NCS: chunks per tile known to the compiler - 0: four or more (the epilogue of a tile leaves over four intervals), 1: one, 2: two or three
-template <int BN, int XF, bool STATS, bool BNS = false, int NCS = 0>
+// MIX (round 4, cdnet_conv_args.taps1 = 1): the chunks of the SECOND source carry one tap (the centre) instead of nine - a residual unit's 1x1
+// branch as extra K steps of its second 3x3 convolution, eval mode (model_unet_rev1.py:161-170; conv16ws.hip has the 16-bit form).  The
+// packed weights hold, per output-channel tile, the nine-tap chunks followed by the one-tap chunks (hi | lo images each).
+template <int BN, int XF, bool STATS, bool BNS = false, int NCS = 0, bool MIX = false>
 __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     static_assert(!BNS || (BN == 64 && !STATS), "the BatchNorm-backward statistics epilogue serves 64-channel blocks of backward-data launches");
+    static_assert(!MIX || (!STATS && !BNS && NCS == 0), "one-tap chunks: inference launches with at least four nine-tap chunks");
     using L = Ws32Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, TAPS = 9, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NPW = BN / 32, MPW = 2;
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;    // 8-channel vectors per halo pixel / per mover thread and chunk
     const int NCH = A.nchunk;
+    const int n0c = A.src[0].C / CK;                              // chunks of the first source (MIX: the nine-tap ones)
+    constexpr int W1_SLOT = 2 * CK * BN * 2;                      // MIX: hi | lo images of a one-tap chunk
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_a = smem;
@@ -323,9 +329,17 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         auto dma_w = [&](int wslot) {
             constexpr int NPC = L::W_SLOT / 1024;                 // 1 KB pieces of a chunk; the four mover waves take them in turn
             static_assert(L::W_SLOT % 1024 == 0, "whole wave-instructions");
-            const char *wsrc = reinterpret_cast<const char *>(A.w) + ((size_t)cout_tile * NCH + wk) * L::W_SLOT;
+            const bool one = MIX && wk >= n0c;
+            const char *wsrc = reinterpret_cast<const char *>(A.w) +
+                               (MIX ? (size_t)cout_tile * ((size_t)n0c * L::W_SLOT + (size_t)(NCH - n0c) * W1_SLOT) +
+                                          (one ? (size_t)n0c * L::W_SLOT + (size_t)(wk - n0c) * W1_SLOT : (size_t)wk * L::W_SLOT)
+                                    : ((size_t)cout_tile * NCH + wk) * L::W_SLOT);
             if (++wk == NCH) wk = 0;
             if (A.debug & 4) return;                              // ablation: no weight DMA
+            if (one) {
+                if (pw < W1_SLOT / 1024) glds_piece(wsrc + pw * 1024, (unsigned)lane * 16u, lds_w_addr + wslot * L::W_SLOT + pw * 1024);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < (NPC + 3) / 4; ++i) {
                 const int pc = i * 4 + pw;
@@ -528,9 +542,12 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     // one chunk interval on accumulator set C (halo / weight slots `sl`): 9 taps x MPW x NPW products of three MFMAs; the fragments of a
     // tap are requested one tap (12 MFMAs) ahead.  FIRST: the tile's first chunk starts from zero.  EPI 1: the statistics and the first
     // M block of the finished set P ride behind the MFMAs (every fourth gap one unit), EPI 2: its second M block.
-    auto interval = [&](auto first_c, auto epi_c, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int par, int sl) {
+    auto interval_nt = [&](auto nt_c, auto first_c, auto epi_c, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int par, int sl) {
+        constexpr int NT = decltype(nt_c)::value;                 // taps of this chunk: 9, or 1 (MIX: the centre tap)
+        constexpr int BPL = NT * CK * BN * 2;                     // one image of its packed weights
         constexpr bool FIRST = decltype(first_c)::value;
         constexpr int EPI = decltype(epi_c)::value;
+        static_assert(NT == 9 || (EPI == 0 && !FIRST), "one-tap chunks come after the nine-tap ones");
         if (A.debug & 1) return;                                  // ablation (tools/bench_conv_ws32.py): no fragment reads, no MFMAs
         bf16x8 ah[2][MPW], al[2][MPW], bh[2][NPW], bl[2][NPW];
         const unsigned char *la = lds_a + sl * L::A_SLOT, *lw = lds_w + sl * L::W_SLOT;
@@ -538,21 +555,22 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         constexpr int NRD = 2 * MPW + 2 * NPW;
         auto request_one = [&](int t, int i) {
             const int s2 = t & 1;
-            const int ao = toff(t), bo = bbase + t * 2 * BN * 16;
-            if (i == 0) al[s2][0] = *reinterpret_cast<const bf16x8 *>(la + L::A_PLANE + abase[0][tpar(t)] + ao);
+            const int tq = NT == 9 ? t : 4;                       // (the centre tap's halo offset and row parity)
+            const int ao = toff(tq), bo = bbase + t * 2 * BN * 16;
+            if (i == 0) al[s2][0] = *reinterpret_cast<const bf16x8 *>(la + L::A_PLANE + abase[0][tpar(tq)] + ao);
             else if (i == 1) bh[s2][0] = *reinterpret_cast<const bf16x8 *>(lw + bo);
-            else if (i == 2) ah[s2][0] = *reinterpret_cast<const bf16x8 *>(la + abase[0][tpar(t)] + ao);
-            else if (i == 3) bl[s2][0] = *reinterpret_cast<const bf16x8 *>(lw + L::B_PLANE + bo);
+            else if (i == 2) ah[s2][0] = *reinterpret_cast<const bf16x8 *>(la + abase[0][tpar(tq)] + ao);
+            else if (i == 3) bl[s2][0] = *reinterpret_cast<const bf16x8 *>(lw + BPL + bo);
             else if (NPW == 2 && i == 4) bh[s2][NPW - 1] = *reinterpret_cast<const bf16x8 *>(lw + bo + 512);
-            else if (NPW == 2 && i == 5) bl[s2][NPW - 1] = *reinterpret_cast<const bf16x8 *>(lw + L::B_PLANE + bo + 512);
-            else if (i == NRD - 2) al[s2][1] = *reinterpret_cast<const bf16x8 *>(la + L::A_PLANE + abase[1][tpar(t)] + ao);
-            else if (i == NRD - 1) ah[s2][1] = *reinterpret_cast<const bf16x8 *>(la + abase[1][tpar(t)] + ao);
+            else if (NPW == 2 && i == 5) bl[s2][NPW - 1] = *reinterpret_cast<const bf16x8 *>(lw + BPL + bo + 512);
+            else if (i == NRD - 2) al[s2][1] = *reinterpret_cast<const bf16x8 *>(la + L::A_PLANE + abase[1][tpar(tq)] + ao);
+            else if (i == NRD - 1) ah[s2][1] = *reinterpret_cast<const bf16x8 *>(la + abase[1][tpar(tq)] + ao);
         };
         // after MFMA number g of the interval (program order is issue order: a scheduling fence after every MFMA keeps the next tap's
         // fragment reads - one per MFMA gap, a whole tap ahead of their use - and the epilogue units where they are written; left to
         // itself the scheduler sinks every read to just in front of its first use and the matrix pipe waits out the LDS latency tap by tap)
         auto gap = [&](int t, int m, int g) {
-            if (t + 1 < TAPS && m < NRD) request_one(t + 1, m);
+            if (t + 1 < NT && m < NRD) request_one(t + 1, m);
             if (EPI != 0) {
                 // interval EPI of the tile (1..4): a quarter of the finished set's elements leave, one store (4 instructions) every sixth
                 // gap; the statistics ride in the first interval, two elements (4 instructions) in every third gap.  More than ~5 issued
@@ -581,13 +599,13 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             __builtin_amdgcn_sched_barrier(0);
 #endif
         };
-        static_assert(3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3 && 2 * (TAPS * MPW * NPW) >= NEL,
+        static_assert(NT != 9 || (3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3 && 2 * (TAPS * MPW * NPW) >= NEL),
                       "the deferred epilogue fits the MFMA gaps of an interval");
 #pragma unroll
         for (int i = 0; i < NRD; ++i) request_one(0, i);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
@@ -607,6 +625,9 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
                     gap(t, m0 + 2, g0 + 2);
                 }
         }
+    };
+    auto interval = [&](auto first_c, auto epi_c, f32x16 (&C)[MPW][NPW], const f32x16 (&P)[MPW][NPW], int par, int sl) {
+        interval_nt(std::integral_constant<int, 9>{}, first_c, epi_c, C, P, par, sl);
     };
     using F_ = std::false_type;
     using T_ = std::true_type;
@@ -651,7 +672,8 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             if (HP) interval(F_{}, E4{}, C, P, par, (q + 3) & 1); else interval(F_{}, E0{}, C, P, par, (q + 3) & 1);
             __syncthreads();
             for (int i = 4; i < NCH; ++i) {
-                interval(F_{}, E0{}, C, P, par, (q + i) & 1);
+                if (MIX && i >= n0c) interval_nt(std::integral_constant<int, 1>{}, F_{}, E0{}, C, P, par, (q + i) & 1);
+                else interval(F_{}, E0{}, C, P, par, (q + i) & 1);
                 __syncthreads();
             }
         }
@@ -726,6 +748,8 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
         if ((long long)A.N * A.src[i].Hs * rs * 4 >= (1LL << 31)) return -1;
     }
     const bool bns = A.ws == 2;
+    const bool mix = A.taps1 == 1 && A.nsrc == 2;
+    if (mix && (bns || A.stats || A.src[0].C < 64)) return -1;
     if (bns && (BN != 64 || A.Cout % 64 != 0 || !A.eres || !A.oscale || !A.oshift || !A.eres_scale || !A.eres_shift || !A.stats || A.bias ||
                 A.orelu || A.out_cstride != A.Cout || A.out_coff)) return -1;
     const int smem = L::bytes(ctot, bns);
@@ -805,6 +829,21 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
         }
         return -1;
     }
+    if (mix) {
+        auto launch_mix = [&](auto xf_c) -> int {
+            constexpr int XF = decltype(xf_c)::value;
+            auto kern = conv_ws32_kernel<BN, XF, false, false, 0, true>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return check_launch("hipFuncSetAttribute(conv_ws32 mix)");
+                attr_done = true;
+            }
+            kern<<<grid, 512, smem, st>>>(A);
+            return check_launch("conv_ws32_kernel(mix)");
+        };
+        return xf == 0 ? launch_mix(X0{}) : launch_mix(X2{});
+    }
     if (A.stats) return xf == 0 ? launch(X0{}, std::true_type{}) : (xf == 1 ? launch(X1{}, std::true_type{}) : launch(X2{}, std::true_type{}));
     return xf == 0 ? launch(X0{}, std::false_type{}) : (xf == 1 ? launch(X1{}, std::false_type{}) : launch(X2{}, std::false_type{}));
 }
@@ -814,6 +853,7 @@ int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run) {
     static const int use_ws = getenv("CDNET_CONV_WS32") ? atoi(getenv("CDNET_CONV_WS32")) : 1;
     if ((!use_ws && !(A.debug & 64)) || (A.debug & 32)) return -1;
     if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || (A.eres && A.ws != 2) || (A.ws && A.ws != 2)) return -1;
+    if (A.taps1 != 0 && A.taps1 != 9 && !(A.taps1 == 1 && A.nsrc == 2)) return -1;
     static const int min_chunks = getenv("CDNET_WS32_MIN_CHUNKS") ? atoi(getenv("CDNET_WS32_MIN_CHUNKS")) : 1;      // (4: round 3's first version)
     if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < (A.ws == 2 ? 4 : (min_chunks < 1 ? 1 : min_chunks))) return -1;
     if (A.BN == 64) return try_launch_ws32<64>(A, st, dry_run);

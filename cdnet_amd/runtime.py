@@ -160,16 +160,17 @@ class ConvLayer:
             self.fold_version = ver
         return self.fold
 
-    def eval_pack(self, src_channels):
+    def eval_pack(self, src_channels, allow_f32=False):
         """eval mode, 16-bit path, 3x3 / 1x1 Conv2d + BatchNorm: the packed weights with the BatchNorm scale folded in
         (bf16(w[cout] * scale[cout])) and the shift that is left for the epilogue - what conv_ws16_kernel takes as the accumulators'
         initial value (csrc/conv16ws.hip).  Returns (packed, shift) or None when the layer keeps the epilogue affine (transposed and
         stride-2 layers, the RGB stem's zero-extended pack, fp32 mode)."""
         if not EVAL_FOLD_WEIGHTS or not getattr(self, 'fold_eval', True) or self.kind not in ('conv3', 'conv1') or self.bn is None:
             return None
-        if PRECISION != 'bf16':
-            return None                                      # (fp32 mode keeps the epilogue affine: conv_ws32_kernel applies it per lane at no cost)
-        f32 = False
+        f32 = PRECISION == 'fp32'
+        if f32 and not allow_f32:
+            return None                                      # (fp32 mode keeps the epilogue affine: conv_ws32_kernel applies it per lane at no cost;
+                                                             #  only the residual units' two-launch form folds the scale - into the hi | lo split pack)
         cin_total = sum(src_channels)
         pad = cin_total if cin_total != self.Cin else None       # RGB stem: 3 -> 16 zero-extended reduction channels
         sc, sh = self.eval_fold()
@@ -340,7 +341,7 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True):
     conv1 (BatchNorm folded, ReLU), then conv2 with the 1x1 branch as one-tap chunks of a second source - no stored conv2 output, no
     separate 1x1 pass.  Returns the unit's output as a plain Src, or None when the shape is not conv_ws16_kernel's (the caller then takes
     the three-launch form)."""
-    if not (RU_EVAL_ONE_LAUNCH and EVAL_FOLD_WEIGHTS and PRECISION == 'bf16') or x.pool or x.C % 16 or c2.Cout % 16:
+    if not (RU_EVAL_ONE_LAUNCH and EVAL_FOLD_WEIGHTS) or not getattr(c2, 'fold_eval', True) or x.pool or x.C % 16 or c2.Cout % 16:
         return None
     H, W = x.logical_hw()
     if H % 16 or W % 16 or x.C != cr.Cin:
@@ -355,10 +356,10 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True):
     if tuple(cr.cfg) != tuple(c2.cfg):
         cr.cfg, cr.wp = tuple(c2.cfg), None              # (one configuration for both packs: they lie end to end)
         cr.prepare([x.C], H, W, x.N)
-    ep = c2.eval_pack([h.C])
+    ep = c2.eval_pack([h.C], allow_f32=True)
     if ep is None:
         return None
-    ver = (c2.wpe_version, cr.wp_version, None if cr.bias is None else cr.bias._version)
+    ver = (c2.wpe_version, cr.wp_version, None if cr.bias is None else cr.bias._version, PRECISION)
     if getattr(c2, 'ru_pack', None) is None or c2.ru_pack_version != ver:
         BN = c2.cfg[2]
         ntile = -(-c2.Cout // BN)
@@ -369,7 +370,7 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True):
     keep = engine.CONV_DEBUG
     engine.CONV_DEBUG = keep | 64                        # (the persistent kernel also on small launches: nothing else computes this form)
     try:
-        if keep & 32 or engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1, query_ws=True) != 2:
+        if keep & 32 or not engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1, query_ws=True):
             return None
         out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1)
     finally:

@@ -489,3 +489,37 @@ def test_conv_ws32_bn_backward_statistics_epilogue(case):
     scale1, scale2 = dz.abs().sum((0, 2, 3)).max(), (dz * xhat).abs().sum((0, 2, 3)).max()
     assert float((got[0] - want1).abs().max() / scale1) < 1e-5, float((got[0] - want1).abs().max() / scale1)
     assert float((got[1] - want2).abs().max() / scale2) < 1e-5, float((got[1] - want2).abs().max() / scale2)
+
+
+@pytest.mark.parametrize('case', [dict(N=2, C1=64, H=32, W=48, G=3), dict(N=3, C1=16, H=32, W=32, G=0), dict(N=1, C1=64, H=16, W=16, G=1)])
+def test_conv_ws32_one_tap_second_source(case):
+    """cdnet_conv_args.taps1 = 1 on conv_ws32_kernel (fp32 mode): relu(conv3x3(h; w2 * scale) + conv1x1(x; w1) + shift) in one launch - a
+    residual unit's second convolution with its BatchNorm scale folded into the hi | lo split pack and its 1x1 branch as one-tap chunks of a
+    second source (model_unet_rev1.py:161-170, eval mode) - against the fp64 composition of the two convolutions, 5e-5 of the output scale."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, C1, H, W, G = [case[k] for k in ('N', 'C1', 'H', 'W', 'G')]
+    g = torch.Generator().manual_seed(41 + C1)
+    h = F.relu(torch.randn((N, 64, H, W), generator=g))
+    x = F.relu(torch.randn((N, C1, H, W), generator=g))
+    w2 = torch.randn((64, 64, 3, 3), generator=g) * (1.5 / (9 * 64) ** 0.5)
+    w1 = torch.randn((64, C1, 1, 1), generator=g) * (1.5 / C1 ** 0.5)
+    sc = torch.rand((64,), generator=g) + 0.5
+    shift = torch.randn((64,), generator=g) * 0.3
+    want = F.relu(F.conv2d(h.double(), w2.double() * sc.double().view(-1, 1, 1, 1), None, padding=1) + F.conv2d(x.double(), w1.double(), None) +
+                  shift.double().view(1, -1, 1, 1))
+    cfg = (16, 16, 64)
+    wp = torch.cat([engine.pack_weights(w2.cuda(), cfg, 0, split=True, cout_scale=sc.cuda()), engine.pack_weights(w1.cuda(), cfg, 0, split=True)])
+    srcs = [engine.Src(_nhwc(h)), engine.Src(_nhwc(x))]
+    engine.CONV_DEBUG = 64 | (G << 8)
+    try:
+        assert engine.conv_forward(srcs, wp, 64, cfg, oshift=shift.cuda(), orelu=True, H=H, W=W, taps1=1, query_ws=True) == 1
+        out, _ = engine.conv_forward(srcs, wp, 64, cfg, oshift=shift.cuda(), orelu=True, H=H, W=W, taps1=1)
+        torch.cuda.synchronize()
+        engine.CONV_DEBUG = 32                                # the one-tile kernels have no such form: the ABI says so instead of computing a 3x3
+        with pytest.raises(RuntimeError):
+            engine.conv_forward(srcs, wp, 64, cfg, oshift=shift.cuda(), orelu=True, H=H, W=W, taps1=1)
+    finally:
+        engine.CONV_DEBUG = 0
+    assert _rel(_nchw(out), want) < 5e-5
