@@ -358,12 +358,7 @@ def main():
         cdnet_amd.set_precision(precision)
         model = new_model().eval()
         x = torch.from_numpy(synth.tiles_u8(B, seed=2022 + rank).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
-        if os.environ.get('CDNET_GRAPH', '0') == '1':
-            from cdnet_amd.graphs import GraphedCallable
-            g = GraphedCallable(lambda t: pipeline.infer_tiles(model, t), x)          # the whole tile pipeline = one HIP-graph launch
-            dt = timed(lambda: g(x), steps, warmup)
-        else:
-            dt = timed(lambda: pipeline.infer_tiles(model, x), steps, warmup)
+        dt = timed(lambda: pipeline.infer_tiles(model, x), steps, warmup)
         return dict(metric='tiles/sec inference incl. post-proc, 256x256',
                     workload='CDNet UNet2RevA1_vgg16 (UNet+DAM) inference + direction-diff/CC post-processing, 256x256x3 synthetic tiles',
                     value=world * B * steps / dt, ms_per_step=dt / steps * 1e3, tiles=B, steps=steps)

@@ -775,9 +775,6 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
 #ifndef CDNET_CONV_WS
 #define CDNET_CONV_WS 1
 #endif
-#ifndef CDNET_WS_PIN
-#define CDNET_WS_PIN 0      // 1: consumers issue fragment reads pinned two taps ahead with a scheduling fence behind every MFMA - measured 3-7 % SLOWER than the compiler's own order on every streamed layer (the 4 MFMAs of a tap already cover the LDS latency); kept for experiments
-#endif
 
 #ifdef CDNET_WS_STAMPS
 // debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): wall-clock stamps (100 MHz) of one consumer and one mover wave of one
@@ -1266,28 +1263,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
             for (int ni = 0; ni < NPW; ++ni) bfr[tau % 3][ni] = *reinterpret_cast<const bf16x8 *>(lw + ch * L::B_CHUNK + bbase + (t * 2) * BN * 16 + ni * 512);
         };
-        // fragment read number i of tap tau, in the order the tap's MFMAs use them: a0 b0 [b1] a1
-        constexpr int NRD = MPW + NPW, NMF = MPW * NPW;
-        auto request_one = [&](int tau, int i) {
-            const int ch = tau / TAPS, t = tau % TAPS;
-#if defined(CDNET_WS_ABL) && CDNET_WS_ABL == 1
-            if (tau >= 3) return;                              // ablation build: MFMAs on stale fragments, no LDS reads
-#endif
-            if (i == 0) af[tau % 3][0] = *reinterpret_cast<const bf16x8 *>(la + ch * L::A_BYTES + abase[0][tpar(t)] + toff(t));
-            else if (i == NRD - 1) af[tau % 3][1] = *reinterpret_cast<const bf16x8 *>(la + ch * L::A_BYTES + abase[1][tpar(t)] + toff(t));
-            else bfr[tau % 3][i - 1] = *reinterpret_cast<const bf16x8 *>(lw + ch * L::B_CHUNK + bbase + (t * 2) * BN * 16 + (i - 1) * 512);
-        };
-        (void)request; (void)request_one; (void)NMF;
         request(0);
         request(1);
-#if CDNET_WS_PIN
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int tau = 0; tau < NTAP; ++tau) {
-#if !CDNET_WS_PIN
             if (tau + 2 < NTAP) request(tau + 2);
-#endif
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
@@ -1298,33 +1278,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                     } else {
                         C[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tau % 3][mi], bfr[tau % 3][ni], C[mi][ni], 0, 0, 0);
                     }
-                    // the gap behind this MFMA (program order is issue order: the scheduling fence keeps things where they are written;
-                    // left to itself the scheduler sinks every fragment read to just in front of its first use, and the matrix pipe then
-                    // waits out the LDS latency tap by tap): the fragment reads of the tap two ahead - one per gap - and, in an epilogue
-                    // interval, one unit of the finished tile
-                    const int m = mi * NPW + ni;
-#if CDNET_WS_PIN
-                    if (tau + 2 < NTAP) {
-                        if (m < NRD) request_one(tau + 2, m);
-                        if (m == NMF - 1) {
-#pragma unroll
-                            for (int i = NMF; i < NRD; ++i) request_one(tau + 2, i);
-                        }
-                    }
-                    if (EPI) {
-                        const int sl = (tau * MPW + mi) * NPW + ni;
-                        if (STATS && sl < 2 * NU && (sl & 1) == 0) stat_unit(P, sl / 2, par);
-                        if (sl >= IMG0 && sl < IMG0 + 2 * NU && ((sl - IMG0) & 1) == 0) img_unit(P, (sl - IMG0) / 2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#else
-                    (void)m;
+                    // the gap behind this MFMA: in an epilogue interval, one unit of the finished tile
                     if (EPI) {
                         const int sl = (tau * MPW + mi) * NPW + ni;
                         if (STATS && sl < 2 * NU && (sl & 1) == 0) { __builtin_amdgcn_sched_barrier(0); stat_unit(P, sl / 2, par); __builtin_amdgcn_sched_barrier(0); }
                         if (sl >= IMG0 && sl < IMG0 + 2 * NU && ((sl - IMG0) & 1) == 0) { __builtin_amdgcn_sched_barrier(0); img_unit(P, (sl - IMG0) / 2); __builtin_amdgcn_sched_barrier(0); }
                     }
-#endif
                 }
         }
     };

@@ -1075,25 +1075,16 @@ def synthetic_batch(B, dev, seed=2022, H=256, W=256):
     return t(x), t(lab), t(dirn), t(point), t(weight)
 
 
-def make_bench_step(model, B, dev, rank, world, graph=None):
-    """the benchmark's training step on a fixed synthetic batch.  graph: replay forward + loss + backward from a HIP graph
-    (cdnet_amd.graphs.GraphedTrainStep; measured 6 % slower than the eager launches on the DAM-Unet step - the GPU, not the
-    launch path, bounds it - so only with CDNET_GRAPH=1) - Adam, all-reduce and re-packs stay eager"""
+def make_bench_step(model, B, dev, rank, world):
+    """the benchmark's training step on a fixed synthetic batch: eager launches (a HIP-graph replay of forward + loss + backward was measured
+    6-20 % slower on this step - the GPU, not the launch path, bounds it; cdnet_amd.graphs stays for the launch-bound HRNet step,
+    tools/bench_hrnet.py)"""
     tr = Trainer(model, world_size=world)
     batch = synthetic_batch(B, dev, seed=2022 + rank)
-    if graph is None:
-        graph = world == 1 and os.environ.get('CDNET_GRAPH', '0') == '1'
-    if graph:
-        from .graphs import GraphedTrainStep
-        gstep = GraphedTrainStep(tr, batch)
 
-        def step():
-            return gstep(*batch)
-    else:
-        def step():
-            return tr.train_step(*batch)
+    def step():
+        return tr.train_step(*batch)
     metric = 'tiles/sec (train fwd+bwd+Adam), 256x256'
     workload = ('CDNet UNet2RevA1_vgg16 (UNet+DAM) training step: forward, 5-term loss, backward%s, %s fused Adam; '
-                '256x256x3 synthetic tiles, batch %d per GPU' % (' (one HIP-graph launch)' if graph else '',
-                                                               'RCCL gradient all-reduce,' if world > 1 else '', B))
+                '256x256x3 synthetic tiles, batch %d per GPU' % ('', 'RCCL gradient all-reduce,' if world > 1 else '', B))
     return step, metric, workload

@@ -27,9 +27,13 @@ pytestmark = pytest.mark.gpu
 AJI_MIN = 0.998
 DICE_MIN = 0.998
 ARGMAX_MIN = 0.999
-TILE_FLOOR = 0.995          # bf16 mode, a single 256x256 tile (one nucleus of ~40 merged or split moves a tile's AJI by ~0.003)
-BF16_MEAN_MIN = 0.997       # bf16 mode, mean over the tiles of the MUTUAL score (two gate networks of this round: 0.99830 and 0.99910);
-                            # the bar north_star states - ground-truth AJI / Dice of both sides within 0.002 - is asserted beside it
+# bf16 mode holds the SAME mutual bar as fp32 mode since round 4 (round 3 had lowered it to 0.997 mean / 0.995 per tile): with the eval-mode
+# BatchNorm scale folded into the weights and the residual units' two roundings to fp16 gone (conv_ws16_kernel, one launch for conv2 + the 1x1
+# branch) the gate network of profiles/r04/label_gate.log gives 0.99878-0.99890 per tile, 0.99877 on the 1000x1000 image, 0.99900 on the dense
+# tile (deterministic: the network is trained in fp32 mode from a fixed seed, weights crc32 7e406dad)
+TILE_FLOOR = AJI_MIN
+BF16_MEAN_MIN = AJI_MIN
+# the bar north_star states - ground-truth AJI / Dice of both sides within 0.002 - is asserted beside it
 GT_DELTA_MAX = 0.002
 
 

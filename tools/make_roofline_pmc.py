@@ -9,7 +9,7 @@ import os
 import sys
 
 root, dt = sys.argv[1], sys.argv[2]
-want = ('conv_ws32_kernel', 'conv_f32_kernel') if dt == 'fp32' else ('conv_ws_kernel', 'conv_fwd_kernel')
+want = ('conv_ws32_kernel', 'conv_f32_kernel') if dt == 'fp32' else ('conv_ws16_kernel', 'conv_ws_kernel', 'conv_fwd_kernel')
 out = {'dtype': dt, 'counters': {}}
 dur_ns = None
 for f in sorted(glob.glob(os.path.join(root, 'stats', '*kernel_stats.csv'))):
