@@ -1386,8 +1386,6 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) 
     // (few tiles but long channel loops - the 16x16-pixel bottleneck layers - still take it: the workgroups that exist keep the memory
     //  pipeline full, which the one-tile-per-workgroup kernel does not)
     if (!(A.debug & 64) && ((long long)T * A.nchunk < 16LL * Gmax || (T < Gmax && A.nchunk < 16))) return -1;
-    static const int want_stream = getenv("CDNET_CONV_WS_STREAM") ? atoi(getenv("CDNET_CONV_WS_STREAM")) : 1;
-    if (stream && !want_stream && !(A.debug & 64)) return -1;
     bool all_plain = true, all_fast = true;
     for (int i = 0; i < A.nsrc; ++i) {
         const ConvSrc &s = A.src[i];

@@ -854,8 +854,7 @@ int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run) {
     if ((!use_ws && !(A.debug & 64)) || (A.debug & 32)) return -1;
     if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || (A.eres && A.ws != 2) || (A.ws && A.ws != 2)) return -1;
     if (A.taps1 != 0 && A.taps1 != 9 && !(A.taps1 == 1 && A.nsrc == 2)) return -1;
-    static const int min_chunks = getenv("CDNET_WS32_MIN_CHUNKS") ? atoi(getenv("CDNET_WS32_MIN_CHUNKS")) : 1;      // (4: round 3's first version)
-    if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < (A.ws == 2 ? 4 : (min_chunks < 1 ? 1 : min_chunks))) return -1;
+    if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < (A.ws == 2 ? 4 : 1)) return -1;
     if (A.BN == 64) return try_launch_ws32<64>(A, st, dry_run);
     if (A.BN == 32) return try_launch_ws32<32>(A, st, dry_run);
     return -1;

@@ -1747,14 +1747,12 @@ extern "C" int cdnet_bn_backward(const cdnet_bn_bwd_args *a, const float *gamma,
     if (!dz_reuse) A.dz_out = nullptr;                // (the sums pass stores dz only when the second pass is going to read it)
     // The apply pass re-reads what the reduce pass just streamed (raw + gradients, up to 2 x 134 MB against 256 MB of
     // Infinity Cache): walking it back to front meets the most recently cached lines first instead of chasing the LRU tail.
-    static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
-    A.rev = rev;
+    A.rev = 1;
     bool flat = !window && simple && A.mean && A.scale && draw && ((A.res != nullptr) == (dz_out != nullptr));
     CDNET_REQUIRE(A.relu != 2 || (flat && A.res), "cdnet_bn_backward: relu = 2 (mask from the stored output) needs same-size gradient sources and res");
     const bool f32 = A.f16 == 2;                      // fp32 tensors: flat32 kernels (same-size sources) or the generic ones (pool / pad routing)
     const bool flat32 = f32 && flat && A.C <= 1024;
-    static const int use_w32 = getenv("CDNET_BN_WINDOW32") ? atoi(getenv("CDNET_BN_WINDOW32")) : 1;
-    const bool window32 = f32 && window && use_w32 && A.C % 4 == 0 && A.C <= 1024 && A.shift && A.invstd;
+    const bool window32 = f32 && window && A.C % 4 == 0 && A.C <= 1024 && A.shift && A.invstd;
     if (window32) {
         const int ppb4 = 256 / (A.C / 4);
         const size_t nwin = (size_t)A.N * ((A.H + 1) / 2) * ((A.W + 1) / 2);
@@ -1898,8 +1896,7 @@ extern "C" int cdnet_bn_backward_apply(const cdnet_bn_bwd_args *a, const float *
     int nb = (int)((npix + (size_t)ppb * BN_U - 1) / ((size_t)ppb * BN_U));
     if (nb > bn_blocks_cap()) nb = bn_blocks_cap();
     if (nb < 1) nb = 1;
-    static const int rev = getenv("CDNET_BN_REVERSE") ? atoi(getenv("CDNET_BN_REVERSE")) : 1;
-    A.rev = rev;
+    A.rev = 1;
     A.draw = draw; A.dz_out = nullptr;
     A.k1 = const_cast<float *>(ktab) + 4 * A.C; A.k2 = const_cast<float *>(ktab) + 5 * A.C; A.k3 = const_cast<float *>(ktab) + 6 * A.C;
     if (f32) launch_flat32<true>(A, nb, (hipStream_t)stream);

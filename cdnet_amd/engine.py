@@ -120,13 +120,13 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
         # chunks of loads in flight per workgroup - 128 workgroups of it beat 512 workgroups that each expose every chunk's latency
         # (512 -> 512 @16x16 x16: 54 -> measured in tools/bench_conv_stream.py)
         ws16 = taps == 9 and not transposed and H % 16 == 0 and W % 16 == 0 and min(H, W) == 16 and ctot % 64 == 0 and 256 <= ctot <= 768 \
-            and os.environ.get('CDNET_WS16', '1') == '1'
+
         if ck >= 32 and not ws16:
             return (8, 32, 64)
     if ck == 64:
         ck = 32                       # 2 workgroups per CU (LDS) beat one fat one
     bn = 64 if Cout > 32 else 32
-    if (ctot <= 128 and bn == 64) or (os.environ.get('CDNET_CK16', '1') == '1' and ck >= 16):
+    if ck >= 16:
         ck = 16                       # 34 KB of LDS and <= 168 VGPRs: three workgroups per CU hide the staging latency (measured)
     if ck == 16 and bn > 64:
         bn = 64

@@ -327,8 +327,8 @@ def input_pack(x):
     return out
 
 
-POOL_MATERIALIZE = _os.environ.get('CDNET_POOL_MATERIALIZE', '1') != '0'
-RU_MATERIALIZE = _os.environ.get('CDNET_RU_MATERIALIZE', '1') != '0'
+POOL_MATERIALIZE = True      # max-pooled sources are stored (measured faster than four loads + max per staged element)
+RU_MATERIALIZE = True        # (CDNET_RU_FUSE=0 only) the residual units' outputs are stored once for their three consumers
 RU_FUSE = _os.environ.get('CDNET_RU_FUSE', '1') != '0'       # ResidualUnit: add + ReLU in the epilogue of its conv_1x1
 # eval mode, 16-bit path: BatchNorm scale folded into the packed weights (ConvLayer.eval_pack), and a residual unit's 1x1 branch as extra K
 # steps of its second 3x3 convolution (cdnet_conv_args.taps1 = 1, conv_ws16_kernel)

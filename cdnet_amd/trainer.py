@@ -35,12 +35,11 @@ class BnBwdArgs(C.Structure):
 
 # workgroups of one weight-gradient launch while it runs beside the input-gradient chain (bf16 mode; see _weight_backward):
 # layers of up to 128 x 128 pixels / larger ones
-_WGRAD_WGS_DEEP = int(os.environ.get('CDNET_WGRAD_WGS_DEEP', '128'))
-_WGRAD_WGS_SHALLOW = int(os.environ.get('CDNET_WGRAD_WGS_SHALLOW', '160'))
-_WGRAD_WGS_F32 = int(os.environ.get('CDNET_WGRAD_WGS_F32', '160'))      # (128 / 160 / 256: 989 / 994 / 987 tiles/s, three runs each on one box)
+_WGRAD_WGS_DEEP, _WGRAD_WGS_SHALLOW = 128, 160
+_WGRAD_WGS_F32 = 160                      # (128 / 160 / 256: 989 / 994 / 987 tiles/s, three runs each on one box)
 _RU_1X1_SIDE = os.environ.get('CDNET_RU_1X1_SIDE', '1') != '0'      # residual units' 1x1 backward-data beside the chain
 _WGRAD_DEFER = 0x100                       # CDNET_WGRAD_DEFER_REDUCE (include/cdnet_hip.h)
-_WGRAD_DEEP_HW = int(os.environ.get('CDNET_WGRAD_DEEP_HW', '16384'))
+_WGRAD_DEEP_HW = 16384
 
 
 class _on_stream:
@@ -144,7 +143,7 @@ class Trainer:
         self._cat_cache = {}
         self._wstream, self._events = None, {}
         self._packb_pending = False
-        self._packb_stream = os.environ.get('CDNET_PACKB_STREAM', '1') != '0'      # backward-data re-packs beside the next forward
+        self._packb_stream = True              # backward-data re-packs beside the next forward
         self._side_active = False
         # split-K sums of the weight gradients: deferred and batched (one cdnet_wgrad_reduce_batch launch per ~CDNET_WGRAD_REDUCE_MB of
         # slabs instead of one reduce behind every weight-gradient launch; every call keeps its own slab buffer - 1.4 GB for the UNet)
