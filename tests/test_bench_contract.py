@@ -33,9 +33,30 @@ def test_committed_line_has_the_contract_keys():
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == d['unit'] and 'sample' in c
 
 
+def test_committed_round4_line_carries_the_algorithmic_fraction_and_live_traffic():
+    """profiles/r04/bench_default_line.json (tools/refresh_profiles.sh r04 on the GPU box): `roofline.frac` is the algorithmic fraction
+    (HBM-bound by SURVEY 8d's figures in both precisions), the fp32 mode's 3x MFMA work sits under `mfma_work_frac`, and `traffic` was
+    measured inside that run by the PMC child passes (it must agree with the separately collected summary next to it)."""
+    with open(os.path.join(ROOT, 'profiles', 'r04', 'bench_default_line.json')) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    assert d['dtype'] == 'fp32' and d['n_gpus'] == 1 and d['vs_baseline'] is None and d['config']['process_group'] is None
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(r['frac'] - r['algorithmic_bytes'] / 8000e9 / (r['ms_per_launch'] / 1e3)) < 1e-9 and 0.25 < r['frac'] < 0.6
+    assert abs(r['mfma_work_frac'] - 3 * r['algorithmic_flops'] / 2500e12 / (r['ms_per_launch'] / 1e3)) < 1e-9
+    assert r['traffic_source'].startswith('measured in this run') and 0.98 < r['traffic'] / r['algorithmic_bytes'] < 1.05
+    with open(os.path.join(ROOT, 'profiles', 'r04', 'dominant_conv_fp32_pmc.json')) as f:
+        p = json.load(f)
+    assert abs(r['traffic'] - p['hbm_bytes_per_launch']) < 0.01 * p['hbm_bytes_per_launch']
+    b = d['roofline_bf16']
+    assert b['bound'] == 'hbm' and 'conv_ws16_kernel' in b['kernel'] and abs(b['frac'] - b['hbm_frac']) < 1e-12
+    for k, v in d['roofline_path'].items():
+        assert v['bound'] == 'hbm' and v['peak_TFLOPs'] == 2500.0 and abs(v['frac'] - v['hbm_frac']) < 1e-12, k
+
+
 def test_pmc_summaries_agree_with_their_counters():
-    for dt, esz in (('fp32', 4), ('bf16', 2)):
-        with open(os.path.join(ROOT, 'profiles', 'r03', 'dominant_conv_%s_pmc.json' % dt)) as f:
+    for rnd, dt, esz in (('r03', 'fp32', 4), ('r03', 'bf16', 2), ('r04', 'fp32', 4), ('r04', 'bf16', 2)):
+        with open(os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_%s_pmc.json' % dt)) as f:
             p = json.load(f)
         c = p['counters']
         assert abs(p['hbm_bytes_per_launch'] - (c['FETCH_SIZE'] * 2048 + c['WRITE_SIZE'] * 1024)) < 1.0      # FETCH_SIZE x 2 on gfx950
