@@ -1618,11 +1618,12 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps || (A.taps1 == 1 && A.taps == 9 && A.nsrc == 2), "cdnet_conv_forward: taps1 = %d (0, taps, or 1 beside a nine-tap first source)", A.taps1);
-    if (A.f32) return conv_forward_f32(A, st);
+    if (A.f32) { CDNET_REQUIRE(!A.pool_out, "cdnet_conv_forward(f32): no fused max-pool output in fp32 mode"); return conv_forward_f32(A, st); }
     {
         const int rc = conv_forward_ws16(A, st);
         if (rc >= 0) return rc;
         CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps, "cdnet_conv_forward: a one-tap second source runs on conv_ws16_kernel only (ask cdnet_conv_ws_eligible)");
+        CDNET_REQUIRE(!A.pool_out, "cdnet_conv_forward: the fused max-pool output needs conv_ws16_kernel's out-image form (ask cdnet_conv_ws_eligible)");
     }
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
@@ -1647,9 +1648,9 @@ extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
-    if (A.f32) return conv_forward_f32_ws(A, nullptr, true) == CDNET_OK ? 1 : 0;
+    if (A.f32) return (!A.pool_out && conv_forward_f32_ws(A, nullptr, true) == CDNET_OK) ? 1 : 0;
     if (conv_forward_ws16(A, nullptr, true) == CDNET_OK) return 2;
-    if (A.taps1 != 0 && A.taps1 != A.taps) return 0;
+    if ((A.taps1 != 0 && A.taps1 != A.taps) || A.pool_out) return 0;
     if (!use_ws || (A.debug & 32)) return 0;
     if (!(A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32))) return 0;
     const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, nullptr, true) : try_launch_conv_ws<32, 9>(A, nullptr, true);

@@ -421,6 +421,26 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 unsigned short *dstp = A.out + (((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)) * A.out_cstride + A.out_coff + cout0 + seg * 8;
                 if (ok) *reinterpret_cast<u32x4v *>(dstp) = v[r];
             }
+            if (A.pool_out) {
+                // nn.MaxPool2d(2, 2) of the block's two rows beside the stores (torchvision VGG 'M' layers after a ReLU: the values are
+                // non-negative, their bf16 order is their int16 order): rows r and r + NR / 2 hold the same columns; the column partner of
+                // a pixel sits SPP lanes away.  The lanes of even columns store the block's 8 pooled pixels.
+                auto max4 = [](u32x4v a, u32x4v b) -> u32x4v {       // (xf_max_nonneg_bf8: element access through a union - xform.h)
+                    return __builtin_bit_cast(u32x4v, xf_max_nonneg_bf8(__builtin_bit_cast(xf_u32x4, a), __builtin_bit_cast(xf_u32x4, b)));
+                };
+                const int Hp = A.H >> 1, Wp = A.W >> 1;
+#pragma unroll
+                for (int r = 0; r < NR / 2; ++r) {
+                    XfWords m, o;
+                    m.u = __builtin_bit_cast(xf_u32x4, max4(v[r], v[r + NR / 2]));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o.w[k] = (unsigned)__shfl_xor((int)m.w[k], SPP);
+                    m.u = xf_max_nonneg_bf8(m.u, o.u);
+                    const int px = r * PPR + lp;                 // column of this lane's pixel inside the tile
+                    unsigned short *dstp = A.pool_out + (((size_t)tn * Hp + ((ty0 + pw * 4 + hf * 2) >> 1)) * Wp + ((tx0 + px) >> 1)) * A.Cout + cout0 + seg * 8;
+                    if (ok && !(lp & 1)) *reinterpret_cast<u32x4v *>(dstp) = __builtin_bit_cast(u32x4v, m.u);
+                }
+            }
         };
         // called once per mover interval iv (the consumers' interval); stores what the consumers parked in interval iv - 1
         auto store_prev = [&](int iv) -> bool {
@@ -505,7 +525,14 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 }(), ...);
             }(std::make_integer_sequence<int, IPG>{});
         }
-        if (OUT) store_prev((NI + IPG - 1) / IPG * IPG);         // what the consumers parked in the very last interval
+        if (OUT) {
+            store_prev((NI + IPG - 1) / IPG * IPG);              // what the consumers parked in the very last interval
+            lds_sync();                                          // E: this wave's reads of the out image are done - the consumers park the last tile
+            lds_sync();                                          // F: ... both halves of it are in the image
+            const int tl = t_hi - 1, ln = tl / tiles_img, lr = tl - ln * tiles_img, lty = lr / tiles_x;
+            store_half(0, ln, lty * TH, (lr - lty * tiles_x) * TW);
+            store_half(1, ln, lty * TH, (lr - lty * tiles_x) * TW);
+        }
         return;
     }
 
@@ -709,6 +736,14 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     };
     // the last tile of the run: nothing left to hide behind
     auto serial_epilogue = [&](const f32x16 (&P)[NCI][NPI]) {
+        if (OUT) {
+            // every store of this form is the movers': the last tile goes through the out image too (E: their last reads of it are done)
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < NMO; ++e) micro(P, e, false);
+            __syncthreads();                                     // F
+            return;
+        }
         set_row_bases();
 #pragma unroll
         for (int e = 0; e < NMO; ++e) micro(P, e, true);
@@ -766,6 +801,7 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     const bool out = out_env && pfd != 0 && nch >= 4 && !(nch & 1) && L::bytes(ns, false, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
     const int smem = L::bytes(ns, pfd == 0, stream ? 4 * L::WCH9 : wres, ctot, out);
     if (smem > 160 * 1024) return -1;
+    if (A.pool_out && (!out || !A.orelu || A.out_coff || A.out_cstride != A.Cout)) return -1;      // the fused 2x2 max-pool rides in the movers' store path
     const int T = (A.W / 16) * (A.H / 16) * A.N;
     static int n_cu = 0;
     if (n_cu == 0) {

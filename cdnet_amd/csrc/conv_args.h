@@ -33,6 +33,7 @@ struct ConvArgs {
     const float *eres_scale, *eres_shift;
     int eres_f16, eres_relu;
     int taps1, pad_;
+    unsigned short *pool_out;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");

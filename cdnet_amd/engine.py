@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
                 ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('f32', C.c_int),
                 ('eres', C.c_void_p), ('eres_scale', C.c_void_p), ('eres_shift', C.c_void_p), ('eres_f16', C.c_int), ('eres_relu', C.c_int),
-                ('taps1', C.c_int), ('pad_', C.c_int)]
+                ('taps1', C.c_int), ('pad_', C.c_int), ('pool_out', C.c_void_p)]
 
 
 def _dp(t):
@@ -216,7 +216,7 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0, pool_out=None):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -253,6 +253,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.out_f16 = int(out.dtype == torch.float16)
     a.ws = 0
     a.taps1 = taps1
+    a.pool_out = _dp(pool_out)           # nn.MaxPool2d(2, 2) of the activated output beside it (conv_ws16_kernel's out-image form; ask query_ws first)
     a.debug = CONV_DEBUG
     a.f32 = int(f32)
     assert (out.dtype == torch.float32) == f32

@@ -223,11 +223,15 @@ class Unet(nn.Module):
         t.is_input = True
         self._rt['enc'][0][1].needs_input_grad = False
         feats = {}
-        for kind, layer, out_name in self._rt['enc']:              # forward_backbone (:268-287)
+        enc, tp = self._rt['enc'], None
+        for idx, (kind, layer, out_name) in enumerate(enc):         # forward_backbone (:268-287)
             if kind == 'conv':
-                t = layer.forward([t], training)
+                if not training and idx + 1 < len(enc) and enc[idx + 1][0] == 'pool' and not getattr(runtime, 'DEBUG_NORELU', False):
+                    t, tp = layer.forward_eval_pool([t])           # eval: the max-pool that follows leaves with the convolution's stores
+                else:
+                    t = layer.forward([t], training)
             else:
-                t = pooled(t)
+                t, tp = (tp if tp is not None else pooled(t)), None
             if out_name in self.shortcut_features:
                 feats[out_name] = t
             if out_name == self.bb_out_name:

@@ -180,6 +180,24 @@ class ConvLayer:
             self.wpe_version = ver
         return self.wpe, sh
 
+    def forward_eval_pool(self, srcs):
+        """eval mode: relu(bn(conv(.))) AND its nn.MaxPool2d(2, 2) from one launch (the 'M' layers of the VGG16-BN encoder,
+        model_unet_rev1.py:40-41: conv_ws16_kernel's movers pool the out image beside their stores - no cdnet_src_materialize pass).
+        Returns (Src, pooled Src), or (Src, None) when the launch is not that kernel's (the caller pools as before)."""
+        H, W = srcs[0].logical_hw()
+        if PRECISION == 'bf16' and H % 2 == 0 and W % 2 == 0:
+            self.prepare([s.C for s in srcs], H, W, srcs[0].N)
+            ep = self.eval_pack([s.C for s in srcs])
+            if ep is not None:
+                N = srcs[0].N
+                out = torch.empty((N, H, W, self.Cout), dtype=torch.bfloat16, device=srcs[0].x.device)
+                pout = torch.empty((N, H // 2, W // 2, self.Cout), dtype=torch.bfloat16, device=srcs[0].x.device)
+                kw = dict(oshift=ep[1], orelu=True, H=H, W=W, out=out, pool_out=pout)
+                if engine.conv_forward(srcs, ep[0], self.Cout, self.cfg, self.taps, self.transposed, query_ws=True, **kw) == 2:
+                    engine.conv_forward(srcs, ep[0], self.Cout, self.cfg, self.taps, self.transposed, **kw)
+                    return Src(out), Src(pout)
+        return self.forward(srcs, False), None
+
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, srcs, training, relu=True, H=None, W=None, out_dtype=None, eres=None):
         """Returns the output as a Src (lazy transform attached in train mode).  Raw (pre-BatchNorm) outputs of the

@@ -189,6 +189,11 @@ typedef struct cdnet_conv_args {
      * in eval mode (model_unet_rev1.py:161-170) with the BatchNorm scale folded into conv2's weights and shift + bias in `oshift`. */
     int taps1;
     int pad_;
+    /* Optional second output: nn.MaxPool2d(2, 2) of the (ReLU-activated, bf16) output, dense [N][H/2][W/2][Cout] - the 'M' layers of the
+     * torchvision VGG16-BN encoder (model_unet_rev1.py:40-41) fused into the producing convolution's store path.  16-bit path,
+     * conv_ws16_kernel's out-image form only (cdnet_conv_ws_eligible answers 2 with the pointer set, else leave it NULL and call
+     * cdnet_src_materialize); needs orelu = 1, out_coff = 0, out_cstride = Cout. */
+    uint16_t *pool_out;
 } cdnet_conv_args;
 
 /* packed element count for a weight tensor; nchunk = Cin/CK over all sources */

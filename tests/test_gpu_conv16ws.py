@@ -230,3 +230,41 @@ def test_launches_outside_its_scope_fall_back():
     assert which(stats=st) == 1                               # training forward: BatchNorm statistics stay on conv_ws_kernel
     assert which(H=24) == 0                                   # ragged tiles: the one-tile kernel
     assert which(debug=32) == 0
+
+
+@pytest.mark.parametrize('case', [dict(N=2, Cin=64, Cout=64, H=32, W=48, G=3), dict(N=1, Cin=128, Cout=128, H=32, W=32, G=0),
+                                  dict(N=3, Cin=64, Cout=32, H=16, W=32, G=2), dict(N=1, Cin=64, Cout=64, H=16, W=16, G=1)])
+def test_conv_ws16_fused_max_pool_output(case):
+    """cdnet_conv_args.pool_out: nn.MaxPool2d(2, 2) of the ReLU-activated output from the movers' store path of conv_ws16_kernel's
+    out-image form (the 'M' layers of the VGG16-BN encoder, model_unet_rev1.py:40-41) - the full-resolution output bit-identical to the
+    launch without it, the pooled tensor bit-identical to torch's max_pool2d of that output (a maximum of stored values: exact)."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, G = [case[k] for k in ('N', 'Cin', 'Cout', 'H', 'W', 'G')]
+    g = torch.Generator().manual_seed(7 + Cin + H)
+    x = _bf(torch.randn((N, Cin, H, W), generator=g))
+    w = _bf(torch.randn((Cout, Cin, 3, 3), generator=g) * (1.5 / (9 * Cin) ** 0.5))
+    b = torch.randn((Cout,), generator=g) * 0.3
+    cfg = (16, 16, 64 if Cout > 32 else 32)
+    wp = engine.pack_weights(w.cuda(), cfg, 0)
+    src = [engine.Src(_nhwc(x))]
+    engine.CONV_DEBUG = 64 | (G << 8)
+    try:
+        plain, _ = engine.conv_forward(src, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W)
+        pout = torch.full((N, H // 2, W // 2, Cout), 7.0, dtype=torch.bfloat16, device='cuda')
+        out = torch.empty_like(plain)
+        assert engine.conv_forward(src, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, out=out, pool_out=pout, query_ws=True) == 2
+        engine.conv_forward(src, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, out=out, pool_out=pout)
+        torch.cuda.synchronize()
+        # without the ReLU (signed values) or on the one-tile kernels the pooled output does not exist: the ABI says so
+        assert engine.conv_forward(src, wp, Cout, cfg, oshift=b.cuda(), orelu=False, H=H, W=W, out=out, pool_out=pout, query_ws=True) == 0
+        engine.CONV_DEBUG = 32
+        with pytest.raises(RuntimeError):
+            engine.conv_forward(src, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, out=out, pool_out=pout)
+    finally:
+        engine.CONV_DEBUG = 0
+    assert torch.equal(out, plain)
+    want = F.max_pool2d(_nchw(plain), 2)
+    assert torch.equal(_nchw(pout), want)
+    _close(_nchw(plain), F.relu(F.conv2d(x, w, b, padding=1)), 'conv + relu')
