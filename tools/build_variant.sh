@@ -12,7 +12,7 @@ OBJS=""
 for o in $OBJ/*.o; do
   b=$(basename $o .o)
   if echo " $SRCS " | grep -q " $b.hip "; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-unused-result $FLAGS -I$ROOT/include -c $ROOT/cdnet_amd/csrc/$b.hip -o $TMP/$b.o &
+    hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -Wno-unused-function -Wno-unused-result $FLAGS -I$ROOT/include -c $ROOT/cdnet_amd/csrc/$b.hip -o $TMP/$b.o &
     OBJS="$OBJS $TMP/$b.o"
   else
     OBJS="$OBJS $o"
