@@ -85,7 +85,11 @@ __device__ __forceinline__ void glds_piece16(const void *gbase, unsigned lane_by
 // PFD: 0 = the DMA movers; 4 / 8 / 12 = the register movers with that many halo chunks in flight per thread (NS = 4)
 // OUT: the finished tile leaves through an LDS out image and the MOVERS store it (register movers, an even chunk count >= 4): a store issued by
 // a consumer wave between MFMAs waits for the memory pipeline behind the movers' requests, and the matrix pipe waits with it
-template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT>
+// K32: the consumers of the out-image form run v_mfma_f32_16x16x32_bf16 - K = 32 = two (tap, 8-channel) pairs of a pair of chunks, 9 K steps per
+// barrier interval.  Same FLOP per cycle and per LDS byte as 32x32x16, but the chip holds a higher clock on it under load (tools/micro/
+// mfma_shapes.hip: 1.52 vs 1.36 PFLOP/s on random operands, 1.62 vs 1.58 on zeros).  Another summation order inside an MFMA: the outputs agree
+// with conv_fwd_kernel to the last bf16 bit or two, not bit for bit.
+template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false>
 __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using L = W16Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     constexpr int IPG = PFD > 0 ? PF / 2 : 2;                     // barrier intervals per iteration of the movers' loop
     static_assert(!(STREAM && MIX), "one-tap chunks only with resident weights");
     static_assert(!OUT || (PFD > 0 && NCS == 0), "LDS out image: register movers, tiles of an even number (>= 4) of chunks");
+    static_assert(!K32 || OUT, "the 16x16x32 consumers serve the out-image form");
     static_assert(PFD == 0 ? XF == 0 : (NS == 4 && PF % 4 == 0), "DMA movers: plain sources; register movers: a four-slot ring, sets = slots mod 4");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
@@ -552,6 +557,155 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         }
     }
     __syncthreads();                                             // B0
+    if constexpr (K32) {
+        // ================================ consumers, v_mfma_f32_16x16x32_bf16 ================================
+        // A = weights (16 output channels x 32 k), B = pixels (32 k x 16 pixels of one tile row), D: lane (pixel n = lane & 15, kg = lane >> 4)
+        // holds output channels 4 kg .. 4 kg + 3 of the block.  K step s of a chunk pair: this lane's 8 k = k-block kb = 4 s + kg of the 36
+        // (chunk, tap, channel half) blocks - the fragment addresses differ between the four lane groups and are kept per step.
+        typedef float f32x4a __attribute__((ext_vector_type(4)));
+        constexpr int NCB = BN / 16, NPB = 4;                    // wave: NCB blocks of 16 output channels x the 4 tile rows 4 wm .. 4 wm + 3
+        const int wm = wave, n16 = lane & 15, kg = lane >> 4;
+        int PB9[9], WB9[9], PB1, WB1;                              // (pixel-fragment offsets for even tile rows; an odd row flips the k-half swizzle: ^ 16)
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            const int kb = 4 * st + kg, c2 = kb >= 18 ? 1 : 0, kbp = kb - 18 * c2, tap = kbp >> 1, ch = kbp & 1, tr = tap / 3, tc = tap - 3 * tr;
+            PB9[st] = c2 * A_BYTES + ((wm * 4 + tr) * HW_ + n16 + tc) * PSTR + ((ch ^ (tr & 1)) * 16);
+            WB9[st] = c2 * L::WCH9 + tap * 2 * BN * 16 + ch * BN * 16 + n16 * 16;
+        }
+        {
+            const int c2 = kg >> 1, ch = kg & 1;                 // a pair of one-tap chunks: K = 2 x 16, the centre tap
+            PB1 = c2 * A_BYTES + ((wm * 4 + 1) * HW_ + n16 + 1) * PSTR + ((ch ^ 1) * 16);
+            WB1 = c2 * L::WCH1 + ch * BN * 16 + n16 * 16;
+        }
+        f32x4a accA[NCB][NPB], accB[NCB][NPB], binit[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cout0 + cb * 16 + 4 * kg + r;
+                binit[cb][r] = co < A.Cout ? (A.bias ? A.bias[co] : 0.f) + (A.oshift ? A.oshift[co] : 0.f) : 0.f;
+            }
+        const xf_s16x2 lo_clamp = A.orelu ? xf_s16x2{0, 0} : xf_s16x2{(short)-32768, (short)-32768};
+        unsigned char *const o_lane = lds_o + wave * L::OBLK + n16 * L::OROW + kg * 8;
+        // epilogue of a finished set: unit u = (pb, cb) - 4 consecutive output channels of this lane's pixel in tile row pb - three
+        // micro-operations: convert, ReLU clamp, one 8-byte write into the out image (half pb >> 1, pixel (pb & 1) * 16 + n)
+        constexpr int NMO = NPB * NCB * 3;
+        unsigned e0 = 0, e1 = 0;
+        auto micro = [&](const f32x4a (&P)[NCB][NPB], int e) {
+            const int u = e / 3, k = e % 3, pb = u / NCB, cb = u % NCB;
+            if (k == 0) {
+                const xf_f32x2 a = {P[cb][pb][0], P[cb][pb][1]}, b = {P[cb][pb][2], P[cb][pb][3]};
+                e0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, xf_bf16x2));
+                e1 = __builtin_bit_cast(unsigned, __builtin_convertvector(b, xf_bf16x2));
+            } else if (k == 1) {
+                e0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(xf_s16x2, e0), lo_clamp));
+                e1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(xf_s16x2, e1), lo_clamp));
+            } else {
+                *reinterpret_cast<uint2 *>(o_lane + (pb >> 1) * L::OHALF + (pb & 1) * 16 * L::OROW + cb * 32) = make_uint2(e0, e1);
+            }
+        };
+        // one barrier interval = a pair of run chunks on accumulator set C: NT = 9 -> nine K steps of NCB x 4 MFMAs, NT = 1 -> one.
+        // The fragments of a step are requested one step ahead (two sets).  FIRST: the tile starts from the bias.  EP of 2 (HP): the interval
+        // carries that half (tile rows 2 EP, 2 EP + 1 = out-image half EP) of the finished set's epilogue.
+        auto pair_step = [&](auto nt_c, auto first_c, auto ep_c, f32x4a (&C)[NCB][NPB], const f32x4a (&P)[NCB][NPB], const unsigned char *la, const unsigned char *lw) {
+            constexpr int NT = decltype(nt_c)::value;
+            constexpr bool FIRST = decltype(first_c)::value;
+            constexpr int EP = decltype(ep_c)::value;              // -1: no epilogue
+            constexpr int NST = NT == 9 ? 9 : 1;
+            if (A.debug & 1) return;
+            // weight fragments of a whole step one step ahead (two sets), pixel fragments one tile row ahead (two registers sets of one)
+            bf16x8 wa[2][NCB], pf[2];
+            auto req_w = [&](int st) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) wa[st & 1][cb] = *reinterpret_cast<const bf16x8 *>(lw + (NT == 9 ? WB9[st] : WB1) + cb * 256);
+            };
+            auto req_p = [&](int st, int pb) {
+                const int o = (NT == 9 ? PB9[st] : PB1) ^ ((pb & 1) * 16);
+                pf[(st * NPB + pb) & 1] = *reinterpret_cast<const bf16x8 *>(la + o + pb * HW_ * PSTR);
+            };
+            constexpr int NG = NST * NCB * NPB;
+            constexpr int E0 = EP >= 0 ? EP * NMO / 2 : 0, CNT = EP >= 0 ? NMO / 2 : 0, CNTD = CNT > 0 ? CNT : 1;
+            req_w(0);
+            req_p(0, 0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + 1 < NST) req_w(st + 1);
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) {
+                    if (pb + 1 < NPB) req_p(st, pb + 1); else if (st + 1 < NST) req_p(st + 1, 0);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        const bf16x8 &pv = pf[(st * NPB + pb) & 1];
+                        if (FIRST && st == 0) C[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[st & 1][cb], pv, binit[cb], 0, 0, 0);
+                        else C[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[st & 1][cb], pv, C[cb][pb], 0, 0, 0);
+                        if (CNT > 0) {
+                            const int g = (st * NPB + pb) * NCB + cb;
+                            bool any = false;
+#pragma unroll
+                            for (int i = 0; i < CNT; ++i)
+                                if ((i * NG) / CNTD == g) {
+                                    if (!any) __builtin_amdgcn_sched_barrier(0);
+                                    any = true;
+                                    micro(P, E0 + i);
+                                }
+                            if (any) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+        };
+        using F_ = std::false_type;
+        using T_ = std::true_type;
+        using N9 = std::integral_constant<int, 9>;
+        using N1 = std::integral_constant<int, 1>;
+        using EN = std::integral_constant<int, -1>;
+        using E0_ = std::integral_constant<int, 0>;
+        using E1_ = std::integral_constant<int, 1>;
+        int q = 0, qs = 0;
+        auto slot_a = [&]() -> const unsigned char * { return lds_a + qs * A_BYTES; };
+        auto slot_w = [&](int k) -> const unsigned char * {
+            if (STREAM) return lds_w + (q & 3) * L::WCH9;
+            if (MIX && k >= n0) return lds_w + n0 * L::WCH9 + (k - n0) * L::WCH1;
+            return lds_w + k * L::WCH9;
+        };
+        auto after_pair = [&]() {
+            q += 2;
+            qs = (qs + 2) & 3;
+            __syncthreads();
+        };
+        auto tile_step = [&](auto has_prev, f32x4a (&C)[NCB][NPB], const f32x4a (&P)[NCB][NPB]) {
+            constexpr bool HP = decltype(has_prev)::value;
+            if (HP) pair_step(N9{}, T_{}, E0_{}, C, P, slot_a(), slot_w(0)); else pair_step(N9{}, T_{}, EN{}, C, P, slot_a(), slot_w(0));
+            after_pair();
+            if (HP) pair_step(N9{}, F_{}, E1_{}, C, P, slot_a(), slot_w(2)); else pair_step(N9{}, F_{}, EN{}, C, P, slot_a(), slot_w(2));
+            after_pair();
+            for (int k = 4; k < NCH; k += 2) {
+                if (MIX && k >= n0) pair_step(N1{}, F_{}, EN{}, C, P, slot_a(), slot_w(k));
+                else pair_step(N9{}, F_{}, EN{}, C, P, slot_a(), slot_w(k));
+                after_pair();
+            }
+        };
+        __syncthreads();                                         // B1: run chunks 0, 1 are staged
+        tile_step(F_{}, accA, accB);
+        int j = 1;
+        for (; j + 1 < ntl; j += 2) {
+            tile_step(T_{}, accB, accA);
+            tile_step(T_{}, accA, accB);
+        }
+        const bool tail = j < ntl;
+        if (tail) tile_step(T_{}, accB, accA);
+        for (int i = NI; i % IPG != 0; ++i) __syncthreads();     // the movers' loop runs whole groups of IPG intervals
+        __syncthreads();                                         // E: the movers' last reads of the out image are done
+        if (tail) {
+#pragma unroll
+            for (int e = 0; e < NMO; ++e) micro(accB, e);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NMO; ++e) micro(accA, e);
+        }
+        __syncthreads();                                         // F: the last tile is in the image; the movers store it
+        return;
+    }
     const int wm = wave;
     const int half = lane >> 5, l31 = lane & 31;
     int pbase[NPI][2];                                           // pixel fragment (B operand) of block pi; [.][parity of the tap's row offset]
@@ -827,7 +981,23 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
         if constexpr (OUTOK) {
             if (out) {
                 constexpr bool STREAM_ = decltype(sm_c)::value;
-                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, decltype(mx_c)::value, 0, 4, decltype(pf_c)::value, true>;
+                constexpr bool MIX_ = decltype(mx_c)::value;
+                // the streamed-weight launches - the matrix-bound layers (128+ input channels) - take the 16x16x32 consumers (CDNET_WS16_K32=0:
+                // off): 63 / 62 / 27 us against 72 / 70 / 30 us on 256 -> 256 @64², 512 -> 512 @32², 320 -> 64 @64².  The resident 64 -> 64 layer is
+                // bound by its traffic and does not gain (80 vs 75 us at 16 tiles, 320 vs 322 us at 64); the one-tap form spilled.
+                static const int k32_env = getenv("CDNET_WS16_K32") ? atoi(getenv("CDNET_WS16_K32")) : 1;
+                if constexpr (STREAM_) if (k32_env) {
+                    auto kern_k = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, true>;
+                    static bool attr_k = false;
+                    if (!attr_k) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                            return check_launch("hipFuncSetAttribute(conv_ws16 k32)");
+                        attr_k = true;
+                    }
+                    kern_k<<<grid, 512, smem, st>>>(A);
+                    return check_launch("conv_ws16_kernel(k32)");
+                }
+                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true>;
                 static bool attr_o = false;
                 if (!attr_o) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_o), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
