@@ -147,6 +147,9 @@ class Trainer:
         self._side_active = False
         # split-K sums of the weight gradients: deferred and batched (one cdnet_wgrad_reduce_batch launch per ~CDNET_WGRAD_REDUCE_MB of
         # slabs instead of one reduce behind every weight-gradient launch; every call keeps its own slab buffer - 1.4 GB for the UNet)
+        # Memory: with the default every weight-gradient call keeps its own split-K slab buffer for the trainer's lifetime (`buf(('wslab', ...))`,
+        # ~1.4 GB for the DAM-Unet at 16 tiles, more for HRNet at 512²; a batch-size change re-allocates the buffers of the new shapes and frees
+        # the old ones); CDNET_WGRAD_REDUCE_MB=0 returns to one shared slab and a reduce behind every launch.
         self._rd_mb = float(os.environ.get('CDNET_WGRAD_REDUCE_MB', '300'))        # 0: the reduce inside every call (one shared slab)
         self._rd_pending, self._rd_params, self._rd_bytes, self._rd_tables = [], [], 0, {}
         self._forwards, self._bn_base = 0, 0                 # training forwards run here / counted in a loaded checkpoint
