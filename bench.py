@@ -172,7 +172,7 @@ def committed_pmc(precision, B=16):
     return None, None, None, None
 
 
-def live_pmc_traffic(precision, kernel_names, timeout_s=150):
+def live_pmc_traffic(precision, kernel_names, timeout_s=90):
     """HBM bytes per launch of the dominant kernel measured IN THIS RUN when rocprofv3 is on the box: two child processes
     `rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --mode roofline` (separate passes, the program right
     after `--`, from /tmp: MI355X_MICROARCH.md's HBM / rocprofv3 section), FETCH_SIZE x 2 on gfx950 (a 16-B/lane read stream counts

@@ -19,6 +19,7 @@ class WgradReduceDesc(C.Structure):          # cdnet_wgrad_reduce_desc (include/
 # name -> (restype, argtypes); must list every symbol include/cdnet_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     'cdnet_abi_version': (_i, []),
+    'cdnet_abi_sizeof': (_sz, [C.c_char_p]),
     'cdnet_last_error': (C.c_char_p, []),
     'cdnet_build_info': (C.c_char_p, []),
     'cdnet_ddm_codes': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
@@ -112,8 +113,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.cdnet_abi_version() != 1:
-        raise CdnetHipError('ABI version mismatch')
+    if lib.cdnet_abi_version() != 2:
+        raise CdnetHipError('ABI version mismatch (libcdnet_hip.so is version %d, this binding 2): rebuild with python -m cdnet_amd.csrc.build' % lib.cdnet_abi_version())
     _lib = lib
     return lib
 

@@ -15,3 +15,11 @@ void set_error(const char *fmt, ...) {
 extern "C" int cdnet_abi_version(void) { return CDNET_ABI_VERSION; }
 extern "C" const char *cdnet_last_error(void) { return cdnet::g_err; }
 extern "C" const char *cdnet_build_info(void) { return "cdnet_hip;gfx950;wave64;hipcc"; }
+extern "C" size_t cdnet_abi_sizeof(const char *name) {
+    if (!name) return 0;
+#define CDNET_SZ(T) if (!strcmp(name, #T)) return sizeof(T)
+    CDNET_SZ(cdnet_conv_src); CDNET_SZ(cdnet_conv_args); CDNET_SZ(cdnet_pack_job); CDNET_SZ(cdnet_head_feat); CDNET_SZ(cdnet_wgrad_reduce_desc);
+    CDNET_SZ(cdnet_grad_in); CDNET_SZ(cdnet_bn_bwd_args); CDNET_SZ(cdnet_fuse_term); CDNET_SZ(cdnet_grad_term);
+#undef CDNET_SZ
+    return 0;
+}

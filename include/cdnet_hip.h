@@ -29,9 +29,12 @@ extern "C" {
 #define CDNET_E_WORKSPACE   2   /* workspace too small */
 #define CDNET_E_LAUNCH      3   /* HIP launch error */
 
-#define CDNET_ABI_VERSION   1
+#define CDNET_ABI_VERSION   2   /* 2 (round 4): cdnet_conv_args grew (taps1, pool_out) - a caller built against version 1 must not pass its struct */
 
 int         cdnet_abi_version(void);
+/* sizeof() of an argument struct of this header by name ("cdnet_conv_args", ...), 0 for an unknown name: a binding that mirrors the structs
+ * (ctypes, cgo, JNI) checks its own layout against the library's at load time. */
+size_t      cdnet_abi_sizeof(const char *struct_name);
 const char *cdnet_last_error(void);
 /* static description: "gfx950;wave64;..." */
 const char *cdnet_build_info(void);

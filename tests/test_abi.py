@@ -22,8 +22,22 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'missing export ' + n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.cdnet_abi_version() == 1
+    assert lib.cdnet_abi_version() == 2
     assert b'gfx950' in lib.cdnet_build_info()
+
+
+def test_ctypes_mirrors_have_the_library_struct_sizes():
+    """every argument struct the Python host side mirrors with ctypes has the size the library was compiled with (a field added on one
+    side only would shift every later field silently)"""
+    from cdnet_amd import _lib, engine, runtime, trainer
+    lib = _lib.load()
+    mirrors = {'cdnet_conv_src': engine.ConvSrc, 'cdnet_conv_args': engine.ConvArgs, 'cdnet_pack_job': engine.PackJob,
+               'cdnet_head_feat': runtime.HeadFeat, 'cdnet_wgrad_reduce_desc': _lib.WgradReduceDesc, 'cdnet_grad_in': trainer.GradIn,
+               'cdnet_bn_bwd_args': trainer.BnBwdArgs, 'cdnet_fuse_term': runtime.FuseTerm, 'cdnet_grad_term': trainer.GradTerm}
+    import ctypes
+    for name, cls in mirrors.items():
+        assert lib.cdnet_abi_sizeof(name.encode()) == ctypes.sizeof(cls), name
+    assert lib.cdnet_abi_sizeof(b'no_such_struct') == 0
 
 
 def test_argument_validation_without_gpu():
