@@ -240,9 +240,12 @@ def test_conv_ws16_fused_max_pool_output(case):
     """cdnet_conv_args.pool_out: nn.MaxPool2d(2, 2) of the ReLU-activated output from the movers' store path of conv_ws16_kernel's
     out-image form (the 'M' layers of the VGG16-BN encoder, model_unet_rev1.py:40-41) - the full-resolution output bit-identical to the
     launch without it, the pooled tensor bit-identical to torch's max_pool2d of that output (a maximum of stored values: exact)."""
+    import os
     import torch
     import torch.nn.functional as F
     from cdnet_amd import engine
+    if os.environ.get('CDNET_WS16_OUT', '1') == '0' or os.environ.get('CDNET_WS16_PF', '4') == '0':
+        pytest.skip('the fused max-pool rides in the out-image form, which this environment switches off')
     N, Cin, Cout, H, W, G = [case[k] for k in ('N', 'Cin', 'Cout', 'H', 'W', 'G')]
     g = torch.Generator().manual_seed(7 + Cin + H)
     x = _bf(torch.randn((N, Cin, H, W), generator=g))
