@@ -518,10 +518,17 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                         commit(SA{}, qa); commit(SB{}, qa + 1);
                         dma_w(); dma_w();
                         if (OUT) {
-                            // (the stores sit between the weight DMA and the halo requests: the wait leaves them in flight too)
+                            // (the stores sit between the weight DMA and the halo requests: the wait leaves them in flight too; the compiler
+                            //  fences keep that issue order - the explicit vmcnt below counts on it)
+                            asm volatile("" ::: "memory");
                             const bool stored = store_prev(i0 + M);
+                            asm volatile("" ::: "memory");
                             issue(SA{}); issue(SB{});
-                            if (stored) stream_sync(std::integral_constant<int, 2 * NA + 32 / (64 / (BN / 8))>{}); else stream_sync(NHL{});
+                            // (the stores of a half - NRS of them, plus NRS / 2 pooled ones - are younger than the weight DMA and stay in flight)
+                            constexpr int NRS = 32 / (64 / (BN / 8));
+                            if (!stored) stream_sync(NHL{});
+                            else if (A.pool_out) stream_sync(std::integral_constant<int, 2 * NA + NRS + NRS / 2>{});
+                            else stream_sync(std::integral_constant<int, 2 * NA + NRS>{});
                         } else {
                             issue(SA{}); issue(SB{});
                             stream_sync(NHL{});
