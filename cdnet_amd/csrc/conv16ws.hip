@@ -5,22 +5,30 @@
 //   * OPERAND ROLES SWAPPED against conv_fwd_kernel / conv_ws_kernel: the packed weights are the MFMA's A operand (M = 32 output channels),
 //     the halo pixels its B operand (N = 32 pixels).  An accumulator block then holds, per lane, ONE pixel x 16 output channels, and with
 //     the weight rows read through the permutation sigma (bits 2 and 3 of the row swapped) registers 8s..8s+7 of a lane are 8 CONSECUTIVE
-//     output channels: the finished tile leaves straight from the accumulators as 16-byte NHWC stores (the two lane halves of a pixel
-//     write 32 contiguous bytes) - no LDS out image, no transposing read-back, no store burst by the movers.  The packed weights in
-//     memory are the ones every other kernel reads (the permutation is in the fragment address);
+//     output channels: 16 bytes of the NHWC output per lane without a transpose.  The packed weights in memory are the ones every other
+//     kernel reads (the permutation is in the fragment address);
 //   * bias + folded BatchNorm shift enter as the accumulators' initial value (the first MFMA of a tile takes them as its C operand):
 //     the epilogue is convert, ReLU on the packed 16-bit patterns, store - 10 instructions per 8 outputs, spread over the MFMA gaps of
 //     the next tile (the eval-mode BatchNorm scale is folded into the packed weights by the host, runtime.ConvLayer.eval_pack);
 //   * any number of 16-channel chunks from one up (the stem 16 -> 64, the decoder's 80 -> 16 and 160 -> 32, the 512-channel loops):
 //     one barrier per TWO chunks of the workgroup's run of chunks, wherever tile boundaries fall; weights resident in LDS when the tile's
-//     chunks fit (<= 96 KB), else streamed through a four-slot ring by LDS-DMA two chunks ahead (conv_ws_kernel's scheme);
+//     chunks fit (<= 82 KB), else streamed through a four-slot ring by LDS-DMA two chunks ahead (conv_ws_kernel's scheme);
 //   * a second source may carry ONE tap per chunk instead of nine (cdnet_conv_args.taps1 = 1): the 1x1 branch of a residual unit then is
 //     four more K steps of its second 3x3 convolution - relu(bn2(conv2(h)) + conv_1x1(x)) in one launch, eval mode
 //     (model_unet_rev1.py:161-170), no stored conv2 output, no separate 1x1 pass;
+//   * tiles of an even number (>= 4) of chunks - the heavy layers - leave through an LDS OUT IMAGE [pixel][channel] (16-byte writes of the
+//     consumers, conflict-free 144-byte rows) that the MOVERS store one interval later as whole 128-byte lines (OUT): a store issued by a
+//     consumer between MFMAs waits for the memory pipeline behind the movers' requests, and its 32-byte pieces of a line cost the write
+//     path as much as whole lines.  There every store is the movers' (the last tile of a run goes through the image too), and they can
+//     pool: nn.MaxPool2d(2, 2) of the block's two rows beside the stores (cdnet_conv_args.pool_out).  The other tile shapes (1 - 3
+//     chunks, odd counts) store straight from the accumulators, a pixel block's lines in consecutive gaps;
+//   * the streamed-weight launches (128+ input channels: matrix-bound) run v_mfma_f32_16x16x32_bf16 (K32): the chip holds a higher clock
+//     on it (tools/micro/mfma_shapes.hip);
 //   * waves 4..7 (movers) are conv_ws_kernel's: four halo chunks in flight in registers, requests through buffer descriptors (zero fill by
 //     the range check), generic source transform, four-slot halo ring.
-// Accumulation order per output (chunk, tap, k) is conv_fwd_kernel's; without bias the outputs are bit-identical to it
-// (tests/test_gpu_conv16ws.py); with bias the sum starts from the bias instead of ending with it (one rounding moved).
+// Accumulation order per output (chunk, tap, k) is conv_fwd_kernel's in the 32x32x16 forms: without bias the outputs are bit-identical to
+// it (tests/test_gpu_conv16ws.py); with bias the sum starts from the bias instead of ending with it (one rounding moved); K32 adds 32
+// products per MFMA: one bf16 ulp.
 //
 // Replaces the same reference lines as conv.hip: models/dam/model_unet_rev1.py:86-170, 244-287.
 #include <type_traits>
@@ -42,10 +50,7 @@ struct W16Lds {
     static constexpr int TH = 16, TW = 16, CK = 16;
     static constexpr int PSTR = 32;                               // bytes per halo pixel (16 bf16), k-halves swizzled by the halo row's parity
     static constexpr int NPIX = (TH + 2) * (TW + 2);
-    static constexpr int A_IMG = NPIX * PSTR;                     // the halo image of a chunk: 10 368 B
-    static constexpr int A_DMA = 11 * 1024;                       // ... as a ring slot of the DMA movers: whole 1 KB pieces
-    __host__ __device__ static constexpr int a_bytes(bool dma) { return dma ? A_DMA : A_IMG; }
-    static constexpr int NPIECE = 11;
+    static constexpr int A_IMG = NPIX * PSTR;                     // a ring slot: the halo image of a chunk, 10 368 B
     static constexpr int OROW = BN * 2 + 16;                      // out image: bytes per pixel (padded: conflict-free 16-byte writes of 8 consecutive pixels)
     static constexpr int OBLK = 32 * OROW;                        // a consumer wave's 32-pixel block
     static constexpr int OHALF = 4 * OBLK;                        // pixel block pi of the four consumer waves
@@ -54,7 +59,7 @@ struct W16Lds {
     static constexpr int WCH1 = CK * BN * 2;                      // ... of a one-tap chunk
     static constexpr int RES_MAX = 82 * 1024;                     // resident weights up to this many bytes, else the ring
     __host__ __device__ static int wbytes(int n9, int n1) { return n9 * WCH9 + n1 * WCH1; }
-    __host__ __device__ static int bytes(int ns, bool dma, int wb, int ctot, bool out = false) { return ns * a_bytes(dma) + wb + 2 * ((ctot + 7) / 8 * 8) * 4 + (out ? OUT_BYTES : 0); }
+    __host__ __device__ static int bytes(int ns, int wb, int ctot, bool out = false) { return ns * A_IMG + wb + 2 * ((ctot + 7) / 8 * 8) * 4 + (out ? OUT_BYTES : 0); }
 };
 
 // sigma: the weight row lane m of an A fragment reads (an involution: bits 2 and 3 swapped).  D row m = (r & 3) + 8 (r >> 2) + 4 half then
@@ -65,24 +70,8 @@ __device__ __forceinline__ int sigma32(int m) { return (m & ~12) | ((m & 4) << 1
 // STREAM: the weight chunks stream through a four-slot ring (even chunk count); else all of a tile's chunks are resident
 // MIX: the second source's chunks carry one tap (the centre) instead of nine
 // NCS: chunks per tile known to the compiler - 1: one, 2: two or three, 0: four or more (how the finished tile's epilogue is spread)
-// NS: halo ring slots.  XF 0 (plain bf16 sources): the movers only ISSUE - every halo chunk goes HBM -> LDS by DMA (buffer_load ... lds, 1 KB
-// pieces; zero fill by the descriptor's range check), NS - 2 chunks ahead of the consumers; no staging registers, no ds_write bursts in front
-// of the consumers' fragment reads.  XF 2: four chunks in flight in registers, transformed and written by the movers (NS = 4).
-typedef int i32x4s __attribute__((ext_vector_type(4)));
-// one LDS-DMA piece through a buffer descriptor: 64 lanes x 16 bytes, global (descriptor base + this lane's byte offset; out of range -> zeros)
-// -> LDS (uniform byte address + lane * 16).  Inline assembly: the compiler does not count it - the mover waits by hand (conv32ws.hip).
-__device__ __forceinline__ void blds_piece(i32x4s rsrc, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void glds_piece16(const void *gbase, unsigned lane_bytes, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_bytes), "s"(gbase), "s"(lds_dst) : "memory");
-}
-
-// PFD: 0 = the DMA movers; 4 / 8 / 12 = the register movers with that many halo chunks in flight per thread (NS = 4)
+// NS: halo ring slots (4).  PFD: halo chunks in flight per mover thread (4; 8 and 12 were measured: no gain - the launch is not latency-bound;
+// so was a DMA form of the movers, buffer_load ... lds into a seven-slot ring: profiles/HISTORY.md)
 // OUT: the finished tile leaves through an LDS out image and the MOVERS store it (register movers, an even chunk count >= 4): a store issued by
 // a consumer wave between MFMAs waits for the memory pipeline behind the movers' requests, and the matrix pipe waits with it
 // K32: the consumers of the out-image form run v_mfma_f32_16x16x32_bf16 - K = 32 = two (tap, 8-channel) pairs of a pair of chunks, 9 K steps per
@@ -95,13 +84,13 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
-    constexpr int PF = PFD > 0 ? PFD : 4;
-    constexpr int A_BYTES = L::a_bytes(PFD == 0);                 // halo ring slot stride
-    constexpr int IPG = PFD > 0 ? PF / 2 : 2;                     // barrier intervals per iteration of the movers' loop
+    constexpr int PF = PFD;
+    constexpr int A_BYTES = L::A_IMG;                             // halo ring slot stride
+    constexpr int IPG = PF / 2;                                   // barrier intervals per iteration of the movers' loop
     static_assert(!(STREAM && MIX), "one-tap chunks only with resident weights");
-    static_assert(!OUT || (PFD > 0 && NCS == 0), "LDS out image: register movers, tiles of an even number (>= 4) of chunks");
+    static_assert(!OUT || NCS == 0, "LDS out image: tiles of an even number (>= 4) of chunks");
     static_assert(!K32 || OUT, "the 16x16x32 consumers serve the out-image form");
-    static_assert(PFD == 0 ? XF == 0 : (NS == 4 && PF % 4 == 0), "DMA movers: plain sources; register movers: a four-slot ring, sets = slots mod 4");
+    static_assert(NS == 4 && PF % 4 == 0, "a four-slot halo ring, register sets = slots mod 4");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
 
@@ -146,123 +135,6 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         // ================================ movers (conv_ws_kernel's, without the out path) ================================
         const int ptid = tid - 256, pw = wave - 4;
         if (A.debug & 16) __builtin_amdgcn_s_setprio(2);         // (experiment: the younger half of the workgroup loses the issue arbitration at equal priority)
-        if constexpr (PFD == 0) {
-            // ---- DMA movers.  Piece p of a chunk's halo image = LDS bytes [1024 p, 1024 p + 1024) = 32 halo pixels x 32 B; lane l of the piece
-            // ---- brings the 16 bytes at pixel 32 p + l / 2, position l & 1 - the channel half (l & 1) ^ (halo row & 1) (the consumers'
-            // ---- swizzle, in the SOURCE address).  Wave pw issues pieces pw, pw + 4, pw + 8 (< 11) of every chunk.
-            constexpr int PD = NS - 2;                           // run chunks issued ahead of the consumers' interval
-            constexpr int NJ = 3;
-            int hyx[NJ];
-            unsigned cb[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int pc = pw + 4 * j, pix = 32 * pc + (lane >> 1);
-                const int hy = pix / HW_, hx = pix - hy * HW_;
-                const bool ok = pc < L::NPIECE && pix < NPIX;
-                hyx[j] = ok ? ((hy << 8) | hx) : 0x1f1f;       // (31 = a vector that never exists: bit 31 of the masks is always set)
-                cb[j] = (unsigned)(((lane & 1) ^ (hy & 1)) * 16);
-            }
-            auto mkdesc = [](const void *base, unsigned nbytes) -> i32x4s {
-                const unsigned long long b = (unsigned long long)(size_t)base;
-                const i32x4s d = {(int)__builtin_amdgcn_readfirstlane((int)(unsigned)b), (int)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)),
-                                  (int)__builtin_amdgcn_readfirstlane((int)nbytes), 0x00020000};
-                return d;
-            };
-            const unsigned sb0 = (unsigned)A.N * A.src[0].Hs * (A.src[0].row_stride ? A.src[0].row_stride : A.src[0].Ws * A.src[0].C) * 2u;
-            const unsigned sb1 = A.nsrc > 1 ? (unsigned)A.N * A.src[1].Hs * (A.src[1].row_stride ? A.src[1].row_stride : A.src[1].Ws * A.src[1].C) * 2u : 0u;
-            const i32x4s rs0 = mkdesc(A.src[0].x, sb0), rs1 = mkdesc(A.nsrc > 1 ? A.src[1].x : A.src[0].x, sb1);
-            auto bad_mask = [](int lo, int hi) -> unsigned {
-                lo = lo < 0 ? 0 : (lo > 31 ? 31 : lo);
-                hi = hi < lo ? lo : (hi > 31 ? 31 : hi);
-                return ~(((1u << hi) - 1u) & ~((1u << lo) - 1u));
-            };
-            int ik = 0, ic = 0, in_, iy0, ix0, isl = 0;
-            {
-                in_ = t_lo / tiles_img;
-                const int r = t_lo - in_ * tiles_img, ty = r / tiles_x;
-                iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
-            }
-            unsigned ge[NJ];
-            const unsigned lds_a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_a;
-            auto issue = [&]() {
-                const int si = ik < n0 ? 0 : 1, cc0 = (ik < n0 ? ik : ik - n0) * CK;
-                const ConvSrc &s = A.src[si];
-                if (ik == 0 || ik == n0) {
-                    const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
-                    const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
-                    const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;
-                    const unsigned rowbad = bad_mask(ylo - (iy0 - 1), yhi - (iy0 - 1)), colbad = bad_mask(xlo - (ix0 - 1), xhi - (ix0 - 1));
-                    const unsigned img_b = (unsigned)((in_ * s.Hs + (iy0 - 1 - s.off_y)) * rs + (ix0 - 1 - s.off_x) * s.C) * 2u;
-                    const unsigned rs_b = (unsigned)rs * 2u, c_b = (unsigned)s.C * 2u;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const unsigned hy = (unsigned)hyx[j] >> 8, hx = (unsigned)hyx[j] & 0xffu;
-                        const unsigned t = (rowbad >> hy) | (colbad >> hx);
-                        ge[j] = ((img_b + hy * rs_b + hx * c_b + cb[j]) & 0x7fffffffu) | (t << 31);
-                    }
-                }
-                const i32x4s rsx = si ? rs1 : rs0;
-                const unsigned cc0_b = (unsigned)cc0 * 2u;
-                const unsigned dst = lds_a_addr + (unsigned)isl * A_BYTES + (unsigned)pw * 1024u;
-                if (!(A.debug & 2)) {                            // (2: ablation - no halo requests)
-                    blds_piece(rsx, ge[0] + cc0_b, dst);
-                    blds_piece(rsx, ge[1] + cc0_b, dst + 4096u);
-                    if (pw < 3) blds_piece(rsx, ge[2] + cc0_b, dst + 8192u);
-                }
-                isl = isl + 1 == NS ? 0 : isl + 1;
-                if (ic + 1 < S) {
-                    ++ic;
-                    if (++ik == NCH) {
-                        ik = 0;
-                        ix0 += TW;
-                        if (ix0 >= A.W) { ix0 = 0; iy0 += TH; if (iy0 >= A.H) { iy0 = 0; ++in_; } }
-                    }
-                }
-            };
-            // STREAM: weight chunk wk of the tile -> weight slot (run chunk & 3): 18 / 9 pieces, the four waves in turn
-            int wk = 0, wq = 0;
-            const unsigned lds_w_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_w;
-            auto dma_w = [&]() {
-                constexpr int NPC = L::WCH9 / 1024;
-                const char *wsrc = reinterpret_cast<const char *>(A.w) + ((size_t)cout_tile * NCH + wk) * L::WCH9;
-                const unsigned wdst = lds_w_addr + (unsigned)(wq & 3) * L::WCH9;
-#pragma unroll
-                for (int i = 0; i < (NPC + 3) / 4; ++i) {
-                    const int pc = i * 4 + pw;
-                    if (i * 4 + 3 < NPC || pc < NPC) glds_piece16(wsrc + pc * 1024, (unsigned)lane * 16u, wdst + pc * 1024);
-                }
-                if (++wk == NCH) wk = 0;
-                ++wq;
-            };
-            // everything older than this wave's N youngest vector-memory operations has landed
-            auto wait_keep = [&](auto n3_c, auto n2_c) {
-                constexpr int N3 = decltype(n3_c)::value, N2 = decltype(n2_c)::value;
-                if (pw < 3) __builtin_amdgcn_s_waitcnt((N3 & 15) | (7 << 4) | (15 << 8) | ((N3 >> 4) << 14));
-                else __builtin_amdgcn_s_waitcnt((N2 & 15) | (7 << 4) | (15 << 8) | ((N2 >> 4) << 14));
-            };
-            // resident weights: the halo pieces of PD - 2 chunks may stay in flight across a barrier; streamed weights: the weight DMA of an
-            // interval is issued first and must have landed at its end - only that interval's two halo chunks stay in flight
-            using K3 = std::integral_constant<int, STREAM ? 2 * 3 : (PD - 2) * 3>;
-            using K2 = std::integral_constant<int, STREAM ? 2 * 2 : (PD - 2) * 2>;
-            __syncthreads();                                     // B0 (the consumers' resident weights)
-            if (STREAM) { dma_w(); dma_w(); }
-#pragma unroll
-            for (int c = 0; c < PD; ++c) issue();
-            if (STREAM) wait_keep(std::integral_constant<int, (PD - 2) * 3>{}, std::integral_constant<int, (PD - 2) * 2>{});
-            else wait_keep(K3{}, K2{});
-            __builtin_amdgcn_s_barrier();                        // B1: run chunks 0, 1 (and their weights) are in the LDS
-            for (int i = 0; i < NI; i += 2) {
-                if (STREAM) { dma_w(); dma_w(); }
-                issue(); issue();
-                wait_keep(K3{}, K2{});
-                __builtin_amdgcn_s_barrier();
-                if (STREAM) { dma_w(); dma_w(); }
-                issue(); issue();
-                wait_keep(K3{}, K2{});
-                __builtin_amdgcn_s_barrier();
-            }
-            return;
-        }
         const int slot = ptid % VPP;
         u32x4v pa[PF][NA];
         unsigned eo[XF != 0 ? PF : 1][NA];       // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
@@ -951,16 +823,10 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     if (stream && (mix || (nch & 1))) return -1;
     // halo ring: four slots under the register movers; under the DMA movers (plain sources) seven - five chunks ahead of the consumers -
     // or six beside the one-tap chunks' extra weights
-    // plain sources: CDNET_WS16_PF=0 selects the DMA movers (halo chunks HBM -> LDS by buffer_load ... lds, a seven-slot ring, direct stores by
-    // the consumers) instead of the register movers + LDS out image.  Measured on the dominant layer (tools/bench_ws16_pf.py, 16 / 64 tiles):
-    // DMA 73 / 347 us, register movers with 4 / 8 / 12 chunks in flight and direct stores 74-77 / 353-388 us (depth does not help: the launch
-    // is not latency-bound), register movers + out image stored by the movers 74-76 / 319 us (conv_ws_kernel: 82 / 360 us)
-    static const int pfd_env = getenv("CDNET_WS16_PF") ? atoi(getenv("CDNET_WS16_PF")) : 4;
-    const int pfd = !all_plain ? 4 : (pfd_env == 0 ? 0 : 4);
-    const int ns = pfd != 0 ? 4 : (mix ? 6 : 7);
+    const int ns = 4;
     static const int out_env = getenv("CDNET_WS16_OUT") ? atoi(getenv("CDNET_WS16_OUT")) : 1;
-    const bool out = out_env && pfd != 0 && nch >= 4 && !(nch & 1) && L::bytes(ns, false, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
-    const int smem = L::bytes(ns, pfd == 0, stream ? 4 * L::WCH9 : wres, ctot, out);
+    const bool out = out_env && nch >= 4 && !(nch & 1) && L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
+    const int smem = L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, out);
     if (smem > 160 * 1024) return -1;
     if (A.pool_out && (!out || !A.orelu || A.out_coff || A.out_cstride != A.Cout)) return -1;      // the fused 2x2 max-pool rides in the movers' store path
     const int T = (A.W / 16) * (A.H / 16) * A.N;
@@ -984,7 +850,7 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     dim3 grid(G, ctiles, 1);
     auto go = [&](auto xf_c, auto sm_c, auto mx_c, auto ncs_c, auto pf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
-        constexpr bool OUTOK = decltype(pf_c)::value > 0 && decltype(ncs_c)::value == 0;
+        constexpr bool OUTOK = decltype(ncs_c)::value == 0;
         if constexpr (OUTOK) {
             if (out) {
                 constexpr bool STREAM_ = decltype(sm_c)::value;
@@ -1019,7 +885,7 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
         constexpr bool MIX = decltype(mx_c)::value;
         constexpr int NCS = decltype(ncs_c)::value;
         constexpr int PFD = decltype(pf_c)::value;
-        constexpr int NS = PFD != 0 ? 4 : (MIX ? 6 : 7);
+        constexpr int NS = 4;
         auto kern = conv_ws16_kernel<BN, XF, STREAM, MIX, NCS, NS, PFD, false>;
         static bool attr_done = false;
         if (!attr_done) {
@@ -1039,7 +905,6 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     using T_ = std::true_type;
     auto by_xf = [&](auto sm_c, auto mx_c, auto ncs_c) -> int {
         if (!all_plain) return go(X2{}, sm_c, mx_c, ncs_c, std::integral_constant<int, 4>{});
-        if (pfd == 0) return go(X0{}, sm_c, mx_c, ncs_c, std::integral_constant<int, 0>{});
         return go(X0{}, sm_c, mx_c, ncs_c, std::integral_constant<int, 4>{});
     };
     if (stream) return by_xf(T_{}, F_{}, C0{});                  // (an even chunk count >= 6)

@@ -1,5 +1,5 @@
-"""dominant layer (3x3 64->64 @256x256) on conv_ws16_kernel under the mover variant of CDNET_WS16_PF (0 = DMA, 4 / 8 / 12 = register movers with
-that many halo chunks in flight), 16 and 64 tiles, with the ablations (8 no stores, 2 no halo requests, 1 no MFMAs)"""
+"""dominant layer (3x3 64->64 @256x256) on conv_ws16_kernel, 16 and 64 tiles, with the ablations (8 no stores, 2 no halo requests, 1 no MFMAs);
+the round-4 A/B of the mover variants (DMA / 4, 8, 12 chunks in flight: profiles/HISTORY.md) was taken with this script under CDNET_WS16_PF"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
