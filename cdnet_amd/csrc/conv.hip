@@ -443,8 +443,25 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
     const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
     const int total_tiles = A.N * A.npar * tiles_img;
-    const int cout_tile = blockIdx.y;
     const int nchunk_total = A.nchunk;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in dispatch order (x fastest).  XCD k takes
+    // the k-th contiguous eighth of the (tile, cout block) sequence with the cout blocks of one tile next to each other: neighbouring
+    // tiles - which share halo rows / columns - and the cout blocks of one tile - which read the same input - sit behind one L2 at about
+    // the same time (a 64 -> 256 1x1 layer read its input from HBM four times when the cout blocks were dealt a whole grid apart)
+#if CDNET_CONV_XCD
+    int tile, cout_tile;
+    {
+        const int NC = (int)gridDim.y, lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        const int T = (int)gridDim.x * NC, q = T >> 3, rem = T & 7;
+        const int xcd = lin & 7, idx = lin >> 3;
+        const int seq = xcd < rem ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
+        tile = seq / NC;
+        cout_tile = seq - tile * NC;
+        if (A.debug & 16) { tile = blockIdx.x; cout_tile = blockIdx.y; }          // ablation (CDNET_CONV_DEBUG=16): dispatch order
+    }
+#else
+    const int tile = blockIdx.x, cout_tile = blockIdx.y;
+#endif
 
     // per-lane A base for each of this wave's M tiles
     // (swizzled image: the k-half position follows the parity of the halo row = tile row + the tap's row offset)
@@ -474,19 +491,6 @@ __global__ __launch_bounds__(256, (BN <= 64 ? (CK == 16 && TH == 16 && CDNET_CON
     };
 
     Prefetch<TH, TW, CK, BN, TAPS> P;
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); giving XCD k the k-th
-    // contiguous eighth of the tiles keeps neighbouring tiles - which share halo rows / columns - behind one L2
-#if CDNET_CONV_XCD
-    int tile;
-    {
-        const int T = (int)gridDim.x, q = T >> 3, rem = T & 7;
-        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        tile = xcd < rem ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
-        if (A.debug & 16) tile = blockIdx.x;          // ablation (CDNET_CONV_DEBUG=16): dispatch order
-    }
-#else
-    const int tile = blockIdx.x;
-#endif
     (void)total_tiles;
     {
         int n, par, y0, x0;

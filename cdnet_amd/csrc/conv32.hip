@@ -181,13 +181,16 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs A) {
 
     const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
-    const int cout_tile = blockIdx.y;
-    // XCD-aware tile order (see conv.hip): XCD k serves the k-th contiguous eighth of the tiles
-    int tile;
+    // XCD-aware order (see conv.hip): XCD k serves the k-th contiguous eighth of the (tile, cout block) sequence, the cout blocks of a
+    // tile next to each other
+    int tile, cout_tile;
     {
-        const int T = (int)gridDim.x, q = T >> 3, rem = T & 7;
-        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-        tile = xcd < rem ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
+        const int NC = (int)gridDim.y, lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        const int T = (int)gridDim.x * NC, q = T >> 3, rem = T & 7;
+        const int xcd = lin & 7, idx = lin >> 3;
+        const int seq = xcd < rem ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
+        tile = seq / NC;
+        cout_tile = seq - tile * NC;
     }
     const int z = tile / tiles_img, rt = tile - z * tiles_img;
     const int n = z / A.npar, par = z - n * A.npar;

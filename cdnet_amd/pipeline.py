@@ -6,25 +6,42 @@ boost/argmax -> connected-component chain, without leaving the GPU (only the fin
                   forward (all_img_test == 1) or sliding windows (utils.split_forward_dam), per-view DDM, mean,
                   point-guided boost, CC chain.
 """
+import contextlib
+
 import torch
 
 from . import postproc
 
 
 @torch.no_grad()
-def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False):
-    """x: float32 NCHW [B,3,H,W] on the GPU.  Returns dict(final int32 [B,H,W], counts, pred, ...)."""
+def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, post_stream=None):
+    """x: float32 NCHW [B,3,H,W] on the GPU.  Returns dict(final int32 [B,H,W], counts, pred, ...).
+
+    `post_stream` (a torch.cuda.Stream): the post-processing chain is queued on that stream, ordered after this batch's forward, and
+    the call returns at once - the small, latency-bound connected-component / direction kernels of batch i then run beside the
+    convolutions of batch i + 1 queued on the caller's stream.  The returned tensors belong to `post_stream`: wait for `r['done']`
+    (an event) - or synchronize - before reading them on another stream."""
     assert not model.training
     mask, point, direction = model(x)
     B, _, H, W = mask.shape
-    prob, dcm = postproc.probmaps(mask, direction)                        # test_dam.py:984, 1011-1013
-    code, minmax = postproc.ddm_codes(dcm, classes)                       # generate_dd_map per tile
-    r = postproc.tta_boost_argmax(prob.reshape(B, 1, 3 * H * W), point.reshape(B, 1, H * W),
-                                  code.reshape(B, 1, H * W), minmax.reshape(B, 1, 2), [0], H, W,
-                                  want_stages=want_stages)
-    cc = postproc.cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
-    r.update(cc)
-    r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
+    ctx = contextlib.nullcontext()
+    if post_stream is not None:
+        post_stream.wait_stream(torch.cuda.current_stream())
+        for t in (mask, point, direction):
+            t.record_stream(post_stream)                  # (allocated on the caller's stream, last read on the other one)
+        ctx = torch.cuda.stream(post_stream)
+    with ctx:
+        prob, dcm = postproc.probmaps(mask, direction)                        # test_dam.py:984, 1011-1013
+        code, minmax = postproc.ddm_codes(dcm, classes)                       # generate_dd_map per tile
+        r = postproc.tta_boost_argmax(prob.reshape(B, 1, 3 * H * W), point.reshape(B, 1, H * W),
+                                      code.reshape(B, 1, H * W), minmax.reshape(B, 1, 2), [0], H, W,
+                                      want_stages=want_stages)
+        cc = postproc.cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
+        r.update(cc)
+        r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
+        if post_stream is not None:
+            r['done'] = torch.cuda.Event()
+            r['done'].record(post_stream)
     return r
 
 

@@ -166,3 +166,34 @@ def test_full_size_image_properties():
     if r1['count']:
         areas = torch.bincount(final.flatten().long())[1:]
         assert int(areas.min()) >= 20
+
+
+@pytest.mark.gpu
+def test_post_stream_pipelining_is_bit_identical():
+    """pipeline.infer_tiles(post_stream=...): the post-processing of batch i runs on a second stream beside the forward of batch i + 1.
+    Three different batches queued back to back give exactly the label maps of the serial calls (no buffer of the forward or of the
+    post-processing chain is shared between two batches in flight)."""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import pipeline, synth
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    dev = torch.device('cuda:0')
+    for prec in ('bf16', 'fp32'):
+        cdnet_amd.set_precision(prec)
+        try:
+            torch.manual_seed(7)
+            m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).to(dev).eval()
+            xs = [torch.from_numpy(synth.tiles_u8(8, seed=40 + k).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
+                  for k in range(3)]
+            serial = [pipeline.infer_tiles(m, x) for x in xs]
+            torch.cuda.synchronize()
+            post = torch.cuda.Stream()
+            for rep in range(3):
+                piped = [pipeline.infer_tiles(m, x, post_stream=post) for x in xs]         # no synchronisation in between
+                for r in piped:
+                    r['done'].synchronize()
+                for a, b in zip(serial, piped):
+                    for k in ('final', 'counts', 'pred', 'prob', 'dcm', 'point'):
+                        assert torch.equal(a[k], b[k]), (prec, rep, k)
+        finally:
+            cdnet_amd.set_precision('bf16')

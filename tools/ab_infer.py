@@ -1,5 +1,5 @@
 """same-process A/B of the inference step (64 tiles incl. post-processing) with the round-4 eval-mode fusions switched off one at a time:
-the max-pool beside the convolution's stores, the residual units' two-launch form, the BatchNorm fold into the weights.
+the post-processing stream beside the next batch, the max-pool beside the convolution's stores, the residual units' two-launch form, the BatchNorm fold into the weights.
 usage: python tools/ab_infer.py [bf16|fp32] [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,9 +18,9 @@ x = torch.from_numpy(synth.tiles_u8(B, seed=2022).astype(np.float32) / 255.0).pe
 pool0 = runtime.ConvLayer.forward_eval_pool
 
 
-def timed(label, steps=12):
+def timed(label, steps=12, post=None):
     m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).to(dev).eval()
-    run = lambda: pipeline.infer_tiles(m, x)
+    run = lambda: pipeline.infer_tiles(m, x, post_stream=post)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 1.5:
         run()
@@ -33,8 +33,10 @@ def timed(label, steps=12):
     print('%-44s %7.3f ms  %7.0f tiles/s' % (label, dt * 1e3, B / dt), flush=True)
 
 
+post_stream = torch.cuda.Stream()
 for rep in range(2):
     timed('default')
+    timed('post-processing on a second stream', post=post_stream)
     runtime.ConvLayer.forward_eval_pool = lambda self, srcs: (self.forward(srcs, False), None)
     timed('no max-pool beside the stores')
     runtime.ConvLayer.forward_eval_pool = pool0
