@@ -218,6 +218,25 @@ __device__ __forceinline__ void dz8_at(const BnBwdArgs &A, unsigned p, unsigned 
     dz8<true, F32>(A, (int)n, (int)y, (int)x, c0, sc, sh, mu, is, dz, xh);
 }
 
+// The storage format of the raw tensor (fp16 / bf16) and the ReLU mode (0 none, 1 mask from the recomputed activation, 2 mask from the
+// stored output in `res`) are wave-uniform run-time fields: the pixel loop is instantiated per combination and chosen once at the top
+// (tested per element they cost a scalar branch + an exec-mask save around every dz: ~25 instructions per element, the reduce pass ran at
+// 3.9 TB/s beside the apply pass's 5.1).
+template <typename Body>
+__device__ __forceinline__ void bn_bwd_dispatch(bool f16, int relu, Body &&body) {
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (f16) {
+        if (relu == 0) body(T_{}, std::integral_constant<int, 0>{});
+        else if (relu == 1) body(T_{}, std::integral_constant<int, 1>{});
+        else body(T_{}, std::integral_constant<int, 2>{});
+    } else {
+        if (relu == 0) body(F_{}, std::integral_constant<int, 0>{});
+        else if (relu == 1) body(F_{}, std::integral_constant<int, 1>{});
+        else body(F_{}, std::integral_constant<int, 2>{});
+    }
+}
+
 // Window kernels: the layer's consumers are one 2x2 max-pool plus NF same-size un-shifted tensors (the skip connection).
 // One pooling window per thread: the four activations are read once, the pooled gradient goes to the first maximum
 // (nn.MaxPool2d backward).  All loads are unconditional (clamped coordinates) and issued before any arithmetic.
@@ -234,7 +253,6 @@ __global__ __launch_bounds__(256) void bn_bwd_window_kernel(BnBwdArgs A, int kp)
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     const unsigned H = A.H, W = A.W, Hp = (H + 1) / 2, Wp = (W + 1) / 2, nwin = (unsigned)A.N * Hp * Wp;
     const unsigned ppb = 256 / VPP;
-    const bool f16 = A.f16 != 0, relu = A.relu != 0;
     const GradIn gp = A.gin[kp];
     int kf[2] = {0, 0};
     {
@@ -242,6 +260,8 @@ __global__ __launch_bounds__(256) void bn_bwd_window_kernel(BnBwdArgs A, int kp)
         for (int k = 0; k < A.ngin && m < NF; ++k)
             if (k != kp) kf[m++] = k;
     }
+    bn_bwd_dispatch(A.f16 != 0, A.relu != 0 ? 1 : 0, [&](auto f16_c, auto relu_c) {
+    constexpr bool f16 = decltype(f16_c)::value, relu = decltype(relu_c)::value != 0;
     for (unsigned w0 = first_pixel(ppb, VPP); w0 < nwin; w0 += gridDim.x * ppb) {
         const unsigned w = (APPLY && A.rev) ? nwin - 1 - w0 : w0;
         const unsigned n = w / (Hp * Wp), r = w - n * Hp * Wp;
@@ -300,6 +320,7 @@ __global__ __launch_bounds__(256) void bn_bwd_window_kernel(BnBwdArgs A, int kp)
                 if (ok[q]) *reinterpret_cast<uint4 *>(A.draw + (size_t)pix[q] * A.C + c0) = o[q].u;
         }
     }
+    });
     if (!APPLY) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s_red[tid][j] = s1[j]; s_red[tid][8 + j] = s2[j]; }
@@ -329,41 +350,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(BnBwdArgs A) {
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     const unsigned npix = (unsigned)(A.N * A.H * A.W);
     const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
-    const bool f16 = A.f16 != 0, relu = A.relu != 0, outmask = A.relu == 2;
-    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
-        V16 raw[BN_U], res[BN_U], g[BN_U][NG];
+    bn_bwd_dispatch(A.f16 != 0, A.relu, [&](auto f16_c, auto relu_c) {
+        constexpr bool F16 = decltype(f16_c)::value;
+        constexpr int RELU = decltype(relu_c)::value;
+        for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
+            V16 raw[BN_U], res[BN_U], g[BN_U][NG];
 #pragma unroll
-        for (int u = 0; u < BN_U; ++u) {
-            unsigned p = p0 + u * step;
-            p = p < npix ? p : npix - 1;
-            raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
-            if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
+            for (int u = 0; u < BN_U; ++u) {
+                unsigned p = p0 + u * step;
+                p = p < npix ? p : npix - 1;
+                raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
+                if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
 #pragma unroll
-            for (int k = 0; k < NG; ++k)
-                g[u][k].u = *reinterpret_cast<const uint4 *>(A.gin[k].g + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
-        }
-#pragma unroll
-        for (int u = 0; u < BN_U; ++u) {
-            const bool valid = p0 + u * step < npix;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = ld16(raw[u].h[j], f16);
-                float v = fmaf(x, sc[j], sh[j]);
-                if (RES) v = outmask ? bf2f(res[u].h[j]) : v + ld16(res[u].h[j], f16);     // outmask: res IS the stored output
-                float gs = bf2f(g[u][0].h[j]);
-#pragma unroll
-                for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
-                // the forward rounds the activation to bf16 before the ReLU; rounding keeps the sign
-                const float dz = (!valid || (relu && !(bf2f(f2bf(v)) > 0.f))) ? 0.f : gs;
-                s1[j] += dz;
-                s2[j] = fmaf(dz, (x - mu[j]) * is[j], s2[j]);
-                if (RES) res[u].h[j] = f2bf(dz);                             // (the register is free: dz for the store below)
+                for (int k = 0; k < NG; ++k)
+                    g[u][k].u = *reinterpret_cast<const uint4 *>(A.gin[k].g + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
             }
-            // a residual unit's bn2: dz is the 1x1 branch's gradient and is stored anyway - by this pass, so that the second pass reads
-            // one tensor instead of the NG gradient sources and the mask again (cdnet_bn_backward; it then sees dz rounded to bf16)
-            if (RES && A.dz_out && valid) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)(p0 + u * step) * A.C + c0) = res[u].u;
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const bool valid = p0 + u * step < npix;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = ld16(raw[u].h[j], F16);
+                    float v = fmaf(x, sc[j], sh[j]);
+                    if (RES) v = RELU == 2 ? bf2f(res[u].h[j]) : v + ld16(res[u].h[j], F16);     // RELU 2: res IS the stored output
+                    float gs = bf2f(g[u][0].h[j]);
+#pragma unroll
+                    for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
+                    // the forward rounds the activation to bf16 before the ReLU; rounding keeps the sign
+                    const bool keep = valid & (RELU == 0 || bf2f(f2bf(v)) > 0.f);
+                    const float dz = keep ? gs : 0.f;
+                    s1[j] += dz;
+                    s2[j] = fmaf(dz, (x - mu[j]) * is[j], s2[j]);
+                    if (RES) res[u].h[j] = f2bf(dz);                             // (the register is free: dz for the store below)
+                }
+                // a residual unit's bn2: dz is the 1x1 branch's gradient and is stored anyway - by this pass, so that the second pass reads
+                // one tensor instead of the NG gradient sources and the mask again (cdnet_bn_backward; it then sees dz rounded to bf16)
+                if (RES && A.dz_out && valid) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)(p0 + u * step) * A.C + c0) = res[u].u;
+            }
         }
-    }
+    });
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s_red[tid][j] = s1[j]; s_red[tid][8 + j] = s2[j]; }
     __syncthreads();
@@ -386,43 +411,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(BnBwdArgs A) {
     load8(A.k1, c0, k1, 1.f); load8(A.k2, c0, k2, 0.f); load8(A.k3, c0, k3, 0.f);
     const unsigned npix = (unsigned)(A.N * A.H * A.W);
     const unsigned ppb = 256 / VPP, step = gridDim.x * ppb;
-    const bool f16 = A.f16 != 0, relu = A.relu != 0, outmask = A.relu == 2;
-    for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
-        V16 raw[BN_U], res[BN_U], g[BN_U][NG];
+    const bool rev = A.rev != 0;
+    bn_bwd_dispatch(A.f16 != 0, A.relu, [&](auto f16_c, auto relu_c) {
+        constexpr bool F16 = decltype(f16_c)::value;
+        constexpr int RELU = decltype(relu_c)::value;
+        for (unsigned p0 = first_pixel(ppb, VPP); p0 < npix; p0 += step * BN_U) {
+            V16 raw[BN_U], res[BN_U], g[BN_U][NG];
 #pragma unroll
-        for (int u = 0; u < BN_U; ++u) {
-            unsigned p = p0 + u * step;
-            p = p < npix ? p : npix - 1;
-            p = A.rev ? npix - 1 - p : p;
-            raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
-            if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
+            for (int u = 0; u < BN_U; ++u) {
+                unsigned p = p0 + u * step;
+                p = p < npix ? p : npix - 1;
+                p = rev ? npix - 1 - p : p;
+                raw[u].u = *reinterpret_cast<const uint4 *>(A.raw + (size_t)p * A.C + c0);
+                if (RES) res[u].u = *reinterpret_cast<const uint4 *>(A.res + (size_t)p * A.C + c0);
 #pragma unroll
-            for (int k = 0; k < NG; ++k)
-                g[u][k].u = *reinterpret_cast<const uint4 *>(A.gin[k].g + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
-        }
-#pragma unroll
-        for (int u = 0; u < BN_U; ++u) {
-            const unsigned p = p0 + u * step;
-            V16 o, z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = ld16(raw[u].h[j], f16);
-                float v = fmaf(x, sc[j], sh[j]);
-                if (RES) v = outmask ? bf2f(res[u].h[j]) : v + ld16(res[u].h[j], f16);
-                float gs = bf2f(g[u][0].h[j]);
-#pragma unroll
-                for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
-                const float dz = (relu && !(bf2f(f2bf(v)) > 0.f)) ? 0.f : gs;
-                o.h[j] = f2bf(k1[j] * (dz - k2[j] - (x - mu[j]) * is[j] * k3[j]));
-                z.h[j] = f2bf(dz);
+                for (int k = 0; k < NG; ++k)
+                    g[u][k].u = *reinterpret_cast<const uint4 *>(A.gin[k].g + (size_t)p * A.gin[k].cstride + A.gin[k].coff + c0);
             }
-            if (p < npix) {
-                const unsigned pw = A.rev ? npix - 1 - p : p;
-                *reinterpret_cast<uint4 *>(A.draw + (size_t)pw * A.C + c0) = o.u;
-                if (RES) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)pw * A.C + c0) = z.u;
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const unsigned p = p0 + u * step;
+                V16 o, z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = ld16(raw[u].h[j], F16);
+                    float v = fmaf(x, sc[j], sh[j]);
+                    if (RES) v = RELU == 2 ? bf2f(res[u].h[j]) : v + ld16(res[u].h[j], F16);
+                    float gs = bf2f(g[u][0].h[j]);
+#pragma unroll
+                    for (int k = 1; k < NG; ++k) gs += bf2f(g[u][k].h[j]);
+                    const bool keep = RELU == 0 || bf2f(f2bf(v)) > 0.f;
+                    const float dz = keep ? gs : 0.f;
+                    o.h[j] = f2bf(k1[j] * (dz - k2[j] - (x - mu[j]) * is[j] * k3[j]));
+                    z.h[j] = f2bf(dz);
+                }
+                if (p < npix) {
+                    const unsigned pw = rev ? npix - 1 - p : p;
+                    *reinterpret_cast<uint4 *>(A.draw + (size_t)pw * A.C + c0) = o.u;
+                    if (RES) *reinterpret_cast<uint4 *>(A.dz_out + (size_t)pw * A.C + c0) = z.u;
+                }
             }
         }
-    }
+    });
 }
 
 // fp32 variants of the flat kernels: 4 channels per thread (one float4 per tensor and pixel), BN_U pixels in flight, plain
