@@ -1587,7 +1587,8 @@ extern "C" int cdnet_pack_conv_weights_batch(const cdnet_pack_job *jobs, int n_j
 extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     CDNET_REQUIRE(args, "cdnet_conv_forward: null args");
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
-    CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && A.out, "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
+    CDNET_REQUIRE(A.nsrc >= 1 && A.nsrc <= 2 && A.w && (A.out || A.dot_out), "cdnet_conv_forward: bad pointers / nsrc=%d", A.nsrc);
+    CDNET_REQUIRE(!A.dot_out || (A.dot_w && !A.f32 && !A.pool_out), "cdnet_conv_forward: dot_out needs dot_w, the 16-bit path and no pool_out");
     CDNET_REQUIRE(A.N > 0 && A.H > 0 && A.W > 0 && A.Cout > 0 && A.Cout % 8 == 0, "cdnet_conv_forward: bad size (Cout must be a multiple of 8)");
     {
         int ctot_xf = 0;
@@ -1628,6 +1629,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         if (rc >= 0) return rc;
         CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps, "cdnet_conv_forward: a one-tap second source runs on conv_ws16_kernel only (ask cdnet_conv_ws_eligible)");
         CDNET_REQUIRE(!A.pool_out, "cdnet_conv_forward: the fused max-pool output needs conv_ws16_kernel's out-image form (ask cdnet_conv_ws_eligible)");
+        CDNET_REQUIRE(!A.dot_out, "cdnet_conv_forward: the fused 1x1 classifier (dot_out) needs conv_ws16_kernel's out-image form with resident weights (ask cdnet_conv_ws_eligible)");
     }
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
@@ -1652,9 +1654,9 @@ extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
-    if (A.f32) return (!A.pool_out && conv_forward_f32_ws(A, nullptr, true) == CDNET_OK) ? 1 : 0;
+    if (A.f32) return (!A.pool_out && !A.dot_out && conv_forward_f32_ws(A, nullptr, true) == CDNET_OK) ? 1 : 0;
     if (conv_forward_ws16(A, nullptr, true) == CDNET_OK) return 2;
-    if ((A.taps1 != 0 && A.taps1 != A.taps) || A.pool_out) return 0;
+    if ((A.taps1 != 0 && A.taps1 != A.taps) || A.pool_out || A.dot_out) return 0;
     if (!use_ws || (A.debug & 32)) return 0;
     if (!(A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32))) return 0;
     const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, nullptr, true) : try_launch_conv_ws<32, 9>(A, nullptr, true);

@@ -283,6 +283,15 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         int h_n[2], h_y0[2], h_x0[2];                            // coordinates of tiles jt - 1, jt - 2
         int c_n = in_, c_y0 = iy0, c_x0 = ix0;                   // ... of tile jt
         h_n[0] = h_n[1] = c_n; h_y0[0] = h_y0[1] = c_y0; h_x0[0] = h_x0[1] = c_x0;
+        float dot_w8[8], dot_b0 = 0.f;                           // cdnet_conv_args.dot_w of this lane's 8 channels (its 16-byte segment of a pixel)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot_w8[j] = 0.f;
+        if (OUT && !STREAM && A.dot_out) {
+            const int c8 = cout0 + (lane % (BN / 8)) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot_w8[j] = c8 + j < A.Cout ? A.dot_w[c8 + j] : 0.f;
+            dot_b0 = A.dot_b ? A.dot_b[0] : 0.f;
+        }
         auto store_half = [&](int hf, int tn, int ty0, int tx0) {
             constexpr int SPP = BN / 8;                          // 16-byte segments per pixel
             constexpr int PPR = 64 / SPP, NR = 32 / PPR;         // pixels per wave-instruction, instructions per block
@@ -292,11 +301,33 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) v[r] = *reinterpret_cast<const u32x4v *>(blk + (r * PPR + lp) * L::OROW);
             const bool ok = cout0 + seg * 8 < A.Cout && !(A.debug & 8);
+            if (A.out) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int px = r * PPR + lp;
-                unsigned short *dstp = A.out + (((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)) * A.out_cstride + A.out_coff + cout0 + seg * 8;
-                if (ok) *reinterpret_cast<u32x4v *>(dstp) = v[r];
+                for (int r = 0; r < NR; ++r) {
+                    const int px = r * PPR + lp;
+                    unsigned short *dstp = A.out + (((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)) * A.out_cstride + A.out_coff + cout0 + seg * 8;
+                    if (ok) *reinterpret_cast<u32x4v *>(dstp) = v[r];
+                }
+            }
+            if (!STREAM && A.dot_out) {
+                // the 1x1 classifier over the rounded output (cdnet_conv_args.dot_*): this lane's 8 channels of a pixel against its 8
+                // weights, then the sum over the SPP lanes of the pixel (they are neighbours); the first of them stores the logit
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    XfWords m;
+                    m.u = __builtin_bit_cast(xf_u32x4, v[r]);
+                    float sd = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sd = fmaf(__uint_as_float(m.w[k] << 16), dot_w8[2 * k], sd);
+                        sd = fmaf(__uint_as_float(m.w[k] & 0xffff0000u), dot_w8[2 * k + 1], sd);
+                    }
+#pragma unroll
+                    for (int o = 1; o < SPP; o <<= 1) sd += __shfl_xor(sd, o);
+                    const int px = r * PPR + lp;
+                    if (seg == 0 && !(A.debug & 8))
+                        A.dot_out[((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)] = sd + dot_b0;
+                }
             }
             if (A.pool_out) {
                 // nn.MaxPool2d(2, 2) of the block's two rows beside the stores (torchvision VGG 'M' layers after a ReLU: the values are
@@ -829,6 +860,8 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     const int smem = L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, out);
     if (smem > 160 * 1024) return -1;
     if (A.pool_out && (!out || !A.orelu || A.out_coff || A.out_cstride != A.Cout)) return -1;      // the fused 2x2 max-pool rides in the movers' store path
+    if (A.dot_out && (!out || stream || A.pool_out || A.Cout > BN || A.out_coff || !A.dot_w)) return -1;      // ... and so does the fused 1x1 classifier
+    if (!A.out && !A.dot_out) return -1;
     const int T = (A.W / 16) * (A.H / 16) * A.N;
     static int n_cu = 0;
     if (n_cu == 0) {

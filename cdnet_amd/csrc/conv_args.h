@@ -34,6 +34,8 @@ struct ConvArgs {
     int eres_f16, eres_relu;
     int taps1, pad_;
     unsigned short *pool_out;
+    const float *dot_w, *dot_b;
+    float *dot_out;
 };
 
 static_assert(sizeof(ConvSrc) == sizeof(cdnet_conv_src), "ConvSrc layout");

@@ -5,6 +5,7 @@
 //     normalisation, unbiased for running_var, momentum 0.1, eps 1e-5)
 //   DAM head: point_conv, directionAtt, direction_conv, maskAtt, mask_conv fused per pixel
 //     (models/dam/model_unet_rev1.py:8-17, 227-231, 258-263)
+#include <algorithm>
 #include "common.h"
 #include "xform.h"
 
@@ -232,7 +233,8 @@ __device__ __forceinline__ float quad_sum(float v) { return xf_quad_sum(v); }   
 // four lanes per pixel, 16 channels each: 4x the parallelism and a quarter of the registers of one-thread-per-pixel.
 // FM: the storage / transform of all three features, decided by the launcher - 0 plain bf16 (eval mode with fused epilogues),
 // 1 fp16 raw x scale + shift + residual -> ReLU (training-mode residual-unit outputs), 2 anything (run-time flags; with them the
-// kernel is 9 000 instructions of branches and every join drains the loads in flight)
+// kernel is 9 000 instructions of branches and every join drains the loads in flight), 3 = as 0 without the third feature: `point` already
+// holds the point logit (the producing convolution's fused classifier, cdnet_conv_args.dot_out) and is read instead of written
 template <int FM>
 __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
                                                            int N, int plane, float *__restrict__ mask,
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
     const bool all16 = FM != 2 || (f1.f16 != 2 && f2.f16 != 2 && f3.f16 != 2);
     // FM 0 / 1: fixed conversions of the raw vectors
     auto conv = [&](const HeadFeat &f, const FeatRaw16 &R, int k, float *v) {
-        if (FM == 0) {
+        if (FM == 0 || FM == 3) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const unsigned short *h = reinterpret_cast<const unsigned short *>(&R.r[h2]);
@@ -296,15 +298,22 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
         float v[16];
         // 16-bit features: all three features' vectors in flight at once (one memory round trip per pixel instead of three)
         FeatRaw16 R1, R2, R3;
-        if (all16) {
-            fetch(f3, ii, R3);
+        float pt;
+        if (FM == 3) {
+            pt = point[n * plane + p];
             fetch(f2, ii, R2);
             fetch(f1, ii, R1);
-            conv(f3, R3, 2, v);
         } else {
-            load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+            if (all16) {
+                fetch(f3, ii, R3);
+                fetch(f2, ii, R2);
+                fetch(f1, ii, R1);
+                conv(f3, R3, 2, v);
+            } else {
+                load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
+            }
+            pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         }
-        const float pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         const float g1 = 1.f + 1.f / (1.f + expf(-(w.a1 * pt)));
         if (all16) conv(f2, R2, 1, v);
         else load_feat16(f2, ii, q, s_sc[1], s_sh[1], v);
@@ -324,11 +333,120 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
         }
         if (ok) {
             // the 13 outputs of a pixel are spread over its 4 lanes: lane q writes outputs q, q+4, q+8, (q+12)
-            if (q == 0) { point[n * plane + p] = pt; }
+            if (FM != 3 && q == 0) { point[n * plane + p] = pt; }
 #pragma unroll
             for (int k = 0; k < 9; ++k) if ((k & 3) == q) dirn[(n * 9 + k) * plane + p] = d[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) if (k + 1 == q) mask[(n * 3 + k) * plane + p] = mk[k];
+        }
+    }
+}
+
+// The head on the matrix cores - eval mode, plain bf16 features (what the fused epilogues of the 16-bit path leave).  The three 1x1
+// classifiers are 64 -> {1, 9, 3} GEMMs per pixel: `v_mfma_f32_16x16x32_bf16` with the WEIGHTS as the A operand (row = output, padded to
+// 16) and 16 pixels as the columns of B - a lane's B fragment is 16 contiguous bytes of a pixel (channels 8 kg .. 8 kg + 7 of the k-step),
+// loaded straight from the NHWC tensor, no conversion.  The fp32 weights enter as hi + lo bf16 pairs (two MFMAs per product, 2^-16
+// relative), built once per wave and kept in registers: dam_head_fwd_kernel<0> read its 208 weights per lane from LDS for every pixel
+// (the LDS pipe, not HBM, set its 416 us per 64 tiles).  Lane (col, kg) then holds outputs 4 kg .. 4 kg + 3 of pixel `col`: the gates
+// (revAttention, model_unet_rev1.py:8-17) need the point logit - broadcast from the kg = 0 lane - and the 9-term sum over the direction
+// logits - a partial sum per lane, two cross-lane adds.  HAS_F3 = false: `point` is given (cdnet_conv_args.dot_out).
+typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 hd_bf16x8;
+
+template <bool HAS_F3>
+__global__ __launch_bounds__(256) void dam_head_mfma_kernel(const unsigned short *__restrict__ f1, const unsigned short *__restrict__ f2,
+                                                            const unsigned short *__restrict__ f3, const HeadW *__restrict__ hw, size_t total,
+                                                            int plane, float *__restrict__ mask, float *__restrict__ point,
+                                                            float *__restrict__ dirn) {
+    constexpr int U = 2;                                         // 16-pixel groups in flight per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kg = lane >> 4;
+    union Frag { hd_bf16x8 v; unsigned short h[8]; };
+    // row `col` of a classifier (zero rows beyond its outputs), channels 32 ks + 8 kg .. + 7, as hi | lo
+    auto split = [&](const float *row, int ks, Frag &hi, Frag &lo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = row ? row[ks * 32 + kg * 8 + j] : 0.f;
+            const unsigned short h = f2bf(x);
+            hi.h[j] = h;
+            lo.h[j] = f2bf(x - bf2f(h));
+        }
+    };
+    Frag wd_h[2], wd_l[2], wm_h[2], wm_l[2], wp_h[2], wp_l[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        split(col < 9 ? hw->wd[col] : nullptr, ks, wd_h[ks], wd_l[ks]);
+        split(col < 3 ? hw->wm[col] : nullptr, ks, wm_h[ks], wm_l[ks]);
+        if (HAS_F3) split(col < 1 ? hw->wp : nullptr, ks, wp_h[ks], wp_l[ks]);
+    }
+    float bd4[4], a24[4], bm3[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = 4 * kg + i;
+        bd4[i] = o < 9 ? hw->bd[o] : 0.f;
+        a24[i] = o < 9 ? hw->a2[o] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bm3[i] = hw->bm[i];
+    const float bp = hw->bp, a1 = hw->a1;
+    const hd_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (size_t g0 = ((size_t)blockIdx.x * 4 + wave) * (16 * U); g0 < total; g0 += (size_t)gridDim.x * 4 * (16 * U)) {
+        hd_bf16x8 b1[U][2], b2[U][2], b3[U][2];
+        float ptin[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            size_t px = g0 + u * 16 + col;
+            px = px < total ? px : total - 1;
+            const size_t e = px * 64 + kg * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (HAS_F3) b3[u][ks] = *reinterpret_cast<const hd_bf16x8 *>(f3 + e + ks * 32);
+                b2[u][ks] = *reinterpret_cast<const hd_bf16x8 *>(f2 + e + ks * 32);
+                b1[u][ks] = *reinterpret_cast<const hd_bf16x8 *>(f1 + e + ks * 32);
+            }
+            if (!HAS_F3) ptin[u] = point[px];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            hd_f32x4 aP = zero, aD = zero, aM = zero;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // (small terms first)
+                if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_l[ks].v, b3[u][ks], aP, 0, 0, 0);
+                aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_l[ks].v, b2[u][ks], aD, 0, 0, 0);
+                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_l[ks].v, b1[u][ks], aM, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_h[ks].v, b3[u][ks], aP, 0, 0, 0);
+                aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_h[ks].v, b2[u][ks], aD, 0, 0, 0);
+                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_h[ks].v, b1[u][ks], aM, 0, 0, 0);
+            }
+            float pt;
+            if (HAS_F3) pt = __shfl(aP[0], col) + bp;            // output row 0 lives in the kg = 0 lanes
+            else pt = ptin[u];
+            const float g1 = 1.f + 1.f / (1.f + expf(-(a1 * pt)));
+            float d[4], q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = fmaf(g1, aD[i], bd4[i]);
+                q2 = fmaf(a24[i], d[i], q2);
+            }
+            q2 += __shfl_xor(q2, 16);
+            q2 += __shfl_xor(q2, 32);
+            const float g2 = 1.f + 1.f / (1.f + expf(-q2));
+            const size_t idx = g0 + u * 16 + col;
+            if (idx < total) {
+                const size_t n = idx / plane, p = idx - n * plane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * kg + i < 9) dirn[(n * 9 + 4 * kg + i) * plane + p] = d[i];
+                if (kg == 0) {
+                    if (HAS_F3) point[idx] = pt;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mask[(n * 3 + i) * plane + p] = fmaf(g2, aM[i], bm3[i]);
+                }
+            }
         }
     }
 }
@@ -725,13 +843,28 @@ extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_hea
                                       const float *head_weights, int N, int H, int W, float *mask, float *point,
                                       float *direction, void *stream) {
     CDNET_REQUIRE(f1 && f2 && f3 && head_weights && mask && point && direction, "cdnet_dam_head_forward: null pointer");
-    CDNET_REQUIRE(f1->raw && f2->raw && f3->raw && N > 0 && H > 0 && W > 0, "cdnet_dam_head_forward: bad args");
+    CDNET_REQUIRE(f1->raw && f2->raw && N > 0 && H > 0 && W > 0, "cdnet_dam_head_forward: bad args");
     static_assert(sizeof(HeadW) == CDNET_HEAD_WEIGHT_FLOATS * 4, "head weight block layout");
     const HeadFeat a = mk_feat(*f1), b = mk_feat(*f2), c = mk_feat(*f3);
     auto plain = [](const HeadFeat &f) { return f.f16 == 0 && !f.scale && !f.relu && !f.res; };
     auto train = [](const HeadFeat &f) { return f.f16 == 1 && f.scale && f.relu && f.res; };
     const int grid = lin_grid((size_t)N * H * W * 4);
     const HeadW *hw = reinterpret_cast<const HeadW *>(head_weights);
+    // plain bf16 features (eval mode): the matrix-core kernel (CDNET_HEAD_MFMA=0: the vector-unit kernel, for A/B runs and the tests)
+    static const int mfma_env = getenv("CDNET_HEAD_MFMA") ? atoi(getenv("CDNET_HEAD_MFMA")) : 1;
+    const size_t total = (size_t)N * H * W;
+    const int mgrid = (int)std::min<size_t>(2048, (total + 127) / 128);
+    if (!c.raw) {
+        // no third feature: `point` is an input (the point logit left by the producing convolution, cdnet_conv_args.dot_out)
+        CDNET_REQUIRE(plain(a) && plain(b), "cdnet_dam_head_forward: f3->raw = NULL (point given) needs plain bf16 f1 / f2");
+        if (mfma_env) dam_head_mfma_kernel<false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, nullptr, hw, total, H * W, mask, point, direction);
+        else dam_head_fwd_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
+        return check_launch("cdnet_dam_head_forward");
+    }
+    if (mfma_env && plain(a) && plain(b) && plain(c)) {
+        dam_head_mfma_kernel<true><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, c.raw, hw, total, H * W, mask, point, direction);
+        return check_launch("cdnet_dam_head_forward");
+    }
     if (plain(a) && plain(b) && plain(c)) dam_head_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
     else if (train(a) && train(b) && train(c)) dam_head_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
     else dam_head_fwd_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);

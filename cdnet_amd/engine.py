@@ -23,7 +23,8 @@ class ConvArgs(C.Structure):
                 ('ostride', C.c_int), ('nchunk', C.c_int), ('tile', C.c_int), ('CK', C.c_int), ('BN', C.c_int),
                 ('out_f16', C.c_int), ('debug', C.c_int), ('ws', C.c_int), ('f32', C.c_int),
                 ('eres', C.c_void_p), ('eres_scale', C.c_void_p), ('eres_shift', C.c_void_p), ('eres_f16', C.c_int), ('eres_relu', C.c_int),
-                ('taps1', C.c_int), ('pad_', C.c_int), ('pool_out', C.c_void_p)]
+                ('taps1', C.c_int), ('pad_', C.c_int), ('pool_out', C.c_void_p),
+                ('dot_w', C.c_void_p), ('dot_b', C.c_void_p), ('dot_out', C.c_void_p)]
 
 
 def _dp(t):
@@ -216,7 +217,7 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0, pool_out=None):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0, pool_out=None, dot=None):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -238,25 +239,31 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
         s.fill(a.src[i])
         nchunk += s.C // CK
     a.nsrc = len(srcs)
-    if out is None:
+    if dot is not None:
+        # (weights [Cout] f32, bias [1] f32, logits f32 [N,1,H,W]): the 1x1 classifier over the activated output leaves with the stores and
+        # the output itself is not stored (cdnet_conv_args.dot_out; conv_ws16_kernel's out-image form - ask query_ws first)
+        assert out is None and stats is None and eres is None and bns is None and pool_out is None and not f32 and not transposed
+        a.dot_w, a.dot_b, a.dot_out = dot[0].data_ptr(), dot[1].data_ptr(), dot[2].data_ptr()
+        assert dot[0].numel() == Cout and dot[0].dtype == torch.float32 and dot[2].dtype == torch.float32 and dot[2].numel() == N * H * W
+    elif out is None:
         out = torch.empty((N, H * ostride, W * ostride, Cout), dtype=out_dtype, device=s0.x.device)
     ntiles = ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
     if stats is True:
         stats = torch.empty((N * npar * ntiles, 2, Cout), dtype=torch.float32, device=s0.x.device)
     a.w, a.bias, a.oscale, a.oshift = _dp(wpacked), _dp(bias), _dp(oscale), _dp(oshift)
     a.orelu = int(orelu)
-    a.out, a.Cout, a.out_cstride, a.out_coff = out.data_ptr(), Cout, out.shape[3], 0
+    a.out, a.Cout, a.out_cstride, a.out_coff = (None if out is None else out.data_ptr()), Cout, (Cout if out is None else out.shape[3]), 0
     a.stats = _dp(stats)
     a.N, a.H, a.W = N, H, W
     a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
     a.tile, a.CK, a.BN = tile, CK, BN
-    a.out_f16 = int(out.dtype == torch.float16)
+    a.out_f16 = int(out is not None and out.dtype == torch.float16)
     a.ws = 0
     a.taps1 = taps1
     a.pool_out = _dp(pool_out)           # nn.MaxPool2d(2, 2) of the activated output beside it (conv_ws16_kernel's out-image form; ask query_ws first)
     a.debug = CONV_DEBUG
     a.f32 = int(f32)
-    assert (out.dtype == torch.float32) == f32
+    assert out is None or (out.dtype == torch.float32) == f32
     if eres is not None:                 # fused residual epilogue: eres = Src(other branch[, scale, shift], relu=...)
         assert not transposed and stats is None and not orelu and out.dtype == (torch.float32 if f32 else torch.bfloat16) and tuple(eres.x.shape) == tuple(out.shape)
         assert eres.f32 == f32

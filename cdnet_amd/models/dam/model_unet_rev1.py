@@ -79,10 +79,11 @@ class _RU:
     def layers(self):
         return [self.c1, self.c2, self.cr]
 
-    def forward(self, x, training, store=False):
+    def forward(self, x, training, store=False, dot=None):
+        """dot: (weights, bias) of a 1x1 classifier that is this unit's only reader (eval mode: runtime.residual_unit_eval)"""
         relu2 = not runtime.DEBUG_NORELU
         if not training:
-            f = runtime.residual_unit_eval(self.c1, self.c2, self.cr, x, relu2)      # eval, 16-bit path: conv2 + 1x1 branch in one launch
+            f = runtime.residual_unit_eval(self.c1, self.c2, self.cr, x, relu2, dot=dot)      # eval, 16-bit path: conv2 + 1x1 branch in one launch
             if f is not None:
                 return f
         if runtime.RU_FUSE:
@@ -246,7 +247,12 @@ class Unet(nn.Module):
         f1 = self._rt['ru'][0].forward(t, training, store=True)
         f2 = self._rt['ru'][1].forward(f1, training, store=True)
         if self.VARIANT == 'rev1':
-            f3 = self._rt['ru'][2].forward(f2, training)
+            dot = None
+            if not training and runtime.PRECISION != 'fp32':
+                # the point feature is read by point_conv alone (:252-253): its logits leave with the unit's launch
+                hw = self.head_weight_block()
+                dot = (hw[0:64], hw[832:833])
+            f3 = self._rt['ru'][2].forward(f2, training, dot=dot)
             return f1, f2, f3
         # ablation heads (model_unet_MandD.py:254-266, model_unet_MandDandP.py:254-268)
         f3 = self._rt['ru'][2].forward(f2, training) if self.VARIANT == 'MandDandP' else None
@@ -288,10 +294,15 @@ class Unet(nn.Module):
         N, H, W, _ = f1.x.shape
         dev = f1.x.device
         mask = torch.empty((N, 3, H, W), dtype=torch.float32, device=dev)
-        point = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
         direction = torch.empty((N, 9, H, W), dtype=torch.float32, device=dev)
-        hf = [runtime.head_feat(f) for f in (f1, f2, f3)]
         import ctypes as C
+        if isinstance(f3, runtime.PointLogit):
+            # the point logits came with the point feature's launch: the head reads them (f3.raw = NULL) and writes mask / direction
+            point = f3.point
+            hf = [runtime.head_feat(f1), runtime.head_feat(f2), runtime.HeadFeat()]
+        else:
+            point = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+            hf = [runtime.head_feat(f) for f in (f1, f2, f3)]
         _lib.call('cdnet_dam_head_forward', C.byref(hf[0]), C.byref(hf[1]), C.byref(hf[2]), _lib.ptr(self.head_weight_block()),
                   N, H, W, _lib.ptr(mask), _lib.ptr(point), _lib.ptr(direction), _lib.stream_ptr())
         self._last_feats = (f1, f2, f3)

@@ -352,13 +352,24 @@ RU_FUSE = _os.environ.get('CDNET_RU_FUSE', '1') != '0'       # ResidualUnit: add
 # steps of its second 3x3 convolution (cdnet_conv_args.taps1 = 1, conv_ws16_kernel)
 EVAL_FOLD_WEIGHTS = _os.environ.get('CDNET_EVAL_FOLD', '1') != '0'
 RU_EVAL_ONE_LAUNCH = _os.environ.get('CDNET_RU_EVAL_FUSE', '1') != '0'
+RU_EVAL_POINT_DOT = _os.environ.get('CDNET_RU_POINT_DOT', '1') != '0'       # eval: the point feature's only reader (point_conv) rides in the unit's launch, the feature is not stored
 
 
-def residual_unit_eval(c1, c2, cr, x, relu2=True):
+class PointLogit:
+    """what a residual unit leaves instead of its output when its only reader is a 1x1 classifier (residual_unit_eval(dot=...)): the
+    classifier's logits, f32 [N,1,H,W]"""
+
+    def __init__(self, point):
+        self.point = point
+
+
+def residual_unit_eval(c1, c2, cr, x, relu2=True, dot=None):
     """relu2(bn2(conv2(relu1(bn1(conv1(x))))) + conv_1x1(x)) (model_unet_rev1.py:161-170) in eval mode on the 16-bit path with TWO launches:
     conv1 (BatchNorm folded, ReLU), then conv2 with the 1x1 branch as one-tap chunks of a second source - no stored conv2 output, no
     separate 1x1 pass.  Returns the unit's output as a plain Src, or None when the shape is not conv_ws16_kernel's (the caller then takes
-    the three-launch form)."""
+    the three-launch form).  `dot` = (weights f32 [Cout], bias f32 [1]) of a 1x1 classifier that is the unit's ONLY reader (the DAM head's
+    point_conv over the point feature, model_unet_rev1.py:252-253): its logits leave with the launch (cdnet_conv_args.dot_out), the
+    64-channel output is never stored and a PointLogit comes back - when the launch is not eligible for that, the plain Src as usual."""
     if not (RU_EVAL_ONE_LAUNCH and EVAL_FOLD_WEIGHTS) or not getattr(c2, 'fold_eval', True) or x.pool or x.C % 16 or c2.Cout % 16:
         return None
     H, W = x.logical_hw()
@@ -390,6 +401,12 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True):
     try:
         if keep & 32 or not engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1, query_ws=True):
             return None
+        if dot is not None and RU_EVAL_POINT_DOT and relu2:
+            point = torch.empty((x.N, 1, H, W), dtype=torch.float32, device=x.x.device)
+            d3 = (dot[0], dot[1], point)
+            if engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=d3, query_ws=True) == 2:
+                engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=d3)
+                return PointLogit(point)
         out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1)
     finally:
         engine.CONV_DEBUG = keep

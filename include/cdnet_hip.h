@@ -29,7 +29,8 @@ extern "C" {
 #define CDNET_E_WORKSPACE   2   /* workspace too small */
 #define CDNET_E_LAUNCH      3   /* HIP launch error */
 
-#define CDNET_ABI_VERSION   2   /* 2 (round 4): cdnet_conv_args grew (taps1, pool_out) - a caller built against version 1 must not pass its struct */
+#define CDNET_ABI_VERSION   3   /* 2, 3 (round 4): cdnet_conv_args grew (taps1, pool_out; dot_w, dot_b, dot_out) - a caller built against an older
+                                 version must not pass its struct */
 
 int         cdnet_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("cdnet_conv_args", ...), 0 for an unknown name: a binding that mirrors the structs
@@ -197,6 +198,14 @@ typedef struct cdnet_conv_args {
      * conv_ws16_kernel's out-image form only (cdnet_conv_ws_eligible answers 2 with the pointer set, else leave it NULL and call
      * cdnet_src_materialize); needs orelu = 1, out_coff = 0, out_cstride = Cout. */
     uint16_t *pool_out;
+    /* Optional 1x1 classifier over the (activated, bf16-rounded) output, fused into the store path: dot_out[n][y][x] = dot_b[0] +
+     * sum_c dot_w[c] * out[n][y][x][c] as fp32 [N][H][W] - the DAM head's point logit (model_unet_rev1.py:252-253: point_conv over the
+     * point feature, whose only other reader is nobody: with dot_out set `out` may be NULL and the 64-channel feature is then never
+     * stored).  16-bit path, conv_ws16_kernel's out-image form only (cdnet_conv_ws_eligible answers 2 with the pointers set); needs
+     * Cout <= BN (one output-channel tile), out_coff = 0; no pool_out beside it.  NULL = off. */
+    const float *dot_w;     /* [Cout] */
+    const float *dot_b;     /* [1], device memory */
+    float *dot_out;
 } cdnet_conv_args;
 
 /* packed element count for a weight tensor; nchunk = Cin/CK over all sources */
@@ -267,7 +276,9 @@ typedef struct cdnet_head_feat {
  * direction_conv, maskAtt, mask_conv; revAttention :8-17).  head_weights: device f32 block of
  * CDNET_HEAD_WEIGHT_FLOATS = { point_conv.w[64], direction_conv.w[9][64], mask_conv.w[3][64], point_conv.b,
  * direction_conv.b[9], mask_conv.b[3], directionAtt.w, maskAtt.w[9] }.
- * Outputs f32 NCHW: mask [N][3][H][W], point [N][1][H][W], direction [N][9][H][W] (the tuple Unet.forward returns). */
+ * Outputs f32 NCHW: mask [N][3][H][W], point [N][1][H][W], direction [N][9][H][W] (the tuple Unet.forward returns).
+ * f3->raw = NULL (f1 / f2 plain bf16): `point` is an INPUT - it already holds point_conv(point feature) + bias, left there by the
+ * convolution that produced the point feature (cdnet_conv_args.dot_out) - and only mask / direction are written. */
 #define CDNET_HEAD_WEIGHT_FLOATS 855
 int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_head_feat *f2, const cdnet_head_feat *f3,
                            const float *head_weights, int N, int H, int W, float *mask, float *point,

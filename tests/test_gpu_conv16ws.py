@@ -273,3 +273,70 @@ def test_conv_ws16_fused_max_pool_output(case):
     want = F.max_pool2d(_nchw(plain), 2)
     assert torch.equal(_nchw(pout), want)
     _close(_nchw(plain), F.relu(F.conv2d(x, w, b, padding=1)), 'conv + relu')
+
+
+@pytest.mark.parametrize('case', [dict(N=2, Cin=64, Cout=64, H=32, W=48, G=3, mix=False), dict(N=1, Cin=64, Cout=64, H=32, W=32, G=0, mix=True),
+                                  dict(N=3, Cin=64, Cout=64, H=16, W=32, G=2, mix=True), dict(N=1, Cin=64, Cout=32, H=16, W=16, G=1, mix=False)])
+def test_conv_ws16_fused_classifier_output(case):
+    """cdnet_conv_args.dot_w / dot_b / dot_out: the 1x1 classifier over the activated, bf16-rounded output from the movers' store path of
+    conv_ws16_kernel's out-image form - the DAM head's point logit (model_unet_rev1.py:252-253) without a stored point feature.  The
+    logits equal the fp32 dot product over the output of the plain launch (same rounded values, another summation order: 1e-5 of the
+    magnitude), with or without the feature stored beside them; a launch the form does not serve says so."""
+    import os
+    import torch
+    from cdnet_amd import engine
+    if os.environ.get('CDNET_WS16_OUT', '1') == '0':
+        pytest.skip('the fused classifier rides in the out-image form, which this environment switches off')
+    N, Cin, Cout, H, W, G, mix = [case[k] for k in ('N', 'Cin', 'Cout', 'H', 'W', 'G', 'mix')]
+    g = torch.Generator().manual_seed(11 + Cin + H + Cout)
+    x = _bf(torch.randn((N, Cin, H, W), generator=g))
+    w = _bf(torch.randn((Cout, Cin, 3, 3), generator=g) * (1.5 / (9 * Cin) ** 0.5))
+    b = torch.randn((Cout,), generator=g) * 0.3
+    dw = (torch.randn((Cout,), generator=g) * 0.2).cuda()
+    db = torch.tensor([0.37], device='cuda')
+    cfg = (16, 16, 64 if Cout > 32 else 32)
+    srcs, kw = [engine.Src(_nhwc(x))], {}
+    wp = engine.pack_weights(w.cuda(), cfg, 0)
+    if mix:                                   # a residual unit's second launch: one-tap chunks of a second source behind the nine-tap ones
+        x2 = _bf(torch.randn((N, Cin, H, W), generator=g))
+        w1 = _bf(torch.randn((Cout, Cin, 1, 1), generator=g) * (1.0 / Cin ** 0.5))
+        wp1 = engine.pack_weights(w1.cuda(), cfg, 0)
+        nt = -(-Cout // cfg[2])
+        wp = torch.cat([wp.view(nt, -1), wp1.view(nt, -1)], 1).contiguous().view(-1)
+        srcs.append(engine.Src(_nhwc(x2)))
+        kw = dict(taps1=1)
+    engine.CONV_DEBUG = 64 | (G << 8)
+    try:
+        plain, _ = engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, **kw)
+        torch.cuda.synchronize()
+        want = (plain.float() * dw.view(1, 1, 1, -1)).sum(3) + db
+        pt = torch.full((N, 1, H, W), 7.0, device='cuda')
+        assert engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, dot=(dw, db, pt), query_ws=True, **kw) == 2
+        engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, dot=(dw, db, pt), **kw)          # the output is not stored
+        torch.cuda.synchronize()
+        err = (pt[:, 0] - want).abs().max()
+        assert float(err) <= 1e-5 * float(want.abs().max()) + 1e-6, float(err)
+        # both outputs: the feature beside its logits
+        import ctypes as C
+        from cdnet_amd import _lib
+        a = engine.ConvArgs()
+        for i, s in enumerate(srcs):
+            s.fill(a.src[i])
+        out = torch.empty_like(plain)
+        pt2 = torch.zeros_like(pt)
+        bb = b.cuda()
+        a.nsrc, a.w, a.oshift, a.orelu = len(srcs), wp.data_ptr(), bb.data_ptr(), 1
+        a.out, a.Cout, a.out_cstride, a.out_coff = out.data_ptr(), Cout, Cout, 0
+        a.N, a.H, a.W, a.taps, a.npar, a.ostride, a.nchunk = N, H, W, 9, 1, 1, sum(s.C for s in srcs) // 16
+        a.tile, a.CK, a.BN, a.debug, a.taps1 = cfg[0], cfg[1], cfg[2], engine.CONV_DEBUG, (1 if mix else 0)
+        a.dot_w, a.dot_b, a.dot_out = dw.data_ptr(), db.data_ptr(), pt2.data_ptr()
+        _lib.call('cdnet_conv_forward', C.byref(a), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain) and torch.equal(pt2, pt)
+        # not served: the one-tile kernels, a pooled output beside it
+        engine.CONV_DEBUG = 32
+        assert engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, dot=(dw, db, pt), query_ws=True, **kw) == 0
+        with pytest.raises(RuntimeError):
+            engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, dot=(dw, db, pt), **kw)
+    finally:
+        engine.CONV_DEBUG = 0

@@ -277,6 +277,37 @@ def test_head_forward_backward_fp32():
     assert _rel(dhw.cpu(), want) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(2, 24, 20), (1, 16, 16), (3, 7, 9)])
+def test_head_forward_plain_bf16_features_on_the_matrix_cores(shape):
+    """eval-mode head over plain bf16 features (dam_head_mfma_kernel: weights as hi + lo bf16 pairs on `v_mfma_f32_16x16x32_bf16`) vs the
+    oracle's head in float64 over the same bf16-representable features: 2e-5 of the logit scale; the same with the point logits given
+    instead of the third feature (f3.raw = NULL, cdnet_conv_args.dot_out's consumer).  Ragged pixel counts cover the clamped last group."""
+    import torch
+    from cdnet_amd import _lib, runtime, engine
+    from oracle import models as om
+    torch.manual_seed(5)
+    ref = om.Unet().double()
+    N, H, W = shape
+    f = [torch.randn((N, 64, H, W)).to(torch.bfloat16).double() for _ in range(3)]
+    x_point = ref.point_conv(f[2])
+    x_dir = ref.direction_conv(ref.directionAtt(f[1], x_point))
+    x_mask = ref.mask_conv(ref.maskAtt(f[0], x_dir))
+    ps = [ref.point_conv.weight, ref.direction_conv.weight, ref.mask_conv.weight, ref.point_conv.bias, ref.direction_conv.bias,
+          ref.mask_conv.bias, ref.directionAtt.Conv1x1.weight, ref.maskAtt.Conv1x1.weight]
+    hw = torch.cat([p.detach().reshape(-1).float() for p in ps]).cuda().contiguous()
+    feats = [engine.Src(t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()) for t in f]
+    hf = [runtime.head_feat(s) for s in feats]
+    for given in (False, True):
+        mask = torch.full((N, 3, H, W), 7.0, device='cuda'); dirn = torch.full((N, 9, H, W), 7.0, device='cuda')
+        point = x_point.detach().float().cuda().contiguous() if given else torch.full((N, 1, H, W), 7.0, device='cuda')
+        h3 = runtime.HeadFeat() if given else hf[2]
+        _lib.call('cdnet_dam_head_forward', C.byref(hf[0]), C.byref(hf[1]), C.byref(h3), _lib.ptr(hw), N, H, W, _lib.ptr(mask), _lib.ptr(point),
+                  _lib.ptr(dirn), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert _rel(mask.cpu(), x_mask.detach()) < 2e-5 and _rel(point.cpu(), x_point.detach()) < 2e-5 and _rel(dirn.cpu(), x_dir.detach()) < 2e-5, \
+            (given, _rel(mask.cpu(), x_mask.detach()), _rel(point.cpu(), x_point.detach()), _rel(dirn.cpu(), x_dir.detach()))
+
+
 @pytest.mark.parametrize('eres', [False, True])
 def test_conv_fp32_full_tile_epilogue_is_bit_identical_to_the_general_one(eres):
     """conv_f32_kernel's full-tile epilogue (one base pointer, 32-bit offsets, statistics without bounds tests) against the general

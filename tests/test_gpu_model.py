@@ -166,3 +166,28 @@ def test_ablation_heads_vs_reference_golden(golden, name):
         want = z['%s_%d' % (name, k)].astype(np.float32)
         assert tuple(g.shape) == want.shape
         _check(g, want, '%s output %d' % (name, k), amin=0.97)       # 17 near-tied classes on closed-form weights (bf16 path)
+
+
+@pytest.mark.gpu
+def test_point_logits_from_the_point_feature_launch():
+    """eval mode, 16-bit path: the point feature's only reader is point_conv, so its logits leave with the residual unit's launch
+    (runtime.RU_EVAL_POINT_DOT, cdnet_conv_args.dot_out) and the feature is never stored.  Same rounded feature values, another order of
+    the 64-term fp32 sum: the three outputs agree with the stored-feature form to 1e-5 of the logit scale."""
+    import torch
+    from cdnet_amd import runtime
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    torch.manual_seed(3)
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda().eval()
+    x = torch.rand((2, 3, 64, 96), device='cuda')
+    with torch.no_grad():
+        assert runtime.RU_EVAL_POINT_DOT
+        a = m(x)
+        assert isinstance(m._last_feats[2], runtime.PointLogit)
+        runtime.RU_EVAL_POINT_DOT = False
+        try:
+            b = m(x)
+            assert not isinstance(m._last_feats[2], runtime.PointLogit)
+        finally:
+            runtime.RU_EVAL_POINT_DOT = True
+    for u, v, name in zip(a, b, ('mask', 'point', 'direction')):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-6, name

@@ -37,6 +37,9 @@ post_stream = torch.cuda.Stream()
 for rep in range(2):
     timed('default')
     timed('post-processing on a second stream', post=post_stream)
+    runtime.RU_EVAL_POINT_DOT = False
+    timed('point feature stored, point_conv in the head')
+    runtime.RU_EVAL_POINT_DOT = True
     runtime.ConvLayer.forward_eval_pool = lambda self, srcs: (self.forward(srcs, False), None)
     timed('no max-pool beside the stores')
     runtime.ConvLayer.forward_eval_pool = pool0
