@@ -353,12 +353,14 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
 typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 hd_bf16x8;
 
-template <bool HAS_F3>
+template <bool HAS_F3, bool F32>
 __global__ __launch_bounds__(256) void dam_head_mfma_kernel(const unsigned short *__restrict__ f1, const unsigned short *__restrict__ f2,
                                                             const unsigned short *__restrict__ f3, const HeadW *__restrict__ hw, size_t total,
                                                             int plane, float *__restrict__ mask, float *__restrict__ point,
                                                             float *__restrict__ dirn) {
-    constexpr int U = 2;                                         // 16-pixel groups in flight per wave
+    // F32: fp32-stored features (the fp32 precision mode) - split into hi | lo bf16 like the weights, three MFMAs per product (the
+    // convolutions' arithmetic); one 16-pixel group in flight per wave (the fragments take twice the registers)
+    constexpr int U = F32 ? 1 : 2;                               // 16-pixel groups in flight per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kg = lane >> 4;
     union Frag { hd_bf16x8 v; unsigned short h[8]; };
@@ -391,36 +393,69 @@ __global__ __launch_bounds__(256) void dam_head_mfma_kernel(const unsigned short
     const float bp = hw->bp, a1 = hw->a1;
     const hd_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (size_t g0 = ((size_t)blockIdx.x * 4 + wave) * (16 * U); g0 < total; g0 += (size_t)gridDim.x * 4 * (16 * U)) {
-        hd_bf16x8 b1[U][2], b2[U][2], b3[U][2];
+        Frag b1[U][2], b2[U][2], b3[U][2];                       // 16-bit features: the fragments themselves; F32: their hi parts ...
+        Frag l1[F32 ? U : 1][2], l2[F32 ? U : 1][2], l3[F32 ? U : 1][2];      // ... and lo parts
         float ptin[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             size_t px = g0 + u * 16 + col;
             px = px < total ? px : total - 1;
             const size_t e = px * 64 + kg * 8;
+            if constexpr (F32) {
+                hd_f32x4 r[3][2][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (HAS_F3) b3[u][ks] = *reinterpret_cast<const hd_bf16x8 *>(f3 + e + ks * 32);
-                b2[u][ks] = *reinterpret_cast<const hd_bf16x8 *>(f2 + e + ks * 32);
-                b1[u][ks] = *reinterpret_cast<const hd_bf16x8 *>(f1 + e + ks * 32);
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        if (HAS_F3) r[2][ks][hq] = *reinterpret_cast<const hd_f32x4 *>(reinterpret_cast<const float *>(f3) + e + ks * 32 + hq * 4);
+                        r[1][ks][hq] = *reinterpret_cast<const hd_f32x4 *>(reinterpret_cast<const float *>(f2) + e + ks * 32 + hq * 4);
+                        r[0][ks][hq] = *reinterpret_cast<const hd_f32x4 *>(reinterpret_cast<const float *>(f1) + e + ks * 32 + hq * 4);
+                    }
+                auto cut = [&](const hd_f32x4 (&q)[2], Frag &hi, Frag &lo) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = q[j >> 2][j & 3];
+                        const unsigned short h = f2bf(x);
+                        hi.h[j] = h;
+                        lo.h[j] = f2bf(x - bf2f(h));
+                    }
+                };
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (HAS_F3) cut(r[2][ks], b3[u][ks], l3[u][ks]);
+                    cut(r[1][ks], b2[u][ks], l2[u][ks]);
+                    cut(r[0][ks], b1[u][ks], l1[u][ks]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (HAS_F3) b3[u][ks].v = *reinterpret_cast<const hd_bf16x8 *>(f3 + e + ks * 32);
+                    b2[u][ks].v = *reinterpret_cast<const hd_bf16x8 *>(f2 + e + ks * 32);
+                    b1[u][ks].v = *reinterpret_cast<const hd_bf16x8 *>(f1 + e + ks * 32);
+                }
             }
             if (!HAS_F3) ptin[u] = point[px];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             hd_f32x4 aP = zero, aD = zero, aM = zero;
+            // (small terms first)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                // (small terms first)
-                if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_l[ks].v, b3[u][ks], aP, 0, 0, 0);
-                aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_l[ks].v, b2[u][ks], aD, 0, 0, 0);
-                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_l[ks].v, b1[u][ks], aM, 0, 0, 0);
+                if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_l[ks].v, b3[u][ks].v, aP, 0, 0, 0);
+                aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_l[ks].v, b2[u][ks].v, aD, 0, 0, 0);
+                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_l[ks].v, b1[u][ks].v, aM, 0, 0, 0);
+                if constexpr (F32) {
+                    if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_h[ks].v, l3[u][ks].v, aP, 0, 0, 0);
+                    aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_h[ks].v, l2[u][ks].v, aD, 0, 0, 0);
+                    aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_h[ks].v, l1[u][ks].v, aM, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_h[ks].v, b3[u][ks], aP, 0, 0, 0);
-                aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_h[ks].v, b2[u][ks], aD, 0, 0, 0);
-                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_h[ks].v, b1[u][ks], aM, 0, 0, 0);
+                if (HAS_F3) aP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_h[ks].v, b3[u][ks].v, aP, 0, 0, 0);
+                aD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd_h[ks].v, b2[u][ks].v, aD, 0, 0, 0);
+                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm_h[ks].v, b1[u][ks].v, aM, 0, 0, 0);
             }
             float pt;
             if (HAS_F3) pt = __shfl(aP[0], col) + bp;            // output row 0 lives in the kg = 0 lanes
@@ -857,12 +892,18 @@ extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_hea
     if (!c.raw) {
         // no third feature: `point` is an input (the point logit left by the producing convolution, cdnet_conv_args.dot_out)
         CDNET_REQUIRE(plain(a) && plain(b), "cdnet_dam_head_forward: f3->raw = NULL (point given) needs plain bf16 f1 / f2");
-        if (mfma_env) dam_head_mfma_kernel<false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, nullptr, hw, total, H * W, mask, point, direction);
+        if (mfma_env) dam_head_mfma_kernel<false, false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, nullptr, hw, total, H * W, mask, point, direction);
         else dam_head_fwd_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
         return check_launch("cdnet_dam_head_forward");
     }
     if (mfma_env && plain(a) && plain(b) && plain(c)) {
-        dam_head_mfma_kernel<true><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, c.raw, hw, total, H * W, mask, point, direction);
+        dam_head_mfma_kernel<true, false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, c.raw, hw, total, H * W, mask, point, direction);
+        return check_launch("cdnet_dam_head_forward");
+    }
+    auto plain32 = [](const HeadFeat &f) { return f.f16 == 2 && !f.scale && !f.relu && !f.res; };
+    if (mfma_env && plain32(a) && plain32(b) && plain32(c)) {
+        const int g32 = (int)std::min<size_t>(4096, (total + 63) / 64);
+        dam_head_mfma_kernel<true, true><<<g32, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, c.raw, hw, total, H * W, mask, point, direction);
         return check_launch("cdnet_dam_head_forward");
     }
     if (plain(a) && plain(b) && plain(c)) dam_head_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
