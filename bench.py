@@ -300,7 +300,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
     import cdnet_amd
-    from cdnet_amd import synth, pipeline, trainer
+    from cdnet_amd import synth, pipeline, trainer, streams
     from cdnet_amd.models.dam.model_unet_rev1 import Unet
 
     mode = 'train' if a.mode == 'auto' else a.mode
@@ -360,7 +360,7 @@ def main():
         x = torch.from_numpy(synth.tiles_u8(B, seed=2022 + rank).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
         # batch i's post-processing chain is queued on a second stream and runs beside batch i + 1's forward (pipeline.infer_tiles);
         # every batch's chain has finished when the timed region's closing synchronize returns
-        post = torch.cuda.Stream(device=dev)
+        post = streams.side_stream(dev)             # (a stream on another hardware queue than the compute stream's)
         dt = timed(lambda: pipeline.infer_tiles(model, x, post_stream=post), steps, warmup)
         return dict(metric='tiles/sec inference incl. post-proc, 256x256',
                     workload='CDNet UNet2RevA1_vgg16 (UNet+DAM) inference + direction-diff/CC post-processing, 256x256x3 synthetic tiles '

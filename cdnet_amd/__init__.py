@@ -12,7 +12,7 @@ import os as _os
 # run one after the other: once RCCL has made its streams (torch.distributed, any world size) the trainer's weight-gradient stream
 # could land on the compute stream's queue - measured 1 780 -> 1 456 tiles/s under torch.distributed.run.  More queues make that rarer
 # (read by the HIP runtime when it initialises, so this must run before the first GPU call), and the trainer also checks the stream it
-# picks (Trainer._pick_side_stream).
+# picks (cdnet_amd.streams.side_stream, shared with the inference pipeline).
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 

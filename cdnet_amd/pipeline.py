@@ -17,7 +17,8 @@ from . import postproc
 def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, post_stream=None):
     """x: float32 NCHW [B,3,H,W] on the GPU.  Returns dict(final int32 [B,H,W], counts, pred, ...).
 
-    `post_stream` (a torch.cuda.Stream): the post-processing chain is queued on that stream, ordered after this batch's forward, and
+    `post_stream` (a torch.cuda.Stream; cdnet_amd.streams.side_stream() picks one that does not share the compute stream's hardware
+    queue): the post-processing chain is queued on that stream, ordered after this batch's forward, and
     the call returns at once - the small, latency-bound connected-component / direction kernels of batch i then run beside the
     convolutions of batch i + 1 queued on the caller's stream.  The returned tensors belong to `post_stream`: wait for `r['done']`
     (an event) - or synchronize - before reading them on another stream."""

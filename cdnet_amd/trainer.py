@@ -15,7 +15,7 @@ import time
 
 import torch
 
-from . import _lib, engine, runtime
+from . import _lib, engine, runtime, streams
 from .engine import Src
 
 HEAD_PARAMS = ['point_conv.weight', 'direction_conv.weight', 'mask_conv.weight', 'point_conv.bias',
@@ -545,41 +545,9 @@ class Trainer:
         if os.environ.get('CDNET_WGRAD_STREAM', '1') == '0' or self.dev.type != 'cuda':
             return None
         if self._wstream is None:
-            self._wstream = self._pick_side_stream()
+            self._wstream = streams.side_stream(self.dev)      # (probed: a stream on another hardware queue than the compute stream's)
             self._events = {}
         return self._wstream
-
-    def _pick_side_stream(self):
-        """A stream that really runs beside the current one.  HIP places streams on a few hardware queues in creation order; a side
-        stream that shares the compute stream's queue serialises with it (and the cross-stream events then cost more than one stream
-        would: 1 456 vs 1 622 vs 1 780 tiles/s).  Candidates are timed with two spin kernels: together they take as long as one when the
-        queues differ, twice as long when they do not."""
-        cands = [torch.cuda.Stream(device=self.dev) for _ in range(8)]
-        spin = getattr(torch.cuda, '_sleep', None)
-        if spin is None or os.environ.get('CDNET_SIDE_STREAM_PROBE', '1') == '0':
-            return cands[0]
-        main = torch.cuda.current_stream()
-
-        def timed(other):
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main)
-            if other is not None:
-                other.wait_stream(main)                 # (starts with the compute stream's spin, not before the first event)
-                with torch.cuda.stream(other):
-                    spin(400000)
-            spin(400000)
-            if other is not None:
-                main.wait_stream(other)
-            e1.record(main)
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1)
-        timed(None)
-        alone = min(timed(None), timed(None))
-        for c in cands:
-            if min(timed(c), timed(c)) < 1.5 * alone:
-                return c
-        return cands[0]
 
     def _event(self, k):
         e = self._events.get(k)

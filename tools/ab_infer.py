@@ -33,7 +33,8 @@ def timed(label, steps=12, post=None):
     print('%-44s %7.3f ms  %7.0f tiles/s' % (label, dt * 1e3, B / dt), flush=True)
 
 
-post_stream = torch.cuda.Stream()
+from cdnet_amd import streams
+post_stream = streams.side_stream(dev)
 for rep in range(2):
     timed('default')
     timed('post-processing on a second stream', post=post_stream)
