@@ -41,6 +41,8 @@ rm -rf $ROOT/gpurun_out/step_pmc_*
 bash $ROOT/tools/prof_hrnet_train.sh > $OUT/hrnet_train_b4_512_summary.txt 2>&1
 cp $ROOT/gpurun_out/hrnet_train_prof/t_kernel_stats.csv $OUT/hrnet_train_b4_512_kernel_stats.csv
 rm -rf $ROOT/gpurun_out/hrnet_train_prof
+bash $ROOT/tools/prof_hrnet_traffic.sh bf16 > $OUT/hrnet_train_b4_512_traffic.txt 2>&1
+rm -rf $ROOT/gpurun_out/hr_pmc_*
 cd $ROOT
 python3 -m pytest tests/test_gpu_label_gate.py -q -s -m gpu 2>&1 | tail -60 > $OUT/label_gate.log
 du -sh $OUT; ls $OUT
