@@ -421,8 +421,8 @@ def main():
                        'inference': {'value': i2['value'], 'unit': 'tiles/s', 'ms_per_step': i2['ms_per_step'], 'tiles_per_gpu_per_step': 64, 'steps': i2['steps']}}
         rp['train_' + other] = path_roofline('train', other, B, t2['ms_per_step'])
         rp['infer_' + other] = path_roofline('infer', other, 64, i2['ms_per_step'])
-        im = run_image(a.dtype, 3, 1)
-        im2 = run_image(other, 3, 1)
+        im = run_image(a.dtype, 8, 2)
+        im2 = run_image(other, 8, 2)
         line['image'] = {'metric': im['metric'], 'value': im['value'], 'unit': 'images/s', 'ms_per_image': im['ms_per_step'],
                          'window_evaluations_per_s': im['window_evaluations_per_s'], 'steps': 3, 'warmup': 1, 'dtype': a.dtype,
                          other: {'value': im2['value'], 'ms_per_image': im2['ms_per_step']}}

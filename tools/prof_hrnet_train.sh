@@ -21,8 +21,9 @@ for _ in range(10):
 torch.cuda.synchronize()
 print('ms per step %.2f' % ((time.perf_counter() - t) * 100))
 PY
+python3 /tmp/hr_train.py 2>/dev/null | grep "ms per step" | sed "s/ms per step/ms per step (no profiler)/"
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/hrnet_train_prof -o t -- python3 /tmp/hr_train.py > $GRAFT_REPO_ROOT/gpurun_out/hrnet_train_prof.log 2>&1
-grep "ms per step" $GRAFT_REPO_ROOT/gpurun_out/hrnet_train_prof.log
+grep "ms per step" $GRAFT_REPO_ROOT/gpurun_out/hrnet_train_prof.log | sed "s/ms per step/ms per step under rocprofv3 (its interception slows each of the ~1 600 launch calls)/"
 python3 - <<'PY'
 import csv, os
 rows = list(csv.DictReader(open(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/hrnet_train_prof/t_kernel_stats.csv')))
