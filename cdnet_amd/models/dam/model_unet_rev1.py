@@ -208,7 +208,8 @@ class Unet(nn.Module):
         return self._head_w
 
     def forward_features(self, x, training):
-        """runs the encoder/decoder/residual units; returns the three head features as Src"""
+        """runs the encoder/decoder/residual units; returns the three head features as Src (eval mode, 16-bit path: the third one is a
+        runtime.PointLogit - the point feature's only reader is point_conv, its logits come with the unit's launch)"""
         if self._rt is None:
             self._build_runtime()
         if not x.is_cuda:

@@ -197,3 +197,35 @@ def test_post_stream_pipelining_is_bit_identical():
                         assert torch.equal(a[k], b[k]), (prec, rep, k)
         finally:
             cdnet_amd.set_precision('bf16')
+
+
+@pytest.mark.gpu
+def test_side_stream_is_cached_and_runs_beside_the_compute_stream():
+    """cdnet_amd.streams.side_stream: one stream per device (the trainer's weight-gradient stream and the inference pipeline's
+    post-processing stream), not the current stream, and - what the probe is for - on another hardware queue: two spin kernels, one per
+    stream, take about as long as one."""
+    import torch
+    from cdnet_amd import streams
+    s = streams.side_stream()
+    assert s is streams.side_stream(torch.device('cuda', torch.cuda.current_device()))
+    main = torch.cuda.current_stream()
+    assert s.cuda_stream != main.cuda_stream
+
+    def timed(both):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        if both:
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(2000000)
+        torch.cuda._sleep(2000000)
+        if both:
+            main.wait_stream(s)
+        e1.record(main)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    timed(False)
+    alone = min(timed(False) for _ in range(3))
+    together = min(timed(True) for _ in range(3))
+    assert together < 1.5 * alone, (alone, together)
