@@ -1623,7 +1623,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && A.out_coff % 8 == 0, "cdnet_conv_forward: output channel slice must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps || (A.taps1 == 1 && A.taps == 9 && A.nsrc == 2), "cdnet_conv_forward: taps1 = %d (0, taps, or 1 beside a nine-tap first source)", A.taps1);
-    if (A.f32) { CDNET_REQUIRE(!A.pool_out, "cdnet_conv_forward(f32): no fused max-pool output in fp32 mode"); return conv_forward_f32(A, st); }
+    if (A.f32) return conv_forward_f32(A, st);
     {
         const int rc = conv_forward_ws16(A, st);
         if (rc >= 0) return rc;
@@ -1654,7 +1654,7 @@ extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
     static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
-    if (A.f32) return (!A.pool_out && !A.dot_out && conv_forward_f32_ws(A, nullptr, true) == CDNET_OK) ? 1 : 0;
+    if (A.f32) return (!A.dot_out && conv_forward_f32_ws(A, nullptr, true) == CDNET_OK) ? 1 : 0;
     if (conv_forward_ws16(A, nullptr, true) == CDNET_OK) return 2;
     if ((A.taps1 != 0 && A.taps1 != A.taps) || A.pool_out || A.dot_out) return 0;
     if (!use_ws || (A.debug & 32)) return 0;

@@ -509,6 +509,7 @@ int conv_forward_f32(const ConvArgs &A, hipStream_t st) {
     CDNET_REQUIRE(A.ws != 2, "cdnet_conv_forward(f32): the BatchNorm-backward statistics epilogue (ws = 2) needs the producer / consumer kernel "
                              "(ask cdnet_conv_ws_eligible first)");
     CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps, "cdnet_conv_forward(f32): a one-tap second source runs on conv_ws32_kernel only (ask cdnet_conv_ws_eligible)");
+    CDNET_REQUIRE(!A.pool_out, "cdnet_conv_forward(f32): the fused max-pool output rides in conv_ws32_kernel's epilogue only (ask cdnet_conv_ws_eligible)");
     if (A.taps == 9) return dispatch_conv32<9>(A, st);
     if (A.taps == 4) return dispatch_conv32<4>(A, st);
     return dispatch_conv32<1>(A, st);

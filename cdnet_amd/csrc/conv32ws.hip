@@ -121,10 +121,14 @@ struct Ws32Lds {
 // MIX (round 4, cdnet_conv_args.taps1 = 1): the chunks of the SECOND source carry one tap (the centre) instead of nine - a residual unit's 1x1
 // branch as extra K steps of its second 3x3 convolution, eval mode (model_unet_rev1.py:161-170; conv16ws.hip has the 16-bit form).  The
 // packed weights hold, per output-channel tile, the nine-tap chunks followed by the one-tap chunks (hi | lo images each).
-template <int BN, int XF, bool STATS, bool BNS = false, int NCS = 0, bool MIX = false>
+// POOL (cdnet_conv_args.pool_out, eval mode): nn.MaxPool2d(2, 2) of the activated output beside the stores - the 'M' layers of the VGG16-BN
+// encoder (model_unet_rev1.py:40-41).  A lane holds whole 2x2 windows: registers r, r + 1, r + 8, r + 9 (r = 0, 2, 4, 6) of a block are two
+// neighbouring columns of its two tile rows - four pooled pixels per block and lane, one more store per four (conv16ws.hip has the 16-bit form).
+template <int BN, int XF, bool STATS, bool BNS = false, int NCS = 0, bool MIX = false, bool POOL = false>
 __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
     static_assert(!BNS || (BN == 64 && !STATS), "the BatchNorm-backward statistics epilogue serves 64-channel blocks of backward-data launches");
     static_assert(!MIX || (!STATS && !BNS && NCS == 0), "one-tap chunks: inference launches with at least four nine-tap chunks");
+    static_assert(!POOL || (!STATS && !BNS && !MIX && NCS == 0), "fused max-pool: plain inference launches with at least four chunks");
     using L = Ws32Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, TAPS = 9, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NPW = BN / 32, MPW = 2;
@@ -502,10 +506,21 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) s_col[c] = (unsigned)(c & 3) * pix_b + (unsigned)(c >> 2) * 8u * pix_b;
     char *row_base[4];                                           // rows 4 wm .. 4 wm + 3 of the finished tile, first column
+    // POOL: rows 2 wm, 2 wm + 1 of the pooled tile (dense [N][H / 2][W / 2][Cout] fp32), the lane's offset inside a pooled row
+    const unsigned ppix_b = (unsigned)A.Cout * 4u;
+    const unsigned pl_off = (unsigned)(2 * half) * ppix_b + (unsigned)l31 * 4u;
+    char *const pool_b = POOL ? reinterpret_cast<char *>(reinterpret_cast<float *>(A.pool_out) + cout0) : nullptr;
+    char *prow_base[2] = {nullptr, nullptr};
+    float pl_t0 = 0.f, pl_t1 = 0.f;
     auto set_row_bases = [&]() {
         char *t0 = out_b + ((size_t)(p_n * A.H + p_y0 + wm * 4) * A.W + p_x0) * pix_b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) row_base[r] = t0 + (size_t)r * A.W * pix_b;
+        if (POOL) {
+            char *q0 = pool_b + ((size_t)(p_n * (A.H >> 1) + ((p_y0 + wm * 4) >> 1)) * (A.W >> 1) + (p_x0 >> 1)) * ppix_b;
+            prow_base[0] = q0;
+            prow_base[1] = q0 + (size_t)(A.W >> 1) * ppix_b;
+        }
     };
     auto img_elem = [&](const f32x16 (&P)[MPW][NPW], int e) {
         const int b_ = e / 16, r = e % 16, mi = b_ / NPW, ni = b_ % NPW;
@@ -521,6 +536,23 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
 #else
             *(__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + l_off) = v;
 #endif
+        }
+    };
+    // pooled unit u = (block, window k) of a finished set in three pieces (an MFMA gap takes ~5 instructions): the maxima of the window's
+    // upper and lower pixel pair after the epilogue affine, then ReLU + one store.  Window k: registers 2k, 2k + 1, 2k + 8, 2k + 9 =
+    // pooled row mi of this wave's two, pooled column ((2k >> 2) & 1) * 4 + ((2k & 3) >> 1) (+ 2 half: the lane's offset)
+    auto pool_sub = [&](const f32x16 (&P)[MPW][NPW], int u, int sub) {
+        const int b_ = u / 4, k = u % 4, mi = b_ / NPW, ni = b_ % NPW, r0 = 2 * k;
+        if (sub == 0) pl_t0 = fmaxf(fmaf(P[mi][ni][r0], e_osc[ni], e_osh[ni]), fmaf(P[mi][ni][r0 + 1], e_osc[ni], e_osh[ni]));
+        else if (sub == 1) pl_t1 = fmaxf(fmaf(P[mi][ni][r0 + 8], e_osc[ni], e_osh[ni]), fmaf(P[mi][ni][r0 + 9], e_osc[ni], e_osh[ni]));
+        else {
+            float v = fmaxf(pl_t0, pl_t1);
+            if (orelu) v = fmaxf(v, 0.f);
+            if (e_ok[ni]) {
+                char *sb = prow_base[mi] + ((unsigned)(((r0 >> 2) & 1) * 4 + ((r0 & 3) >> 1)) * ppix_b + (unsigned)(ni * 128));
+                asm volatile("" : "+s"(sb));
+                *(__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + pl_off) = v;
+            }
         }
     };
     constexpr int NEL = MPW * NPW * 16;                          // elements of a set per lane; a quarter of them leaves per chunk interval
@@ -581,6 +613,8 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
                 constexpr int QEL = NEL / 4;
                 if ((EPI == 1 || EPI == 5 || EPI == 6) && STATS && g % 3 == 1 && 2 * (g / 3) + 1 < NEL) { stat_elem(P, 2 * (g / 3), par); stat_elem(P, 2 * (g / 3) + 1, par); }
                 if (EPI <= 4 && g % 6 == 3 && g / 6 < QEL) img_elem(P, (EPI - 1) * QEL + g / 6);
+                // POOL: the quarter's block has four windows, three pieces each, in the gaps 5, 11, .. 71
+                if (POOL && EPI <= 4 && g % 6 == 5 && g / 6 < 12) pool_sub(P, (EPI - 1) * 4 + (g / 6) / 3, (g / 6) % 3);
                 if (EPI == 5 && g % 3 != 1 && 2 * (g / 3) + (g % 3 == 2 ? 1 : 0) < NEL) img_elem(P, 2 * (g / 3) + (g % 3 == 2 ? 1 : 0));
                 if ((EPI == 6 || EPI == 7) && g % 3 == 0 && g / 3 < NEL / 2) img_elem(P, (EPI - 6) * (NEL / 2) + g / 3);
                 if (BNS && EPI <= 4) {
@@ -694,6 +728,10 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
         set_row_bases();
 #pragma unroll
         for (int e = 0; e < NEL; ++e) img_elem(P, e);
+        if (POOL) {
+#pragma unroll
+            for (int u = 0; u < NEL / 4; ++u) { pool_sub(P, u, 0); pool_sub(P, u, 1); pool_sub(P, u, 2); }
+        }
         if (BNS) {
             // the last tile of the run: its raw values straight from global memory (accumulator layout: 128-byte lines), then this wave's
             // partial row - the two lane halves hold the same couts
@@ -810,7 +848,23 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
     using X2 = std::integral_constant<int, 2>;
     const int xf = all_plain ? 0 : (all_fast ? 1 : 2);
     if (A.nchunk < 4 && (BN != 64 || xf == 2)) return -1;          // (no small-tile instantiation for these)
+    const bool pool = A.pool_out != nullptr;
+    if (pool && (BN != 64 || bns || mix || A.stats || A.nchunk < 4 || xf != 0 || !A.orelu || A.out_coff || A.out_cstride != A.Cout)) return -1;
     if (dry_run) return CDNET_OK;
+    if (pool) {
+        if constexpr (BN == 64) {
+            auto kern = conv_ws32_kernel<64, 0, false, false, 0, false, true>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return check_launch("hipFuncSetAttribute(conv_ws32 pool)");
+                attr_done = true;
+            }
+            kern<<<grid, 512, smem, st>>>(A);
+            return check_launch("conv_ws32_kernel(pool)");
+        }
+        return -1;
+    }
     if (bns) {
         if constexpr (BN == 64) {
             auto launch_bns = [&](auto xf_c) -> int {

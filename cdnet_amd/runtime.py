@@ -182,7 +182,8 @@ class ConvLayer:
 
     def forward_eval_pool(self, srcs):
         """eval mode: relu(bn(conv(.))) AND its nn.MaxPool2d(2, 2) from one launch (the 'M' layers of the VGG16-BN encoder,
-        model_unet_rev1.py:40-41: conv_ws16_kernel's movers pool the out image beside their stores - no cdnet_src_materialize pass).
+        model_unet_rev1.py:40-41: conv_ws16_kernel's movers pool the out image beside their stores, conv_ws32_kernel's consumers the windows
+        they hold - no cdnet_src_materialize pass).
         Returns (Src, pooled Src), or (Src, None) when the launch is not that kernel's (the caller pools as before)."""
         H, W = srcs[0].logical_hw()
         if PRECISION == 'bf16' and H % 2 == 0 and W % 2 == 0:
@@ -196,6 +197,17 @@ class ConvLayer:
                 if engine.conv_forward(srcs, ep[0], self.Cout, self.cfg, self.taps, self.transposed, query_ws=True, **kw) == 2:
                     engine.conv_forward(srcs, ep[0], self.Cout, self.cfg, self.taps, self.transposed, **kw)
                     return Src(out), Src(pout)
+        if PRECISION == 'fp32' and H % 2 == 0 and W % 2 == 0 and self.bn is not None and not DEBUG_NORELU:
+            # fp32 mode: conv_ws32_kernel's consumers hold whole 2x2 windows - the pooled value leaves beside the stores
+            self.prepare([s.C for s in srcs], H, W, srcs[0].N)
+            sc, sh = self.eval_fold()
+            N = srcs[0].N
+            out = torch.empty((N, H, W, self.Cout), dtype=torch.float32, device=srcs[0].x.device)
+            pout = torch.empty((N, H // 2, W // 2, self.Cout), dtype=torch.float32, device=srcs[0].x.device)
+            kw = dict(oscale=sc, oshift=sh, orelu=True, H=H, W=W, out=out, pool_out=pout)
+            if engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, query_ws=True, **kw) == 1:
+                engine.conv_forward(srcs, self.wp, self.Cout, self.cfg, self.taps, self.transposed, **kw)
+                return Src(out), Src(pout)
         return self.forward(srcs, False), None
 
     # -- forward ------------------------------------------------------------------------------------

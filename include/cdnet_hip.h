@@ -194,9 +194,10 @@ typedef struct cdnet_conv_args {
     int taps1;
     int pad_;
     /* Optional second output: nn.MaxPool2d(2, 2) of the (ReLU-activated, bf16) output, dense [N][H/2][W/2][Cout] - the 'M' layers of the
-     * torchvision VGG16-BN encoder (model_unet_rev1.py:40-41) fused into the producing convolution's store path.  16-bit path,
-     * conv_ws16_kernel's out-image form only (cdnet_conv_ws_eligible answers 2 with the pointer set, else leave it NULL and call
-     * cdnet_src_materialize); needs orelu = 1, out_coff = 0, out_cstride = Cout. */
+     * torchvision VGG16-BN encoder (model_unet_rev1.py:40-41) fused into the producing convolution's store path.  16-bit path:
+     * conv_ws16_kernel's out-image form (cdnet_conv_ws_eligible answers 2 with the pointer set); fp32 mode (float tensors): conv_ws32_kernel
+     * with plain sources, >= 4 chunks, BN = 64 (answer 1).  Otherwise leave it NULL and call cdnet_src_materialize.  Needs orelu = 1,
+     * out_coff = 0, out_cstride = Cout. */
     uint16_t *pool_out;
     /* Optional 1x1 classifier over the (activated, bf16-rounded) output, fused into the store path: dot_out[n][y][x] = dot_b[0] +
      * sum_c dot_w[c] * out[n][y][x][c] as fp32 [N][H][W] - the DAM head's point logit (model_unet_rev1.py:252-253: point_conv over the

@@ -554,3 +554,47 @@ def test_conv_ws32_one_tap_second_source(case):
     finally:
         engine.CONV_DEBUG = 0
     assert _rel(_nchw(out), want) < 5e-5
+
+
+@pytest.mark.parametrize('case', [dict(N=2, Cin=64, Cout=64, H=32, W=48, G=3, neg=False), dict(N=1, Cin=128, Cout=128, H=32, W=32, G=0, neg=True),
+                                  dict(N=3, Cin=64, Cout=64, H=16, W=16, G=1, neg=True)])
+def test_conv_ws32_fused_max_pool_output(case):
+    """cdnet_conv_args.pool_out in fp32 mode: nn.MaxPool2d(2, 2) of relu(conv * scale + shift) from conv_ws32_kernel's epilogue (a lane
+    holds whole 2x2 windows) - the 'M' layers of the VGG16-BN encoder (model_unet_rev1.py:40-41) without a cdnet_src_materialize pass.  The
+    full-resolution output is bit-identical to the launch without it, the pooled tensor bit-identical to torch's max_pool2d of that output
+    (a maximum of stored values: exact) - also with negative epilogue scales (the affine comes before the maximum); the one-tile kernels
+    and launches with statistics say they do not serve it."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, Cin, Cout, H, W, G, neg = [case[k] for k in ('N', 'Cin', 'Cout', 'H', 'W', 'G', 'neg')]
+    g = torch.Generator().manual_seed(23 + Cin + H)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (1.5 / (9 * Cin) ** 0.5)
+    sc = torch.rand((Cout,), generator=g) + 0.5
+    if neg:
+        sc = sc * torch.where(torch.rand((Cout,), generator=g) < 0.3, -1.0, 1.0)
+    sh = torch.randn((Cout,), generator=g) * 0.3
+    cfg = (16, 16, 64)
+    wp = engine.pack_weights(w.cuda(), cfg, 0, split=True)
+    src = [engine.Src(_nhwc(x))]
+    kw = dict(oscale=sc.cuda(), oshift=sh.cuda(), orelu=True, H=H, W=W)
+    engine.CONV_DEBUG = 64 | (G << 8)
+    try:
+        plain, _ = engine.conv_forward(src, wp, Cout, cfg, **kw)
+        out = torch.empty_like(plain)
+        pout = torch.full((N, H // 2, W // 2, Cout), 7.0, dtype=torch.float32, device='cuda')
+        assert engine.conv_forward(src, wp, Cout, cfg, out=out, pool_out=pout, query_ws=True, **kw) == 1
+        engine.conv_forward(src, wp, Cout, cfg, out=out, pool_out=pout, **kw)
+        torch.cuda.synchronize()
+        st = torch.empty((N * (H // 16) * (W // 16), 2, Cout), dtype=torch.float32, device='cuda')
+        assert engine.conv_forward(src, wp, Cout, cfg, out=out.clone(), pool_out=pout.clone(), query_ws=True, H=H, W=W, orelu=True, stats=st) == 0
+        engine.CONV_DEBUG = 32
+        with pytest.raises(RuntimeError):
+            engine.conv_forward(src, wp, Cout, cfg, out=out.clone(), pool_out=pout.clone(), **kw)
+    finally:
+        engine.CONV_DEBUG = 0
+    assert torch.equal(out, plain)
+    assert torch.equal(_nchw(pout), F.max_pool2d(_nchw(plain), 2))
+    want = F.relu(F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    assert _rel(_nchw(plain), want) < 5e-5
