@@ -700,6 +700,96 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs A) {
 }
 
 
+// 16-bit form with the term count known to the compiler and every load of a pixel issued before the first conversion: the generic kernel
+// above walks its terms one after the other (a run-time loop over the argument struct, four dependent taps per up-sampled term) and ran the
+// fuse sums of HRNet's modules at 1.2-1.7 TB/s.  Same arithmetic, term by term in the same order: bit-identical results.
+template <int NT>
+__global__ __launch_bounds__(256) void fuse_sum16_kernel(FuseArgs A) {
+    const unsigned VPP = (unsigned)A.C / 8u;
+    const unsigned total = (unsigned)A.N * (unsigned)A.H * (unsigned)A.W * VPP;       // (the launcher checks that it fits 32 bits)
+    const unsigned W_ = (unsigned)A.W, H_ = (unsigned)A.H;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned slot = i % VPP, pix = i / VPP;
+        const unsigned x = pix % W_, yy = pix / W_, y = yy % H_, n = yy / H_;
+        const int c0 = (int)slot * 8;
+        uint4 raw[NT][4];
+        float hy[NT], hx[NT], ly[NT], lx[NT];
+        float4 sc[NT][2], sh[NT][2];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const FuseTerm &T = A.t[k];
+            sc[k][0] = sc[k][1] = sh[k][0] = sh[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            raw[k][1] = raw[k][2] = raw[k][3] = make_uint4(0, 0, 0, 0);
+            const unsigned short *base = T.x + (size_t)n * T.Hs * T.Ws * A.C + c0;
+            if (T.Hs == A.H && T.Ws == A.W) {
+                raw[k][0] = *reinterpret_cast<const uint4 *>(base + ((size_t)y * W_ + x) * A.C);
+                hy[k] = hx[k] = 1.f; ly[k] = lx[k] = 0.f;
+            } else {
+                const float sy = (float)T.Hs / (float)A.H, sx = (float)T.Ws / (float)A.W;
+                float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+                fy = fy < 0.f ? 0.f : fy;
+                fx = fx < 0.f ? 0.f : fx;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < T.Hs - 1 ? 1 : 0), x1 = x0 + (x0 < T.Ws - 1 ? 1 : 0);
+                ly[k] = fy - (float)y0; lx[k] = fx - (float)x0; hy[k] = 1.f - ly[k]; hx[k] = 1.f - lx[k];
+                raw[k][0] = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * T.Ws + x0) * A.C);
+                raw[k][1] = *reinterpret_cast<const uint4 *>(base + ((size_t)y0 * T.Ws + x1) * A.C);
+                raw[k][2] = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * T.Ws + x0) * A.C);
+                raw[k][3] = *reinterpret_cast<const uint4 *>(base + ((size_t)y1 * T.Ws + x1) * A.C);
+            }
+            if (T.scale) {
+                const float4 *ps = reinterpret_cast<const float4 *>(T.scale + c0), *pq = reinterpret_cast<const float4 *>(T.shift + c0);
+                sc[k][0] = ps[0]; sc[k][1] = ps[1]; sh[k][0] = pq[0]; sh[k][1] = pq[1];
+            }
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const FuseTerm &T = A.t[k];
+            const bool up = !(T.Hs == A.H && T.Ws == A.W);
+            const float scv[8] = {sc[k][0].x, sc[k][0].y, sc[k][0].z, sc[k][0].w, sc[k][1].x, sc[k][1].y, sc[k][1].z, sc[k][1].w};
+            const float shv[8] = {sh[k][0].x, sh[k][0].y, sh[k][0].z, sh[k][0].w, sh[k][1].x, sh[k][1].y, sh[k][1].z, sh[k][1].w};
+            auto cvt = [&](const uint4 &u, float *v) {
+                const unsigned w[4] = {u.x, u.y, u.z, u.w};
+                if (T.f16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[q] & 0xffffu));
+                        v[2 * q + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[q] >> 16));
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+                }
+                if (T.scale) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], scv[j], shv[j]);
+                }
+            };
+            if (!up) {
+                float v[8];
+                cvt(raw[k][0], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            } else {
+                float a[8], b[8], c[8], d[8];
+                cvt(raw[k][0], a); cvt(raw[k][1], b); cvt(raw[k][2], c); cvt(raw[k][3], d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += hy[k] * (hx[k] * a[j] + lx[k] * b[j]) + ly[k] * (hx[k] * c[j] + lx[k] * d[j]);
+            }
+        }
+        unsigned short oh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oh[j] = f2bf(A.relu ? fmaxf(acc[j], 0.f) : acc[j]);
+        uint4 ou;
+        ou.x = oh[0] | ((unsigned)oh[1] << 16); ou.y = oh[2] | ((unsigned)oh[3] << 16);
+        ou.z = oh[4] | ((unsigned)oh[5] << 16); ou.w = oh[6] | ((unsigned)oh[7] << 16);
+        *reinterpret_cast<uint4 *>(A.out + (size_t)pix * A.out_cstride + A.out_coff + c0) = ou;
+    }
+}
+
 // transpose of the bilinear up-sampling inside fuse_sum (gather form, deterministic): din[ys][xs] = sum over the output
 // pixels (y, x) whose interpolation reads (ys, xs) of their weight x dout[y][x].  dout may be a channel slice.
 template <bool F32>
@@ -970,8 +1060,17 @@ static int fuse_sum_impl(const cdnet_fuse_term *terms, int nterm, int N, int H, 
     A.nterm = nterm; A.N = N; A.H = H; A.W = W; A.C = C; A.relu = relu; A.out = reinterpret_cast<unsigned short *>(out);
     A.out_cstride = out_cstride ? out_cstride : C; A.out_coff = out_coff;
     CDNET_REQUIRE(A.out_cstride % 8 == 0 && out_coff % 8 == 0 && out_coff + C <= A.out_cstride, "cdnet_fuse_sum: output channel slice");
-    if (f32) fuse_sum_kernel<true><<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
-    else fuse_sum_kernel<false><<<lin_grid((size_t)N * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(A);
+    const size_t total = (size_t)N * H * W * (C / 8);
+    const int grid = lin_grid(total);
+    if (f32) fuse_sum_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(A);
+    else if (total < (1ull << 31)) {
+        switch (nterm) {
+            case 1: fuse_sum16_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(A); break;
+            case 2: fuse_sum16_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(A); break;
+            case 3: fuse_sum16_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(A); break;
+            default: fuse_sum16_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(A); break;
+        }
+    } else fuse_sum_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(A);
     return check_launch("cdnet_fuse_sum");
 }
 
