@@ -231,10 +231,10 @@ __device__ __forceinline__ void load_feat16(const HeadFeat &f, size_t pix, int q
 __device__ __forceinline__ float quad_sum(float v) { return xf_quad_sum(v); }        // sum over the 4 lanes of a pixel
 
 // four lanes per pixel, 16 channels each: 4x the parallelism and a quarter of the registers of one-thread-per-pixel.
-// FM: the storage / transform of all three features, decided by the launcher - 0 plain bf16 (eval mode with fused epilogues),
-// 1 fp16 raw x scale + shift + residual -> ReLU (training-mode residual-unit outputs), 2 anything (run-time flags; with them the
-// kernel is 9 000 instructions of branches and every join drains the loads in flight), 3 = as 0 without the third feature: `point` already
-// holds the point logit (the producing convolution's fused classifier, cdnet_conv_args.dot_out) and is read instead of written
+// FM: the storage / transform of all three features, decided by the launcher - 1 fp16 raw x scale + shift + residual -> ReLU
+// (training-mode residual-unit outputs of the unfused form), 2 anything (run-time flags; with them the kernel is 9 000 instructions of
+// branches and every join drains the loads in flight).  Plain stored features - eval mode and the fused training forward - take
+// dam_head_mfma_kernel below.
 template <int FM>
 __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(HeadFeat f1, HeadFeat f2, HeadFeat f3, const HeadW *__restrict__ hw,
                                                            int N, int plane, float *__restrict__ mask,
@@ -260,14 +260,7 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
     const bool all16 = FM != 2 || (f1.f16 != 2 && f2.f16 != 2 && f3.f16 != 2);
     // FM 0 / 1: fixed conversions of the raw vectors
     auto conv = [&](const HeadFeat &f, const FeatRaw16 &R, int k, float *v) {
-        if (FM == 0 || FM == 3) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const unsigned short *h = reinterpret_cast<const unsigned short *>(&R.r[h2]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[h2 * 8 + j] = bf2f(h[j]);
-            }
-        } else if (FM == 1) {
+        if (FM == 1) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
                 xf_bnrelu_f16_to_f32<true>(__builtin_bit_cast(xf_u32x4, R.r[h2]), __builtin_bit_cast(xf_u32x4, R.s[h2]), s_sc[k] + q * 16 + h2 * 8,
@@ -298,22 +291,15 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
         float v[16];
         // 16-bit features: all three features' vectors in flight at once (one memory round trip per pixel instead of three)
         FeatRaw16 R1, R2, R3;
-        float pt;
-        if (FM == 3) {
-            pt = point[n * plane + p];
+        if (all16) {
+            fetch(f3, ii, R3);
             fetch(f2, ii, R2);
             fetch(f1, ii, R1);
+            conv(f3, R3, 2, v);
         } else {
-            if (all16) {
-                fetch(f3, ii, R3);
-                fetch(f2, ii, R2);
-                fetch(f1, ii, R1);
-                conv(f3, R3, 2, v);
-            } else {
-                load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
-            }
-            pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
+            load_feat16(f3, ii, q, s_sc[2], s_sh[2], v);
         }
+        const float pt = quad_sum(xf_dot16(w.wp + q * 16, v)) + w.bp;
         const float g1 = 1.f + 1.f / (1.f + expf(-(w.a1 * pt)));
         if (all16) conv(f2, R2, 1, v);
         else load_feat16(f2, ii, q, s_sc[1], s_sh[1], v);
@@ -333,7 +319,7 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
         }
         if (ok) {
             // the 13 outputs of a pixel are spread over its 4 lanes: lane q writes outputs q, q+4, q+8, (q+12)
-            if (FM != 3 && q == 0) { point[n * plane + p] = pt; }
+            if (q == 0) { point[n * plane + p] = pt; }
 #pragma unroll
             for (int k = 0; k < 9; ++k) if ((k & 3) == q) dirn[(n * 9 + k) * plane + p] = d[k];
 #pragma unroll
@@ -346,7 +332,7 @@ __global__ __launch_bounds__(256, (FM == 2 ? 1 : 4)) void dam_head_fwd_kernel(He
 // classifiers are 64 -> {1, 9, 3} GEMMs per pixel: `v_mfma_f32_16x16x32_bf16` with the WEIGHTS as the A operand (row = output, padded to
 // 16) and 16 pixels as the columns of B - a lane's B fragment is 16 contiguous bytes of a pixel (channels 8 kg .. 8 kg + 7 of the k-step),
 // loaded straight from the NHWC tensor, no conversion.  The fp32 weights enter as hi + lo bf16 pairs (two MFMAs per product, 2^-16
-// relative), built once per wave and kept in registers: dam_head_fwd_kernel<0> read its 208 weights per lane from LDS for every pixel
+// relative), built once per wave and kept in registers: the vector-unit kernel above reads its 208 weights per lane from LDS for every pixel
 // (the LDS pipe, not HBM, set its 416 us per 64 tiles).  Lane (col, kg) then holds outputs 4 kg .. 4 kg + 3 of pixel `col`: the gates
 // (revAttention, model_unet_rev1.py:8-17) need the point logit - broadcast from the kg = 0 lane - and the 9-term sum over the direction
 // logits - a partial sum per lane, two cross-lane adds.  HAS_F3 = false: `point` is given (cdnet_conv_args.dot_out).
@@ -975,29 +961,26 @@ extern "C" int cdnet_dam_head_forward(const cdnet_head_feat *f1, const cdnet_hea
     auto train = [](const HeadFeat &f) { return f.f16 == 1 && f.scale && f.relu && f.res; };
     const int grid = lin_grid((size_t)N * H * W * 4);
     const HeadW *hw = reinterpret_cast<const HeadW *>(head_weights);
-    // plain bf16 features (eval mode): the matrix-core kernel (CDNET_HEAD_MFMA=0: the vector-unit kernel, for A/B runs and the tests)
-    static const int mfma_env = getenv("CDNET_HEAD_MFMA") ? atoi(getenv("CDNET_HEAD_MFMA")) : 1;
+    // plain stored features (eval mode, the fused training forward): the matrix-core kernel
     const size_t total = (size_t)N * H * W;
     const int mgrid = (int)std::min<size_t>(2048, (total + 127) / 128);
     if (!c.raw) {
         // no third feature: `point` is an input (the point logit left by the producing convolution, cdnet_conv_args.dot_out)
         CDNET_REQUIRE(plain(a) && plain(b), "cdnet_dam_head_forward: f3->raw = NULL (point given) needs plain bf16 f1 / f2");
-        if (mfma_env) dam_head_mfma_kernel<false, false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, nullptr, hw, total, H * W, mask, point, direction);
-        else dam_head_fwd_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
+        dam_head_mfma_kernel<false, false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, nullptr, hw, total, H * W, mask, point, direction);
         return check_launch("cdnet_dam_head_forward");
     }
-    if (mfma_env && plain(a) && plain(b) && plain(c)) {
+    if (plain(a) && plain(b) && plain(c)) {
         dam_head_mfma_kernel<true, false><<<mgrid, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, c.raw, hw, total, H * W, mask, point, direction);
         return check_launch("cdnet_dam_head_forward");
     }
     auto plain32 = [](const HeadFeat &f) { return f.f16 == 2 && !f.scale && !f.relu && !f.res; };
-    if (mfma_env && plain32(a) && plain32(b) && plain32(c)) {
+    if (plain32(a) && plain32(b) && plain32(c)) {
         const int g32 = (int)std::min<size_t>(4096, (total + 63) / 64);
         dam_head_mfma_kernel<true, true><<<g32, 256, 0, (hipStream_t)stream>>>(a.raw, b.raw, c.raw, hw, total, H * W, mask, point, direction);
         return check_launch("cdnet_dam_head_forward");
     }
-    if (plain(a) && plain(b) && plain(c)) dam_head_fwd_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
-    else if (train(a) && train(b) && train(c)) dam_head_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
+    if (train(a) && train(b) && train(c)) dam_head_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
     else dam_head_fwd_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a, b, c, hw, N, H * W, mask, point, direction);
     return check_launch("cdnet_dam_head_forward");
 }
