@@ -1259,9 +1259,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         const unsigned char *la = lds_a + c0 * L::A_BYTES, *lw = lds_w + c0 * L::B_CHUNK;
         auto request = [&](int tau) {
             const int ch = tau / TAPS, t = tau % TAPS;
-#if defined(CDNET_WS_ABL) && CDNET_WS_ABL == 1
-            if (tau >= 3) return;                              // ablation build: MFMAs on stale fragments, no LDS reads
-#endif
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi) af[tau % 3][mi] = *reinterpret_cast<const bf16x8 *>(la + ch * L::A_BYTES + abase[mi][tpar(t)] + toff(t));
 #pragma unroll

@@ -34,18 +34,6 @@
 
 using namespace cdnet;
 
-#ifndef CDNET_WS32_NT_STORES
-#define CDNET_WS32_NT_STORES 1
-#endif
-#ifndef CDNET_WS32_SCALAR_SUB
-#define CDNET_WS32_SCALAR_SUB 1
-#endif
-#ifndef CDNET_WS32_MOVER_PRIO
-#define CDNET_WS32_MOVER_PRIO 0   // s_setprio of the mover waves (the younger half of the workgroup loses the VALU arbitration at equal priority)
-#endif
-#ifndef CDNET_WS32_PIN
-#define CDNET_WS32_PIN 1      // a scheduling fence behind every MFMA of the consumers (0: the compiler's own order - A/B switch)
-#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -63,7 +51,6 @@ __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
         const f32x2 x = {v[2 * k], v[2 * k + 1]};
         const bf16x2 h = __builtin_convertvector(x, bf16x2);
         const unsigned hb = __builtin_bit_cast(unsigned, h);
-#if CDNET_WS32_SCALAR_SUB
         // two plain subtractions instead of the v_pk_add_f32 the compiler would make of them: a packed fp32 instruction of a mover wave
         // is expensive beside the consumers' MFMA stream (measured on wgrad_ws32_kernel, wgrad.hip: wg_split8)
         float d0, d1;
@@ -71,10 +58,6 @@ __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
         asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(x[1]), "v"(__builtin_bit_cast(float, hb & 0xffff0000u)));
         const f32x2 df = {d0, d1};
         const bf16x2 l = __builtin_convertvector(df, bf16x2);
-#else
-        const f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
-        const bf16x2 l = __builtin_convertvector(x - hf, bf16x2);
-#endif
         hi[k] = hb;
         lo[k] = __builtin_bit_cast(unsigned, l);
     }
@@ -175,9 +158,6 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
 
     if (wave >= 4) {
         // ================================ movers ================================
-#if CDNET_WS32_MOVER_PRIO
-        __builtin_amdgcn_s_setprio(CDNET_WS32_MOVER_PRIO);
-#endif
         const int ptid = tid - 256, pw = wave - 4;
         const int slot = ptid % VPP;
         f32x4 pa[2][NA][2];                      // two chunks of halo vectors in flight (8 channels = two float4 each)
@@ -531,11 +511,7 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
             char *sb = row_base[mi * 2 + (r >> 3)] + (s_col[((r >> 2) & 1) * 4 + (r & 3)] + (unsigned)(ni * 128));
             asm volatile("" : "+s"(sb));
             // (global_, not flat_: the asm hid the pointer's origin; uniform base + 32-bit lane offset = the store's saddr form)
-#if CDNET_WS32_NT_STORES
             __builtin_nontemporal_store(v, (__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + l_off));
-#else
-            *(__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)sb + l_off) = v;
-#endif
         }
     };
     // pooled unit u = (block, window k) of a finished set in three pieces (an MFMA gap takes ~5 instructions): the maxima of the window's
@@ -629,9 +605,7 @@ __global__ __launch_bounds__(512) void conv_ws32_kernel(ConvArgs A) {
                     }
                 }
             }
-#if CDNET_WS32_PIN
             __builtin_amdgcn_sched_barrier(0);
-#endif
         };
         static_assert(NT != 9 || (3 * (NEL / 2) <= TAPS * MPW * NPW * 3 && 6 * (NEL / 4) <= TAPS * MPW * NPW * 3 && 2 * (TAPS * MPW * NPW) >= NEL),
                       "the deferred epilogue fits the MFMA gaps of an interval");

@@ -906,9 +906,6 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
 // Same products and the same three-MFMA order per tap as wgrad_f32_kernel; the pixels are summed in another order (other tiles),
 // so the results agree to fp32 rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------------------
-#ifndef CDNET_WG32_MOVER_PRIO
-#define CDNET_WG32_MOVER_PRIO 0
-#endif
 constexpr int TH32 = 4, NPIX_A32 = (TH32 + 2) * HALO_W, NPIX_G32 = TH32 * TW;
 
 // XF: source transform: 0 plain fp32, 1 x * scale + shift -> ReLU, 2 run-time flags (scale / shift, residual, ReLU).  TAPS: 9 (3x3), or 1
@@ -949,9 +946,6 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
     if (wave >= 4) {
         // ------------------------------- movers -------------------------------
         if (ntl == 0) return;                                    // (a slice without tiles: the consumers store a slab of zeros)
-#if CDNET_WG32_MOVER_PRIO
-        __builtin_amdgcn_s_setprio(CDNET_WG32_MOVER_PRIO);
-#endif
         if (A.debug & 2) {                                       // ablation: consumers alone (whatever the LDS holds)
             for (int j = -1; j < ntl2; ++j) __syncthreads();
             return;
