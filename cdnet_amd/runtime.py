@@ -411,12 +411,21 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True, dot=None):
     keep = engine.CONV_DEBUG
     engine.CONV_DEBUG = keep | 64                        # (the persistent kernel also on small launches: nothing else computes this form)
     try:
-        if keep & 32 or not engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1, query_ws=True):
+        # (which kernel serves the launch depends on its shape and flags only: asked once per shape)
+        elig = c2.__dict__.setdefault('_ru_eligible', {})
+        key = (x.N, H, W, x.C, h.C, PRECISION, keep, bool(relu2))
+        if key not in elig:
+            elig[key] = bool(not (keep & 32) and engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W,
+                                                                   taps1=1, query_ws=True))
+        if not elig[key]:
             return None
         if dot is not None and RU_EVAL_POINT_DOT and relu2:
             point = torch.empty((x.N, 1, H, W), dtype=torch.float32, device=x.x.device)
             d3 = (dot[0], dot[1], point)
-            if engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=d3, query_ws=True) == 2:
+            if key + ('dot',) not in elig:
+                elig[key + ('dot',)] = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1,
+                                                           dot=d3, query_ws=True) == 2
+            if elig[key + ('dot',)]:
                 engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=d3)
                 return PointLogit(point)
         out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1)
