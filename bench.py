@@ -52,6 +52,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the headline measurement (+ roofline)')
     ap.add_argument('--no-infer-extra', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-forced-allreduce', action='store_true', help='skip the 1-rank forced all-reduce leg (it creates a one-rank RCCL group at the end of the run)')
+    ap.add_argument('--no-live-pmc', action='store_true', help='quote the dominant kernel\'s HBM traffic from the committed summary instead of two rocprofv3 --pmc child passes')
     return ap.parse_args()
 
 
@@ -130,6 +132,68 @@ def cpu_baseline_infer(n_tiles=4):
                        'probmaps/DDM/boost/CC chain (1 thread), median of %d repetitions after 2 warm-ups' % (n_tiles, cores, reps))
 
 
+def cpu_baseline_cdm(n_tiles=16):
+    """oracle/cdm_oracle.c (the plain-C restatement of LabelEncoding + get_centerpoint2, my_transforms_direction.py:650-885) on the label
+    images of the GPU leg, one thread (the reference runs it per sample inside a DataLoader worker)"""
+    from oracle import cdm as oc
+    labs = cdm_labels(n_tiles)
+
+    def run():
+        for b in range(n_tiles):
+            oc.label_encoding(labs[b])
+    med, reps = _median_time(run, 1, 5, 30.0)
+    return dict(value=n_tiles / med, unit='tiles/s', cores=1, kind='port', cpu=cpu_model(), seconds_per_iteration=med,
+                sample='%d synthetic 256x256 label images (60 ellipse nuclei each, SURVEY 8d recipe): oracle/cdm_oracle.c, 1 thread, median of '
+                       '%d repetitions after 1 warm-up (a C port: the reference\'s numba / per-nucleus Python loop is slower)' % (n_tiles, reps))
+
+
+def cpu_baseline_image_postproc():
+    """the direction-difference maps of the 8 views + mean / boost / arg-max + CC chain of ONE 1000x1000 image
+    (getDirectionDiffMap.py:44, test_dam.py:455-563) by the plain-C oracle, 1 thread"""
+    from cdnet_amd import synth
+    from oracle import postproc as orc
+    probs, points, dcms = synth.postproc_case(1000, 1000, 500, 5)
+    med, reps = _median_time(lambda: orc.postprocess_views(probs, points, dcms), 1, 5, 30.0)
+    return dict(value=1.0 / med, unit='images/s', cores=1, kind='port', cpu=cpu_model(), seconds_per_iteration=med,
+                sample='one synthetic 1000x1000 image, 8 views (500 nuclei): oracle/postproc_oracle.c generate_dd_map x 8 + fuse / boost / argmax + '
+                       'fill holes / remove small / label / dilate, 1 thread, median of %d repetitions after 1 warm-up (the network forward is '
+                       'not part of this leg)' % reps)
+
+
+def cpu_baseline_unet(n_tiles=4):
+    """BASELINE config 1 as the reference runs it: plain UNet (models/unet.py:53-106) train step on 4 x 256x256x3 tiles, PyTorch fp32 CPU
+    (oracle/models.py UNet + oracle/train.py unet_train_iteration, pinned to train_util.train by tests/golden/unet_train_iter.npz)"""
+    import torch
+    from oracle import models as om
+    from oracle import train as ot
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = om.UNet(3)
+    opt = ot.make_adam(net)
+    x, lab, weight = [t.cpu() for t in unet_batch(n_tiles, torch.device('cpu'))]
+    med, reps = _median_time(lambda: ot.unet_train_iteration(net, opt, x, lab, weight), 1, 3, 40.0)
+    return dict(value=n_tiles / med, unit='tiles/s', cores=cores, kind='port', cpu=cpu_model(), seconds_per_iteration=med,
+                sample='%d synthetic 256x256 tiles per iteration = BASELINE config 1 at its own size: oracle fp32 PyTorch-CPU UNet train iteration '
+                       '(%d threads), median of %d repetitions after 1 warm-up' % (n_tiles, cores, reps))
+
+
+def cdm_labels(n_tiles, seed=2022):
+    """channel 0 of the 3-class label PNG (> 127 = inside) for `n_tiles` synthetic 256x256 tiles with 60 ellipse nuclei each"""
+    import numpy as np
+    from cdnet_amd import synth
+    rs = np.random.RandomState(seed)
+    return np.stack([(synth.ellipse_instances(256, 256, 60, rs, 5, 12, 10) > 0).astype(np.uint8) * 255 for _ in range(n_tiles)])
+
+
+def unet_batch(B, dev, seed=2022):
+    """config 1's batch: uniform RGB tiles, {0,1,2} labels from ellipse nuclei, constant weight map 20"""
+    import torch
+    from cdnet_amd.trainer import synthetic_batch
+    x, lab, _, _, weight = synthetic_batch(B, dev, seed=seed)
+    return x, lab, weight
+
+
 def dominant_roofline(ms, B, precision, traffic=None, traffic_src=None, mfma_busy=None, clock=None, kernel=None):
     """The `roofline` object of the dominant layer (3x3 conv 64->64 @256x256 x B tiles) from its measured launch duration `ms` (pure
     arithmetic - tests/test_bench_contract.py calls it on the CPU).  `frac` is the ALGORITHMIC fraction of SURVEY 8d:
@@ -172,7 +236,7 @@ def committed_pmc(precision, B=16):
     return None, None, None, None
 
 
-def live_pmc_traffic(precision, kernel_names, timeout_s=90):
+def live_pmc_traffic(precision, kernel_names, timeout_s=60):
     """HBM bytes per launch of the dominant kernel measured IN THIS RUN when rocprofv3 is on the box: two child processes
     `rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --mode roofline` (separate passes, the program right
     after `--`, from /tmp: MI355X_MICROARCH.md's HBM / rocprofv3 section), FETCH_SIZE x 2 on gfx950 (a 16-B/lane read stream counts
@@ -180,6 +244,7 @@ def live_pmc_traffic(precision, kernel_names, timeout_s=90):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     if os.environ.get('CDNET_BENCH_LIVE_PMC', '1') == '0':
@@ -200,9 +265,20 @@ def live_pmc_traffic(precision, kernel_names, timeout_s=90):
             d = os.path.join(out, ctr)
             cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 't', '--',
                    sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'roofline', '--dtype', precision, '--steps', '20']
-            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, 'rocprofv3 --pmc %s failed (rc %d)' % (ctr, r.returncode)
+            # the profiler and the program it starts form their own process group: on a timeout the WHOLE group is killed and reaped
+            # before anything else is timed (killing only the launcher would leave `bench.py --mode roofline` running on this GPU)
+            proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return None, 'rocprofv3 --pmc %s pass exceeded %d s (its process group was killed and reaped)' % (ctr, timeout_s)
+            if rc != 0:
+                return None, 'rocprofv3 --pmc %s failed (rc %d)' % (ctr, rc)
             per = {}
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 with open(f) as fh:
@@ -361,7 +437,12 @@ def main():
         # batch i's post-processing chain is queued on a second stream and runs beside batch i + 1's forward (pipeline.infer_tiles);
         # every batch's chain has finished when the timed region's closing synchronize returns
         post = streams.side_stream(dev)             # (a stream on another hardware queue than the compute stream's)
-        dt = timed(lambda: pipeline.infer_tiles(model, x, post_stream=post), steps, warmup)
+        last = {}
+
+        def step():
+            last['r'] = pipeline.infer_tiles(model, x, post_stream=post)
+        dt = timed(step, steps, warmup)
+        pipeline.check_tiles(last['r'])             # the reference's constant-DDM assertion (test_dam.py:535), from the device flag, outside the timed region
         return dict(metric='tiles/sec inference incl. post-proc, 256x256',
                     workload='CDNet UNet2RevA1_vgg16 (UNet+DAM) inference + direction-diff/CC post-processing, 256x256x3 synthetic tiles '
                              '(post-processing of batch i on a second stream beside the forward of batch i+1)',
@@ -377,6 +458,97 @@ def main():
                     workload='CDNet inference of 1000x1000 images (BASELINE config 3): 8 TTA views x 25 windows of 256/40, per-view '
                              'direction-difference maps, boost, CC chain',
                     value=world * steps / dt, ms_per_step=dt / steps * 1e3, window_evaluations_per_s=world * 200 * steps / dt, steps=steps)
+
+    def run_cdm(B, steps, warmup):
+        """centripetal-direction-map generation (`LabelEncoding` + `get_centerpoint2`, my_transforms_direction.py:650-885) of
+        one batch of label images on the device: label image u8 -> 3-class label u8, centre-point map f16, direction classes u8"""
+        from cdnet_amd.my_transforms_direction import label_encoding_batch
+        lab0 = torch.from_numpy(cdm_labels(B, 2022 + rank)).to(dev)
+        dt = timed(lambda: label_encoding_batch(lab0), steps, warmup, settle_s=0.3)
+        ms = dt / steps * 1e3
+        alg = B * 256 * 256 * 5                    # algorithmic bytes: 1 B/px read (label) + 1 + 2 + 1 B/px written (label3, point f16, direction)
+        return dict(metric='tiles/sec, centripetal-direction-map generation (LabelEncoding), 256x256 labels with 60 nuclei', value=world * B * steps / dt,
+                    unit='tiles/s', ms_per_batch=ms, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup, dtype='u8/f64',
+                    roofline=dict(bound='hbm', achieved=alg / ms / 1e6, peak=HBM_PEAK_GBS, unit='GB/s', frac=alg / ms / 1e6 / HBM_PEAK_GBS,
+                                  algorithmic_bytes=alg, traffic=None,
+                                  note='5 B/pixel algorithmic (u8 label in; u8 label3 + f16 point + u8 direction out).  The chain is 14 launches; '
+                                       'its time is the centre search (8 rays x 30 dependent fp64 bisection gathers per nucleus pixel) and the '
+                                       'labelling passes - latency-bound work, priced against HBM only because the path has no other roof'))
+
+    def run_train_e2e(precision, B, steps, warmup):
+        """the training step WITH its input pipeline's device part: target generation of the batch (label_encoding_batch, as
+        cdnet_amd/data_folder.py runs it per batch) + train_step, per iteration.  side=True: the targets of batch i + 1 are generated on the
+        probed side stream beside the step of batch i (double-buffered), as a prefetching loader would"""
+        from cdnet_amd.my_transforms_direction import label_encoding_batch
+        cdnet_amd.set_precision(precision)
+        tr = trainer.Trainer(new_model(), world_size=world)
+        x, _, _, _, weight = trainer.synthetic_batch(B, dev, seed=2022 + rank)
+        lab0 = torch.from_numpy(cdm_labels(B, 2022 + rank)).to(dev)
+
+        def targets():
+            l3, point, dirn = label_encoding_batch(lab0)
+            return torch.div(l3, 127, rounding_mode='floor'), dirn, point         # {0,127,255} -> {0,1,2} (train_util_dam.py:107-108)
+
+        def step():
+            lab, dirn, point = targets()
+            tr.train_step(x, lab, dirn, point, weight)
+        dt = timed(step, steps, warmup)
+        return dict(value=world * B * steps / dt, unit='tiles/s', ms_per_step=dt / steps * 1e3, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup,
+                    dtype=precision, workload='label_encoding_batch (CDM generation of the batch on the device) + train_step per iteration, same stream')
+
+    def run_unet_cfg1(precision, B, steps, warmup):
+        """BASELINE config 1 at its own size: plain UNet (models/unet.py:53-106) train step, 4 x 256x256x3 tiles"""
+        from cdnet_amd.models.unet import UNet
+        cdnet_amd.set_precision(precision)
+        torch.manual_seed(2022)
+        tr = trainer.UNetTrainer(UNet(num_classes=3).to(dev), world_size=world)
+        x, lab, weight = unet_batch(B, dev, seed=2022 + rank)
+        dt = timed(lambda: tr.train_step(x, lab, weight), steps, warmup, settle_s=0.5)
+        return dict(metric='tiles/sec (train fwd+bwd+Adam), plain UNet 3-class, 256x256', value=world * B * steps / dt, unit='tiles/s',
+                    ms_per_step=dt / steps * 1e3, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup, dtype=precision,
+                    workload='BASELINE config 1: UNet 3-class (31.04 M parameters), %d x 256x256x3 synthetic tiles, forward, CE x weight + dice, backward, Adam' % B)
+
+    def run_image_postproc(steps, warmup):
+        """BASELINE.md section 4 (d) on the device: everything after get_probmaps for one 1000x1000 image with 8 views (per-view
+        direction-difference maps, mean, boost, arg-max, CC chain)"""
+        from cdnet_amd import postproc
+        probs, points, dcms = synth.postproc_case(1000, 1000, 500, 5)
+        t = lambda a_: torch.from_numpy(a_).to(dev)[None]
+        pr, po, dc = t(probs), t(points), t(dcms)
+        dt = timed(lambda: postproc.postprocess_views(pr, po, dc), steps, warmup, settle_s=0.3)
+        return dict(metric='images/sec, DDM x 8 views + boost/argmax + CC chain of one 1000x1000 image', value=world * steps / dt, unit='images/s',
+                    ms_per_image=dt / steps * 1e3, steps=steps, warmup=warmup, dtype='u8/i32')
+
+    def run_forced_allreduce(precision, B, steps, warmup):
+        """the 1-rank step with the bucketed all-reduce path forced (CDNET_FORCE_ALLREDUCE=1) on a one-rank RCCL group: the same-box baseline
+        for the overlap machinery's cost before the first multi-GPU run.  Runs LAST: RCCL's streams change the stream -> hardware-queue deal,
+        the side stream is probed again after the group exists (cdnet_amd.streams)"""
+        import socket
+        made = False
+        if not dist.is_initialized():
+            with socket.socket() as so:
+                so.bind(('127.0.0.1', 0))
+                port = so.getsockname()[1]
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+            made = True
+        os.environ['CDNET_FORCE_ALLREDUCE'] = '1'
+        try:
+            cdnet_amd.set_precision(precision)
+            tr = trainer.Trainer(new_model(), world_size=1)
+            batch = trainer.synthetic_batch(B, dev, seed=2022 + rank)
+            dt = timed(lambda: tr.train_step(*batch), steps, warmup)
+            st = tr.ar_stats or {}
+            probe = streams.PROBES[-1] if streams.PROBES else None
+            return dict(ms_per_step=dt / steps * 1e3, value=B * steps / dt, unit='tiles/s', steps=steps, warmup=warmup, dtype=precision,
+                        buckets=st.get('buckets'), buckets_released_during_backward=st.get('released_during_backward'),
+                        bucket_mb=tr.bucket * 4 / (1 << 20), process_group='%s, %d rank(s)' % (dist.get_backend(), dist.get_world_size()),
+                        side_stream_probe=probe)
+        finally:
+            os.environ.pop('CDNET_FORCE_ALLREDUCE', None)
+            if made:
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
 
     other = 'fp32' if a.dtype == 'bf16' else 'bf16'
     extras = not a.no_extras
@@ -421,20 +593,41 @@ def main():
                        'inference': {'value': i2['value'], 'unit': 'tiles/s', 'ms_per_step': i2['ms_per_step'], 'tiles_per_gpu_per_step': 64, 'steps': i2['steps']}}
         rp['train_' + other] = path_roofline('train', other, B, t2['ms_per_step'])
         rp['infer_' + other] = path_roofline('infer', other, 64, i2['ms_per_step'])
-        im = run_image(a.dtype, 8, 2)
-        im2 = run_image(other, 8, 2)
+        IMG_STEPS, IMG_WARMUP = 8, 2
+        im = run_image(a.dtype, IMG_STEPS, IMG_WARMUP)
+        im2 = run_image(other, IMG_STEPS, IMG_WARMUP)
         line['image'] = {'metric': im['metric'], 'value': im['value'], 'unit': 'images/s', 'ms_per_image': im['ms_per_step'],
-                         'window_evaluations_per_s': im['window_evaluations_per_s'], 'steps': 3, 'warmup': 1, 'dtype': a.dtype,
-                         other: {'value': im2['value'], 'ms_per_image': im2['ms_per_step']}}
+                         'window_evaluations_per_s': im['window_evaluations_per_s'], 'steps': im['steps'], 'warmup': IMG_WARMUP, 'dtype': a.dtype,
+                         other: {'value': im2['value'], 'ms_per_image': im2['ms_per_step'], 'steps': im2['steps'], 'warmup': IMG_WARMUP}}
+        line['image_postproc'] = run_image_postproc(10, 2)
+        # SURVEY 8a-9 / VERDICT r04 #5: the target generation timed alone and inside the step
+        line['cdm'] = run_cdm(B, 20, 3)
+        e2e = run_train_e2e(a.dtype, B, max(5, a.steps // 2), 2)
+        e2e['vs_value'] = e2e['value'] / head['value']
+        line['train_e2e'] = e2e
+        # BASELINE config 1 at its own size
+        line['unet_cfg1'] = run_unet_cfg1(a.dtype, 4, 10, 2)
     if rp:
         line['roofline_path'] = rp
+    line['config']['side_stream_probe'] = streams.PROBES[-1] if streams.PROBES else None       # (the trainer's / pipeline's second stream)
     if rank == 0:
         cdnet_amd.set_precision(a.dtype)
-        line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype, live_pmc=(world == 1 and extras))
+        line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype, live_pmc=(world == 1 and extras and not a.no_live_pmc))
         if extras and world == 1:
             line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)
+        if extras and mode == 'train' and world == 1 and not a.no_forced_allreduce:
+            fa = run_forced_allreduce(a.dtype, B, max(5, a.steps // 2), 2)
+            fa['vs_value'] = fa['value'] / head['value']
+            line['dp1_forced_allreduce'] = fa
         if not a.no_cpu_baseline and world == 1:
+            # every reported rate has its CPU leg beside it: the headline's under `cpu_baseline`, the others under
+            # their own keys; all are bounded samples (a few repetitions of a few tiles / one image), ~40 s of host time in total
             line['cpu_baseline'] = cpu_baseline_infer() if mode == 'infer' else cpu_baseline_train()
+            if extras and mode == 'train':
+                line['cpu_baseline_infer'] = cpu_baseline_infer()
+                line['cpu_baseline_cdm'] = cpu_baseline_cdm()
+                line['cpu_baseline_image_postproc'] = cpu_baseline_image_postproc()
+                line['cpu_baseline_unet_cfg1'] = cpu_baseline_unet()
         print(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()                    # rank 0 times the roofline kernel after the timed region: leave together

@@ -22,6 +22,7 @@ SIGNATURES = {
     'cdnet_abi_sizeof': (_sz, [C.c_char_p]),
     'cdnet_last_error': (C.c_char_p, []),
     'cdnet_build_info': (C.c_char_p, []),
+    'cdnet_spin': (_i, [_i, _vp]),
     'cdnet_ddm_codes': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     'cdnet_ddm_normalize': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'cdnet_probmaps': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

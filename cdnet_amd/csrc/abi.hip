@@ -23,3 +23,15 @@ extern "C" size_t cdnet_abi_sizeof(const char *name) {
 #undef CDNET_SZ
     return 0;
 }
+
+// a wave that only waits: the stream probe's load (see include/cdnet_hip.h)
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int cdnet_spin(int microseconds, void *stream) {
+    CDNET_REQUIRE(microseconds >= 0 && microseconds <= 1000000, "cdnet_spin: 0 .. 1 000 000 microseconds");
+    spin_kernel<<<1, 64, 0, (hipStream_t)stream>>>((long long)microseconds * 100);
+    return cdnet::check_launch("cdnet_spin");
+}

@@ -120,8 +120,7 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
         # 16x16-pixel layers with long channel loops (the bottleneck convolutions): the persistent producer / consumer kernel keeps four
         # chunks of loads in flight per workgroup - 128 workgroups of it beat 512 workgroups that each expose every chunk's latency
         # (512 -> 512 @16x16 x16: 54 -> measured in tools/bench_conv_stream.py)
-        ws16 = taps == 9 and not transposed and H % 16 == 0 and W % 16 == 0 and min(H, W) == 16 and ctot % 64 == 0 and 256 <= ctot <= 768 \
-
+        ws16 = taps == 9 and not transposed and H % 16 == 0 and W % 16 == 0 and min(H, W) == 16 and ctot % 64 == 0 and 256 <= ctot <= 768
         if ck >= 32 and not ws16:
             return (8, 32, 64)
     if ck == 64:

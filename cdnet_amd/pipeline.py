@@ -21,7 +21,12 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
     queue): the post-processing chain is queued on that stream, ordered after this batch's forward, and
     the call returns at once - the small, latency-bound connected-component / direction kernels of batch i then run beside the
     convolutions of batch i + 1 queued on the caller's stream.  The returned tensors belong to `post_stream`: wait for `r['done']`
-    (an event) - or synchronize - before reading them on another stream."""
+    (an event) - or synchronize - before reading them on another stream.
+
+    The reference asserts on a tile whose direction-difference map is constant (0/0 -> NaN, test_dam.py:535).  Serial form: the same
+    AssertionError here, as postproc.postprocess_views raises it.  Pipelined form (`post_stream`): a host-side assert would drain the
+    pipeline, so the test is made on the device - `r['ddm_constant']` (bool [B], one flag per tile) - and `check_tiles(r)` raises the
+    reference's assertion once the caller has waited for `r['done']`."""
     assert not model.training
     mask, point, direction = model(x)
     B, _, H, W = mask.shape
@@ -40,10 +45,23 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
         cc = postproc.cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
         r.update(cc)
         r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
+        mm = minmax.reshape(B, 2)
+        r['ddm_constant'] = mm[:, 0] == mm[:, 1]
         if post_stream is not None:
             r['done'] = torch.cuda.Event()
             r['done'].record(post_stream)
+    if post_stream is None:
+        check_tiles(r)
     return r
+
+
+def check_tiles(r):
+    """the reference's `assert(np.min(enhanced_boundary) >= 0)` (test_dam.py:535: NaN when a tile's direction-difference map is constant) for
+    a result of infer_tiles; reads the device flag (synchronises with the stream that produced it)"""
+    if 'done' in r:
+        r['done'].synchronize()
+    bad = torch.nonzero(r['ddm_constant']).flatten().tolist()
+    assert not bad, ('tile(s) %s have a constant direction-difference map: 0/0 -> NaN; the reference asserts here (test_dam.py:535)' % bad)
 
 
 @torch.no_grad()

@@ -163,8 +163,9 @@ class ConvLayer:
     def eval_pack(self, src_channels, allow_f32=False):
         """eval mode, 16-bit path, 3x3 / 1x1 Conv2d + BatchNorm: the packed weights with the BatchNorm scale folded in
         (bf16(w[cout] * scale[cout])) and the shift that is left for the epilogue - what conv_ws16_kernel takes as the accumulators'
-        initial value (csrc/conv16ws.hip).  Returns (packed, shift) or None when the layer keeps the epilogue affine (transposed and
-        stride-2 layers, the RGB stem's zero-extended pack, fp32 mode)."""
+        initial value (csrc/conv16ws.hip).  The RGB stem's zero-extended pack (3 -> 16 reduction channels) is folded like any other.  Returns
+        (packed, shift) or None when the layer keeps the epilogue affine (transposed and stride-2 layers, layers without BatchNorm, fp32 mode
+        unless `allow_f32`)."""
         if not EVAL_FOLD_WEIGHTS or not getattr(self, 'fold_eval', True) or self.kind not in ('conv3', 'conv1') or self.bn is None:
             return None
         f32 = PRECISION == 'fp32'
@@ -390,44 +391,47 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True, dot=None):
     c2.prepare([c2.Cin], H, W, x.N)
     if tuple(c2.cfg[:2]) != (16, 16):
         return None
-    h = c1.forward([x], False, relu=True)
-    cr.prepare([x.C], H, W, x.N)
-    if tuple(c2.cfg[:2]) != (16, 16):
-        return None
-    if tuple(cr.cfg) != tuple(c2.cfg):
-        cr.cfg, cr.wp = tuple(c2.cfg), None              # (one configuration for both packs: they lie end to end)
-        cr.prepare([x.C], H, W, x.N)
-    ep = c2.eval_pack([h.C], allow_f32=True)
+    ep = c2.eval_pack([c1.Cout], allow_f32=True)         # (every shape question is asked before conv1 runs: an ineligible unit computes nothing twice)
     if ep is None:
         return None
-    ver = (c2.wpe_version, cr.wp_version, None if cr.bias is None else cr.bias._version, PRECISION)
+    f32 = PRECISION == 'fp32'
+    # the 1x1 branch's pack in c2's configuration, in a buffer of this form's own (`cr` and its packs - which the trainer's batched re-pack
+    # holds raw pointers to - are left alone): the two packs lie end to end per output-channel tile
+    rver = (cr.weight._version, WEIGHTS_EPOCH[0], tuple(c2.cfg), f32)
+    if getattr(c2, 'ru_wr', None) is None or c2.ru_wr_version != rver:
+        c2.ru_wr = engine.pack_weights(cr.weight.detach(), c2.cfg, 0, out=getattr(c2, 'ru_wr', None), split=f32)
+        c2.ru_wr_version = rver
+    ver = (c2.wpe_version, rver, None if cr.bias is None else cr.bias._version, PRECISION)
     if getattr(c2, 'ru_pack', None) is None or c2.ru_pack_version != ver:
         BN = c2.cfg[2]
         ntile = -(-c2.Cout // BN)
-        a, b = ep[0].view(ntile, -1), cr.wp.view(ntile, -1)      # per output-channel tile: the nine-tap chunks, then the one-tap chunks
+        a, b = ep[0].view(ntile, -1), c2.ru_wr.view(ntile, -1)   # per output-channel tile: the nine-tap chunks, then the one-tap chunks
         c2.ru_pack = torch.cat([a, b], 1).contiguous().view(-1)
         c2.ru_shift = ep[1] if cr.bias is None else ep[1] + cr.bias.detach()
         c2.ru_pack_version = ver
+    hC = c1.Cout
     keep = engine.CONV_DEBUG
     engine.CONV_DEBUG = keep | 64                        # (the persistent kernel also on small launches: nothing else computes this form)
     try:
-        # (which kernel serves the launch depends on its shape and flags only: asked once per shape)
+        # (which kernel serves the launch depends on its shape and flags only: asked once per shape, on a placeholder for conv1's output)
         elig = c2.__dict__.setdefault('_ru_eligible', {})
-        key = (x.N, H, W, x.C, h.C, PRECISION, keep, bool(relu2))
-        if key not in elig:
-            elig[key] = bool(not (keep & 32) and engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W,
-                                                                   taps1=1, query_ws=True))
+        key = (x.N, H, W, x.C, hC, PRECISION, keep, bool(relu2))
+        want_dot = dot is not None and RU_EVAL_POINT_DOT and relu2
+        if key not in elig or (want_dot and key + ('dot',) not in elig):
+            hp = Src(torch.empty((x.N, H, W, hC), dtype=act_dtype(), device=x.x.device))
+            kw = dict(oshift=c2.ru_shift, H=H, W=W, taps1=1, query_ws=True)
+            elig[key] = bool(not (keep & 32) and engine.conv_forward([hp, x], c2.ru_pack, c2.Cout, c2.cfg, 9, orelu=relu2, **kw))
+            if want_dot:
+                d0 = (dot[0], dot[1], torch.empty((x.N, 1, H, W), dtype=torch.float32, device=x.x.device))
+                elig[key + ('dot',)] = elig[key] and engine.conv_forward([hp, x], c2.ru_pack, c2.Cout, c2.cfg, 9, orelu=True, dot=d0, **kw) == 2
         if not elig[key]:
             return None
-        if dot is not None and RU_EVAL_POINT_DOT and relu2:
+        h = c1.forward([x], False, relu=True)
+        assert h.C == hC and not h.pool and h.scale is None
+        if want_dot and elig[key + ('dot',)]:
             point = torch.empty((x.N, 1, H, W), dtype=torch.float32, device=x.x.device)
-            d3 = (dot[0], dot[1], point)
-            if key + ('dot',) not in elig:
-                elig[key + ('dot',)] = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1,
-                                                           dot=d3, query_ws=True) == 2
-            if elig[key + ('dot',)]:
-                engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=d3)
-                return PointLogit(point)
+            engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=(dot[0], dot[1], point))
+            return PointLogit(point)
         out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1)
     finally:
         engine.CONV_DEBUG = keep

@@ -5,25 +5,46 @@ import os
 import torch
 
 _SIDE = {}
+PROBES = []          # one record per probe that ran: dict(device, group, alone_ms, picked, together_ms) - tests / bench.py read it
+
+
+def _group_state():
+    """RCCL creates its own streams when the process group comes up: HIP then deals later streams onto the hardware queues differently, and a
+    side stream picked BEFORE may now share the compute stream's queue.  The cache is keyed on this, so the first call after
+    init_process_group probes again."""
+    try:
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized())
+    except Exception:
+        return False
+
+
+def _spin(us, stream):
+    from . import _lib
+    _lib.call('cdnet_spin', int(us), stream.cuda_stream)
 
 
 def side_stream(device=None):
-    """One stream per device, chosen once.  HIP places streams on a few hardware queues in creation order; a side stream that shares the
-    compute stream's queue serialises with it, and the cross-stream events then cost more than one stream would (training: 1 456 vs 1 622
-    vs 1 780 tiles/s; inference with the post-processing stream: 9 490 vs 10 300 vs 10 700 tiles/s - the stream a process gets from
-    torch.cuda.Stream() depends on how many it created before).  Candidates are timed with two spin kernels: together they take as long
-    as one when the queues differ, twice as long when they do not.  CDNET_SIDE_STREAM_PROBE=0: the first candidate, unprobed."""
+    """One stream per device (and per process-group state), chosen once.  HIP places streams on a few hardware queues in creation order; a
+    side stream that shares the compute stream's queue serialises with it, and the cross-stream events then cost more than one stream would
+    (training: 1 456 vs 1 622 vs 1 780 tiles/s; inference with the post-processing stream: 9 490 vs 10 300 vs 10 700 tiles/s - the stream a
+    process gets from torch.cuda.Stream() depends on how many it created before).  Candidates are timed with two spin kernels of the
+    library's own (`cdnet_spin`: one wave waiting on the constant 100 MHz counter, no memory traffic): together they take as long as one
+    when the queues differ, twice as long when they do not.  No candidate passing is not an error: the first one is used and the record in
+    `PROBES` says so.  CDNET_SIDE_STREAM_PROBE=0: the first candidate, unprobed."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, _group_state())
     hit = _SIDE.get(key)
     if hit is not None:
         return hit
     cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
-    spin = getattr(torch.cuda, '_sleep', None)
     pick = cands[0]
-    if spin is not None and os.environ.get('CDNET_SIDE_STREAM_PROBE', '1') != '0':
+    rec = dict(device=idx, group=key[1], alone_ms=None, together_ms=None, picked=0, probed=False)
+    if os.environ.get('CDNET_SIDE_STREAM_PROBE', '1') != '0':
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream()
+            SPIN_US = 300
 
             def timed(other):
                 torch.cuda.synchronize()
@@ -31,9 +52,8 @@ def side_stream(device=None):
                 e0.record(main)
                 if other is not None:
                     other.wait_stream(main)                 # (starts with the compute stream's spin, not before the first event)
-                    with torch.cuda.stream(other):
-                        spin(400000)
-                spin(400000)
+                    _spin(SPIN_US, other)
+                _spin(SPIN_US, main)
                 if other is not None:
                     main.wait_stream(other)
                 e1.record(main)
@@ -41,9 +61,13 @@ def side_stream(device=None):
                 return e0.elapsed_time(e1)
             timed(None)
             alone = min(timed(None), timed(None))
-            for c in cands:
-                if min(timed(c), timed(c)) < 1.5 * alone:
+            rec.update(alone_ms=alone, probed=True)
+            for i, c in enumerate(cands):
+                t = min(timed(c), timed(c))
+                if t < 1.5 * alone:
                     pick = c
+                    rec.update(picked=i, together_ms=t)
                     break
+    PROBES.append(rec)
     _SIDE[key] = pick
     return pick

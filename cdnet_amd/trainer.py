@@ -142,6 +142,7 @@ class Trainer:
         self.tape = []
         self._cat_cache = {}
         self._wstream, self._events = None, {}
+        self.ar_stats = None                     # buckets of the last step's all-reduce: total / released before backward ended
         self._packb_pending = False
         self._packb_stream = True              # backward-data re-packs beside the next forward
         self._side_active = False
@@ -699,6 +700,7 @@ class Trainer:
                 # ends - runs while Adam already updates the ranges above it
                 ranges = self._ar.finish(wait=False)
                 works = self._ar.works
+                self.ar_stats = dict(buckets=len(works), released_during_backward=self._ar.early)
                 self._ar = None
             else:
                 bucketed_allreduce(f.G, f.n_used, self.bucket)

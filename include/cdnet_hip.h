@@ -39,6 +39,10 @@ size_t      cdnet_abi_sizeof(const char *struct_name);
 const char *cdnet_last_error(void);
 /* static description: "gfx950;wave64;..." */
 const char *cdnet_build_info(void);
+/* One wavefront that spins for `microseconds` of the constant 100 MHz counter on `stream` and touches no memory (at most 1 s).  The host
+ * side's stream probe times two of them on two streams (cdnet_amd/streams.py): streams that share a hardware queue run them one after the
+ * other.  Replaces nothing of the reference (nn.DataParallel has no streams of its own, train.py:185); a diagnostic of the runtime. */
+int         cdnet_spin(int microseconds, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Direction-difference map.   Replaces data_prepare/getDirectionDiffMap.py:44-108 `generate_dd_map`

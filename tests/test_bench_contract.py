@@ -95,3 +95,13 @@ def test_path_roofline_helper():
     assert abs(r['frac'] - (1540.0 * 16 + 4 * 81.9) / 8000.0 / 16.0) < 1e-12                # 24.97 GB algorithmic per step
     b = bench.path_roofline('infer', 'bf16', 64, 8.0)
     assert b['bound'] == 'hbm' and b['peak_TFLOPs'] == 2500.0 and b['mfma_work_frac'] == b['mfma_frac']
+
+
+def test_check_tiles_raises_the_references_constant_ddm_assertion():
+    """pipeline.check_tiles: the device flag of infer_tiles -> the reference's assertion (test_dam.py:535); host logic, CPU tensors"""
+    import pytest
+    import torch
+    from cdnet_amd import pipeline
+    pipeline.check_tiles({'ddm_constant': torch.tensor([False, False, False])})
+    with pytest.raises(AssertionError, match='constant direction-difference map'):
+        pipeline.check_tiles({'ddm_constant': torch.tensor([False, True, False])})

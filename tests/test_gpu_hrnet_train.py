@@ -309,3 +309,28 @@ def test_residual_1x1_backward_beside_the_chain_is_bit_identical_on_hrnet(monkey
                 assert torch.equal(grads[0][n], g[n]), n
     finally:
         cdnet_amd.set_precision(before)
+
+
+def test_cfg5_step_at_its_own_size():
+    """BASELINE config 5's per-rank shape: HRNet18_rev1 (seg_hrnet_rev1.py:289-548), 4 tiles of 512x512, training step in the 16-bit mode
+    (the one tools/bench_hrnet.py times): deterministic bit for bit from the same state, finite, and five Adam steps learn"""
+    import torch
+    from cdnet_amd import trainer
+    from cdnet_amd.models.dam.seg_hrnet_rev1 import HighResolutionNet
+
+    class O:
+        model = {'out_c': 3}
+    dev = torch.device('cuda:0')
+    batch = trainer.synthetic_batch(4, dev, seed=5, H=512, W=512)
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        m = HighResolutionNet(O()).cuda().train()
+        tr = trainer.Trainer(m)
+        runs.append(torch.stack([tr.train_step(*batch).clone() for _ in range(5)]).cpu().numpy())
+        del tr, m
+        torch.cuda.empty_cache()
+    assert np.isfinite(runs[0]).all()
+    assert np.array_equal(runs[0], runs[1]), 'the 4 x 512x512 HRNet step is not deterministic'
+    assert runs[0][-1, 0] < runs[0][0, 0], runs[0][:, 0]
+    print('cfg 5 4 x 512x512: loss %.5f -> %.5f after 5 steps' % (runs[0][0, 0], runs[0][-1, 0]))

@@ -205,7 +205,7 @@ def test_side_stream_is_cached_and_runs_beside_the_compute_stream():
     post-processing stream), not the current stream, and - what the probe is for - on another hardware queue: two spin kernels, one per
     stream, take about as long as one."""
     import torch
-    from cdnet_amd import streams
+    from cdnet_amd import _lib, streams
     s = streams.side_stream()
     assert s is streams.side_stream(torch.device('cuda', torch.cuda.current_device()))
     main = torch.cuda.current_stream()
@@ -217,9 +217,8 @@ def test_side_stream_is_cached_and_runs_beside_the_compute_stream():
         e0.record(main)
         if both:
             s.wait_stream(main)
-            with torch.cuda.stream(s):
-                torch.cuda._sleep(2000000)
-        torch.cuda._sleep(2000000)
+            _lib.call('cdnet_spin', 1000, s.cuda_stream)
+        _lib.call('cdnet_spin', 1000, main.cuda_stream)
         if both:
             main.wait_stream(s)
         e1.record(main)
@@ -228,4 +227,6 @@ def test_side_stream_is_cached_and_runs_beside_the_compute_stream():
     timed(False)
     alone = min(timed(False) for _ in range(3))
     together = min(timed(True) for _ in range(3))
+    assert 0.9 < alone < 1.3, alone                       # (the spin kernel waits on the constant 100 MHz counter: 1 000 us asked)
     assert together < 1.5 * alone, (alone, together)
+    assert streams.PROBES and streams.PROBES[-1]['probed']

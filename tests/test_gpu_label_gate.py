@@ -7,10 +7,11 @@ actually segments nuclei; the SAME weights then run (a) through the product path
 infer_image incl. TTA + sliding windows + device post-processing - and (b) through the fp32 CPU oracle
 (oracle.models.Unet + oracle.infer + oracle.postproc, each pinned to the reference).  The two instance-label maps are scored
 against each other with the reference's own metrics (stats_utils.get_fast_aji / get_dice_1, test_dam.py:591-669): AJI and
-Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.002.  fp32 mode holds that mutual bar on every case
-(its label maps are identical); bf16 mode is held to north_star's literal bar - AJI / Dice of BOTH sides against the ground truth (the
-rendered instance map) within 0.002 - plus a mutual floor of 0.997 (mean) / 0.995 (single tile): one merged nucleus of ~40 moves a tile's
-mutual AJI by 0.003 without moving its ground-truth score.
+Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.002.  BOTH modes hold that mutual bar on every case (fp32
+mode's label maps are identical to the oracle's; bf16 mode has held the same 0.998 per tile since round 4 - the 0.997 mean / 0.995 per-tile
+floors of round 3 are gone), and beside it north_star's literal bar: AJI / Dice of BOTH sides against the ground truth (the rendered instance
+map) within 0.002.  Since round 5 the bf16 bar is checked on more than one draw: `test_second_draw` trains a second network (another seed,
+other batches) and scores both networks on two 1000x1000 images - four mutual AJI values, all printed, all held to the bar.
 
 Both arithmetic modes of the product path are gated in one run: every test is parametrised over 'fp32' (fp32 activations,
 split-bf16 x3 MFMA products - the like-for-like mode) and 'bf16' (cdnet_amd.set_precision, restored afterwards).  The gate
@@ -37,7 +38,7 @@ BF16_MEAN_MIN = AJI_MIN
 GT_DELTA_MAX = 0.002
 
 
-def _train(precision, steps=300, B=8, seed=0):
+def _train(precision, steps=300, B=8, seed=0, data_seed=100):
     import torch
     import cdnet_amd
     from cdnet_amd import synth, trainer
@@ -49,7 +50,7 @@ def _train(precision, steps=300, B=8, seed=0):
     dev = torch.device('cuda:0')
     batches = []
     for k in range(4):
-        x, lab, dirn, point, weight, _ = synth.nuclei_batch(B, 128, 128, 100 + k, n=22)
+        x, lab, dirn, point, weight, _ = synth.nuclei_batch(B, 128, 128, data_seed + k, n=22)
         batches.append([torch.from_numpy(a).to(dev) for a in (x, lab, dirn, point, weight)])
     first = last = None
     for s in range(steps):
@@ -101,6 +102,22 @@ def gate_net():
     for k, v in sorted(m.state_dict().items()):
         crc = zlib.crc32(v.detach().cpu().contiguous().numpy().tobytes(), crc)
     print('label gate network: 300 fp32-mode steps, seed 0, weights crc32 %08x' % crc)
+    yield m, _oracle_of(m), crc
+    cdnet_amd.set_precision(before)
+
+
+@pytest.fixture(scope='module')
+def gate_net2():
+    """a second draw of the gate network: another initialisation seed, other training batches"""
+    import zlib
+    import cdnet_amd
+    before = cdnet_amd.get_precision()
+    m = _train('fp32', seed=1, data_seed=500)
+    m.eval()
+    crc = 0
+    for k, v in sorted(m.state_dict().items()):
+        crc = zlib.crc32(v.detach().cpu().contiguous().numpy().tobytes(), crc)
+    print('label gate network 2: 300 fp32-mode steps, seed 1, weights crc32 %08x' % crc)
     yield m, _oracle_of(m), crc
     cdnet_amd.set_precision(before)
 
@@ -203,3 +220,41 @@ def test_dense_touching_nuclei_boost(trained):
     (ga, gd), (wa, wd) = _score('dense vs truth (HIP)', r['final'][0].cpu().numpy(), inst[0], 60), _score('dense vs truth (oracle)', w['final'], inst[0], 60)
     print('label gate [%s] dense tile vs ground truth: AJI %.5f (oracle %.5f), Dice %.5f (oracle %.5f)' % (prec, ga, wa, gd, wd))
     assert abs(ga - wa) <= GT_DELTA_MAX and abs(gd - wd) <= GT_DELTA_MAX, (prec, ga, wa, gd, wd)
+
+
+def test_second_draw(gate_net, gate_net2):
+    """the bf16 bar on more than one draw (round 4 cleared it by 0.0007 on ONE network and ONE image): two networks (training seeds 0 / 1,
+    different batches) x two 1000x1000 images (seeds 4242 / 9191), 8 TTA views x 25 windows each - all four mutual AJI / Dice values of the
+    bf16 path against the fp32 CPU oracle are printed and held to the bar; fp32 mode must give identical label maps on all four"""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import pipeline, synth
+    from oracle import infer as oinf
+    before = cdnet_amd.get_precision()
+    rows = []
+    try:
+        for ni, (m, ref, crc) in enumerate((gate_net, gate_net2)):
+            for seed in (4242, 9191):
+                rs = np.random.RandomState(seed)
+                inst = synth.ellipse_instances(1000, 1000, 700, rs, 5, 14, 10)
+                img = synth.render_nuclei(inst, rs)
+                key = 'image' if (ni == 0 and seed == 4242) else ('image', ni, seed)
+                w = _oracle(key, lambda: oinf.infer_image(ref, img, tta=True, all_img_test=0, patch_size=256, overlap=40))
+                for prec in ('fp32', 'bf16'):
+                    cdnet_amd.set_precision(prec)
+                    with torch.no_grad():
+                        r = pipeline.infer_image(m, torch.from_numpy(img).cuda(), tta=True, all_img_test=0, patch_size=256, overlap=40)
+                    got = r['final'].cpu().numpy()
+                    aji, dice = _score('net %d image %d' % (ni, seed), got, w['final'], 200)
+                    (ga, gd), (wa, wd) = _score('vs truth (HIP)', got, inst, 200), _score('vs truth (oracle)', w['final'], inst, 200)
+                    rows.append((ni, crc, seed, prec, aji, dice, ga, wa, int(r['count']), int(w['count'])))
+                    print('label gate draw: network %d (crc32 %08x) image seed %d [%s]: mutual AJI %.5f Dice %.5f; vs truth AJI %.5f (oracle %.5f); '
+                          'instances %d/%d' % rows[-1])
+    finally:
+        cdnet_amd.set_precision(before)
+    for ni, crc, seed, prec, aji, dice, ga, wa, n_g, n_w in rows:
+        if prec == 'fp32':
+            assert aji == 1.0 and dice == 1.0, (ni, seed, aji, dice)                   # identical label maps
+        else:
+            assert aji >= AJI_MIN and dice >= DICE_MIN, (ni, seed, aji, dice)
+        assert abs(ga - wa) <= GT_DELTA_MAX, (ni, seed, prec, ga, wa)

@@ -145,3 +145,43 @@ def test_linearised_network_gradients_tight():
     worst = min(cos, key=cos.get)
     assert cos[worst] > 0.97, (worst, cos[worst])
     assert np.median(list(cos.values())) > 0.995
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_cfg1_at_its_own_size(precision):
+    """BASELINE config 1 as named: plain UNet, 4 x 256x256x3 tiles (models/unet.py:53-106, train_util.py:58-200) - the 512 -> 1024 -> 1024 middle
+    runs on 16x16 pixels here (4x4 at the fixture size of the other tests).  The first step's loss against the fp32 CPU oracle on the same
+    weights and batch; the step is deterministic bit for bit (two trainers from the same state); five Adam steps learn."""
+    import torch
+    import cdnet_amd
+    from cdnet_amd import trainer
+    from cdnet_amd.models.unet import UNet
+    from oracle import models as om
+    from oracle import train as ot
+    before = cdnet_amd.get_precision()
+    cdnet_amd.set_precision(precision)
+    try:
+        dev = torch.device('cuda:0')
+        torch.manual_seed(3)
+        ref = om.UNet(3)
+        x, lab, _, _, weight = trainer.synthetic_batch(4, torch.device('cpu'), seed=11)
+        runs = []
+        for rep in range(2):
+            m = UNet(num_classes=3)
+            m.load_state_dict(ref.state_dict())
+            tr = trainer.UNetTrainer(m.cuda())
+            xd, ld, wd = x.to(dev), lab.to(dev), weight.to(dev)
+            runs.append([tr.train_step(xd, ld, wd).clone() for _ in range(5)])
+        torch.cuda.synchronize()
+        a = torch.stack(runs[0]).cpu().numpy()
+        b = torch.stack(runs[1]).cpu().numpy()
+        assert np.array_equal(a, b), 'the 4 x 256x256 UNet step is not deterministic'
+        ref.train()
+        with torch.no_grad():
+            L = ot.unet_losses(ref(x), lab, weight)
+        want = [float(L['total']), float(L['ce']), float(L['dice'])]
+        np.testing.assert_allclose(a[0], want, rtol=2e-4 if precision == 'fp32' else 3e-3)
+        assert a[-1, 0] < a[0, 0], a[:, 0]
+        print('cfg 1 [%s] 4 x 256x256: loss %.5f (oracle %.5f) -> %.5f after 5 steps' % (precision, a[0, 0], want[0], a[-1, 0]))
+    finally:
+        cdnet_amd.set_precision(before)
