@@ -367,6 +367,11 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at communicator creation)
+    # goes to stderr - file descriptor 1 points at stderr until the line is printed
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -383,7 +388,9 @@ def main():
     if mode == 'roofline':
         # exactly the measurement that fills the `roofline` object of the normal run, alone in the process, so that
         # `rocprofv3 --kernel-trace --stats -- python3 bench.py --mode roofline` averages this kernel and nothing else
-        print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps, precision=a.dtype)}))
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
+        print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps, precision=a.dtype)}), flush=True)
         return
 
     def timed(step, steps, warmup, settle_s=1.0):
@@ -475,10 +482,12 @@ def main():
                                        'its time is the centre search (8 rays x 30 dependent fp64 bisection gathers per nucleus pixel) and the '
                                        'labelling passes - latency-bound work, priced against HBM only because the path has no other roof'))
 
-    def run_train_e2e(precision, B, steps, warmup):
+    def run_train_e2e(precision, B, steps, warmup, prefetch):
         """the training step WITH its input pipeline's device part: target generation of the batch (label_encoding_batch, as
-        cdnet_amd/data_folder.py runs it per batch) + train_step, per iteration.  side=True: the targets of batch i + 1 are generated on the
-        probed side stream beside the step of batch i (double-buffered), as a prefetching loader would"""
+        cdnet_amd/data_folder.py runs it per batch) + train_step, per iteration.  prefetch=False: both on the compute stream, one after the
+        other.  prefetch=True: the targets of batch i + 1 are generated on the probed side stream while the step of batch i runs (double
+        buffering, what a prefetching loader does); every iteration still generates one batch of targets and the closing synchronize covers
+        both streams"""
         from cdnet_amd.my_transforms_direction import label_encoding_batch
         cdnet_amd.set_precision(precision)
         tr = trainer.Trainer(new_model(), world_size=world)
@@ -488,13 +497,35 @@ def main():
         def targets():
             l3, point, dirn = label_encoding_batch(lab0)
             return torch.div(l3, 127, rounding_mode='floor'), dirn, point         # {0,127,255} -> {0,1,2} (train_util_dam.py:107-108)
+        if not prefetch:
+            def step():
+                lab, dirn, point = targets()
+                tr.train_step(x, lab, dirn, point, weight)
+        else:
+            side = streams.side_stream(dev)
+            state = {}
 
-        def step():
-            lab, dirn, point = targets()
-            tr.train_step(x, lab, dirn, point, weight)
+            def produce():
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)                            # (lab0 and the allocator's blocks are the compute stream's)
+                with torch.cuda.stream(side):
+                    t = targets()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                for q in t:
+                    q.record_stream(main)                         # (made on the side stream, read by the step on the compute stream)
+                state['next'] = (t, ev)
+            produce()
+
+            def step():
+                (lab, dirn, point), ev = state['next']
+                torch.cuda.current_stream().wait_event(ev)
+                produce()                                         # batch i + 1's targets: queued before step i, run beside it
+                tr.train_step(x, lab, dirn, point, weight)
         dt = timed(step, steps, warmup)
         return dict(value=world * B * steps / dt, unit='tiles/s', ms_per_step=dt / steps * 1e3, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup,
-                    dtype=precision, workload='label_encoding_batch (CDM generation of the batch on the device) + train_step per iteration, same stream')
+                    dtype=precision, workload='label_encoding_batch (CDM generation of one batch on the device) + train_step per iteration; ' +
+                    ('targets of batch i + 1 generated on a second stream beside step i (prefetching loader)' if prefetch else 'same stream, one after the other'))
 
     def run_unet_cfg1(precision, B, steps, warmup):
         """BASELINE config 1 at its own size: plain UNet (models/unet.py:53-106) train step, 4 x 256x256x3 tiles"""
@@ -602,8 +633,10 @@ def main():
         line['image_postproc'] = run_image_postproc(10, 2)
         # SURVEY 8a-9 / VERDICT r04 #5: the target generation timed alone and inside the step
         line['cdm'] = run_cdm(B, 20, 3)
-        e2e = run_train_e2e(a.dtype, B, max(5, a.steps // 2), 2)
+        e2e = run_train_e2e(a.dtype, B, max(5, a.steps // 2), 2, prefetch=True)
         e2e['vs_value'] = e2e['value'] / head['value']
+        e2s = run_train_e2e(a.dtype, B, max(5, a.steps // 2), 2, prefetch=False)
+        e2e['serial'] = {'value': e2s['value'], 'ms_per_step': e2s['ms_per_step'], 'vs_value': e2s['value'] / head['value'], 'workload': e2s['workload']}
         line['train_e2e'] = e2e
         # BASELINE config 1 at its own size
         line['unet_cfg1'] = run_unet_cfg1(a.dtype, 4, 10, 2)
@@ -628,7 +661,10 @@ def main():
                 line['cpu_baseline_cdm'] = cpu_baseline_cdm()
                 line['cpu_baseline_image_postproc'] = cpu_baseline_image_postproc()
                 line['cpu_baseline_unet_cfg1'] = cpu_baseline_unet()
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist.is_initialized():
         dist.barrier()                    # rank 0 times the roofline kernel after the timed region: leave together
         dist.destroy_process_group()

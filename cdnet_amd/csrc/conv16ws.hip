@@ -43,6 +43,23 @@ using namespace cdnet;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
+#ifdef CDNET_WS_STAMPS
+// debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS, tools/ws16_stamps.py): wall-clock stamps (100 MHz) of consumer wave 0 and mover wave 4
+// of ONE workgroup over a window of barrier intervals in the middle of its run, parked in LDS (6 KB behind the kernel's own) and dumped at the
+// end; the production build carries none of it
+__device__ unsigned long long g_ws16_stamps[3 * 1024];      // consumer stamps from 0, mover (loader) stamps from 1024, storer stamps (SPLIT) from 2048 (255 each + a zero)
+extern "C" __attribute__((visibility("default"))) int cdnet_debug_ws16_stamps(unsigned long long *dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws16_stamps), sizeof(g_ws16_stamps)) == hipSuccess ? 0 : 1;
+}
+#define W16_STAMP(id) do { if (stamp_on && stamp_iv >= stamp_i0 && sn < 255) { s_stamp[sn++] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(id); } } while (0)
+#define W16_STAMP_NEXT() do { ++stamp_iv; } while (0)
+#define W16_STAMP_BYTES (3 * 256 * 8)
+#else
+#define W16_STAMP(id) do { } while (0)
+#define W16_STAMP_NEXT() do { } while (0)
+#define W16_STAMP_BYTES 0
+#endif
+
 namespace {
 
 template <int BN>
@@ -78,12 +95,23 @@ __device__ __forceinline__ int sigma32(int m) { return (m & ~12) | ((m & 4) << 1
 // barrier interval.  Same FLOP per cycle and per LDS byte as 32x32x16, but the chip holds a higher clock on it under load (tools/micro/
 // mfma_shapes.hip: 1.52 vs 1.36 PFLOP/s on random operands, 1.62 vs 1.58 on zeros).  Another summation order inside an MFMA: the outputs agree
 // with conv_fwd_kernel to the last bf16 bit or two, not bit for bit.
-template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false>
+// SPLIT (round 5; out-image form, resident weights, plain sources): waves 4, 5 LOAD (halo requests, ring writes), waves 6, 7 STORE (out image ->
+// HBM).  Stamped (tools/ws16_stamps.py, profiles/r05/): with all four movers doing both, a mover's interval was wait + ring writes 0.9 us, THEN
+// 1.15 us stalled in the issue of its four stores (the write path takes a CU's 16 KB per interval at the rate HBM drains it beside the reads),
+// the consumers waiting 0.5 us of every 2.4 at the barrier; the two kinds of work wait on different things and a wave can only wait on one.
+// PAIR (round 5; every chunk of a pair from one source, i.e. even chunk counts per source): a halo request covers a PAIR of chunks - 32 channels =
+// 64 contiguous bytes of a pixel = one whole request to the memory side - instead of one chunk's 32 bytes.  Measured at 64 tiles (1.07 GB, beyond
+// every cache): with 32-byte pieces the L1 sent 1.26 GB of 64-byte read requests to the L2 for 0.68 GB of halo bytes and the L2 fetched 0.86 GB from
+// HBM for the layer's 0.54 GB input (profiles/r05/ws16_pmc_64tiles.txt) - the launch was bound by its own over-fetch.  Register set R of a pair
+// holds half of the pair's vectors (lane -> pixel v / 4, 16-byte segment v % 4: chunk (v % 4) / 2 of the pair, k-half v % 2); both sets are
+// written into the pair's two ring slots in the same interval, as before.
+template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false, bool SPLIT = false, bool PAIR = false>
 __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using L = W16Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
-    constexpr int VPP = CK / 8, NA = (NPIX * VPP + 255) / 256;
+    constexpr int NMV = SPLIT ? 128 : 256;                        // threads that load (SPLIT: waves 4, 5)
+    constexpr int VPP = CK / 8, NA = (NPIX * VPP + NMV - 1) / NMV;
     constexpr int PF = PFD;
     constexpr int A_BYTES = L::A_IMG;                             // halo ring slot stride
     constexpr int IPG = PF / 2;                                   // barrier intervals per iteration of the movers' loop
@@ -91,6 +119,8 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     static_assert(!OUT || NCS == 0, "LDS out image: tiles of an even number (>= 4) of chunks");
     static_assert(!K32 || OUT, "the 16x16x32 consumers serve the out-image form");
     static_assert(NS == 4 && PF % 4 == 0, "a four-slot halo ring, register sets = slots mod 4");
+    static_assert(!SPLIT || (OUT && !STREAM && XF == 0), "loader / storer waves: the out-image form with resident weights and plain sources");
+    static_assert(!PAIR || NCS == 0, "pair requests: tiles of an even number (>= 4) of chunks");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
 
@@ -130,22 +160,34 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     const int S = ntl * NCH;                                      // chunks of this workgroup's run
     if (S == 0) return;
     const int NI = (S + 1) >> 1;                                  // barrier intervals: two run chunks each
+#ifdef CDNET_WS_STAMPS
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(lds_o + (OUT ? L::OUT_BYTES : 0)) + (wave >= 6 ? 512 : (wave >= 4 ? 256 : 0));
+    const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4 || (SPLIT && wave == 6));
+    const int stamp_i0 = NI > 80 ? NI / 2 - 24 : 0;
+    int sn = 0, stamp_iv = 0;
+#endif
 
     if (wave >= 4) {
         // ================================ movers (conv_ws_kernel's, without the out path) ================================
         const int ptid = tid - 256, pw = wave - 4;
         if (A.debug & 16) __builtin_amdgcn_s_setprio(2);         // (experiment: the younger half of the workgroup loses the issue arbitration at equal priority)
-        const int slot = ptid % VPP;
+        constexpr int VPQ = PAIR ? 2 * VPP : VPP;                 // 16-byte vectors per halo pixel of a request group (PAIR: a pair of chunks)
+        constexpr int NG = PAIR ? 2 : 1;                          // register-set groups that share one lane -> (pixel, segment) map
+        const int slot = ptid % VPQ;                              // this thread's 16-byte segment (PAIR: chunk slot >> 1 of the pair, k-half slot & 1)
+        const int khalf = slot & 1, c2 = slot >> 1;
         u32x4v pa[PF][NA];
         unsigned eo[XF != 0 ? PF : 1][NA];       // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
-        int hyx[NA], doff[NA];
+        int hyx[NG][NA], doff[NG][NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int pix = (ptid + i * 256) / VPP;
-            const int hy = pix / HW_, hx = pix - hy * HW_;
-            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 8) | hx) : 0x1f1f;
-            doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
-        }
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int v = ptid + (g * NA + i) * NMV;
+                const int pix = v / VPQ;
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                hyx[g][i] = v < NPIX * VPQ ? ((hy << 8) | hx) : 0x1f1f;
+                doff[g][i] = pix * PSTR + ((khalf ^ (hy & 1)) * 16);
+            }
         const unsigned src_bytes0 = (unsigned)A.N * A.src[0].Hs * (A.src[0].row_stride ? A.src[0].row_stride : A.src[0].Ws * A.src[0].C) * 2u;
         const unsigned src_bytes1 = A.nsrc > 1 ? (unsigned)A.N * A.src[1].Hs * (A.src[1].row_stride ? A.src[1].row_stride : A.src[1].Ws * A.src[1].C) * 2u : 0u;
         const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(A.src[0].x), 0, (int)src_bytes0, 0x00020000);
@@ -167,16 +209,19 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             iy0 = ty * TH; ix0 = (r - ty * tiles_x) * TW;
         }
         int ck = 0;
-        unsigned ge[NA];
+        unsigned ge[NG][NA];
         auto chunk_src = [&](int k, int &si, int &cc0) {
+            if (PAIR) k &= ~1;                                    // (the pair's first chunk: both register sets of a pair request from its base)
             if (k < n0) { si = 0; cc0 = k * CK; } else { si = 1; cc0 = (k - n0) * CK; }
         };
         auto issue = [&](auto rc) {
             constexpr int R = decltype(rc)::value;
+            constexpr int G = PAIR ? (R & 1) : 0;                 // PAIR: which half of the pair's vectors this register set holds
             int si, cc0;
             chunk_src(ik, si, cc0);
             const ConvSrc &s = A.src[si];
-            if (ik == 0 || ik == n0) {
+            const int ikb = PAIR ? (ik & ~1) : ik;
+            if (ikb == 0 || ikb == n0) {
                 const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
                 const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
                 const int xlo = s.off_x > 0 ? s.off_x : 0, xhi = A.W < s.off_x + s.Ws ? A.W : s.off_x + s.Ws;
@@ -185,16 +230,16 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 const unsigned rs_b = (unsigned)rs * 2u, c_b = (unsigned)s.C * 2u;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const unsigned hy = (unsigned)hyx[i] >> 8, hx = (unsigned)hyx[i] & 0xffu;
+                    const unsigned hy = (unsigned)hyx[G][i] >> 8, hx = (unsigned)hyx[G][i] & 0xffu;
                     const unsigned t = (rowbad >> hy) | (colbad >> hx);
-                    ge[i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 16u) & 0x7fffffffu) | (t << 31);
+                    ge[G][i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 16u) & 0x7fffffffu) | (t << 31);
                 }
             }
             const __amdgpu_buffer_rsrc_t rsx = si ? rsx1 : rsx0;
             const unsigned cc0_b = (unsigned)cc0 * 2u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const unsigned voff = ge[i] + cc0_b;
+                const unsigned voff = ge[G][i] + cc0_b;
                 if (XF != 0) eo[R][i] = voff;
                 if (!(A.debug & 2)) pa[R][i] = bload(rsx, voff);     // (2: ablation - no halo requests)
             }
@@ -220,7 +265,9 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            unsigned char *dst0 = lds_a + (R & 3) * A_BYTES;
+            constexpr int G = PAIR ? (R & 1) : 0;
+            // (PAIR: this thread's vectors belong to chunk c2 of the pair - ring slot (R & 2) + c2 - whichever of the pair's two sets R is)
+            unsigned char *dst0 = lds_a + (PAIR ? ((R & 2) + c2) : (R & 3)) * A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -241,8 +288,8 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                     const unsigned keep = (int)eo[R][i] < 0 ? 0u : 0xffffffffu;      // outside the image / source: zeros (after the transform)
                     val &= keep;
                 }
-                if (i < NA - 1 || ptid + i * 256 < NPIX * VPP)
-                    *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val;
+                if (ptid + (G * NA + i) * NMV < NPIX * VPQ)
+                    *reinterpret_cast<u32x4v *>(dst0 + doff[G][i]) = val;
             }
         };
         // STREAM: weight chunk wk of the tile -> weight slot (run chunk & 3) by LDS-DMA (the packed chunk is the LDS image)
@@ -292,11 +339,15 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             for (int j = 0; j < 8; ++j) dot_w8[j] = c8 + j < A.Cout ? A.dot_w[c8 + j] : 0.f;
             dot_b0 = A.dot_b ? A.dot_b[0] : 0.f;
         }
-        auto store_half = [&](int hf, int tn, int ty0, int tx0) {
+        auto store_half = [&](int hf, int tn, int ty0, int tx0) __attribute__((always_inline)) {
+            // the block of consumer wave bw leaves; SPLIT: storer wave k (6, 7) carries the blocks of consumer waves 2k, 2k + 1 (a run-time loop:
+            // one copy of the body)
+            for (int bi = 0; bi < (SPLIT ? 2 : 1); ++bi) {
+            const int bw = SPLIT ? 2 * (wave - 6) + bi : pw;
             constexpr int SPP = BN / 8;                          // 16-byte segments per pixel
             constexpr int PPR = 64 / SPP, NR = 32 / PPR;         // pixels per wave-instruction, instructions per block
             const int seg = lane % SPP, lp = lane / SPP;
-            const unsigned char *blk = lds_o + hf * L::OHALF + pw * L::OBLK + seg * 16;
+            const unsigned char *blk = lds_o + hf * L::OHALF + bw * L::OBLK + seg * 16;
             u32x4v v[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) v[r] = *reinterpret_cast<const u32x4v *>(blk + (r * PPR + lp) * L::OROW);
@@ -305,7 +356,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const int px = r * PPR + lp;
-                    unsigned short *dstp = A.out + (((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)) * A.out_cstride + A.out_coff + cout0 + seg * 8;
+                    unsigned short *dstp = A.out + (((size_t)tn * A.H + ty0 + bw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)) * A.out_cstride + A.out_coff + cout0 + seg * 8;
                     if (ok) *reinterpret_cast<u32x4v *>(dstp) = v[r];
                 }
             }
@@ -326,7 +377,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                     for (int o = 1; o < SPP; o <<= 1) sd += __shfl_xor(sd, o);
                     const int px = r * PPR + lp;
                     if (seg == 0 && !(A.debug & 8))
-                        A.dot_out[((size_t)tn * A.H + ty0 + pw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)] = sd + dot_b0;
+                        A.dot_out[((size_t)tn * A.H + ty0 + bw * 4 + hf * 2 + (px >> 4)) * A.W + tx0 + (px & 15)] = sd + dot_b0;
                 }
             }
             if (A.pool_out) {
@@ -345,9 +396,10 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                     for (int k = 0; k < 4; ++k) o.w[k] = (unsigned)__shfl_xor((int)m.w[k], SPP);
                     m.u = xf_max_nonneg_bf8(m.u, o.u);
                     const int px = r * PPR + lp;                 // column of this lane's pixel inside the tile
-                    unsigned short *dstp = A.pool_out + (((size_t)tn * Hp + ((ty0 + pw * 4 + hf * 2) >> 1)) * Wp + ((tx0 + px) >> 1)) * A.Cout + cout0 + seg * 8;
+                    unsigned short *dstp = A.pool_out + (((size_t)tn * Hp + ((ty0 + bw * 4 + hf * 2) >> 1)) * Wp + ((tx0 + px) >> 1)) * A.Cout + cout0 + seg * 8;
                     if (ok && !(lp & 1)) *reinterpret_cast<u32x4v *>(dstp) = __builtin_bit_cast(u32x4v, m.u);
                 }
+            }
             }
         };
         // called once per mover interval iv (the consumers' interval); stores what the consumers parked in interval iv - 1
@@ -387,8 +439,36 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         auto for_sets = [&](auto f) {                            // f(integral_constant<int, k>) for k = 0 .. PF - 1
             [&]<int... K>(std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }(std::make_integer_sequence<int, PF>{});
         };
+        if constexpr (SPLIT) {
+            if (wave >= 6) {
+                // ================================ storers (SPLIT) ================================
+                // interval i: what the consumers parked in interval i - 1 (half a tile: the blocks of two consumer waves per storer wave)
+                // leaves as whole 128-byte lines; this wave may sit in the issue of its stores for most of the interval - nobody waits
+                // for it before the barrier
+                __syncthreads();                                 // B0
+                __syncthreads();                                 // B1
+                const int NIP = (NI + IPG - 1) / IPG * IPG;      // (the loaders' loop runs whole groups of IPG intervals)
+                for (int i = 0; i < NIP; ++i) {
+                    W16_STAMP(21);
+                    store_prev(i);
+                    W16_STAMP(22);
+                    lds_sync();
+                    W16_STAMP(23); W16_STAMP_NEXT();
+                }
+                store_prev(NIP);                                 // what the consumers parked in the very last interval
+                lds_sync();                                      // E
+                lds_sync();                                      // F
+                const int tl = t_hi - 1, ln = tl / tiles_img, lr = tl - ln * tiles_img, lty = lr / tiles_x;
+                store_half(0, ln, lty * TH, (lr - lty * tiles_x) * TW);
+                store_half(1, ln, lty * TH, (lr - lty * tiles_x) * TW);
+#ifdef CDNET_WS_STAMPS
+                if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws16_stamps[2048 + i] = s_stamp[i]; g_ws16_stamps[2048 + sn] = 0; }
+#endif
+                return;
+            }
+        }
         for_sets([&](auto k) { issue(k); });
-        for (int c = ptid; c < ctot; c += 256) {
+        for (int c = ptid; c < ctot; c += NMV) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
             const int cc = c < c0n ? c : c - c0n;
             s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
@@ -414,9 +494,11 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                     using SA = std::integral_constant<int, RA>;
                     using SB = std::integral_constant<int, RB>;
                     if (!STREAM) {
-                        commit(SA{}, qa); issue(SA{}); commit(SB{}, qa + 1); issue(SB{});
-                        store_prev(i0 + M);
+                        W16_STAMP(1); commit(SA{}, qa); W16_STAMP(2); issue(SA{}); commit(SB{}, qa + 1); issue(SB{}); W16_STAMP(3);
+                        if constexpr (!SPLIT) store_prev(i0 + M);
+                        W16_STAMP(4);
                         if (OUT) lds_sync(); else __syncthreads();
+                        W16_STAMP(5); W16_STAMP_NEXT();
                     } else {
                         commit(SA{}, qa); commit(SB{}, qa + 1);
                         dma_w(); dma_w();
@@ -440,7 +522,10 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 }(), ...);
             }(std::make_integer_sequence<int, IPG>{});
         }
-        if (OUT) {
+        if (OUT && SPLIT) {
+            lds_sync();                                          // E, F: the storers' (above)
+            lds_sync();
+        } else if (OUT) {
             store_prev((NI + IPG - 1) / IPG * IPG);              // what the consumers parked in the very last interval
             lds_sync();                                          // E: this wave's reads of the out image are done - the consumers park the last tile
             lds_sync();                                          // F: ... both halves of it are in the image
@@ -448,6 +533,9 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             store_half(0, ln, lty * TH, (lr - lty * tiles_x) * TW);
             store_half(1, ln, lty * TH, (lr - lty * tiles_x) * TW);
         }
+#ifdef CDNET_WS_STAMPS
+        if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws16_stamps[1024 + i] = s_stamp[i]; g_ws16_stamps[1024 + sn] = 0; }
+#endif
         return;
     }
 
@@ -760,7 +848,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     auto after_chunk = [&]() {
         ++q;
         qs = qs + 1 == NS ? 0 : qs + 1;
-        if ((q & 1) == 0) __syncthreads();
+        if ((q & 1) == 0) { W16_STAMP(11); __syncthreads(); W16_STAMP(12); W16_STAMP_NEXT(); } else W16_STAMP(13);
     };
     // tile j on set C; P = the finished tile j - 1: its epilogue rides in the first chunk steps
     auto tile_step = [&](auto has_prev, f32x16 (&C)[NCI][NPI], const f32x16 (&P)[NCI][NPI]) {
@@ -825,6 +913,9 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     if (q & 1) __syncthreads();                                  // the last, half-filled interval
     for (int i = NI; i % IPG != 0; ++i) __syncthreads();         // the movers' loop runs whole groups of IPG intervals
     if (tail) serial_epilogue(accB); else serial_epilogue(accA);
+#ifdef CDNET_WS_STAMPS
+    if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws16_stamps[i] = s_stamp[i]; g_ws16_stamps[sn] = 0; }
+#endif
 }
 
 }  // namespace
@@ -856,8 +947,9 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     // or six beside the one-tap chunks' extra weights
     const int ns = 4;
     static const int out_env = getenv("CDNET_WS16_OUT") ? atoi(getenv("CDNET_WS16_OUT")) : 1;
-    const bool out = out_env && nch >= 4 && !(nch & 1) && L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, true) <= 160 * 1024;
-    const int smem = L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, out);
+    // (the out-image form requests its halo by chunk PAIRS: every pair from one source)
+    const bool out = out_env && nch >= 4 && !(nch & 1) && !(n0 & 1) && L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, true) + W16_STAMP_BYTES <= 160 * 1024;
+    const int smem = L::bytes(ns, stream ? 4 * L::WCH9 : wres, ctot, out) + W16_STAMP_BYTES;
     if (smem > 160 * 1024) return -1;
     if (A.pool_out && (!out || !A.orelu || A.out_coff || A.out_cstride != A.Cout)) return -1;      // the fused 2x2 max-pool rides in the movers' store path
     if (A.dot_out && (!out || stream || A.pool_out || A.Cout > BN || A.out_coff || !A.dot_w)) return -1;      // ... and so does the fused 1x1 classifier
@@ -881,8 +973,12 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
     if (G < 1) G = 1;
     if (dry_run) return CDNET_OK;
     dim3 grid(G, ctiles, 1);
+#ifndef CDNET_WS16_PAIR_DEFAULT
+#define CDNET_WS16_PAIR_DEFAULT 1
+#endif
     auto go = [&](auto xf_c, auto sm_c, auto mx_c, auto ncs_c, auto pf_c) -> int {
         constexpr int XF = decltype(xf_c)::value;
+        constexpr bool PAIR_ = CDNET_WS16_PAIR_DEFAULT != 0;    // (A/B builds: tools/build_variant.sh nopair "-DCDNET_WS16_PAIR_DEFAULT=0" conv16ws.hip)
         constexpr bool OUTOK = decltype(ncs_c)::value == 0;
         if constexpr (OUTOK) {
             if (out) {
@@ -893,7 +989,7 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
                 // bound by its traffic and does not gain (80 vs 75 us at 16 tiles, 320 vs 322 us at 64); the one-tap form spilled.
                 static const int k32_env = getenv("CDNET_WS16_K32") ? atoi(getenv("CDNET_WS16_K32")) : 1;
                 if constexpr (STREAM_) if (k32_env) {
-                    auto kern_k = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, true>;
+                    auto kern_k = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, true, false, PAIR_>;
                     static bool attr_k = false;
                     if (!attr_k) {
                         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -903,7 +999,21 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
                     kern_k<<<grid, 512, smem, st>>>(A);
                     return check_launch("conv_ws16_kernel(k32)");
                 }
-                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true>;
+                // resident weights, plain sources: two loader + two storer waves (SPLIT) - an experiment, off by default (CDNET_WS16_SPLIT=1):
+                // measured 600 vs 405 us at 64 tiles on a box whose launch was bound by its read requests (two loader waves issue them slower than four)
+                static const int split_env = getenv("CDNET_WS16_SPLIT") ? atoi(getenv("CDNET_WS16_SPLIT")) : 0;
+                if constexpr (!STREAM_ && XF == 0) if (split_env) {
+                    auto kern_s = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, true, PAIR_>;
+                    static bool attr_s = false;
+                    if (!attr_s) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                            return check_launch("hipFuncSetAttribute(conv_ws16 split)");
+                        attr_s = true;
+                    }
+                    kern_s<<<grid, 512, smem, st>>>(A);
+                    return check_launch("conv_ws16_kernel(split)");
+                }
+                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, false, PAIR_>;
                 static bool attr_o = false;
                 if (!attr_o) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_o), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

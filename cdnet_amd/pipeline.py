@@ -50,7 +50,7 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
         if post_stream is not None:
             r['done'] = torch.cuda.Event()
             r['done'].record(post_stream)
-    if post_stream is None:
+    if post_stream is None and not torch.cuda.is_current_stream_capturing():      # (inside a HIP-graph capture nothing may synchronise: the flag stays for the caller)
         check_tiles(r)
     return r
 

@@ -1,0 +1,31 @@
+"""A/B of the dominant 16-bit layers with the loader / storer split of conv_ws16_kernel on and off (two child processes per setting would see two
+clock states; this runs both settings in ONE process by launching through two library builds... the switch is read once per process, so:
+   for S in 0 1; do CDNET_WS16_SPLIT=$S python tools/ab_ws16_split.py; done"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cdnet_amd import engine
+dev = torch.device('cuda:0')
+print('CDNET_WS16_SPLIT=%s lib=%s' % (os.environ.get('CDNET_WS16_SPLIT', '(default 0)'), os.path.basename(os.environ.get('CDNET_LIB_PATH', 'libcdnet_hip.so'))))
+for B in (16, 64):
+    for (cin, cout, taps1) in ((64, 64, 0), (256, 256, 0)):
+        if cin == 256 and B == 64:
+            continue
+        HW = 256 if cin == 64 else 64
+        x = (torch.rand((B, HW, HW, cin), device=dev) - 0.3).to(torch.bfloat16)
+        w = torch.randn((cout, cin, 3, 3), device=dev) * 0.06
+        cfg = (16, 16, 64)
+        wp = engine.pack_weights(w, cfg, 0)
+        out = torch.empty((B, HW, HW, cout), dtype=torch.bfloat16, device=dev)
+        engine.CONV_DEBUG = 64
+        run = lambda: engine.conv_forward([engine.Src(x)], wp, cout, cfg, out=out)
+        t0, k = time.perf_counter(), 0
+        while k < 3 or time.perf_counter() - t0 < 1.0:
+            run(); k += 1
+            if k % 16 == 0: torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30): run()
+        e1.record(); torch.cuda.synchronize()
+        print('  %d tiles 3x3 %d->%d @%d: %.1f us' % (B, cin, cout, HW, e0.elapsed_time(e1) / 30 * 1e3), flush=True)
+engine.CONV_DEBUG = 0
