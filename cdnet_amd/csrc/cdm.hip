@@ -91,31 +91,74 @@ __global__ __launch_bounds__(256) void cdm_prep_inst_kernel(const int32_t *__res
     inside[o] = in1 ? 255 : 0;
 }
 
-// 3. get_centerpoint2 (:650-685): centerness of every instance pixel; per-instance maximum (double bits are monotone)
-__global__ __launch_bounds__(256) void cdm_centerness_kernel(const int32_t *__restrict__ inst, int H, int W, Rays R,
-                                                             double *__restrict__ cness, unsigned long long *__restrict__ best, int maxid) {
-    const int n = blockIdx.z;
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
-    const int32_t *s = inst + (size_t)n * H * W;
-    const int id = s[(size_t)y * W + x];
-    if (id <= 0) return;
-    double ma = 0, mi = 10000000;
-    for (int k = 0; k < 8; ++k) {
-        double l = 0, r = 1000;
-        for (int t = 0; t < 30; ++t) {
-            const double mid = (l + r) / 2;
-            const double fy = y + R.s[k] * mid, fx = x + R.c[k] * mid;        // -ffp-contract=off: mul then add, like CPython
-            const long long ny = (long long)rint(fy), nx = (long long)rint(fx);
-            const bool in = ny >= 0 && ny < H && nx >= 0 && nx < W && s[(size_t)ny * W + nx] == id;
-            if (in) l = mid; else r = mid;
+// per-instance maximum of non-negative doubles (their bit patterns order like the values): the lanes of a wave that hold the same instance
+// id combine first, ONE atomic per (wave, id) - a nucleus spans a few hundred pixels and every one of them used to hit the same address
+__device__ __forceinline__ void wave_max_to(unsigned long long *__restrict__ table, int k, unsigned long long v, bool active) {
+    const int lane = (int)(threadIdx.x + threadIdx.y * blockDim.x) & 63;      // (blocks are (64, 4) or (256, 1): a wave is 64 consecutive threads)
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lk = __shfl(k, leader);
+        const bool mine = active && k == lk;
+        unsigned long long m = mine ? v : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = ((unsigned long long)(unsigned)__shfl_xor((int)(m >> 32), o) << 32) | (unsigned)__shfl_xor((int)(m & 0xffffffffu), o);
+            m = other > m ? other : m;
         }
-        ma = r > ma ? r : ma;
-        mi = r < mi ? r : mi;
+        if (lane == leader) atomicMax(&table[lk], m);
+        todo &= ~__ballot(mine);
+        active = active && !mine;
     }
-    const double c = mi / ma;
-    cness[(size_t)n * H * W + (size_t)y * W + x] = c;
-    atomicMax(&best[(size_t)n * maxid + id], (unsigned long long)__double_as_longlong(c));
+}
+
+// 3. get_centerpoint2 (:650-685): centerness of every instance pixel; per-instance maximum (double bits are monotone)
+// the pixels that belong to an instance, appended to a per-image list (any order: the centerness of a pixel is its own, the per-instance
+// maximum does not depend on the order) - the long bisection loop then runs on full waves instead of the ~30 % of lanes a row of 64
+// pixels has inside nuclei
+__global__ __launch_bounds__(256) void cdm_list_kernel(const int32_t *__restrict__ inst, int plane, int *__restrict__ list, int *__restrict__ count) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < plane && inst[(size_t)n * plane + i] > 0;
+    const unsigned long long m = __ballot(on);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&count[n], __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (on) list[(size_t)n * plane + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+__global__ __launch_bounds__(256) void cdm_centerness_kernel(const int32_t *__restrict__ inst, const int *__restrict__ list,
+                                                             const int *__restrict__ count, int H, int W, Rays R,
+                                                             double *__restrict__ cness, unsigned long long *__restrict__ best, int maxid) {
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if ((e & ~63) >= count[n]) return;                            // (whole waves beyond the list leave)
+    const int32_t *s = inst + (size_t)n * H * W;
+    const bool on = e < count[n];
+    const int p = on ? list[(size_t)n * H * W + e] : 0;
+    const int y = p / W, x = p - y * W;
+    const int id = on ? s[p] : 0;
+    double c = 0;
+    if (on) {
+        double ma = 0, mi = 10000000;
+        for (int k = 0; k < 8; ++k) {
+            double l = 0, r = 1000;
+            for (int t = 0; t < 30; ++t) {
+                const double mid = (l + r) / 2;
+                const double fy = y + R.s[k] * mid, fx = x + R.c[k] * mid;        // -ffp-contract=off: mul then add, like CPython
+                const int ny = (int)rint(fy), nx = (int)rint(fx);                 // (|.| <= 1000 + the image size: exact in 32 bits)
+                const bool in = ny >= 0 && ny < H && nx >= 0 && nx < W && s[ny * W + nx] == id;
+                if (in) l = mid; else r = mid;
+            }
+            ma = r > ma ? r : ma;
+            mi = r < mi ? r : mi;
+        }
+        c = mi / ma;
+        cness[(size_t)n * H * W + p] = c;
+    }
+    wave_max_to(best + (size_t)n * maxid, id, (unsigned long long)__double_as_longlong(c), on);
 }
 
 // first pixel in raster order that attains the maximum (`if centerness > now`, :680)
@@ -146,44 +189,94 @@ __global__ __launch_bounds__(256) void cdm_dmax_kernel(const int32_t *__restrict
                                                        int maxid, unsigned long long *__restrict__ dmax) {
     const int n = blockIdx.z;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
+    const bool inb = x < W && y < H;
     const int32_t *s = inst + (size_t)n * H * W;
-    int ids[5];
-    ids[0] = s[(size_t)y * W + x];
-    ids[1] = y > 0 ? s[(size_t)(y - 1) * W + x] : 0;
-    ids[2] = y < H - 1 ? s[(size_t)(y + 1) * W + x] : 0;
-    ids[3] = x > 0 ? s[(size_t)y * W + x - 1] : 0;
-    ids[4] = x < W - 1 ? s[(size_t)y * W + x + 1] : 0;
+    int ids[5] = {0, 0, 0, 0, 0};
+    if (inb) {
+        ids[0] = s[(size_t)y * W + x];
+        ids[1] = y > 0 ? s[(size_t)(y - 1) * W + x] : 0;
+        ids[2] = y < H - 1 ? s[(size_t)(y + 1) * W + x] : 0;
+        ids[3] = x > 0 ? s[(size_t)y * W + x - 1] : 0;
+        ids[4] = x < W - 1 ? s[(size_t)y * W + x + 1] : 0;
+    }
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
         const int k = ids[a];
-        if (k <= 0) continue;
-        bool dup = false;
+        bool use = k > 0;
 #pragma unroll
-        for (int b = 0; b < 5; ++b) dup |= (b < a && ids[b] == k);
-        if (dup) continue;
-        const int c = center[(size_t)n * maxid + k];
-        const int cy = c / W, cx = c % W;
-        const double d = sqrt((double)(y - cy) * (y - cy) + (double)(x - cx) * (x - cx));
-        atomicMax(&dmax[(size_t)n * maxid + k], (unsigned long long)__double_as_longlong(d));
+        for (int b = 0; b < 5; ++b) use = use && !(b < a && ids[b] == k);
+        double d = 0;
+        if (use) {
+            const int c = center[(size_t)n * maxid + k];
+            const int cy = c / W, cx = c % W;
+            d = sqrt((double)(y - cy) * (y - cy) + (double)(x - cx) * (x - cx));
+        }
+        wave_max_to(dmax + (size_t)n * maxid, k, (unsigned long long)__double_as_longlong(d), use);
     }
 }
 
-// 5. the 11x11 stencil on (1 - d/(dmax+1e-7)) * nucleus of the last instance covering the pixel, then the angle bin
-__global__ __launch_bounds__(256) void cdm_direction_kernel(const uint8_t *__restrict__ in, const int32_t *__restrict__ inst, int H,
-                                                            int W, const int *__restrict__ center, const unsigned long long *__restrict__ dmax,
-                                                            int maxid, uint8_t *__restrict__ direction) {
+// 4b. per pixel q: K = the LAST instance whose dilated nucleus covers q (the largest id in its cross neighbourhood) and the normalised
+// distance value the stencil reads there, f(q; K) = (float)(1 - d(q, centre_K) / (dmax_K + 1e-7)) - computed ONCE per pixel instead of once
+// per (pixel, tap): the 11x11 stencil of a pixel p reads f(q; K_p), and K_q = K_p for every tap except where nuclei touch
+__global__ __launch_bounds__(256) void cdm_field_kernel(const int32_t *__restrict__ inst, int H, int W, const int *__restrict__ center,
+                                                        const unsigned long long *__restrict__ dmax, int maxid, int32_t *__restrict__ Kp,
+                                                        float *__restrict__ F0) {
     const int n = blockIdx.z;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
-    const size_t o = (size_t)n * H * W + (size_t)y * W + x;
-    if (!(in[o] > 127)) { direction[o] = 0; return; }                          // new_label_inside == 0 -> background (:855-865)
     const int32_t *s = inst + (size_t)n * H * W;
     int k = s[(size_t)y * W + x];
     if (y > 0) k = max(k, s[(size_t)(y - 1) * W + x]);
     if (y < H - 1) k = max(k, s[(size_t)(y + 1) * W + x]);
     if (x > 0) k = max(k, s[(size_t)y * W + x - 1]);
     if (x < W - 1) k = max(k, s[(size_t)y * W + x + 1]);
+    float f = 0.f;
+    if (k > 0) {
+        const int c = center[(size_t)n * maxid + k];
+        const int cy = c / W, cx = c % W;
+        const double dm = __longlong_as_double((long long)dmax[(size_t)n * maxid + k]) + 0.0000001;
+        const double d = sqrt((double)(y - cy) * (y - cy) + (double)(x - cx) * (x - cx));
+        f = (float)((1 - d / dm) * 1.0);
+    }
+    const size_t o = (size_t)n * H * W + (size_t)y * W + x;
+    Kp[o] = k;
+    F0[o] = f;
+}
+
+// 5. the 11x11 stencil on (1 - d/(dmax+1e-7)) * nucleus of the last instance covering the pixel, then the angle bin
+__global__ __launch_bounds__(256) void cdm_direction_kernel(const uint8_t *__restrict__ in, const int32_t *__restrict__ inst,
+                                                            const int32_t *__restrict__ Kp, const float *__restrict__ F0, int H, int W,
+                                                            const int *__restrict__ center, const unsigned long long *__restrict__ dmax,
+                                                            int maxid, uint8_t *__restrict__ direction) {
+    // the block's 4 x 64 pixels and their 5-pixel apron of (K, f) in LDS: a tap is two LDS reads and one compare
+    constexpr int WR = 4 + 10, WC = 64 + 10;
+    __shared__ int32_t sK[WR][WC + 1];
+    __shared__ float sF[WR][WC + 1];
+    __shared__ float sWy[11][11], sWx[11][11];                   // the stencil's float32 taps (float)(j / (i*i + j*j)), (float)(i / ...), once per block
+    const int n = blockIdx.z;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const size_t img = (size_t)n * H * W;
+    if (tid < 121) {
+        const int j = tid / 11 - 5, i = tid % 11 - 5;
+        const double den = (double)(i * i + j * j);
+        sWy[j + 5][i + 5] = (i == 0 && j == 0) ? 0.f : (float)(j / den);      // Sobel.kernel: float32 taps (:112-113)
+        sWx[j + 5][i + 5] = (i == 0 && j == 0) ? 0.f : (float)(i / den);
+    }
+    for (int idx = tid; idx < WR * WC; idx += 256) {
+        const int r = idx / WC, c = idx - r * WC;
+        const int yy = y0 - 5 + r, xx = x0 - 5 + c;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        sK[r][c] = ok ? Kp[img + (size_t)yy * W + xx] : -1;      // (-1: below every instance id - a tap outside the image is no member)
+        sF[r][c] = ok ? F0[img + (size_t)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t o = img + (size_t)y * W + x;
+    if (!(in[o] > 127)) { direction[o] = 0; return; }                          // new_label_inside == 0 -> background (:855-865)
+    const int32_t *s = inst + img;
+    const int k = sK[threadIdx.y + 5][threadIdx.x + 5];
     float gy = 0.f, gx = 0.f;
     if (k > 0) {
         const int c = center[(size_t)n * maxid + k];
@@ -193,15 +286,22 @@ __global__ __launch_bounds__(256) void cdm_direction_kernel(const uint8_t *__res
         for (int j = -5; j <= 5; ++j) {
             const int yy = y + j;
             if (yy < 0 || yy >= H) continue;
+#pragma unroll
             for (int i = -5; i <= 5; ++i) {
                 const int xx = x + i;
                 if (xx < 0 || xx >= W || (i == 0 && j == 0)) continue;
-                if (!in_dilated(s, H, W, yy, xx, k)) continue;
-                const double d = sqrt((double)(yy - cy) * (yy - cy) + (double)(xx - cx) * (xx - cx));
-                const float f = (float)((1 - d / dm) * 1.0);
-                const double den = (double)(i * i + j * j);
-                sy += (double)(float)(j / den) * f;                         // Sobel.kernel: float32 taps (:112-113)
-                sx += (double)(float)(i / den) * f;
+                const int kq = sK[threadIdx.y + 5 + j][threadIdx.x + 5 + i];
+                if (kq < k) continue;                               // every id around the tap is smaller: not in the dilated nucleus of k
+                float f;
+                if (kq == k) f = sF[threadIdx.y + 5 + j][threadIdx.x + 5 + i];
+                else {
+                    // a later instance also covers the tap (touching nuclei): membership and value for k itself
+                    if (!in_dilated(s, H, W, yy, xx, k)) continue;
+                    const double d = sqrt((double)(yy - cy) * (yy - cy) + (double)(xx - cx) * (xx - cx));
+                    f = (float)((1 - d / dm) * 1.0);
+                }
+                sy += (double)sWy[j + 5][i + 5] * f;
+                sx += (double)sWx[j + 5][i + 5] * f;
             }
         }
         gy = (float)sy; gx = (float)sx;
@@ -271,17 +371,26 @@ inline dim3 grid_rows(int N, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4)
 // the per-instance stage shared by both input kinds: centre search, distance normalisation, 11x11 stencil + angle bins, point map.
 // `inside_u8` (> 127 = new_label_inside) masks the classes; `counts[n]` = largest instance id of image n
 static int cdm_direction_stage(const uint8_t *label_ch0, const int32_t *inst, const int32_t *counts, int N, int H, int W, int maxid, const Rays &R,
-                               const GaussK &G, double *cness, double *tmp, unsigned long long *best, unsigned long long *dmax, int *center,
+                               const GaussK &G, double *cness, double *tmp, int *list_count, unsigned long long *best, unsigned long long *dmax, int *center,
                                uint8_t *direction, uint16_t *point_f16, int32_t *inst_out, int32_t *counts_out, hipStream_t st) {
     const dim3 gr = grid_rows(N, H, W), br(64, 4);
     const int plane = H * W;
     const size_t nk = (size_t)N * maxid;
     cdm_init_kernel<<<(unsigned)((nk + 255) / 256), 256, 0, st>>>(best, dmax, center, nk);
-    cdm_centerness_kernel<<<gr, br, 0, st>>>(inst, H, W, R, cness, best, maxid);
+    // (the list lives in the float64 scratch plane `tmp` until the K | f planes take it over; its counters in the first N ints of the
+    //  connected-component chunk table, which nothing reads any more at this point)
+    int *list = reinterpret_cast<int *>(tmp);
+    if (hipMemsetAsync(list_count, 0, (size_t)N * 4, st) != hipSuccess) return check_launch("memset list count");
+    cdm_list_kernel<<<dim3(cdiv(plane, 256), N), 256, 0, st>>>(inst, plane, list, list_count);
+    cdm_centerness_kernel<<<dim3(cdiv(plane, 256), N), 256, 0, st>>>(inst, list, list_count, H, W, R, cness, best, maxid);
     int g = cdiv(plane, 256); if (g > 1024) g = 1024;
     cdm_argmax_kernel<<<dim3(g, N), 256, 0, st>>>(inst, cness, best, plane, maxid, center);
     cdm_dmax_kernel<<<gr, br, 0, st>>>(inst, H, W, center, maxid, dmax);
-    cdm_direction_kernel<<<gr, br, 0, st>>>(label_ch0, inst, H, W, center, dmax, maxid, direction);
+    // (K | f planes: 4 + 4 bytes per pixel in the float64 scratch plane `tmp`, which the Gaussian below only needs afterwards)
+    int32_t *Kp = reinterpret_cast<int32_t *>(tmp);
+    float *F0 = reinterpret_cast<float *>(tmp) + (size_t)N * plane;
+    cdm_field_kernel<<<gr, br, 0, st>>>(inst, H, W, center, dmax, maxid, Kp, F0);
+    cdm_direction_kernel<<<gr, br, 0, st>>>(label_ch0, inst, Kp, F0, H, W, center, dmax, maxid, direction);
     // point map: impulses of 255 at the centres, separable Gaussian in float64
     if (hipMemsetAsync(cness, 0, (size_t)N * plane * 8, st) != hipSuccess) return check_launch("memset lp");
     cdm_scatter_centers_kernel<<<dim3(cdiv(maxid, 256), N), 256, 0, st>>>(center, counts, maxid, plane, cness);
@@ -344,7 +453,7 @@ extern "C" int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int 
     int rc = label8_raster(m1, N, H, W, L, aux, chunk, lab, counts, st);
     if (rc) return rc;
     cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst, maxid);
-    return cdm_direction_stage(label_ch0, inst, counts, N, H, W, maxid, R, G, cness, tmp, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
+    return cdm_direction_stage(label_ch0, inst, counts, N, H, W, maxid, R, G, cness, tmp, chunk, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
 }
 
 
@@ -395,5 +504,5 @@ extern "C" int cdnet_label_encoding_instances(const int32_t *label_inst, int N, 
     cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst, maxid);
     // every id below maxid may exist (watershed marker ids are kept, not renumbered)
     cdm_fill_counts_kernel<<<1, 64, 0, st>>>(counts, N, maxid - 1);
-    return cdm_direction_stage(inside, inst, counts, N, H, W, maxid, R, G, cness, tmp, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
+    return cdm_direction_stage(inside, inst, counts, N, H, W, maxid, R, G, cness, tmp, reinterpret_cast<int *>(ws + o[3]), best, dmax, center, direction, point_f16, inst_out, counts_out, st);
 }

@@ -47,7 +47,7 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 // debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS, tools/ws16_stamps.py): wall-clock stamps (100 MHz) of consumer wave 0 and mover wave 4
 // of ONE workgroup over a window of barrier intervals in the middle of its run, parked in LDS (6 KB behind the kernel's own) and dumped at the
 // end; the production build carries none of it
-__device__ unsigned long long g_ws16_stamps[3 * 1024];      // consumer stamps from 0, mover (loader) stamps from 1024, storer stamps (SPLIT) from 2048 (255 each + a zero)
+__device__ unsigned long long g_ws16_stamps[3 * 1024];      // consumer stamps from 0, mover stamps from 1024 (255 each + a zero; the third region served the storer waves of a removed experiment)
 extern "C" __attribute__((visibility("default"))) int cdnet_debug_ws16_stamps(unsigned long long *dst) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws16_stamps), sizeof(g_ws16_stamps)) == hipSuccess ? 0 : 1;
 }
@@ -95,22 +95,18 @@ __device__ __forceinline__ int sigma32(int m) { return (m & ~12) | ((m & 4) << 1
 // barrier interval.  Same FLOP per cycle and per LDS byte as 32x32x16, but the chip holds a higher clock on it under load (tools/micro/
 // mfma_shapes.hip: 1.52 vs 1.36 PFLOP/s on random operands, 1.62 vs 1.58 on zeros).  Another summation order inside an MFMA: the outputs agree
 // with conv_fwd_kernel to the last bf16 bit or two, not bit for bit.
-// SPLIT (round 5; out-image form, resident weights, plain sources): waves 4, 5 LOAD (halo requests, ring writes), waves 6, 7 STORE (out image ->
-// HBM).  Stamped (tools/ws16_stamps.py, profiles/r05/): with all four movers doing both, a mover's interval was wait + ring writes 0.9 us, THEN
-// 1.15 us stalled in the issue of its four stores (the write path takes a CU's 16 KB per interval at the rate HBM drains it beside the reads),
-// the consumers waiting 0.5 us of every 2.4 at the barrier; the two kinds of work wait on different things and a wave can only wait on one.
 // PAIR (round 5; every chunk of a pair from one source, i.e. even chunk counts per source): a halo request covers a PAIR of chunks - 32 channels =
 // 64 contiguous bytes of a pixel = one whole request to the memory side - instead of one chunk's 32 bytes.  Measured at 64 tiles (1.07 GB, beyond
 // every cache): with 32-byte pieces the L1 sent 1.26 GB of 64-byte read requests to the L2 for 0.68 GB of halo bytes and the L2 fetched 0.86 GB from
 // HBM for the layer's 0.54 GB input (profiles/r05/ws16_pmc_64tiles.txt) - the launch was bound by its own over-fetch.  Register set R of a pair
 // holds half of the pair's vectors (lane -> pixel v / 4, 16-byte segment v % 4: chunk (v % 4) / 2 of the pair, k-half v % 2); both sets are
 // written into the pair's two ring slots in the same interval, as before.
-template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false, bool SPLIT = false, bool PAIR = false>
+template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false, bool PAIR = false>
 __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using L = W16Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
-    constexpr int NMV = SPLIT ? 128 : 256;                        // threads that load (SPLIT: waves 4, 5)
+    constexpr int NMV = 256;                                      // mover threads
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + NMV - 1) / NMV;
     constexpr int PF = PFD;
     constexpr int A_BYTES = L::A_IMG;                             // halo ring slot stride
@@ -119,7 +115,6 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     static_assert(!OUT || NCS == 0, "LDS out image: tiles of an even number (>= 4) of chunks");
     static_assert(!K32 || OUT, "the 16x16x32 consumers serve the out-image form");
     static_assert(NS == 4 && PF % 4 == 0, "a four-slot halo ring, register sets = slots mod 4");
-    static_assert(!SPLIT || (OUT && !STREAM && XF == 0), "loader / storer waves: the out-image form with resident weights and plain sources");
     static_assert(!PAIR || NCS == 0, "pair requests: tiles of an even number (>= 4) of chunks");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
@@ -162,7 +157,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     const int NI = (S + 1) >> 1;                                  // barrier intervals: two run chunks each
 #ifdef CDNET_WS_STAMPS
     unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(lds_o + (OUT ? L::OUT_BYTES : 0)) + (wave >= 6 ? 512 : (wave >= 4 ? 256 : 0));
-    const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4 || (SPLIT && wave == 6));
+    const bool stamp_on = blockIdx.x == 17 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
     const int stamp_i0 = NI > 80 ? NI / 2 - 24 : 0;
     int sn = 0, stamp_iv = 0;
 #endif
@@ -339,11 +334,9 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             for (int j = 0; j < 8; ++j) dot_w8[j] = c8 + j < A.Cout ? A.dot_w[c8 + j] : 0.f;
             dot_b0 = A.dot_b ? A.dot_b[0] : 0.f;
         }
-        auto store_half = [&](int hf, int tn, int ty0, int tx0) __attribute__((always_inline)) {
-            // the block of consumer wave bw leaves; SPLIT: storer wave k (6, 7) carries the blocks of consumer waves 2k, 2k + 1 (a run-time loop:
-            // one copy of the body)
-            for (int bi = 0; bi < (SPLIT ? 2 : 1); ++bi) {
-            const int bw = SPLIT ? 2 * (wave - 6) + bi : pw;
+        auto store_half = [&](int hf, int tn, int ty0, int tx0) {
+            {
+            const int bw = pw;                                   // the block of consumer wave pw leaves through mover wave pw
             constexpr int SPP = BN / 8;                          // 16-byte segments per pixel
             constexpr int PPR = 64 / SPP, NR = 32 / PPR;         // pixels per wave-instruction, instructions per block
             const int seg = lane % SPP, lp = lane / SPP;
@@ -439,34 +432,6 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         auto for_sets = [&](auto f) {                            // f(integral_constant<int, k>) for k = 0 .. PF - 1
             [&]<int... K>(std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }(std::make_integer_sequence<int, PF>{});
         };
-        if constexpr (SPLIT) {
-            if (wave >= 6) {
-                // ================================ storers (SPLIT) ================================
-                // interval i: what the consumers parked in interval i - 1 (half a tile: the blocks of two consumer waves per storer wave)
-                // leaves as whole 128-byte lines; this wave may sit in the issue of its stores for most of the interval - nobody waits
-                // for it before the barrier
-                __syncthreads();                                 // B0
-                __syncthreads();                                 // B1
-                const int NIP = (NI + IPG - 1) / IPG * IPG;      // (the loaders' loop runs whole groups of IPG intervals)
-                for (int i = 0; i < NIP; ++i) {
-                    W16_STAMP(21);
-                    store_prev(i);
-                    W16_STAMP(22);
-                    lds_sync();
-                    W16_STAMP(23); W16_STAMP_NEXT();
-                }
-                store_prev(NIP);                                 // what the consumers parked in the very last interval
-                lds_sync();                                      // E
-                lds_sync();                                      // F
-                const int tl = t_hi - 1, ln = tl / tiles_img, lr = tl - ln * tiles_img, lty = lr / tiles_x;
-                store_half(0, ln, lty * TH, (lr - lty * tiles_x) * TW);
-                store_half(1, ln, lty * TH, (lr - lty * tiles_x) * TW);
-#ifdef CDNET_WS_STAMPS
-                if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws16_stamps[2048 + i] = s_stamp[i]; g_ws16_stamps[2048 + sn] = 0; }
-#endif
-                return;
-            }
-        }
         for_sets([&](auto k) { issue(k); });
         for (int c = ptid; c < ctot; c += NMV) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
@@ -495,7 +460,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                     using SB = std::integral_constant<int, RB>;
                     if (!STREAM) {
                         W16_STAMP(1); commit(SA{}, qa); W16_STAMP(2); issue(SA{}); commit(SB{}, qa + 1); issue(SB{}); W16_STAMP(3);
-                        if constexpr (!SPLIT) store_prev(i0 + M);
+                        store_prev(i0 + M);
                         W16_STAMP(4);
                         if (OUT) lds_sync(); else __syncthreads();
                         W16_STAMP(5); W16_STAMP_NEXT();
@@ -522,10 +487,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 }(), ...);
             }(std::make_integer_sequence<int, IPG>{});
         }
-        if (OUT && SPLIT) {
-            lds_sync();                                          // E, F: the storers' (above)
-            lds_sync();
-        } else if (OUT) {
+        if (OUT) {
             store_prev((NI + IPG - 1) / IPG * IPG);              // what the consumers parked in the very last interval
             lds_sync();                                          // E: this wave's reads of the out image are done - the consumers park the last tile
             lds_sync();                                          // F: ... both halves of it are in the image
@@ -611,15 +573,21 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             constexpr int EP = decltype(ep_c)::value;              // -1: no epilogue
             constexpr int NST = NT == 9 ? 9 : 1;
             if (A.debug & 1) return;
+            // LDS-typed bases; resident weights: the slot bases of a tile's first pairs are compile-time constants and the compiler would keep
+            // a fragment address per (pair, step) in registers (21 spilled) - opaque bases cost one add per read, as in the streamed form
+            typedef const __attribute__((address_space(3))) unsigned char *lds_cp;
+            lds_cp la3 = (lds_cp)la, lw3 = (lds_cp)lw;
+            if constexpr (!STREAM) asm volatile("" : "+s"(la3), "+s"(lw3));
             // weight fragments of a whole step one step ahead (two sets), pixel fragments one tile row ahead (two registers sets of one)
             bf16x8 wa[2][NCB], pf[2];
             auto req_w = [&](int st) {
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) wa[st & 1][cb] = *reinterpret_cast<const bf16x8 *>(lw + (NT == 9 ? WB9[st] : WB1) + cb * 256);
+                for (int cb = 0; cb < NCB; ++cb)
+                    wa[st & 1][cb] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(lw3 + (NT == 9 ? WB9[st] : WB1) + cb * 256);
             };
             auto req_p = [&](int st, int pb) {
                 const int o = (NT == 9 ? PB9[st] : PB1) ^ ((pb & 1) * 16);
-                pf[(st * NPB + pb) & 1] = *reinterpret_cast<const bf16x8 *>(la + o + pb * HW_ * PSTR);
+                pf[(st * NPB + pb) & 1] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(la3 + o + pb * HW_ * PSTR);
             };
             constexpr int NG = NST * NCB * NPB;
             constexpr int E0 = EP >= 0 ? EP * NMO / 2 : 0, CNT = EP >= 0 ? NMO / 2 : 0, CNTD = CNT > 0 ? CNT : 1;
@@ -986,10 +954,11 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
                 constexpr bool MIX_ = decltype(mx_c)::value;
                 // the streamed-weight launches - the matrix-bound layers (128+ input channels) - take the 16x16x32 consumers (CDNET_WS16_K32=0:
                 // off): 63 / 62 / 27 us against 72 / 70 / 30 us on 256 -> 256 @64², 512 -> 512 @32², 320 -> 64 @64².  The resident 64 -> 64 layer is
-                // bound by its traffic and does not gain (80 vs 75 us at 16 tiles, 320 vs 322 us at 64); the one-tap form spilled.
+                // bound by power and does not gain (round 5, without spills and with pair requests: 74.0 vs 72.5 us at 16 tiles, 298 vs 297.5 us at
+                // 64 - profiles/HISTORY.md); the one-tap form spilled.
                 static const int k32_env = getenv("CDNET_WS16_K32") ? atoi(getenv("CDNET_WS16_K32")) : 1;
                 if constexpr (STREAM_) if (k32_env) {
-                    auto kern_k = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, true, false, PAIR_>;
+                    auto kern_k = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, true, PAIR_>;
                     static bool attr_k = false;
                     if (!attr_k) {
                         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -999,21 +968,7 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
                     kern_k<<<grid, 512, smem, st>>>(A);
                     return check_launch("conv_ws16_kernel(k32)");
                 }
-                // resident weights, plain sources: two loader + two storer waves (SPLIT) - an experiment, off by default (CDNET_WS16_SPLIT=1):
-                // measured 600 vs 405 us at 64 tiles on a box whose launch was bound by its read requests (two loader waves issue them slower than four)
-                static const int split_env = getenv("CDNET_WS16_SPLIT") ? atoi(getenv("CDNET_WS16_SPLIT")) : 0;
-                if constexpr (!STREAM_ && XF == 0) if (split_env) {
-                    auto kern_s = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, true, PAIR_>;
-                    static bool attr_s = false;
-                    if (!attr_s) {
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_s), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                            return check_launch("hipFuncSetAttribute(conv_ws16 split)");
-                        attr_s = true;
-                    }
-                    kern_s<<<grid, 512, smem, st>>>(A);
-                    return check_launch("conv_ws16_kernel(split)");
-                }
-                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, false, PAIR_>;
+                auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, PAIR_>;
                 static bool attr_o = false;
                 if (!attr_o) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_o), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -223,6 +223,28 @@ __global__ __launch_bounds__(256) void tta_mean_kernel(const float *__restrict__
     }
 }
 
+// one view in its own frame (the tile pipeline): the "mean" over views IS the view - nothing to average or to store; what is left of
+// tta_mean_kernel is the maximum of the point map (test_dam.py:530), four pixels per thread
+__global__ __launch_bounds__(256) void point_max_kernel(const float *__restrict__ points, int plane, unsigned *pmax_key) {
+    __shared__ float s_red[4];
+    const int img = blockIdx.y;
+    const float *pt = points + (size_t)img * plane;
+    float m = -INFINITY;
+    const int n4 = plane >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(pt)[i];
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < (plane & 3)) m = fmaxf(m, pt[(n4 << 2) + threadIdx.x]);
+    m = wave_maxf(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        if (m != -INFINITY) atomicMax(&pmax_key[img], f2key(m));
+    }
+}
+
 __global__ __launch_bounds__(256) void boost_argmax_kernel(const float *__restrict__ probs, const float *__restrict__ prob_mean,
                                                            const float *__restrict__ point_mean,
                                                            const uint8_t *__restrict__ codes, const int32_t *__restrict__ minmax,
@@ -659,8 +681,10 @@ extern "C" int cdnet_tta_boost_argmax(const float *probs, const float *points, c
                                       const int32_t *minmax, int I, int V, const int *view_xform_host, int H, int W,
                                       float *prob_mean, float *point_mean, uint8_t *ddm16, uint8_t *pred,
                                       float *pmax_ws, void *stream) {
-    CDNET_REQUIRE(probs && points && codes && minmax && point_mean && pred && pmax_ws && view_xform_host,
-                  "cdnet_tta_boost_argmax: null pointer");
+    CDNET_REQUIRE(probs && points && codes && minmax && pred && pmax_ws && view_xform_host, "cdnet_tta_boost_argmax: null pointer");
+    // point_mean may be NULL for ONE view in its own frame (V == 1, view_xform 0): the mean over views is the view itself
+    const bool single = V == 1 && view_xform_host[0] == 0 && !point_mean && !prob_mean;
+    CDNET_REQUIRE(point_mean || single, "cdnet_tta_boost_argmax: point_mean is required unless V == 1, view_xform[0] == 0 and prob_mean == NULL");
     CDNET_REQUIRE(I > 0 && H > 0 && W > 0 && V >= 1 && V <= 16, "cdnet_tta_boost_argmax: bad size I=%d V=%d", I, V);
     hipStream_t st = (hipStream_t)stream;
     ViewXf xf;
@@ -670,8 +694,16 @@ extern "C" int cdnet_tta_boost_argmax(const float *probs, const float *points, c
     }
     if (hipMemsetAsync(pmax_ws, 0, sizeof(float) * I, st) != hipSuccess) return check_launch("memset pmax");
     dim3 grid = grid_rows(I, H, W);
-    tta_mean_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, points, V, xf, H, W, prob_mean, point_mean,
-                                                  reinterpret_cast<unsigned *>(pmax_ws));
+    if (single && ((size_t)points & 15) == 0 && ((H * W) & 3) == 0) {
+        // (x / 1.0f == x: the point map itself is the mean boost_argmax_kernel reads)
+        int g = cdiv(H * W / 4, 256); if (g > 64) g = 64;
+        point_max_kernel<<<dim3(g, I), 256, 0, st>>>(points, H * W, reinterpret_cast<unsigned *>(pmax_ws));
+        point_mean = const_cast<float *>(points);
+    } else {
+        CDNET_REQUIRE(point_mean, "cdnet_tta_boost_argmax: point_mean is required for this shape (pixel count not a multiple of 4 or unaligned points)");
+        tta_mean_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, points, V, xf, H, W, prob_mean, point_mean,
+                                                      reinterpret_cast<unsigned *>(pmax_ws));
+    }
     boost_argmax_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, prob_mean, point_mean, codes, minmax, V, xf, H, W,
                                                       reinterpret_cast<const unsigned *>(pmax_ws), ddm16, pred);
     return check_launch("cdnet_tta_boost_argmax");

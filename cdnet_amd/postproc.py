@@ -84,7 +84,9 @@ def tta_boost_argmax(probs, points, codes, minmax, xforms, H, W, want_stages=Tru
     probs, points, codes, minmax = probs.contiguous(), points.contiguous(), codes.contiguous(), minmax.contiguous()
     assert probs.numel() == I * V * 3 * H * W and points.numel() == I * V * H * W and codes.numel() == I * V * H * W
     prob_mean = torch.empty((I, 3, H, W), dtype=torch.float32, device=dev) if want_stages else None
-    point_mean = torch.empty((I, H, W), dtype=torch.float32, device=dev)
+    # one view in its own frame: the mean over views is the view - no copy (the library takes the maximum of the point map from `points`)
+    single = V == 1 and int(xforms[0]) == 0 and not want_stages and (H * W) % 4 == 0 and points.data_ptr() % 16 == 0
+    point_mean = None if single else torch.empty((I, H, W), dtype=torch.float32, device=dev)
     ddm16 = torch.empty((I, H, W), dtype=torch.uint8, device=dev) if want_stages else None
     pred = torch.empty((I, H, W), dtype=torch.uint8, device=dev)
     pmax = torch.empty((I,), dtype=torch.float32, device=dev)
@@ -92,7 +94,7 @@ def tta_boost_argmax(probs, points, codes, minmax, xforms, H, W, want_stages=Tru
     _lib.call('cdnet_tta_boost_argmax', _lib.ptr(probs), _lib.ptr(points), _lib.ptr(codes), _lib.ptr(minmax),
               I, V, C.cast(xf, C.c_void_p), H, W, _lib.ptr(prob_mean), _lib.ptr(point_mean), _lib.ptr(ddm16),
               _lib.ptr(pred), _lib.ptr(pmax), _lib.stream_ptr())
-    return dict(prob_mean=prob_mean, point_mean=point_mean, ddm16=ddm16, pred=pred)
+    return dict(prob_mean=prob_mean, point_mean=points.reshape(I, H, W) if single else point_mean, ddm16=ddm16, pred=pred)
 
 
 _WS = {}

@@ -81,7 +81,9 @@ int cdnet_probmaps(const float *mask_logits, const float *dir_logits, int N, int
  *   codes  u8  [I][V][h_v][w_v]      minmax i32 [I][V][2]          (from cdnet_ddm_codes, N = I*V)
  * Outputs (image frame [H][W]): prob_mean f32 [I][3][H][W] (before the boost), point_mean f32 [I][H][W],
  *   ddm16 u8 [I][H][W] = 16 * mean_v DDM_v when every view has min=0,max in {1,2} (else the f64 path is used and
- *   ddm16 is 255), pred u8 [I][H][W] = argmax class.  Any of prob_mean / ddm16 may be NULL.
+ *   ddm16 is 255), pred u8 [I][H][W] = argmax class.  Any of prob_mean / ddm16 may be NULL.  point_mean may be NULL only for ONE view in
+ *   its own frame (V == 1, view_xform[0] == 0, prob_mean NULL, H*W a multiple of 4, points 16-byte aligned): the mean over views is the view
+ *   itself, nothing is averaged or stored (the 256x256 tile pipeline).
  *   pmax_ws: f32 workspace [I] (global max of point_mean).
  * ---------------------------------------------------------------------------------------------------- */
 int cdnet_tta_boost_argmax(const float *probs, const float *points, const uint8_t *codes, const int32_t *minmax,

@@ -1,12 +1,13 @@
-"""A/B of the dominant 16-bit layers with the loader / storer split of conv_ws16_kernel on and off (two child processes per setting would see two
-clock states; this runs both settings in ONE process by launching through two library builds... the switch is read once per process, so:
-   for S in 0 1; do CDNET_WS16_SPLIT=$S python tools/ab_ws16_split.py; done"""
+"""Same-box A/B of conv_ws16_kernel builds on the dominant 16-bit layers (3x3 64 -> 64 @256x256 at 16 and 64 tiles, 256 -> 256 @64x64 at 16):
+   bash tools/build_variant.sh nopair "-DCDNET_WS16_PAIR_DEFAULT=0" conv16ws.hip
+   for L in nopair "" nopair ""; do CDNET_LIB_PATH=${L:+$PWD/cdnet_amd/libcdnet_hip_$L.so} python tools/ab_ws16.py; done
+(alternate the builds: the boxes of the pool and the chip's clock state differ by more than most changes)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cdnet_amd import engine
 dev = torch.device('cuda:0')
-print('CDNET_WS16_SPLIT=%s lib=%s' % (os.environ.get('CDNET_WS16_SPLIT', '(default 0)'), os.path.basename(os.environ.get('CDNET_LIB_PATH', 'libcdnet_hip.so'))))
+print('lib=%s' % (os.path.basename(os.environ.get('CDNET_LIB_PATH', 'libcdnet_hip.so'))))
 for B in (16, 64):
     for (cin, cout, taps1) in ((64, 64, 0), (256, 256, 0)):
         if cin == 256 and B == 64:

@@ -3,7 +3,6 @@
   bash tools/build_variant.sh stamps "-DCDNET_WS_STAMPS" conv16ws.hip
   CDNET_LIB_PATH=cdnet_amd/libcdnet_hip_stamps.so python tools/ws16_stamps.py [tiles = 64]
 
-CDNET_WS16_SPLIT=0 selects the four-mover form (every mover loads and stores), the default is two loader + two storer waves (wave 6 stamps too).
 One consumer wave (wave 0) and one mover wave (wave 4) of one workgroup stamp the 100 MHz wall clock over ~45 barrier intervals in the
 middle of the workgroup's run.  Printed per variant (random / all-zero operands x full / no stores / no halo requests): the launch time and,
 per interval, where each role spends it -
