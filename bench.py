@@ -222,16 +222,16 @@ def dominant_roofline(ms, B, precision, traffic=None, traffic_src=None, mfma_bus
 
 
 def committed_pmc(precision, B=16):
-    """(traffic bytes per launch, source note, matrix-pipe busy fraction, clock MHz) of the dominant kernel from the newest committed PMC
-    summary (tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv_<dtype>_pmc.json)"""
-    f32 = precision == 'fp32'
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
-        tj = os.path.join(ROOT, 'profiles', rnd, 'dominant_conv_fp32_pmc.json' if f32 else 'dominant_conv_bf16_pmc.json')
-        if os.path.exists(tj) and B == 16:
+    """(traffic bytes per launch, source note, matrix-pipe busy fraction, clock MHz) of the dominant kernel at B tiles per launch from the newest
+    committed PMC summary (tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv_<dtype>[_<B>tiles]_pmc.json)"""
+    name = 'dominant_conv_%s%s_pmc.json' % (precision, '' if B == 16 else '_%dtiles' % B)
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+        tj = os.path.join(ROOT, 'profiles', rnd, name)
+        if os.path.exists(tj):
             with open(tj) as f:
                 pj = json.load(f)
             return (pj.get('hbm_bytes_per_launch'),
-                    'profiles/%s/%s (rocprofv3 --pmc passes of `bench.py --mode roofline`, not re-measured in this run)' % (rnd, os.path.basename(tj)),
+                    'profiles/%s/%s (rocprofv3 --pmc passes of `bench.py --mode roofline --batch %d`, not re-measured in this run)' % (rnd, name, B),
                     pj.get('mfma_busy_frac'), pj.get('clock_mhz'))
     return None, None, None, None
 
@@ -390,7 +390,7 @@ def main():
         # `rocprofv3 --kernel-trace --stats -- python3 bench.py --mode roofline` averages this kernel and nothing else
         sys.stdout.flush()
         os.dup2(fd_out, 1)
-        print(json.dumps({'roofline': time_dominant_conv(torch, 16, steps=a.steps, precision=a.dtype)}), flush=True)
+        print(json.dumps({'roofline': time_dominant_conv(torch, a.batch or 16, steps=a.steps, precision=a.dtype)}), flush=True)
         return
 
     def timed(step, steps, warmup, settle_s=1.0):
@@ -647,7 +647,13 @@ def main():
         cdnet_amd.set_precision(a.dtype)
         line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype, live_pmc=(world == 1 and extras and not a.no_live_pmc))
         if extras and world == 1:
-            line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)
+            # the 16-bit path's dominant layer at the INFERENCE batch (64 tiles: 1.07 GB of tensors, beyond the 256 MB Infinity Cache - at 16 tiles
+            # the 268 MB working set is re-used across launches out of that cache and the figure flatters the kernel); 16 tiles beside it
+            if other == 'bf16':
+                line['roofline_bf16'] = time_dominant_conv(torch, 64, precision='bf16')
+                line['roofline_bf16_16tiles'] = time_dominant_conv(torch, 16, precision='bf16')
+            else:
+                line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)
         if extras and mode == 'train' and world == 1 and not a.no_forced_allreduce:
             fa = run_forced_allreduce(a.dtype, B, max(5, a.steps // 2), 2)
             fa['vs_value'] = fa['value'] / head['value']

@@ -114,8 +114,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.cdnet_abi_version() != 3:
-        raise CdnetHipError('ABI version mismatch (libcdnet_hip.so is version %d, this binding 3): rebuild with python -m cdnet_amd.csrc.build' % lib.cdnet_abi_version())
+    if lib.cdnet_abi_version() != 4:
+        raise CdnetHipError('ABI version mismatch (libcdnet_hip.so is version %d, this binding 4): rebuild with python -m cdnet_amd.csrc.build' % lib.cdnet_abi_version())
     _lib = lib
     return lib
 

@@ -113,31 +113,29 @@ __device__ __forceinline__ void wave_max_to(unsigned long long *__restrict__ tab
 }
 
 // 3. get_centerpoint2 (:650-685): centerness of every instance pixel; per-instance maximum (double bits are monotone)
-// the pixels that belong to an instance, appended to a per-image list (any order: the centerness of a pixel is its own, the per-instance
-// maximum does not depend on the order) - the long bisection loop then runs on full waves instead of the ~30 % of lanes a row of 64
-// pixels has inside nuclei
-__global__ __launch_bounds__(256) void cdm_list_kernel(const int32_t *__restrict__ inst, int plane, int *__restrict__ list, int *__restrict__ count) {
-    const int n = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool on = i < plane && inst[(size_t)n * plane + i] > 0;
-    const unsigned long long m = __ballot(on);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&count[n], __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (on) list[(size_t)n * plane + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
-}
-
-__global__ __launch_bounds__(256) void cdm_centerness_kernel(const int32_t *__restrict__ inst, const int *__restrict__ list,
-                                                             const int *__restrict__ count, int H, int W, Rays R,
+// 3. get_centerpoint2 (:650-685): centerness of every instance pixel; per-instance maximum (double bits are monotone).  A block takes 256
+// consecutive pixels and compacts the ones that belong to an instance into its first waves (ballot + prefix counts through LDS): the long
+// bisection loop runs on full waves instead of the ~30 % of lanes a row of pixels has inside nuclei, the other waves leave at once
+__global__ __launch_bounds__(256) void cdm_centerness_kernel(const int32_t *__restrict__ inst, int H, int W, Rays R,
                                                              double *__restrict__ cness, unsigned long long *__restrict__ best, int maxid) {
+    __shared__ int s_cnt[4], s_pix[256];
     const int n = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if ((e & ~63) >= count[n]) return;                            // (whole waves beyond the list leave)
-    const int32_t *s = inst + (size_t)n * H * W;
-    const bool on = e < count[n];
-    const int p = on ? list[(size_t)n * H * W + e] : 0;
+    const int plane = H * W;
+    const int32_t *s = inst + (size_t)n * plane;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool member = i < plane && s[i] > 0;
+    const unsigned long long m = __ballot(member);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[w] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; ++k) base += s_cnt[k];
+    if (member) s_pix[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+    if ((int)(threadIdx.x & ~63u) >= total) return;               // (whole waves beyond the block's list leave)
+    const bool on = (int)threadIdx.x < total;
+    const int p = on ? s_pix[threadIdx.x] : 0;
     const int y = p / W, x = p - y * W;
     const int id = on ? s[p] : 0;
     double c = 0;
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(256) void cdm_centerness_kernel(const int32_t *__re
             mi = r < mi ? r : mi;
         }
         c = mi / ma;
-        cness[(size_t)n * H * W + p] = c;
+        cness[(size_t)n * plane + p] = c;
     }
     wave_max_to(best + (size_t)n * maxid, id, (unsigned long long)__double_as_longlong(c), on);
 }
@@ -371,18 +369,13 @@ inline dim3 grid_rows(int N, int H, int W) { return dim3(cdiv(W, 64), cdiv(H, 4)
 // the per-instance stage shared by both input kinds: centre search, distance normalisation, 11x11 stencil + angle bins, point map.
 // `inside_u8` (> 127 = new_label_inside) masks the classes; `counts[n]` = largest instance id of image n
 static int cdm_direction_stage(const uint8_t *label_ch0, const int32_t *inst, const int32_t *counts, int N, int H, int W, int maxid, const Rays &R,
-                               const GaussK &G, double *cness, double *tmp, int *list_count, unsigned long long *best, unsigned long long *dmax, int *center,
+                               const GaussK &G, double *cness, double *tmp, unsigned long long *best, unsigned long long *dmax, int *center,
                                uint8_t *direction, uint16_t *point_f16, int32_t *inst_out, int32_t *counts_out, hipStream_t st) {
     const dim3 gr = grid_rows(N, H, W), br(64, 4);
     const int plane = H * W;
     const size_t nk = (size_t)N * maxid;
     cdm_init_kernel<<<(unsigned)((nk + 255) / 256), 256, 0, st>>>(best, dmax, center, nk);
-    // (the list lives in the float64 scratch plane `tmp` until the K | f planes take it over; its counters in the first N ints of the
-    //  connected-component chunk table, which nothing reads any more at this point)
-    int *list = reinterpret_cast<int *>(tmp);
-    if (hipMemsetAsync(list_count, 0, (size_t)N * 4, st) != hipSuccess) return check_launch("memset list count");
-    cdm_list_kernel<<<dim3(cdiv(plane, 256), N), 256, 0, st>>>(inst, plane, list, list_count);
-    cdm_centerness_kernel<<<dim3(cdiv(plane, 256), N), 256, 0, st>>>(inst, list, list_count, H, W, R, cness, best, maxid);
+    cdm_centerness_kernel<<<dim3(cdiv(plane, 256), N), 256, 0, st>>>(inst, H, W, R, cness, best, maxid);
     int g = cdiv(plane, 256); if (g > 1024) g = 1024;
     cdm_argmax_kernel<<<dim3(g, N), 256, 0, st>>>(inst, cness, best, plane, maxid, center);
     cdm_dmax_kernel<<<gr, br, 0, st>>>(inst, H, W, center, maxid, dmax);
@@ -453,7 +446,7 @@ extern "C" int cdnet_label_encoding(const uint8_t *label_ch0, int N, int H, int 
     int rc = label8_raster(m1, N, H, W, L, aux, chunk, lab, counts, st);
     if (rc) return rc;
     cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst, maxid);
-    return cdm_direction_stage(label_ch0, inst, counts, N, H, W, maxid, R, G, cness, tmp, chunk, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
+    return cdm_direction_stage(label_ch0, inst, counts, N, H, W, maxid, R, G, cness, tmp, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
 }
 
 
@@ -504,5 +497,5 @@ extern "C" int cdnet_label_encoding_instances(const int32_t *label_inst, int N, 
     cdm_grow_kernel<<<gr, br, 0, st>>>(lab, H, W, inst, maxid);
     // every id below maxid may exist (watershed marker ids are kept, not renumbered)
     cdm_fill_counts_kernel<<<1, 64, 0, st>>>(counts, N, maxid - 1);
-    return cdm_direction_stage(inside, inst, counts, N, H, W, maxid, R, G, cness, tmp, reinterpret_cast<int *>(ws + o[3]), best, dmax, center, direction, point_f16, inst_out, counts_out, st);
+    return cdm_direction_stage(inside, inst, counts, N, H, W, maxid, R, G, cness, tmp, best, dmax, center, direction, point_f16, inst_out, counts_out, st);
 }

@@ -29,8 +29,9 @@ extern "C" {
 #define CDNET_E_WORKSPACE   2   /* workspace too small */
 #define CDNET_E_LAUNCH      3   /* HIP launch error */
 
-#define CDNET_ABI_VERSION   3   /* 2, 3 (round 4): cdnet_conv_args grew (taps1, pool_out; dot_w, dot_b, dot_out) - a caller built against an older
-                                 version must not pass its struct */
+#define CDNET_ABI_VERSION   4   /* 2, 3 (round 4): cdnet_conv_args grew (taps1, pool_out; dot_w, dot_b, dot_out) - a caller built against an older
+                                 version must not pass its struct.  4 (round 5): cdnet_spin added; cdnet_tta_boost_argmax accepts point_mean == NULL
+                                 for one view in its own frame (no struct changed) */
 
 int         cdnet_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("cdnet_conv_args", ...), 0 for an unknown name: a binding that mirrors the structs

@@ -1,7 +1,7 @@
 """Fold the passes of tools/prof_roofline_pmc.sh into one JSON (stdout): per-launch means of every counter over the dispatches of
 the dominant kernel, HBM traffic (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md), the matrix pipe's busy fraction and the
 effective clock (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration; reads high on launches shorter than ~0.3 ms, ibid.).
-usage: python tools/make_roofline_pmc.py <dir> <fp32|bf16>"""
+usage: python tools/make_roofline_pmc.py <dir> <fp32|bf16> [tiles per launch = 16]"""
 import csv
 import glob
 import json
@@ -9,8 +9,9 @@ import os
 import sys
 
 root, dt = sys.argv[1], sys.argv[2]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 want = ('conv_ws32_kernel', 'conv_f32_kernel') if dt == 'fp32' else ('conv_ws16_kernel', 'conv_ws_kernel', 'conv_fwd_kernel')
-out = {'dtype': dt, 'counters': {}}
+out = {'dtype': dt, 'tiles_per_launch': B, 'counters': {}}
 dur_ns = None
 for f in sorted(glob.glob(os.path.join(root, 'stats', '*kernel_stats.csv'))):
     for r in csv.DictReader(open(f)):
@@ -33,14 +34,14 @@ if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
     out['write_bytes'] = c['WRITE_SIZE'] * 1024
     out['hbm_bytes_per_launch'] = out['fetch_bytes_corrected_x2'] + out['write_bytes']
     esz = 4 if dt == 'fp32' else 2
-    out['algorithmic_bytes_per_launch'] = 2 * 16 * 256 * 256 * 64 * esz
+    out['algorithmic_bytes_per_launch'] = 2 * B * 256 * 256 * 64 * esz
 if 'GRBM_GUI_ACTIVE' in c and dur_ns:
     out['clock_mhz'] = c['GRBM_GUI_ACTIVE'] / 8.0 / dur_ns * 1e3
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in c:
         # busy cycles are summed over the chip's SIMDs (1024 = 256 CUs x 4); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
         out['mfma_busy_frac'] = c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * c['GRBM_GUI_ACTIVE'] / 8.0)
-        mfmas = (3 if dt == 'fp32' else 1) * 2.0 * 16 * 256 * 256 * 64 * 64 * 9 / 32768.0
+        mfmas = (3 if dt == 'fp32' else 1) * 2.0 * B * 256 * 256 * 64 * 64 * 9 / 32768.0
         out['mfma_busy_cycles_expected_32_per_mfma'] = mfmas * 32
-out['note'] = ('means over the dispatches of the kernel in `bench.py --mode roofline --dtype %s --steps 40` (43 launches incl. warm-up); separate '
-               'rocprofv3 --pmc passes; FETCH_SIZE x 2 (gfx950 counts half of a 16-B/lane read stream)' % dt)
+out['note'] = ('means over the dispatches of the kernel in `bench.py --mode roofline --dtype %s --batch %d --steps 40` (incl. warm-up); separate '
+               'rocprofv3 --pmc passes; FETCH_SIZE x 2 (gfx950 counts half of a 16-B/lane read stream)' % (dt, B))
 print(json.dumps(out, indent=1))

@@ -26,17 +26,22 @@ prof image_1000_fp32 --mode image --dtype fp32 --steps 3 --warmup 1
 prof image_1000_bf16 --mode image --dtype bf16 --steps 3 --warmup 1
 rm -rf $RAW/*/t_kernel_trace.csv
 # the dominant kernel alone: --stats pass + the PMC passes, folded into dominant_conv_<dtype>_pmc.json
-for DT in fp32 bf16; do
-  bash $ROOT/tools/prof_roofline_pmc.sh $DT $RAW/roofline_$DT > /dev/null 2>&1
-  cp $RAW/roofline_$DT/summary.json $OUT/dominant_conv_${DT}_pmc.json
-  cp $RAW/roofline_$DT/roofline_line.json $OUT/dominant_conv_${DT}_roofline_line.json
-  cp $RAW/roofline_$DT/stats/t_kernel_stats.csv $OUT/dominant_conv_${DT}_kernel_stats.csv
-  rm -rf $RAW/roofline_$DT/pmc*/*kernel_trace.csv $RAW/roofline_$DT/stats/*kernel_trace.csv
+for V in "fp32 16" "bf16 16" "bf16 64"; do
+  set -- $V; DT=$1; B=$2
+  SUF=$([ "$B" = 16 ] && echo "" || echo "_${B}tiles")
+  bash $ROOT/tools/prof_roofline_pmc.sh $DT $RAW/roofline_$DT$SUF $B > /dev/null 2>&1
+  cp $RAW/roofline_$DT$SUF/summary.json $OUT/dominant_conv_${DT}${SUF}_pmc.json
+  cp $RAW/roofline_$DT$SUF/roofline_line.json $OUT/dominant_conv_${DT}${SUF}_roofline_line.json
+  cp $RAW/roofline_$DT$SUF/stats/t_kernel_stats.csv $OUT/dominant_conv_${DT}${SUF}_kernel_stats.csv
+  rm -rf $RAW/roofline_$DT$SUF/pmc*/*kernel_trace.csv $RAW/roofline_$DT$SUF/stats/*kernel_trace.csv
 done
 cd /tmp
 for DT in fp32 bf16; do
   bash $ROOT/tools/prof_step_traffic.sh $DT > $OUT/train_b16_${DT}_step_traffic.txt 2>&1
+  bash $ROOT/tools/prof_step_traffic.sh $DT infer > $OUT/infer_b64_${DT}_step_traffic.txt 2>&1
 done
+bash $ROOT/tools/prof_cdm.sh > /dev/null 2>&1
+cp $ROOT/gpurun_out/cdm_kernel_stats.csv $OUT/cdm_kernel_stats.csv
 rm -rf $ROOT/gpurun_out/step_pmc_*
 bash $ROOT/tools/prof_hrnet_train.sh > $OUT/hrnet_train_b4_512_summary.txt 2>&1
 cp $ROOT/gpurun_out/hrnet_train_prof/t_kernel_stats.csv $OUT/hrnet_train_b4_512_kernel_stats.csv
