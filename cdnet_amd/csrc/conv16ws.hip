@@ -101,20 +101,27 @@ __device__ __forceinline__ int sigma32(int m) { return (m & ~12) | ((m & 4) << 1
 // HBM for the layer's 0.54 GB input (profiles/r05/ws16_pmc_64tiles.txt) - the launch was bound by its own over-fetch.  Register set R of a pair
 // holds half of the pair's vectors (lane -> pixel v / 4, 16-byte segment v % 4: chunk (v % 4) / 2 of the pair, k-half v % 2); both sets are
 // written into the pair's two ring slots in the same interval, as before.
-template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false, bool PAIR = false>
+// QUAD (round 5; resident weights, every source a multiple of 64 channels): BOTH pairs of a 128-byte piece of a pixel (four chunks = a whole line
+// of the memory side) are requested in the same interval, every second interval, instead of one pair per interval.  With the pairs one interval
+// (~2 us) apart the line fetched for the first was gone from the L2 for a third of the second requests at 64 tiles - 0.86 GB fetched for a
+// 0.54 GB input (profiles/r05/dominant_conv_bf16_64tiles_pmc.json).  Three pair register sets: the even pairs use group 0, the odd pairs
+// alternate between groups 1 and 2 (a quad is requested when its first pair's group has just been written to the ring and the odd group of the
+// quad before last is free); the ring slot of a pair is its parity, whatever group it arrived in.
+template <int BN, int XF, bool STREAM, bool MIX, int NCS, int NS, int PFD, bool OUT, bool K32 = false, bool PAIR = false, bool QUAD = false>
 __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     using L = W16Lds<BN>;
     constexpr int TH = 16, TW = 16, CK = 16, PSTR = L::PSTR, HW_ = TW + 2, NPIX = L::NPIX;
     constexpr int NCI = BN / 32, NPI = 2;                         // consumer wave: NCI blocks of 32 output channels x two blocks of 32 pixels
     constexpr int NMV = 256;                                      // mover threads
     constexpr int VPP = CK / 8, NA = (NPIX * VPP + NMV - 1) / NMV;
-    constexpr int PF = PFD;
+    constexpr int PF = QUAD ? 6 : PFD;
     constexpr int A_BYTES = L::A_IMG;                             // halo ring slot stride
-    constexpr int IPG = PF / 2;                                   // barrier intervals per iteration of the movers' loop
+    constexpr int IPG = QUAD ? 4 : PF / 2;                        // barrier intervals per iteration of the movers' loop
     static_assert(!(STREAM && MIX), "one-tap chunks only with resident weights");
     static_assert(!OUT || NCS == 0, "LDS out image: tiles of an even number (>= 4) of chunks");
     static_assert(!K32 || OUT, "the 16x16x32 consumers serve the out-image form");
-    static_assert(NS == 4 && PF % 4 == 0, "a four-slot halo ring, register sets = slots mod 4");
+    static_assert(NS == 4 && (QUAD || PF % 4 == 0), "a four-slot halo ring, register sets = slots mod 4");
+    static_assert(!QUAD || (PAIR && !STREAM && OUT), "quad requests: the out-image form with resident weights and pair requests");
     static_assert(!PAIR || NCS == 0, "pair requests: tiles of an even number (>= 4) of chunks");
     const int NCH = A.nchunk;
     const int n0 = A.src[0].C / CK;                               // chunks of the first source (nine taps)
@@ -165,7 +172,6 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
     if (wave >= 4) {
         // ================================ movers (conv_ws_kernel's, without the out path) ================================
         const int ptid = tid - 256, pw = wave - 4;
-        if (A.debug & 16) __builtin_amdgcn_s_setprio(2);         // (experiment: the younger half of the workgroup loses the issue arbitration at equal priority)
         constexpr int VPQ = PAIR ? 2 * VPP : VPP;                 // 16-byte vectors per halo pixel of a request group (PAIR: a pair of chunks)
         constexpr int NG = PAIR ? 2 : 1;                          // register-set groups that share one lane -> (pixel, segment) map
         const int slot = ptid % VPQ;                              // this thread's 16-byte segment (PAIR: chunk slot >> 1 of the pair, k-half slot & 1)
@@ -247,9 +253,10 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                 }
             }
         };
-        // run chunk c_ (register set R = c_ % 4) -> ring slot c_ % 4
-        auto commit = [&](auto rc, int c_) {
+        // run chunk c_ (register set R = c_ % 4) -> ring slot c_ % 4 (QUAD: the register set is any of six, the slot pair is given: SB = 0 / 2)
+        auto commit3 = [&](auto rc, int c_, auto sb_c) {
             constexpr int R = decltype(rc)::value;
+            constexpr int SB = decltype(sb_c)::value;
             int si, cc0;
             chunk_src(ck, si, cc0);
             if (c_ + 1 < S) { if (++ck == NCH) ck = 0; }
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             }
             constexpr int G = PAIR ? (R & 1) : 0;
             // (PAIR: this thread's vectors belong to chunk c2 of the pair - ring slot (R & 2) + c2 - whichever of the pair's two sets R is)
-            unsigned char *dst0 = lds_a + (PAIR ? ((R & 2) + c2) : (R & 3)) * A_BYTES;
+            unsigned char *dst0 = lds_a + (SB >= 0 ? SB + c2 : (PAIR ? ((R & 2) + c2) : (R & 3))) * A_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
                     *reinterpret_cast<u32x4v *>(dst0 + doff[G][i]) = val;
             }
         };
+        auto commit = [&](auto rc, int c_) __attribute__((always_inline)) { commit3(rc, c_, std::integral_constant<int, -1>{}); };
         // STREAM: weight chunk wk of the tile -> weight slot (run chunk & 3) by LDS-DMA (the packed chunk is the LDS image)
         int wk = 0, wq = 0;
         auto dma_w = [&]() {
@@ -432,6 +440,47 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         auto for_sets = [&](auto f) {                            // f(integral_constant<int, k>) for k = 0 .. PF - 1
             [&]<int... K>(std::integer_sequence<int, K...>) { (f(std::integral_constant<int, K>{}), ...); }(std::make_integer_sequence<int, PF>{});
         };
+        if constexpr (QUAD) {
+            // ================================ movers, quad requests ================================
+            using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;       // group 0: the even pairs
+            using R2 = std::integral_constant<int, 2>; using R3 = std::integral_constant<int, 3>;       // group 1 | the odd pairs,
+            using R4 = std::integral_constant<int, 4>; using R5 = std::integral_constant<int, 5>;       // group 2 | alternating
+            using S0 = std::integral_constant<int, 0>; using S2 = std::integral_constant<int, 2>;       // ring slots of an even / odd pair
+            issue(R0{}); issue(R1{}); issue(R2{}); issue(R3{});                                         // quad 0: pairs 0, 1
+            for (int c = ptid; c < ctot; c += NMV) {
+                const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
+                const int cc = c < c0n ? c : c - c0n;
+                s_xf[c] = Sx.scale ? Sx.scale[cc] : 1.f;
+                s_xf[xfs + c] = Sx.shift ? Sx.shift[cc] : 0.f;
+            }
+            __syncthreads();                                     // B0: table (+ resident weights)
+            commit3(R0{}, 0, S0{}); commit3(R1{}, 1, S0{});        // pair 0
+            issue(R0{}); issue(R1{}); issue(R4{}); issue(R5{});  // quad 1: pair 2 -> group 0, pair 3 -> group 2
+            __syncthreads();                                     // B1: run chunks 0, 1 staged
+            // interval i: the consumers work on pair i, pair i + 1 is staged here; a quad is requested in the odd intervals
+            for (int i0 = 0; i0 < NI; i0 += 4) {
+                W16_STAMP(1); commit3(R2{}, 2 * i0 + 2, S2{}); commit3(R3{}, 2 * i0 + 3, S2{}); W16_STAMP(3);      // pair i0 + 1 (group 1)
+                store_prev(i0); W16_STAMP(4); lds_sync(); W16_STAMP(5); W16_STAMP_NEXT();
+                W16_STAMP(1); commit3(R0{}, 2 * i0 + 4, S0{}); commit3(R1{}, 2 * i0 + 5, S0{});                    // pair i0 + 2 (group 0)
+                issue(R0{}); issue(R1{}); issue(R2{}); issue(R3{}); W16_STAMP(3);                                // pairs i0 + 4, i0 + 5 -> groups 0, 1
+                store_prev(i0 + 1); W16_STAMP(4); lds_sync(); W16_STAMP(5); W16_STAMP_NEXT();
+                W16_STAMP(1); commit3(R4{}, 2 * i0 + 6, S2{}); commit3(R5{}, 2 * i0 + 7, S2{}); W16_STAMP(3);      // pair i0 + 3 (group 2)
+                store_prev(i0 + 2); W16_STAMP(4); lds_sync(); W16_STAMP(5); W16_STAMP_NEXT();
+                W16_STAMP(1); commit3(R0{}, 2 * i0 + 8, S0{}); commit3(R1{}, 2 * i0 + 9, S0{});                    // pair i0 + 4 (group 0)
+                issue(R0{}); issue(R1{}); issue(R4{}); issue(R5{}); W16_STAMP(3);                                // pairs i0 + 6, i0 + 7 -> groups 0, 2
+                store_prev(i0 + 3); W16_STAMP(4); lds_sync(); W16_STAMP(5); W16_STAMP_NEXT();
+            }
+            store_prev((NI + IPG - 1) / IPG * IPG);              // what the consumers parked in the very last interval
+            lds_sync();                                          // E
+            lds_sync();                                          // F
+            const int tl = t_hi - 1, ln = tl / tiles_img, lr = tl - ln * tiles_img, lty = lr / tiles_x;
+            store_half(0, ln, lty * TH, (lr - lty * tiles_x) * TW);
+            store_half(1, ln, lty * TH, (lr - lty * tiles_x) * TW);
+#ifdef CDNET_WS_STAMPS
+            if (stamp_on) { for (int i = 0; i < sn; ++i) g_ws16_stamps[1024 + i] = s_stamp[i]; g_ws16_stamps[1024 + sn] = 0; }
+#endif
+            return;
+        }
         for_sets([&](auto k) { issue(k); });
         for (int c = ptid; c < ctot; c += NMV) {
             const ConvSrc &Sx = c < c0n ? A.src[0] : A.src[1];
@@ -726,7 +775,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
         return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(xf_s16x2, v), lo_clamp));
     };
     unsigned char *const o_lane = lds_o + wave * L::OBLK + l31 * L::OROW + half * 16;      // OUT: this lane's pixel in its wave's block
-    auto micro = [&](const f32x16 (&P)[NCI][NPI], int e, bool direct) {
+    auto micro = [&](const f32x16 (&P)[NCI][NPI], int e, bool direct) __attribute__((always_inline)) {
         const int gi = e / (4 * UG), j = e % (4 * UG);
         const int pi = gi / NCI, ci = gi % NCI;
         const f32x16 &v = P[ci][pi];
@@ -737,7 +786,7 @@ __global__ __launch_bounds__(512) void conv_ws16_kernel(ConvArgs A) {
             else { dd[s][0] = relu2(dd[s][0]); dd[s][1] = relu2(dd[s][1]); dd[s][2] = relu2(dd[s][2]); dd[s][3] = relu2(dd[s][3]); }
         } else {
             const int s = j - 3 * UG;
-            if (OUT && !direct) {
+            if constexpr (OUT) {                                 // (every store of the out-image form is the movers': `direct` is never set there)
                 const u32x4v val = {dd[s][0], dd[s][1], dd[s][2], dd[s][3]};
                 *reinterpret_cast<u32x4v *>(o_lane + pi * L::OHALF + ci * 64 + s * 32) = val;
             } else if (cout0 + ci * 32 + s * 16 < A.Cout && !(A.debug & 8)) {
@@ -967,6 +1016,25 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
                     }
                     kern_k<<<grid, 512, smem, st>>>(A);
                     return check_launch("conv_ws16_kernel(k32)");
+                }
+#ifndef CDNET_WS16_QUAD_DEFAULT
+#define CDNET_WS16_QUAD_DEFAULT 1
+#endif
+                // resident weights, every source a multiple of 64 channels, tensors beyond the 256 MB Infinity Cache (the 64-tile inference
+                // launches): whole 128-byte pieces of a pixel per request interval (QUAD) - HBM reads of the dominant layer 0.88 -> 0.69 GB per
+                // 64 tiles (1.32 -> 1.14 x the algorithmic traffic), the launch time unchanged on a box bound by power (310 vs 302-309 us); at 16
+                // tiles, where the L2 / Infinity Cache keep the line between its two pairs anyway, the pair form is 1-2 % faster and stays
+                const long long io_bytes = 2LL * A.N * A.H * A.W * (ctot + A.Cout);
+                if constexpr (!STREAM_ && PAIR_ && CDNET_WS16_QUAD_DEFAULT != 0) if (!(n0 & 3) && !(n1 & 3) && (io_bytes >= (512LL << 20) || (A.debug & 16))) {      // (debug bit 16: tests - the quad form on small launches)
+                    auto kern_q = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, true, true>;
+                    static bool attr_q = false;
+                    if (!attr_q) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                            return check_launch("hipFuncSetAttribute(conv_ws16 quad)");
+                        attr_q = true;
+                    }
+                    kern_q<<<grid, 512, smem, st>>>(A);
+                    return check_launch("conv_ws16_kernel(quad)");
                 }
                 auto kern_o = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, false, PAIR_>;
                 static bool attr_o = false;

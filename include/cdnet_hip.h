@@ -175,7 +175,8 @@ typedef struct cdnet_conv_args {
     int debug;              /* 0 in production.  Kernel-selection switches for the tests: 32 = never take the wave-specialised
                                persistent kernels (conv_ws_kernel; conv_ws32_kernel of the fp32 path), 64 = take them even for
                                small launches; bits 8..: at most (debug >> 8) persistent workgroups per output-channel tile (long
-                               runs of tiles on small test shapes; conv_ws32_kernel); other bits: ablations of tools/bench_conv.py */
+                               runs of tiles on small test shapes; conv_ws32_kernel); 16 (16-bit path): conv_ws16_kernel's quad-request form whatever the
+                               launch's size (production: tensors beyond the Infinity Cache); other bits: ablations of tools/bench_conv.py */
     int ws;                 /* 0, or 2 (fp32 mode, conv_ws32_kernel only - ask cdnet_conv_ws_eligible): the launch also leaves the first
                                BatchNorm-backward pass of the layer its output feeds; eres / oscale / oshift / eres_scale / eres_shift /
                                stats then carry that layer's raw output, scale, shift, mean, invstd and the partial rows f32

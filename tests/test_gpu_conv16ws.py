@@ -71,7 +71,8 @@ def _case(N, cins, Cout, H, W, xf=0, bias=False, relu=False, offs=None, res=Fals
     cfg = (16, 16, 64 if Cout > 32 else 32)
     wp = engine.pack_weights(w.cuda(), cfg, 0)
     outs = {}
-    for name, dbg in [('one-tile', 32)] + [('ws16_%d' % gr, 64 | (gr << 8)) for gr in grids]:
+    # (debug bit 16: the quad-request form of the movers, which production takes only for tensors beyond the Infinity Cache)
+    for name, dbg in [('one-tile', 32)] + [('ws16_%d' % gr, 64 | (gr << 8)) for gr in grids] + [('ws16quad_%d' % grids[0], 64 | 16 | (grids[0] << 8))]:
         engine.CONV_DEBUG = dbg
         try:
             cs = cstride or Cout
@@ -309,6 +310,11 @@ def test_conv_ws16_fused_classifier_output(case):
     try:
         plain, _ = engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, **kw)
         torch.cuda.synchronize()
+        engine.CONV_DEBUG = 64 | 16 | (G << 8)                   # the quad-request form of the movers: the same bits
+        quad, _ = engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(quad, plain)
+        engine.CONV_DEBUG = 64 | (G << 8)
         want = (plain.float() * dw.view(1, 1, 1, -1)).sum(3) + db
         pt = torch.full((N, 1, H, W), 7.0, device='cuda')
         assert engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, dot=(dw, db, pt), query_ws=True, **kw) == 2
