@@ -25,8 +25,8 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
 
     The reference asserts on a tile whose direction-difference map is constant (0/0 -> NaN, test_dam.py:535).  Serial form: the same
     AssertionError here, as postproc.postprocess_views raises it.  Pipelined form (`post_stream`): a host-side assert would drain the
-    pipeline, so the test is made on the device - `r['ddm_constant']` (bool [B], one flag per tile) - and `check_tiles(r)` raises the
-    reference's assertion once the caller has waited for `r['done']`."""
+    pipeline, so the test is left to `check_tiles(r)`: it reads the (min, max) codes the DDM kernel already leaves in `r['minmax']` (int32
+    [B, 2]; no extra launch in the chain) once the caller has waited for `r['done']`, and raises the reference's assertion."""
     assert not model.training
     mask, point, direction = model(x)
     B, _, H, W = mask.shape
@@ -45,8 +45,6 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
         cc = postproc.cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
         r.update(cc)
         r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
-        mm = minmax.reshape(B, 2)
-        r['ddm_constant'] = mm[:, 0] == mm[:, 1]
         if post_stream is not None:
             r['done'] = torch.cuda.Event()
             r['done'].record(post_stream)
@@ -60,7 +58,12 @@ def check_tiles(r):
     a result of infer_tiles; reads the device flag (synchronises with the stream that produced it)"""
     if 'done' in r:
         r['done'].synchronize()
-    bad = torch.nonzero(r['ddm_constant']).flatten().tolist()
+    if 'ddm_constant' in r:                                     # (a precomputed flag tensor, bool [B])
+        flags = r['ddm_constant'].cpu()
+    else:
+        mm = r['minmax'].reshape(-1, 2).cpu()
+        flags = mm[:, 0] == mm[:, 1]
+    bad = torch.nonzero(flags).flatten().tolist()
     assert not bad, ('tile(s) %s have a constant direction-difference map: 0/0 -> NaN; the reference asserts here (test_dam.py:535)' % bad)
 
 

@@ -105,3 +105,13 @@ def test_check_tiles_raises_the_references_constant_ddm_assertion():
     pipeline.check_tiles({'ddm_constant': torch.tensor([False, False, False])})
     with pytest.raises(AssertionError, match='constant direction-difference map'):
         pipeline.check_tiles({'ddm_constant': torch.tensor([False, True, False])})
+
+
+def test_check_tiles_reads_the_ddm_kernels_minmax():
+    """without a flag tensor check_tiles compares the (min, max) codes cdnet_ddm_codes left per tile"""
+    import pytest
+    import torch
+    from cdnet_amd import pipeline
+    pipeline.check_tiles({'minmax': torch.tensor([[0, 2], [0, 1]], dtype=torch.int32)})
+    with pytest.raises(AssertionError, match=r'tile\(s\) \[1\]'):
+        pipeline.check_tiles({'minmax': torch.tensor([[0, 2], [1, 1], [0, 1]], dtype=torch.int32)})
