@@ -44,8 +44,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'train'), choices=['auto', 'train', 'infer', 'image', 'roofline'],
-                    help="'roofline': only the dominant-kernel measurement of the roofline object (the command profiles/<round>/dominant_conv_* are taken with)")
+    ap.add_argument('--mode', default=os.environ.get('CDNET_BENCH_MODE', 'train'), choices=['auto', 'train', 'infer', 'image', 'roofline', 'forced_allreduce'],
+                    help="'roofline': only the dominant-kernel measurement of the roofline object (the command profiles/<round>/dominant_conv_* are taken with); "
+                         "'forced_allreduce': only the 1-rank step with the all-reduce forced (the child process of the default run's dp1_forced_allreduce leg)")
     ap.add_argument('--dtype', default=os.environ.get('CDNET_BENCH_DTYPE', 'fp32'), choices=['bf16', 'fp32'],
                     help='arithmetic of the headline value; the other precision is reported beside it')
     ap.add_argument('--batch', type=int, default=None, help='tiles per GPU per step')
@@ -192,6 +193,32 @@ def unet_batch(B, dev, seed=2022):
     from cdnet_amd.trainer import synthetic_batch
     x, lab, _, _, weight = synthetic_batch(B, dev, seed=seed)
     return x, lab, weight
+
+
+def child_json(args, timeout_s):
+    """one more `bench.py` as a fresh child process in its own process group (killed and reaped as a group on a timeout); returns the dict of
+    its JSON line or a dict(error=...).  Used for the leg that creates an RCCL process group: a hang there must not take the main line with it,
+    and nothing is ever re-executed in a process that holds the GPU."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, start_new_session=True, text=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.communicate()
+        return dict(error='child exceeded %d s (its process group was killed and reaped)' % timeout_s)
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    if proc.returncode != 0 or not lines:
+        return dict(error='child failed (rc %s)' % proc.returncode)
+    return json.loads(lines[-1])
 
 
 def dominant_roofline(ms, B, precision, traffic=None, traffic_src=None, mfma_busy=None, clock=None, kernel=None):
@@ -581,6 +608,12 @@ def main():
                 torch.cuda.synchronize()
                 dist.destroy_process_group()
 
+    if mode == 'forced_allreduce':
+        fa = run_forced_allreduce(a.dtype, a.batch or 16, a.steps, a.warmup)
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
+        print(json.dumps(fa), flush=True)
+        return
     other = 'fp32' if a.dtype == 'bf16' else 'bf16'
     extras = not a.no_extras
     if mode == 'train':
@@ -655,8 +688,12 @@ def main():
             else:
                 line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)
         if extras and mode == 'train' and world == 1 and not a.no_forced_allreduce:
-            fa = run_forced_allreduce(a.dtype, B, max(5, a.steps // 2), 2)
-            fa['vs_value'] = fa['value'] / head['value']
+            # (a child process: the leg creates a one-rank RCCL group - a hang or a crash there costs this key, not the line)
+            torch.cuda.synchronize()
+            fa = child_json(['--mode', 'forced_allreduce', '--dtype', a.dtype, '--steps', str(max(5, a.steps // 2)), '--warmup', '2',
+                             '--batch', str(B)], 240)
+            if 'value' in fa:
+                fa['vs_value'] = fa['value'] / head['value']
             line['dp1_forced_allreduce'] = fa
         if not a.no_cpu_baseline and world == 1:
             # every reported rate has its CPU leg beside it: the headline's under `cpu_baseline`, the others under

@@ -140,18 +140,28 @@ __global__ __launch_bounds__(256) void cdm_centerness_kernel(const int32_t *__re
     const int id = on ? s[p] : 0;
     double c = 0;
     if (on) {
-        double ma = 0, mi = 10000000;
-        for (int k = 0; k < 8; ++k) {
-            double l = 0, r = 1000;
-            for (int t = 0; t < 30; ++t) {
-                const double mid = (l + r) / 2;
+        // the eight rays' bisections step together: each ray's 30 steps are its own dependent chain (a gather per step), eight of them in flight
+        double lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo[k] = 0; hi[k] = 1000; }
+        for (int t = 0; t < 30; ++t) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double mid = (lo[k] + hi[k]) / 2;
                 const double fy = y + R.s[k] * mid, fx = x + R.c[k] * mid;        // -ffp-contract=off: mul then add, like CPython
                 const int ny = (int)rint(fy), nx = (int)rint(fx);                 // (|.| <= 1000 + the image size: exact in 32 bits)
-                const bool in = ny >= 0 && ny < H && nx >= 0 && nx < W && s[ny * W + nx] == id;
-                if (in) l = mid; else r = mid;
+                const bool inb = ny >= 0 && ny < H && nx >= 0 && nx < W;
+                const int v = s[inb ? ny * W + nx : p];                           // (an unconditional load: the eight gathers of a step issue together)
+                const bool in = inb && v == id;
+                lo[k] = in ? mid : lo[k];
+                hi[k] = in ? hi[k] : mid;
             }
-            ma = r > ma ? r : ma;
-            mi = r < mi ? r : mi;
+        }
+        double ma = 0, mi = 10000000;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ma = hi[k] > ma ? hi[k] : ma;
+            mi = hi[k] < mi ? hi[k] : mi;
         }
         c = mi / ma;
         cness[(size_t)n * plane + p] = c;

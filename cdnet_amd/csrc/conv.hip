@@ -891,18 +891,27 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         // the run) and out-of-range vectors are zeroed by a mask, so that the compiler can count the loads in flight
         // (s_waitcnt vmcnt(N)) instead of draining them at a join.
         const int ptid = tid - 256;
-        const int slot = ptid % VPP;
+        // Round 5 (conv_ws16_kernel's finding, conv16ws.hip): a request takes a chunk PAIR - 32 channels = 64 contiguous bytes of a pixel, a whole
+        // sector of the memory side - instead of one chunk's 32 bytes (every sector was requested twice).  Lane -> pixel v / 4, 16-byte segment
+        // v % 4 = chunk (v % 4) / 2 of the pair, k-half v % 2; register set R of a pair holds half of the pair's vectors (group R & 1), both sets
+        // are written into the pair's two ring slots in the same interval.  The launcher guarantees pairs inside one source (n0 even).
+        constexpr int VPQ = 2 * VPP, NG = 2;
+        const int slot = ptid % VPQ;
+        const int khalf = slot & 1, c2 = slot >> 1;
         u32x4v pa[PF][NA];
         unsigned eo[PF][NA];                     // byte offsets of the requests (read again for a residual operand); bit 31 = zero fill
-        // per-thread constants: halo coordinates and LDS offsets of its NA vectors
-        int hyx[NA], doff[NA];
+        // per-thread constants: halo coordinates and LDS offsets of its vectors
+        int hyx[NG][NA], doff[NG][NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int pix = (ptid + i * 256) / VPP;
-            const int hy = pix / HW_, hx = pix - hy * HW_;
-            hyx[i] = ptid + i * 256 < NPIX * VPP ? ((hy << 8) | hx) : 0x1f1f;      // (31 = a vector that never exists: bit 31 of the masks is always set)
-            doff[i] = pix * PSTR + ((slot ^ (hy & 1)) * 16);
-        }
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int v = ptid + (g * NA + i) * 256;
+                const int pix = v / VPQ;
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                hyx[g][i] = v < NPIX * VPQ ? ((hy << 8) | hx) : 0x1f1f;      // (31 = a vector that never exists: bit 31 of the masks is always set)
+                doff[g][i] = pix * PSTR + ((khalf ^ (hy & 1)) * 16);
+            }
         // Requests through buffer descriptors (conv_ws32_kernel's recipe, round 3): a vector outside the image / the source window carries
         // bit 31 in its byte offset and reads as zeros (the launcher admits tensors below 2 GB) - no select, no 64-bit address arithmetic and,
         // for plain sources, no mask per vector: every vector instruction of a mover wave costs the consumers' MFMA stream issue time.
@@ -935,14 +944,15 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         int ck = 0;
         // staging geometry of the current tile and source (the chunks of one source share it): element offset of each vector
         // without the chunk's channel offset, validity mask
-        unsigned ge[NA];                         // byte offset of channel 0 of the tile's vectors in the current source, bit 31 = zero fill
+        unsigned ge[NG][NA];                     // byte offset of channel 0 of the tile's vectors in the current source, bit 31 = zero fill
         const int n0 = A.src[0].C / CK;
         auto issue = [&](auto rc) {
             constexpr int R = decltype(rc)::value;
+            constexpr int G = R & 1;                              // which half of the pair's vectors this register set holds
             int si, cc0;
-            chunk_src(ik, si, cc0);
+            chunk_src(ik & ~1, si, cc0);                          // (the pair's first chunk: both sets request from its base)
             const ConvSrc &s = A.src[si];
-            if (ik == 0 || ik == n0) {
+            if ((ik & ~1) == 0 || (ik & ~1) == n0) {
                 const int rs = s.row_stride ? s.row_stride : s.Ws * s.C;
                 // halo row r <-> y = iy0 - 1 + r, halo column c <-> x = ix0 - 1 + c; valid = inside the image and the source window
                 const int ylo = s.off_y > 0 ? s.off_y : 0, yhi = A.H < s.off_y + s.Hs ? A.H : s.off_y + s.Hs;
@@ -952,16 +962,16 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                 const unsigned rs_b = (unsigned)rs * 2u, c_b = (unsigned)s.C * 2u;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const unsigned hy = (unsigned)hyx[i] >> 8, hx = (unsigned)hyx[i] & 0xffu;
+                    const unsigned hy = (unsigned)hyx[G][i] >> 8, hx = (unsigned)hyx[G][i] & 0xffu;
                     const unsigned t = (rowbad >> hy) | (colbad >> hx);
-                    ge[i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 16u) & 0x7fffffffu) | (t << 31);
+                    ge[G][i] = ((img_b + hy * rs_b + hx * c_b + (unsigned)slot * 16u) & 0x7fffffffu) | (t << 31);
                 }
             }
             const __amdgpu_buffer_rsrc_t rsx = si ? rsx1 : rsx0;
             const unsigned cc0_b = (unsigned)cc0 * 2u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const unsigned voff = ge[i] + cc0_b;                   // (a zero-fill vector keeps bit 31: beyond every tensor the launcher admits)
+                const unsigned voff = ge[G][i] + cc0_b;                // (a zero-fill vector keeps bit 31: beyond every tensor the launcher admits)
                 eo[R][i] = voff;
                 pa[R][i] = bload(rsx, voff);
             }
@@ -978,8 +988,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
         // chunk c_ of the run (register set R = c_ % 4) -> ring slot c_ % 4
         auto commit = [&](auto rc, int c_) {
             constexpr int R = decltype(rc)::value;
+            constexpr int G = R & 1;
             int si, cc0;
-            chunk_src(ck, si, cc0);
+            chunk_src(ck & ~1, si, cc0);
             if (c_ + 1 < S) { if (++ck == NCH) ck = 0; }
             const ConvSrc &s = A.src[si];
             const float *xf = s_xf + (si ? c0n : 0) + cc0 + slot * 8;
@@ -988,7 +999,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { sc[j] = xf[j]; sh[j] = xf[xfs + j]; }
             }
-            unsigned char *dst0 = lds_a + R * L::A_BYTES;
+            unsigned char *dst0 = lds_a + ((R & 2) + c2) * L::A_BYTES;      // (this thread's vectors belong to chunk c2 of the pair, whichever set R is)
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 u32x4v val;
@@ -1013,10 +1024,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs A) {
                     val &= keep;
                 }
 #ifdef CDNET_WS_STAMPS
-                if (A.debug & 1024) { if (val[0] == 0x12345678u) *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val; continue; }
+                if (A.debug & 1024) { if (val[0] == 0x12345678u) *reinterpret_cast<u32x4v *>(dst0 + doff[G][i]) = val; continue; }
 #endif
-                if (i < NA - 1 || ptid + i * 256 < NPIX * VPP)
-                    *reinterpret_cast<u32x4v *>(dst0 + doff[i]) = val;
+                if (ptid + (G * NA + i) * 256 < NPIX * VPQ)
+                    *reinterpret_cast<u32x4v *>(dst0 + doff[G][i]) = val;
             }
         };
         // ---- out path: mover wave w stores the region of consumer wave w.  Piece pc = (M tile mi, pixel half ch, cout pass kk): the four
@@ -1358,6 +1369,7 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) 
     if (A.ws == 2) return -1;                                    // (BatchNorm-backward sums beside the stores: the fp32 kernel only, conv32ws.hip)
     if (A.eres) return -1;                                       // fused residual epilogues stay on conv_fwd_kernel
     if (A.nchunk < 4 || A.nchunk % 4 != 0) return -1;            // whole pairs of barrier intervals (two chunks each) per tile
+    if ((A.src[0].C / 16) & 1) return -1;                        // (the movers request by chunk pairs: every pair inside one source)
     const bool stream = A.nchunk != 4;                           // 128+ input channels / two sources: the weight chunks stream through the LDS
     if (A.H % 16 != 0 || A.W % 16 != 0) return -1;               // full tiles only
     for (int i = 0; i < A.nsrc; ++i) {
@@ -1613,7 +1625,10 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         CDNET_REQUIRE(!(A.src[i].pool && A.src[i].res), "cdnet_conv_forward: pool+residual source unsupported");
         nchunk += A.src[i].C / A.CK;
     }
-    CDNET_REQUIRE(nchunk == A.nchunk, "cdnet_conv_forward: nchunk %d != %d", A.nchunk, nchunk);
+    // (a one-tap second source of the 16-bit path may carry ONE padding chunk of zero weights beyond its channels - an even chunk count for
+    //  conv_ws16_kernel's out-image form; only that kernel computes the one-tap form, and it refuses nothing silently: see below)
+    const bool padded = A.nchunk == nchunk + 1 && A.taps1 == 1 && A.taps == 9 && A.nsrc == 2 && !A.f32;
+    CDNET_REQUIRE(nchunk == A.nchunk || padded, "cdnet_conv_forward: nchunk %d != %d", A.nchunk, nchunk);
     CDNET_REQUIRE((A.taps == 9 && A.npar == 1 && A.ostride == 1) || (A.taps == 1 && A.npar == 1 && A.ostride == 1) ||
                   (A.taps == 4 && A.npar == 4 && A.ostride == 2) || (A.taps == 1 && A.npar == 4 && A.ostride == 2),
                   "cdnet_conv_forward: taps=%d npar=%d ostride=%d", A.taps, A.npar, A.ostride);

@@ -216,7 +216,8 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
-                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0, pool_out=None, dot=None):
+                 orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0, pool_out=None, dot=None,
+                 pad_chunks=0):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -254,7 +255,11 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.out, a.Cout, a.out_cstride, a.out_coff = (None if out is None else out.data_ptr()), Cout, (Cout if out is None else out.shape[3]), 0
     a.stats = _dp(stats)
     a.N, a.H, a.W = N, H, W
-    a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk
+    # pad_chunks (taps1 = 1, plain 16-bit sources only): that many more one-tap chunks than the second source has channels for - their packed
+    # weights are zeros (the caller's pack holds them), what the movers read for them is the neighbouring pixel's channels (zeros past the tensor's
+    # end); it makes the chunk count even, which conv_ws16_kernel's out-image form with pair requests needs
+    assert pad_chunks == 0 or (taps1 == 1 and not f32 and all(s.scale is None and not s.relu and s.res is None and not s.f16 for s in srcs))
+    a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk + pad_chunks
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out is not None and out.dtype == torch.float16)
     a.ws = 0

@@ -401,12 +401,19 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True, dot=None):
     if getattr(c2, 'ru_wr', None) is None or c2.ru_wr_version != rver:
         c2.ru_wr = engine.pack_weights(cr.weight.detach(), c2.cfg, 0, out=getattr(c2, 'ru_wr', None), split=f32)
         c2.ru_wr_version = rver
-    ver = (c2.wpe_version, rver, None if cr.bias is None else cr.bias._version, PRECISION)
+    # 16-bit path, an odd number of one-tap chunks (the first unit: 16 input channels): one more one-tap chunk of ZERO weights makes the chunk
+    # count even - conv_ws16_kernel's out-image form (whole-line stores by the movers, pair requests) instead of the consumers' direct stores:
+    # 548 -> ~440 us per 64 tiles on that launch (engine.conv_forward(pad_chunks=))
+    pad = 1 if (not f32 and (x.C // 16) % 2 == 1 and c2.cfg[1] == 16) else 0
+    ver = (c2.wpe_version, rver, None if cr.bias is None else cr.bias._version, PRECISION, pad)
     if getattr(c2, 'ru_pack', None) is None or c2.ru_pack_version != ver:
         BN = c2.cfg[2]
         ntile = -(-c2.Cout // BN)
         a, b = ep[0].view(ntile, -1), c2.ru_wr.view(ntile, -1)   # per output-channel tile: the nine-tap chunks, then the one-tap chunks
-        c2.ru_pack = torch.cat([a, b], 1).contiguous().view(-1)
+        parts = [a, b]
+        if pad:
+            parts.append(torch.zeros((ntile, 16 * BN), dtype=a.dtype, device=a.device))      # (a one-tap chunk: CK x BN bf16 patterns)
+        c2.ru_pack = torch.cat(parts, 1).contiguous().view(-1)
         c2.ru_shift = ep[1] if cr.bias is None else ep[1] + cr.bias.detach()
         c2.ru_pack_version = ver
     hC = c1.Cout
@@ -419,7 +426,7 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True, dot=None):
         want_dot = dot is not None and RU_EVAL_POINT_DOT and relu2
         if key not in elig or (want_dot and key + ('dot',) not in elig):
             hp = Src(torch.empty((x.N, H, W, hC), dtype=act_dtype(), device=x.x.device))
-            kw = dict(oshift=c2.ru_shift, H=H, W=W, taps1=1, query_ws=True)
+            kw = dict(oshift=c2.ru_shift, H=H, W=W, taps1=1, query_ws=True, pad_chunks=pad)
             elig[key] = bool(not (keep & 32) and engine.conv_forward([hp, x], c2.ru_pack, c2.Cout, c2.cfg, 9, orelu=relu2, **kw))
             if want_dot:
                 d0 = (dot[0], dot[1], torch.empty((x.N, 1, H, W), dtype=torch.float32, device=x.x.device))
@@ -430,9 +437,9 @@ def residual_unit_eval(c1, c2, cr, x, relu2=True, dot=None):
         assert h.C == hC and not h.pool and h.scale is None
         if want_dot and elig[key + ('dot',)]:
             point = torch.empty((x.N, 1, H, W), dtype=torch.float32, device=x.x.device)
-            engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=(dot[0], dot[1], point))
+            engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=True, H=H, W=W, taps1=1, dot=(dot[0], dot[1], point), pad_chunks=pad)
             return PointLogit(point)
-        out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1)
+        out, _ = engine.conv_forward([h, x], c2.ru_pack, c2.Cout, c2.cfg, 9, oshift=c2.ru_shift, orelu=relu2, H=H, W=W, taps1=1, pad_chunks=pad)
     finally:
         engine.CONV_DEBUG = keep
     return Src(out)

@@ -269,10 +269,11 @@ def test_ws_kernel_bit_identical_plain_stats_and_folded(case):
     _close(_nchw(bb[0]), want, 'ws plain')
 
 
-@pytest.mark.parametrize('chans', [(16, 48), (64, 64), (64, 128)])
+@pytest.mark.parametrize('chans', [(32, 32), (64, 64), (64, 128)])
 def test_ws_kernel_bit_identical_two_sources_residual_and_fused_epilogue(chans):
-    """two lazily transformed sources (a padded small one with an offset, one with a residual branch): 16 + 48 channels = the resident
-    form, 64 + 64 and 64 + 128 = the streamed-weights form; full 16x16 tiles so that the producer / consumer kernel takes the launch"""
+    """two lazily transformed sources (a padded small one with an offset, one with a residual branch): 32 + 32 channels = the resident
+    form, 64 + 64 and 64 + 128 = the streamed-weights form; full 16x16 tiles so that the producer / consumer kernel takes the launch
+    (its movers request by chunk pairs since round 5: every source an even number of 16-channel chunks)"""
     import torch
     from cdnet_amd import engine
     g = torch.Generator().manual_seed(3)

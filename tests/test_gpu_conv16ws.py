@@ -346,3 +346,38 @@ def test_conv_ws16_fused_classifier_output(case):
             engine.conv_forward(srcs, wp, Cout, cfg, oshift=b.cuda(), orelu=True, H=H, W=W, dot=(dw, db, pt), **kw)
     finally:
         engine.CONV_DEBUG = 0
+
+
+@pytest.mark.parametrize('case', [dict(N=2, H=32, W=48, G=3), dict(N=1, H=16, W=32, G=0)])
+def test_residual_unit_with_16_channel_input_takes_the_out_image_form(case):
+    """the first residual unit of the DAM head (model_unet_rev1.py:161-170, x has 16 channels): ONE one-tap chunk behind the four nine-tap ones is
+    an odd chunk count - with one more one-tap chunk of zero weights (engine.conv_forward(pad_chunks=1)) the launch takes conv_ws16_kernel's out-image
+    form.  What the movers read for the padding chunk is the neighbouring pixel's channels (zeros past the tensor's end); its weights are zeros, the
+    result equals the unpadded launch bit for bit and the float reference to bf16 rounding."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, H, W, G = [case[k] for k in ('N', 'H', 'W', 'G')]
+    g = torch.Generator().manual_seed(5 + H + W)
+    h = _bf(torch.randn((N, 64, H, W), generator=g))
+    x = _bf(torch.randn((N, 16, H, W), generator=g))
+    w = _bf(torch.randn((64, 64, 3, 3), generator=g) * (1.5 / (9 * 64) ** 0.5))
+    w1 = _bf(torch.randn((64, 16, 1, 1), generator=g) * 0.25)
+    b = torch.randn((64,), generator=g) * 0.3
+    cfg = (16, 16, 64)
+    a, b1 = engine.pack_weights(w.cuda(), cfg, 0).view(1, -1), engine.pack_weights(w1.cuda(), cfg, 0).view(1, -1)
+    plain_pack = torch.cat([a, b1], 1).contiguous().view(-1)
+    padded_pack = torch.cat([a, b1, torch.zeros((1, 16 * 64), dtype=a.dtype, device=a.device)], 1).contiguous().view(-1)
+    srcs = [engine.Src(_nhwc(h)), engine.Src(_nhwc(x))]
+    engine.CONV_DEBUG = 64 | (G << 8)
+    try:
+        kw = dict(oshift=b.cuda(), orelu=True, H=H, W=W, taps1=1)
+        assert engine.conv_forward(srcs, padded_pack, 64, cfg, 9, query_ws=True, pad_chunks=1, **kw) == 2
+        plain, _ = engine.conv_forward(srcs, plain_pack, 64, cfg, 9, **kw)
+        padded, _ = engine.conv_forward(srcs, padded_pack, 64, cfg, 9, pad_chunks=1, **kw)
+        torch.cuda.synchronize()
+    finally:
+        engine.CONV_DEBUG = 0
+    assert torch.equal(padded, plain)
+    want = F.relu(F.conv2d(h, w, None, padding=1) + F.conv2d(x, w1) + b.view(1, -1, 1, 1))
+    _close(_nchw(padded), want, 'padded one-tap chunk')
