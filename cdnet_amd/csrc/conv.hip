@@ -1625,9 +1625,10 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         CDNET_REQUIRE(!(A.src[i].pool && A.src[i].res), "cdnet_conv_forward: pool+residual source unsupported");
         nchunk += A.src[i].C / A.CK;
     }
-    // (a one-tap second source of the 16-bit path may carry ONE padding chunk of zero weights beyond its channels - an even chunk count for
-    //  conv_ws16_kernel's out-image form; only that kernel computes the one-tap form, and it refuses nothing silently: see below)
-    const bool padded = A.nchunk == nchunk + 1 && A.taps1 == 1 && A.taps == 9 && A.nsrc == 2 && !A.f32;
+    // (the second source of a two-source 3x3 launch of the 16-bit path may carry ONE padding chunk of zero weights beyond its channels - an even
+    //  chunk count for conv_ws16_kernel's out-image form with pair requests; what a kernel reads for that chunk is the neighbouring pixel's
+    //  channels, or zeros past the tensor's end: finite values times zero weights)
+    const bool padded = A.nchunk == nchunk + 1 && A.taps == 9 && A.nsrc == 2 && !A.f32;
     CDNET_REQUIRE(nchunk == A.nchunk || padded, "cdnet_conv_forward: nchunk %d != %d", A.nchunk, nchunk);
     CDNET_REQUIRE((A.taps == 9 && A.npar == 1 && A.ostride == 1) || (A.taps == 1 && A.npar == 1 && A.ostride == 1) ||
                   (A.taps == 4 && A.npar == 4 && A.ostride == 2) || (A.taps == 1 && A.npar == 4 && A.ostride == 2),

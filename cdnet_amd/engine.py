@@ -255,10 +255,10 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.out, a.Cout, a.out_cstride, a.out_coff = (None if out is None else out.data_ptr()), Cout, (Cout if out is None else out.shape[3]), 0
     a.stats = _dp(stats)
     a.N, a.H, a.W = N, H, W
-    # pad_chunks (taps1 = 1, plain 16-bit sources only): that many more one-tap chunks than the second source has channels for - their packed
+    # pad_chunks (two plain 16-bit sources only): that many more chunks than the second source has channels for - their packed
     # weights are zeros (the caller's pack holds them), what the movers read for them is the neighbouring pixel's channels (zeros past the tensor's
     # end); it makes the chunk count even, which conv_ws16_kernel's out-image form with pair requests needs
-    assert pad_chunks == 0 or (taps1 == 1 and not f32 and all(s.scale is None and not s.relu and s.res is None and not s.f16 for s in srcs))
+    assert pad_chunks == 0 or (len(srcs) == 2 and taps == 9 and not f32 and all(s.scale is None and not s.relu and s.res is None and not s.f16 for s in srcs))
     a.taps, a.npar, a.ostride, a.nchunk = taps, npar, ostride, nchunk + pad_chunks
     a.tile, a.CK, a.BN = tile, CK, BN
     a.out_f16 = int(out is not None and out.dtype == torch.float16)

@@ -244,7 +244,8 @@ class Unet(nn.Module):
             sh, sw = skip.logical_hw()
             uh, uw = u.logical_hw()
             u.off = pad_offsets((uh, uw), (sh, sw))                # F.pad (:126-131)
-            t = conv2.forward([u, skip], training, H=sh, W=sw)      # cat([x, skip]) -> conv2 -> bn2 -> relu (:133-141)
+            tt = None if training else conv2.forward_eval_swapped([u, skip], H=sh, W=sw)      # (eval, 16-bit: an odd chunk count made even - runtime.py)
+            t = tt if tt is not None else conv2.forward([u, skip], training, H=sh, W=sw)      # cat([x, skip]) -> conv2 -> bn2 -> relu (:133-141)
         f1 = self._rt['ru'][0].forward(t, training, store=True)
         f2 = self._rt['ru'][1].forward(f1, training, store=True)
         if self.VARIANT == 'rev1':

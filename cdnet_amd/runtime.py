@@ -181,6 +181,44 @@ class ConvLayer:
             self.wpe_version = ver
         return self.wpe, sh
 
+    def forward_eval_swapped(self, srcs, relu=True, H=None, W=None):
+        """eval mode, 16-bit path, torch.cat([x, skip]) -> conv3x3 -> BatchNorm -> ReLU of a decoder block (model_unet_rev1.py:133-141) whose first
+        source has an ODD number of 16-channel chunks (the last block: 16 + 64 channels = five chunks, conv_ws16_kernel's consumers-store form:
+        399 us per 64 tiles for 0.8 GB).  The convolution does not care in which order its input channels arrive: the sources are passed as
+        [skip, x] with the weight's input channels permuted to match, and one padding chunk of zero weights behind x makes the count even - the
+        out-image form with pair requests.  Returns the output Src, or None when the launch is not that kernel's (the caller takes forward())."""
+        if PRECISION != 'bf16' or self.kind != 'conv3' or self.bn is None or len(srcs) != 2 or not EVAL_FOLD_WEIGHTS or not getattr(self, 'fold_eval', True):
+            return None
+        a, b = srcs
+        if (a.C // 16) % 2 == 0 or (b.C // 16) % 2 or a.C % 16 or b.C % 16 or a.C + b.C != self.Cin:
+            return None
+        if any(s.scale is not None or s.relu or s.res is not None or s.f16 or s.pool for s in srcs):
+            return None
+        if H is None:
+            H, W = b.logical_hw()
+        if H % 16 or W % 16:
+            return None
+        self.prepare([s.C for s in srcs], H, W, a.N)
+        if tuple(self.cfg[:2]) != (16, 16):
+            return None
+        sc, sh = self.eval_fold()
+        ver = (self.weight._version, self.fold_version, WEIGHTS_EPOCH[0], tuple(self.cfg))
+        if getattr(self, 'wps', None) is None or self.wps_version != ver:
+            w = self.weight.detach()
+            wz = torch.zeros((w.shape[0], 16, w.shape[2], w.shape[3]), dtype=w.dtype, device=w.device)
+            wperm = torch.cat([w[:, a.C:], w[:, :a.C], wz], 1).contiguous()          # input channels: [skip | x | padding chunk]
+            self.wps = engine.pack_weights(wperm, self.cfg, 0, cout_scale=sc)
+            self.wps_version = ver
+        kw = dict(oshift=sh, orelu=relu and not DEBUG_NORELU, H=H, W=W, pad_chunks=1)
+        key = (a.N, H, W, a.C, b.C, a.off, b.off)
+        elig = self.__dict__.setdefault('_swapped_eligible', {})
+        if key not in elig:
+            elig[key] = engine.conv_forward([b, a], self.wps, self.Cout, self.cfg, 9, query_ws=True, **kw) == 2
+        if not elig[key]:
+            return None
+        out, _ = engine.conv_forward([b, a], self.wps, self.Cout, self.cfg, 9, **kw)
+        return Src(out)
+
     def forward_eval_pool(self, srcs):
         """eval mode: relu(bn(conv(.))) AND its nn.MaxPool2d(2, 2) from one launch (the 'M' layers of the VGG16-BN encoder,
         model_unet_rev1.py:40-41: conv_ws16_kernel's movers pool the out image beside their stores, conv_ws32_kernel's consumers the windows

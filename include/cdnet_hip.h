@@ -169,8 +169,8 @@ typedef struct cdnet_conv_args {
     int taps;               /* 9: 3x3 pad 1; 1: 1x1; 4: sub-pixel 2x2 of ConvTranspose2d(k4,s2,p1) */
     int npar;               /* 1, or 4 sub-pixel parities (ConvTranspose2d stride 2) */
     int ostride;            /* 1, or 2 for the transposed convolutions */
-    int nchunk;             /* total Cin chunks over both sources (taps1 = 1, 16-bit path: one more is allowed - a padding one-tap chunk whose packed
-                               weights are zeros, making the count even for conv_ws16_kernel's out-image form) */
+    int nchunk;             /* total Cin chunks over both sources (two-source 3x3 launches of the 16-bit path: one more is allowed - a padding chunk
+                               behind the second source whose packed weights are zeros, making the count even for conv_ws16_kernel's out-image form) */
     int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
     int out_f16;            /* 1: store the output as fp16 instead of bf16 */
     int debug;              /* 0 in production.  Kernel-selection switches for the tests: 32 = never take the wave-specialised

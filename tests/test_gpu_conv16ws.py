@@ -381,3 +381,33 @@ def test_residual_unit_with_16_channel_input_takes_the_out_image_form(case):
     assert torch.equal(padded, plain)
     want = F.relu(F.conv2d(h, w, None, padding=1) + F.conv2d(x, w1) + b.view(1, -1, 1, 1))
     _close(_nchw(padded), want, 'padded one-tap chunk')
+
+
+@pytest.mark.parametrize('case', [dict(N=2, H=32, W=48, G=3, Cout=16), dict(N=1, H=16, W=32, G=0, Cout=64)])
+def test_decoder_block_with_swapped_sources_and_a_padding_chunk(case):
+    """cat([x (16 channels), skip (64)]) -> 3x3 convolution (model_unet_rev1.py:133-141) as [skip, x] with the weight's input channels permuted and one
+    padding chunk of zero weights behind x (runtime.ConvLayer.forward_eval_swapped): five chunks become six - conv_ws16_kernel's out-image form
+    with pair requests.  Another summation order than the [x, skip] launch (bf16 rounding apart), the same convolution."""
+    import torch
+    import torch.nn.functional as F
+    from cdnet_amd import engine
+    N, H, W, G, Cout = [case[k] for k in ('N', 'H', 'W', 'G', 'Cout')]
+    g = torch.Generator().manual_seed(17 + H + Cout)
+    x = _bf(torch.randn((N, 16, H, W), generator=g))
+    skip = _bf(torch.randn((N, 64, H, W), generator=g))
+    w = _bf(torch.randn((Cout, 80, 3, 3), generator=g) * (1.5 / (9 * 80) ** 0.5))
+    b = torch.randn((Cout,), generator=g) * 0.3
+    cfg = (16, 16, 64 if Cout > 32 else 32)
+    wperm = torch.cat([w[:, 16:], w[:, :16], torch.zeros((Cout, 16, 3, 3))], 1).contiguous()
+    wp = engine.pack_weights(wperm.cuda(), cfg, 0)
+    srcs = [engine.Src(_nhwc(skip)), engine.Src(_nhwc(x))]
+    engine.CONV_DEBUG = 64 | (G << 8)
+    try:
+        kw = dict(oshift=b.cuda(), orelu=True, H=H, W=W, pad_chunks=1)
+        assert engine.conv_forward(srcs, wp, Cout, cfg, 9, query_ws=True, **kw) == 2
+        got, _ = engine.conv_forward(srcs, wp, Cout, cfg, 9, **kw)
+        torch.cuda.synchronize()
+    finally:
+        engine.CONV_DEBUG = 0
+    want = F.relu(F.conv2d(torch.cat([x, skip], 1), w, b, padding=1))
+    _close(_nchw(got), want, 'swapped sources + padding chunk')

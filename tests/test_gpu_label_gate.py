@@ -11,7 +11,8 @@ Dice >= 0.998, i.e. a ground-truth score of either side can differ by at most 0.
 mode's label maps are identical to the oracle's; bf16 mode has held the same 0.998 per tile since round 4 - the 0.997 mean / 0.995 per-tile
 floors of round 3 are gone), and beside it north_star's literal bar: AJI / Dice of BOTH sides against the ground truth (the rendered instance
 map) within 0.002.  Since round 5 the bf16 bar is checked on more than one draw: `test_second_draw` trains a second network (another seed,
-other batches) and scores both networks on two 1000x1000 images - four mutual AJI values, all printed, all held to the bar.
+other batches) and scores both networks on two 600x600 images (8 views x 9 windows) - four mutual AJI values, all printed, all held to the bar
+(on 1000x1000 images of the same seeds round 5 measured 0.99872 / 0.99868 / 0.99893 / 0.99912: profiles/r05/label_gate.log).
 
 Both arithmetic modes of the product path are gated in one run: every test is parametrised over 'fp32' (fp32 activations,
 split-bf16 x3 MFMA products - the like-for-like mode) and 'bf16' (cdnet_amd.set_precision, restored afterwards).  The gate
@@ -224,29 +225,30 @@ def test_dense_touching_nuclei_boost(trained):
 
 def test_second_draw(gate_net, gate_net2):
     """the bf16 bar on more than one draw (round 4 cleared it by 0.0007 on ONE network and ONE image): two networks (training seeds 0 / 1,
-    different batches) x two 1000x1000 images (seeds 4242 / 9191), 8 TTA views x 25 windows each - all four mutual AJI / Dice values of the
-    bf16 path against the fp32 CPU oracle are printed and held to the bar; fp32 mode is held to 0.9999 (identical label maps or a few pixels)"""
+    different batches) x two 600x600 images (seeds 4242 / 9191; 8 TTA views x 9 windows of 256 / 40 each - the CPU oracle of a 1000x1000 image
+    takes a minute and a half per draw on the GPU box's host) - all four mutual AJI / Dice values of the bf16 path against the fp32 CPU oracle
+    are printed and held to the bar; fp32 mode is held to 0.9999 (identical label maps or a few pixels)"""
     import torch
     import cdnet_amd
     from cdnet_amd import pipeline, synth
     from oracle import infer as oinf
     before = cdnet_amd.get_precision()
     rows = []
+    S = 600
     try:
         for ni, (m, ref, crc) in enumerate((gate_net, gate_net2)):
             for seed in (4242, 9191):
                 rs = np.random.RandomState(seed)
-                inst = synth.ellipse_instances(1000, 1000, 700, rs, 5, 14, 10)
+                inst = synth.ellipse_instances(S, S, 250, rs, 5, 14, 10)
                 img = synth.render_nuclei(inst, rs)
-                key = 'image' if (ni == 0 and seed == 4242) else ('image', ni, seed)
-                w = _oracle(key, lambda: oinf.infer_image(ref, img, tta=True, all_img_test=0, patch_size=256, overlap=40))
+                w = _oracle(('draw', ni, seed), lambda: oinf.infer_image(ref, img, tta=True, all_img_test=0, patch_size=256, overlap=40))
                 for prec in ('fp32', 'bf16'):
                     cdnet_amd.set_precision(prec)
                     with torch.no_grad():
                         r = pipeline.infer_image(m, torch.from_numpy(img).cuda(), tta=True, all_img_test=0, patch_size=256, overlap=40)
                     got = r['final'].cpu().numpy()
-                    aji, dice = _score('net %d image %d' % (ni, seed), got, w['final'], 200)
-                    (ga, gd), (wa, wd) = _score('vs truth (HIP)', got, inst, 200), _score('vs truth (oracle)', w['final'], inst, 200)
+                    aji, dice = _score('net %d image %d' % (ni, seed), got, w['final'], 80)
+                    (ga, gd), (wa, wd) = _score('vs truth (HIP)', got, inst, 80), _score('vs truth (oracle)', w['final'], inst, 80)
                     rows.append((ni, crc, seed, prec, aji, dice, ga, wa, int(r['count']), int(w['count'])))
                     print('label gate draw: network %d (crc32 %08x) image seed %d [%s]: mutual AJI %.5f Dice %.5f; vs truth AJI %.5f (oracle %.5f); '
                           'instances %d/%d' % rows[-1])
@@ -254,8 +256,8 @@ def test_second_draw(gate_net, gate_net2):
         cdnet_amd.set_precision(before)
     for ni, crc, seed, prec, aji, dice, ga, wa, n_g, n_w in rows:
         if prec == 'fp32':
-            # (identical label maps on image 4242 with both networks; image 9191 differs from the fp32 CPU oracle on a handful of pixels with
-            #  both networks - bf16x3 products are not IEEE fp32 products: mutual AJI 0.99999, first measured in round 5)
+            # (identical label maps or a handful of pixels: bf16x3 products are not IEEE fp32 products - on 1000x1000 images of the same seeds
+            #  round 5 measured 1.0 and 0.99999, profiles/r05/label_gate.log)
             assert aji >= 0.9999 and dice >= 0.9999, (ni, seed, aji, dice)
         else:
             assert aji >= AJI_MIN and dice >= DICE_MIN, (ni, seed, aji, dice)

@@ -1,5 +1,6 @@
 """Main-stream timeline of the last training step in a rocprofv3 kernel trace (tools/prof_train.sh): start, gap before the kernel,
-duration, workgroups, name - and the busy / gap totals of both streams.  usage: python tools/step_timeline.py <t_kernel_trace.csv> [-v]"""
+duration, workgroups, name - and the busy / gap totals of both streams.  usage: python tools/step_timeline.py <t_kernel_trace.csv> [-v] [--mark=<kernel name part>]
+(the step = the launches after the second-to-last marker kernel up to the last one; default marker adam_kernel, inference: --mark=input_pack_kernel)"""
 import collections
 import csv
 import sys
@@ -11,7 +12,8 @@ for r in rows:
     by[r['Queue_Id']].append(r)
 dur = lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 main = max(by.values(), key=lambda rs: sum(dur(r) for r in rs))
-idx = [i for i, r in enumerate(main) if 'adam_kernel' in r['Kernel_Name']]
+mark = ([a.split('=', 1)[1] for a in sys.argv if a.startswith('--mark=')] or ['adam_kernel'])[0]
+idx = [i for i, r in enumerate(main) if mark in r['Kernel_Name']]
 step = main[idx[-2] + 1:idx[-1] + 1]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 short = lambda n: (n.split('(anonymous namespace)::')[1] if '(anonymous namespace)::' in n else n)[:48]
