@@ -9,10 +9,10 @@ from cdnet_amd import engine
 dev = torch.device('cuda:0')
 print('lib=%s' % (os.path.basename(os.environ.get('CDNET_LIB_PATH', 'libcdnet_hip.so'))))
 for B in (16, 64):
-    for (cin, cout, taps1) in ((64, 64, 0), (256, 256, 0)):
+    for (cin, cout, taps1) in ((64, 64, 0), (16, 64, 0), (256, 256, 0)):
         if cin == 256 and B == 64:
             continue
-        HW = 256 if cin == 64 else 64
+        HW = 64 if cin == 256 else 256
         x = (torch.rand((B, HW, HW, cin), device=dev) - 0.3).to(torch.bfloat16)
         w = torch.randn((cout, cin, 3, 3), device=dev) * 0.06
         cfg = (16, 16, 64)
