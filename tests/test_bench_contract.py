@@ -115,3 +115,32 @@ def test_check_tiles_reads_the_ddm_kernels_minmax():
     pipeline.check_tiles({'minmax': torch.tensor([[0, 2], [0, 1]], dtype=torch.int32)})
     with pytest.raises(AssertionError, match=r'tile\(s\) \[1\]'):
         pipeline.check_tiles({'minmax': torch.tensor([[0, 2], [1, 1], [0, 1]], dtype=torch.int32)})
+
+
+def test_committed_round5_line_carries_every_leg_and_its_cpu_baseline():
+    """profiles/r05/bench_default_line.json: the legs the round-4 verdict asked for - the target generation alone and inside the step, BASELINE
+    config 1 at its own size, the 1000x1000 post-processing, the 1-rank step with the all-reduce forced, a CPU baseline beside every rate, the
+    image leg's true protocol, and the 16-bit dominant layer quoted at the 64-tile size with the PMC summary of THAT size beside it"""
+    with open(os.path.join(ROOT, 'profiles', 'r05', 'bench_default_line.json')) as f:
+        d = json.loads([ln for ln in f.read().splitlines() if ln.startswith('{')][-1])
+    assert d['dtype'] == 'fp32' and d['n_gpus'] == 1 and d['vs_baseline'] is None and d['scaling'] == 'weak'
+    for k in ('inference', 'bf16', 'image', 'image_postproc', 'cdm', 'train_e2e', 'unet_cfg1', 'dp1_forced_allreduce', 'roofline', 'roofline_bf16',
+              'roofline_bf16_16tiles', 'roofline_path', 'cpu_baseline', 'cpu_baseline_infer', 'cpu_baseline_cdm', 'cpu_baseline_image_postproc',
+              'cpu_baseline_unet_cfg1'):
+        assert k in d, k
+    assert d['image']['steps'] == 8 and d['image']['warmup'] == 2
+    assert d['train_e2e']['vs_value'] >= 0.95 and d['train_e2e']['serial']['vs_value'] >= 0.95
+    assert abs(d['train_e2e']['vs_value'] - d['train_e2e']['value'] / d['value']) < 1e-9
+    assert d['cdm']['roofline']['bound'] == 'hbm' and d['cdm']['roofline']['algorithmic_bytes'] == 16 * 256 * 256 * 5
+    assert d['unet_cfg1']['tiles_per_gpu_per_step'] == 4
+    fa = d['dp1_forced_allreduce']
+    assert fa['process_group'] == 'nccl, 1 rank(s)' and fa['buckets'] == fa['buckets_released_during_backward'] == 4 and 0.9 < fa['vs_value'] < 1.1
+    assert fa['side_stream_probe']['group'] is True and d['config']['side_stream_probe']['group'] is False
+    for k in ('cpu_baseline', 'cpu_baseline_infer', 'cpu_baseline_cdm', 'cpu_baseline_image_postproc', 'cpu_baseline_unet_cfg1'):
+        assert d[k]['kind'] == 'port' and d[k]['cores'] >= 1 and 'sample' in d[k] and d[k]['value'] > 0, k
+    b = d['roofline_bf16']
+    assert '64 tiles' in b['kernel'] and b['algorithmic_bytes'] == 2 * 64 * 256 * 256 * 64 * 2 and 0.3 < b['frac'] < 0.6
+    with open(os.path.join(ROOT, 'profiles', 'r05', 'dominant_conv_bf16_64tiles_pmc.json')) as f:
+        p = json.load(f)
+    assert p['tiles_per_launch'] == 64 and p['algorithmic_bytes_per_launch'] == b['algorithmic_bytes']
+    assert 1.0 < p['hbm_bytes_per_launch'] / p['algorithmic_bytes_per_launch'] < 1.2          # quad requests: 1.15 x (1.32 x with pairs)
