@@ -776,10 +776,6 @@ int launch_conv(const ConvArgs &A, hipStream_t st) {
 // step 0.80 us (36 MFMAs per wave: the matrix pipe at the clock the chip holds under this load), barrier 0.22 us, conversion +
 // LDS writes 1.2 us and global stores 2.5 us per tile, both in the consumers' serial path: 8.0 us per tile, 128 us per launch.
 // ------------------------------------------------------------------------------------------------------
-#ifndef CDNET_CONV_WS
-#define CDNET_CONV_WS 1
-#endif
-
 #ifdef CDNET_WS_STAMPS
 // debug build only (CDNET_HIPCC_FLAGS=-DCDNET_WS_STAMPS): wall-clock stamps (100 MHz) of one consumer and one mover wave of one
 // workgroup, parked in LDS and dumped at the end of the kernel; read back with cdnet_debug_ws_stamps
@@ -1645,8 +1641,7 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         CDNET_REQUIRE(!A.dot_out, "cdnet_conv_forward: the fused 1x1 classifier (dot_out) needs conv_ws16_kernel's out-image form with resident weights (ask cdnet_conv_ws_eligible)");
     }
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
-    static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
-    if ((use_ws || (A.debug & 64)) && !(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
+    if (!(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {
         const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, st) : try_launch_conv_ws<32, 9>(A, st);
         if (rc >= 0) return rc;
     }
@@ -1666,11 +1661,10 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
 extern "C" int cdnet_conv_ws_eligible(const cdnet_conv_args *args) {
     if (!args) return 0;
     const ConvArgs &A = *reinterpret_cast<const ConvArgs *>(args);
-    static const int use_ws = getenv("CDNET_CONV_WS") ? atoi(getenv("CDNET_CONV_WS")) : CDNET_CONV_WS;
     if (A.f32) return (!A.dot_out && conv_forward_f32_ws(A, nullptr, true) == CDNET_OK) ? 1 : 0;
     if (conv_forward_ws16(A, nullptr, true) == CDNET_OK) return 2;
     if ((A.taps1 != 0 && A.taps1 != A.taps) || A.pool_out || A.dot_out) return 0;
-    if (!use_ws || (A.debug & 32)) return 0;
+    if (A.debug & 32) return 0;
     if (!(A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32))) return 0;
     const int rc = A.BN == 64 ? try_launch_conv_ws<64, 9>(A, nullptr, true) : try_launch_conv_ws<32, 9>(A, nullptr, true);
     return rc == CDNET_OK ? 1 : 0;

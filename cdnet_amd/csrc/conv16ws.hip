@@ -1001,12 +1001,11 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
             if (out) {
                 constexpr bool STREAM_ = decltype(sm_c)::value;
                 constexpr bool MIX_ = decltype(mx_c)::value;
-                // the streamed-weight launches - the matrix-bound layers (128+ input channels) - take the 16x16x32 consumers (CDNET_WS16_K32=0:
-                // off): 63 / 62 / 27 us against 72 / 70 / 30 us on 256 -> 256 @64², 512 -> 512 @32², 320 -> 64 @64².  The resident 64 -> 64 layer is
+                // the streamed-weight launches - the matrix-bound layers (128+ input channels) - take the 16x16x32 consumers:
+                // 63 / 62 / 27 us against 72 / 70 / 30 us on 256 -> 256 @64², 512 -> 512 @32², 320 -> 64 @64².  The resident 64 -> 64 layer is
                 // bound by power and does not gain (round 5, without spills and with pair requests: 74.0 vs 72.5 us at 16 tiles, 298 vs 297.5 us at
                 // 64 - profiles/HISTORY.md); the one-tap form spilled.
-                static const int k32_env = getenv("CDNET_WS16_K32") ? atoi(getenv("CDNET_WS16_K32")) : 1;
-                if constexpr (STREAM_) if (k32_env) {
+                if constexpr (STREAM_) {
                     auto kern_k = conv_ws16_kernel<BN, XF, STREAM_, MIX_, 0, 4, decltype(pf_c)::value, true, true, PAIR_>;
                     static bool attr_k = false;
                     if (!attr_k) {
@@ -1082,8 +1081,7 @@ static int try_launch_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
 
 // called by cdnet_conv_forward first (16-bit path); -1 = not eligible
 int conv_forward_ws16(const ConvArgs &A, hipStream_t st, bool dry_run) {
-    static const int use = getenv("CDNET_CONV_WS16") ? atoi(getenv("CDNET_CONV_WS16")) : 1;
-    if ((!use && !(A.debug & 64)) || (A.debug & 32) || (A.debug & 128)) return -1;      // (128: tests - the older persistent kernel instead)
+    if ((A.debug & 32) || (A.debug & 128)) return -1;      // (128: tests - the older persistent kernel instead)
     if (A.f32 || A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || A.eres || A.ws || A.stats || A.oscale || A.out_f16) return -1;
     if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < 1 || A.Cout % 16 != 0) return -1;
     if (A.BN == 64) return try_launch_ws16<64>(A, st, dry_run);

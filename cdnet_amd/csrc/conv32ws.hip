@@ -878,8 +878,7 @@ static int try_launch_ws32(const ConvArgs &A, hipStream_t st, bool dry_run) {
 
 // called by conv_forward_f32 first; -1 = not eligible (the caller falls back to conv_f32_kernel)
 int conv_forward_f32_ws(const ConvArgs &A, hipStream_t st, bool dry_run) {
-    static const int use_ws = getenv("CDNET_CONV_WS32") ? atoi(getenv("CDNET_CONV_WS32")) : 1;
-    if ((!use_ws && !(A.debug & 64)) || (A.debug & 32)) return -1;
+    if (A.debug & 32) return -1;
     if (A.taps != 9 || A.npar != 1 || A.ostride != 1 || A.tile != 16 || A.CK != 16 || (A.eres && A.ws != 2) || (A.ws && A.ws != 2)) return -1;
     if (A.taps1 != 0 && A.taps1 != 9 && !(A.taps1 == 1 && A.nsrc == 2)) return -1;
     if (A.H % 16 != 0 || A.W % 16 != 0 || A.nchunk < (A.ws == 2 ? 4 : 1)) return -1;

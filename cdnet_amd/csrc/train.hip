@@ -206,8 +206,7 @@ constexpr int BN_MAX_BLOCKS = 2048;      // workspace rows
 // finalize pass (one workgroup per channel walking the partial rows with a 2 * C stride) has a quarter of the rows to sum - measured
 // (bench.py, 16 tiles): 2048 blocks 1 641 tiles/s, 1024 1 645-1 655, 768 1 652-1 655, 512 1 654-1 663, 256 1 605-1 609
 static int bn_blocks_cap() {
-    static const int v = getenv("CDNET_BN_BLOCKS") ? atoi(getenv("CDNET_BN_BLOCKS")) : 512;
-    return v < 1 ? 1 : (v > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : v);
+    return 512 > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : 512;
 }
 
 template <bool F32 = false>

@@ -137,10 +137,8 @@ def dominant_kernel_name(precision):
     """the kernel cdnet_conv_forward runs the dominant layer (3x3 64 -> 64 on full 16x16 tiles) on - what bench.py's `roofline` object and
     the profile filters name"""
     if precision == 'fp32':
-        return 'conv_ws32_kernel<64,0,false>' if os.environ.get('CDNET_CONV_WS32', '1') != '0' else 'conv_f32_kernel<16,16,64,4,1,9>'
-    if os.environ.get('CDNET_CONV_WS16', '1') != '0':
-        return 'conv_ws16_kernel<64,0,false,false,0,4,4,true>'
-    return 'conv_ws_kernel<64,9,0,false,false>' if os.environ.get('CDNET_CONV_WS', '1') != '0' else 'conv_fwd_kernel<16,16,16,64,4,1,9>'
+        return 'conv_ws32_kernel<64,0,false>'
+    return 'conv_ws16_kernel<64,0,false,false,0,4,4,true>'
 
 
 def packed_elems(Cout, nchunk, taps, CK, BN, npar):

@@ -46,7 +46,7 @@ def raw_dtype():
     return torch.float32 if PRECISION == 'fp32' else torch.float16
 
 
-DEBUG_NORELU = bool(int(_os.environ.get('CDNET_DEBUG_NORELU', '0')))   # debug aid (tools/debug_train.py): linearised network
+DEBUG_NORELU = False   # debug aid (tools/debug_train.py): linearised network
 TAPE = None              # set by cdnet_amd.trainer around a training forward: layers append themselves in execution order
 WEIGHTS_EPOCH = [0]      # bumped by the fused Adam step (it updates parameters behind torch's version counters)
 LAYERS = weakref.WeakSet()   # every live ConvLayer (the trainer batches their weight re-packs)
@@ -398,12 +398,12 @@ def input_pack(x):
 
 POOL_MATERIALIZE = True      # max-pooled sources are stored (measured faster than four loads + max per staged element)
 RU_MATERIALIZE = True        # (CDNET_RU_FUSE=0 only) the residual units' outputs are stored once for their three consumers
-RU_FUSE = _os.environ.get('CDNET_RU_FUSE', '1') != '0'       # ResidualUnit: add + ReLU in the epilogue of its conv_1x1
+RU_FUSE = True       # ResidualUnit: add + ReLU in the epilogue of its conv_1x1
 # eval mode, 16-bit path: BatchNorm scale folded into the packed weights (ConvLayer.eval_pack), and a residual unit's 1x1 branch as extra K
 # steps of its second 3x3 convolution (cdnet_conv_args.taps1 = 1, conv_ws16_kernel)
-EVAL_FOLD_WEIGHTS = _os.environ.get('CDNET_EVAL_FOLD', '1') != '0'
-RU_EVAL_ONE_LAUNCH = _os.environ.get('CDNET_RU_EVAL_FUSE', '1') != '0'
-RU_EVAL_POINT_DOT = _os.environ.get('CDNET_RU_POINT_DOT', '1') != '0'       # eval: the point feature's only reader (point_conv) rides in the unit's launch, the feature is not stored
+EVAL_FOLD_WEIGHTS = True
+RU_EVAL_ONE_LAUNCH = True
+RU_EVAL_POINT_DOT = True       # eval: the point feature's only reader (point_conv) rides in the unit's launch, the feature is not stored
 
 
 class PointLogit:

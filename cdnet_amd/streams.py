@@ -1,7 +1,5 @@
 """A second HIP stream that really runs beside the compute stream (the trainer's weight-gradient stream, the inference pipeline's
 post-processing stream)."""
-import os
-
 import torch
 
 _SIDE = {}
@@ -31,7 +29,7 @@ def side_stream(device=None):
     process gets from torch.cuda.Stream() depends on how many it created before).  Candidates are timed with two spin kernels of the
     library's own (`cdnet_spin`: one wave waiting on the constant 100 MHz counter, no memory traffic): together they take as long as one
     when the queues differ, twice as long when they do not.  No candidate passing is not an error: the first one is used and the record in
-    `PROBES` says so.  CDNET_SIDE_STREAM_PROBE=0: the first candidate, unprobed."""
+    `PROBES` says so."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, _group_state())
@@ -41,33 +39,32 @@ def side_stream(device=None):
     cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
     pick = cands[0]
     rec = dict(device=idx, group=key[1], alone_ms=None, together_ms=None, picked=0, probed=False)
-    if os.environ.get('CDNET_SIDE_STREAM_PROBE', '1') != '0':
-        with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
-            SPIN_US = 300
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream()
+        SPIN_US = 300
 
-            def timed(other):
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(main)
-                if other is not None:
-                    other.wait_stream(main)                 # (starts with the compute stream's spin, not before the first event)
-                    _spin(SPIN_US, other)
-                _spin(SPIN_US, main)
-                if other is not None:
-                    main.wait_stream(other)
-                e1.record(main)
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1)
-            timed(None)
-            alone = min(timed(None), timed(None))
-            rec.update(alone_ms=alone, probed=True)
-            for i, c in enumerate(cands):
-                t = min(timed(c), timed(c))
-                if t < 1.5 * alone:
-                    pick = c
-                    rec.update(picked=i, together_ms=t)
-                    break
+        def timed(other):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            if other is not None:
+                other.wait_stream(main)                 # (starts with the compute stream's spin, not before the first event)
+                _spin(SPIN_US, other)
+            _spin(SPIN_US, main)
+            if other is not None:
+                main.wait_stream(other)
+            e1.record(main)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        timed(None)
+        alone = min(timed(None), timed(None))
+        rec.update(alone_ms=alone, probed=True)
+        for i, c in enumerate(cands):
+            t = min(timed(c), timed(c))
+            if t < 1.5 * alone:
+                pick = c
+                rec.update(picked=i, together_ms=t)
+                break
     PROBES.append(rec)
     _SIDE[key] = pick
     return pick

@@ -11,7 +11,6 @@ sequence); the nn.Parameters of the model are views into them.
 """
 import ctypes as C
 import os
-import time
 
 import torch
 
@@ -37,7 +36,8 @@ class BnBwdArgs(C.Structure):
 # layers of up to 128 x 128 pixels / larger ones
 _WGRAD_WGS_DEEP, _WGRAD_WGS_SHALLOW = 128, 160
 _WGRAD_WGS_F32 = 160                      # (128 / 160 / 256: 989 / 994 / 987 tiles/s, three runs each on one box)
-_RU_1X1_SIDE = os.environ.get('CDNET_RU_1X1_SIDE', '1') != '0'      # residual units' 1x1 backward-data beside the chain
+_RU_1X1_SIDE = True      # residual units' 1x1 backward-data beside the chain (tests flip it: same gradients either way)
+WGRAD_STREAM = True       # weight gradients on a second stream beside the input-gradient chain
 _WGRAD_DEFER = 0x100                       # CDNET_WGRAD_DEFER_REDUCE (include/cdnet_hip.h)
 _WGRAD_DEEP_HW = 16384
 
@@ -129,7 +129,7 @@ class Trainer:
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.quirk = int(quirk_sample0)
         self.world = world_size
-        self.bucket = int(float(os.environ.get('CDNET_BUCKET_MB', bucket_mb)) * (1 << 20) // 4)
+        self.bucket = int(float(bucket_mb) * (1 << 20) // 4)
         self.flat = FlatState(model)
         model._head_flat = self.flat.P[:self.flat.n_head] if self.flat.n_head == 855 else None
         self.dev = self.flat.P.device
@@ -542,8 +542,8 @@ class Trainer:
         return draw
 
     def _side_stream(self):
-        """second HIP stream for the weight-gradient kernels (CDNET_WGRAD_STREAM=0: everything on one stream)"""
-        if os.environ.get('CDNET_WGRAD_STREAM', '1') == '0' or self.dev.type != 'cuda':
+        """second HIP stream for the weight-gradient kernels (trainer.WGRAD_STREAM = False: everything on one stream)"""
+        if not WGRAD_STREAM or self.dev.type != 'cuda':
             return None
         if self._wstream is None:
             self._wstream = streams.side_stream(self.dev)      # (probed: a stream on another hardware queue than the compute stream's)
@@ -557,8 +557,6 @@ class Trainer:
         return e
 
     def _weight_backward(self, L, srcs, g, H, W):
-        if os.environ.get('CDNET_DEBUG_SKIP_WGRAD') == '1':      # timing experiments only (tools/): the input-gradient chain alone
-            return
         lib = _lib.load()
         N = g.shape[0]
         Cout = L.Cout

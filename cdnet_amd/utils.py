@@ -6,7 +6,6 @@
   AverageMeter                                         utils.py:755-774
   adjust_learning_rate                                 utils.py:965-977
 """
-import os
 
 import numpy as np
 import torch
@@ -83,7 +82,6 @@ def split_forward_views(model, image, size, overlap, xforms=(0,), direction_clas
         by_shape.setdefault((g_[3], g_[4], g_[5] * g_[6]), []).append(i)
     # (128: two batches of four views for a 1000 x 1000 image.  All eight views in one batch is another 3 % in steady state, but its multi-GB
     #  tensors make the caching allocator's behaviour - and the time - depend on what the process ran before: 24 to 65 ms per image)
-    max_batch = int(os.environ.get('CDNET_WINDOW_BATCH', max_batch))
     for (th, tw, n), idxs in by_shape.items():
         max_batch = max(1, min(max_batch, (1 << 24) // (th * tw)))      # at most 256 windows of 256 x 256 (64 of 512 x 512) per network batch
         if n <= max_batch:
