@@ -368,6 +368,8 @@ class FuseNode:
             gl = tr.take(grads, id(o))
             if gl is None:
                 return
+            if relu and self._residual_tail(tr, grads, gl, terms, o, H, W, Cc):
+                return
             if relu or len(gl) > 1 or gl[0].coff or gl[0].cstride not in (0, Cc):
                 d = tr.buf(('dfuse', self.name), o.shape, o.dtype)
                 tr.grad_sum(gl, o if relu else None, o.shape[0] * H * W, Cc, d)
@@ -383,6 +385,47 @@ class FuseNode:
                 _lib.call('cdnet_upsample_bilinear_backward_f32' if d.dtype == torch.float32 else 'cdnet_upsample_bilinear_backward', _lib.ptr(d),
                           N, H, W, Cc, dcs, dco, t.Hs, t.Ws, _lib.ptr(din), _lib.stream_ptr())
                 add(t.x, tr.G(din, t.Hs, t.Ws))
+
+
+def _residual_tail(self, tr, grads, gl, terms, o, H, W, Cc):
+    """relu(bn(y) + x) with x stored and y read by this node alone (BasicBlock / Bottleneck tails, seg_hrnet_rev1.py:76-92, :113-133): the
+    masked sum of the consumers' gradients is the first thing y's BatchNorm backward computes anyway (the kernels' residual form: mask read
+    from the stored output, dz stored for the other branch - what the DAM head's residual units use), so the separate grad_sum pass - one
+    more read and write of the tensor - is skipped and the gradient list goes to y's layer as it is.  Returns False when the shape is not that."""
+    if DEBUG_NORELU:
+        return False
+    if len(terms) == 1:
+        # relu(bn(y)) stored for a stride-2 reader (`_plain`, the down-sampling chains): y's BatchNorm backward takes the ReLU mask from its
+        # own forward values - no masked sum at all
+        y = terms[0]
+        P = tr._producer.get(id(y.x)) if y.scale is not None else None
+        if P is None or P.bn is None or getattr(P, 'node_res', None) is not None or tr._readers.get(id(y.x), 0) != 1 or id(y.x) in grads \
+                or tuple(y.x.shape) != tuple(o.shape) or getattr(P, 'fused_res_of', None) is not None or (y.Hs, y.Ws) != (H, W):
+            return False
+        P.node_relu, P.node_res = True, None
+        grads[id(y.x)] = gl
+        return True
+    if len(terms) != 2 or len(gl) > 3:
+        return False
+    bn_t = [t for t in terms if t.scale is not None]
+    if not bn_t or any((t.Hs, t.Ws) != (H, W) for t in terms):
+        return False
+    # (two BatchNorm terms - a Bottleneck with its downsample branch: the one whose layer comes first in backward takes the list, the other
+    #  one reads the dz that pass stores)
+    y = max(bn_t, key=lambda t: tr._tape_pos.get(id(tr._producer.get(id(t.x))), -1))
+    x = terms[1] if terms[0] is y else terms[0]
+    P = tr._producer.get(id(y.x))
+    if P is None or P.bn is None or getattr(P, 'node_res', None) is not None or tr._readers.get(id(y.x), 0) != 1 or id(y.x) in grads \
+            or tuple(y.x.shape) != tuple(o.shape) or getattr(P, 'fused_res_of', None) is not None:
+        return False
+    if any(g.pooled or g.oy or g.ox or (g.Hg, g.Wg) != (H, W) for g in gl):
+        return False
+    P.node_relu, P.node_res, P.node_res_grad_to = 2, o, x.x
+    grads[id(y.x)] = gl
+    return True
+
+
+FuseNode._residual_tail = _residual_tail
 
 
 def input_pack(x):

@@ -321,8 +321,11 @@ class Trainer:
         # who reads what: a BatchNorm layer whose raw output has exactly one reader - a 3x3 convolution - gets the first pass of its
         # backward (the channel sums) from that reader's backward-data launch (_input_backward), see _stats_fusable
         self._readers, self._producer, self._bn_partials = {}, {}, {}
+        self._tape_pos = {id(Lt): k for k, Lt in enumerate(self.tape)}
         for Lt in self.tape:
             if isinstance(Lt, runtime.FuseNode):
+                for t in Lt.saved[0]:                # (counted too: FuseNode.backward hands a residual sum's BatchNorm term its gradients unsummed
+                    self._readers[id(t.x)] = self._readers.get(id(t.x), 0) + 1       # only when nothing else reads that term)
                 continue
             for sx in Lt.saved[0]:
                 self._readers[id(sx.x)] = self._readers.get(id(sx.x), 0) + 1
@@ -538,7 +541,10 @@ class Trainer:
                   _lib.ptr(bn.weight.grad) if has_bn else None, _lib.ptr(bn.bias.grad) if has_bn else None,
                   _lib.ptr(ws), ws.numel(), _lib.ptr(draw), _lib.ptr(dz), _lib.stream_ptr())
         if res is not None:
-            add(res, _G(dz, Ho, Wo))        # gradient of the residual branch = dz; its producer (conv_1x1) is on the tape
+            # gradient of the residual branch = dz; its producer (conv_1x1) is on the tape.  (HRNet's residual sums: `res` is the stored
+            # output the mask is read from, the branch is the block's input - FuseNode.backward names it)
+            add(getattr(L, 'node_res_grad_to', None) if getattr(L, 'node_res_grad_to', None) is not None else res, _G(dz, Ho, Wo))
+            L.node_res_grad_to = None
         return draw
 
     def _side_stream(self):
