@@ -414,7 +414,15 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int PA = pstride(CI), PG = pstride(CO);
     constexpr int A_BYTES = NPIX_A * PA, G_BYTES = NPIX_G * PG, STAGE = A_BYTES + G_BYTES;
-    static_assert(CI_T * CO_T == 4, "one 32x32 quadrant per consumer wave");
+    static_assert(CI_T * CO_T == 4 || CI_T * CO_T == 1, "one 32x32 quadrant per consumer wave, or one 32x32 block for all four");
+    // KQ (<1, 1>: layers with at most 32 output channels - HRNet's 18-channel branch at 512 x 512, the decoder's 16-channel block): ONE
+    // 32 x 32 block of dW, and the four consumer waves split the tile's eight rows (the k dimension) instead of the block - on 64 x 64 blocks
+    // three of the four quadrants multiplied zero padding and the consumers' 72 MFMAs per tile, not the 16 KB the tile brings, set the tile
+    // period (1.0-1.3 TB/s).  The four partial blocks are folded through the LDS in a fixed order at the end.  The slab keeps the <1, 4>
+    // layout the caller sized it for (128 columns per row, the first 32 written; the reduce skips columns beyond Cout).
+    constexpr bool KQ = CI_T * CO_T == 1;
+    constexpr int CO_SLAB = KQ ? 128 : CO;
+    static_assert(!KQ || 2 * STAGE >= TAPS * 16 * 64 * 4, "the fold of the four partial blocks goes through the staging buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // two staging buffers [A | G]
     typedef s16x4 __attribute__((address_space(3))) * lptr;
 
@@ -511,7 +519,11 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
             commit_a<XF>(P, A.src, ib * CI, 0, 0, 0, A.H, A.W, nb, ptid, s_xf);
             commit_g(G, nb + A_BYTES, ptid);
         };
-        if (ntl == 0) { __syncthreads(); return; }
+        if (ntl == 0) {
+            __syncthreads();
+            if (KQ) for (int i = 0; i < 6; ++i) __syncthreads();      // (the consumers' fold)
+            return;
+        }
         issue(P0, G0, 0);
         issue(P1, G1, 1);
         commit(P0, G0, 0);
@@ -536,11 +548,12 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
 #ifdef CDNET_WS_STAMPS
         if (stamp_on) g_wg_stamps[sbase + sn] = 0;
 #endif
+        if (KQ) for (int i = 0; i < 6; ++i) __syncthreads();          // (the consumers' fold: every wave meets every barrier)
         return;
     }
     // ------------------------------- consumers -------------------------------
     const int quad = wave;
-    const int wci = quad / CO_T, wco = quad % CO_T;
+    const int wci = KQ ? 0 : quad / CO_T, wco = KQ ? 0 : quad % CO_T;
     const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     auto tap_off = [&](int t) -> int {
         if (TAPS == 9) return ((t / 3) * HALO_W + t % 3) * PA;
@@ -573,6 +586,21 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
             return __builtin_bit_cast(bf16x8, av);
         };
         if (A.debug & 1) {
+        } else if (TAPS == 9 && KQ) {
+            // this wave's two tile rows r0, r0 + 1: halo rows r0 .. r0 + 3 (12 fragments), two gradient fragments, 18 MFMAs
+            const int r0 = 2 * quad;
+            bf16x8 row[4][3], gq[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) row[r][kx] = frag(a_lane + ((r0 + r) * HALO_W + kx) * PA, PA);
+            gq[0] = frag(g_lane + r0 * TW * PG, PG);
+            gq[1] = frag(g_lane + (r0 + 1) * TW * PG, PG);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row[k + t / 3][t % 3], gq[k], acc[t], 0, 0, 0);
         } else if (TAPS == 9) {
             // 3x3: the k-step of tile row ky multiplies halo rows ky, ky+1, ky+2 (three column shifts each) - consecutive k-steps share
             // two of the three rows.  A ring of four halo rows of fragments: every k-step reads ONE new halo row (3 fragments) and one
@@ -597,8 +625,9 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            const int ky0 = KQ ? 2 * quad : 0, ky1 = KQ ? 2 * quad + 2 : TH;
 #pragma unroll 2
-            for (int ky = 0; ky < TH; ++ky) {             // one k-step = one tile row of 16 pixels
+            for (int ky = ky0; ky < ky1; ++ky) {          // one k-step = one tile row of 16 pixels
                 const bf16x8 gf = frag(g_lane + ky * TW * PG, PG);
                 const int abase = a_lane + ky * HALO_W * PA;
 #pragma unroll
@@ -610,15 +639,38 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
         __syncthreads();
         WG_STAMP(12);
     }
+    if (KQ) {
+        // ((wave 0 + wave 1) + wave 2) + wave 3 through the (dead) staging buffers: deterministic
+        float *s_acc = reinterpret_cast<float *>(smem);
+#pragma unroll 1
+        for (int w = 1; w < 4; ++w) {
+            if (quad == w) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_acc[(t * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (quad == 0) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += s_acc[(t * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (quad != 0) return;
+    }
     // slab [ks][par][ib][cb][tap][CI][CO]; D rows = ci (regs + lane half), cols = co (lane & 31)
-    float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
+    const int co_blocks_slab = (A.Cout + CO_SLAB - 1) / CO_SLAB;
+    float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks_slab + (KQ ? 0 : cb)) * (size_t)(TAPS * CI * CO_SLAB);
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            slab[((size_t)t * CI + ci) * CO + wco * 32 + l31] = acc[t][r];
+            slab[((size_t)t * CI + ci) * CO_SLAB + wco * 32 + l31] = acc[t][r];
         }
     WG_STAMP(13);
 #ifdef CDNET_WS_STAMPS
@@ -1396,6 +1448,16 @@ int launch_wgrad(const WgradArgs &A, hipStream_t st) {
     const ConvSrc &s = A.src;
     if (s.f16 == 2) return launch_wgrad_f32<CI_T, CO_T, TAPS>(A, st);
     const bool res = s.res != nullptr;
+    if constexpr (CI_T == 1 && CO_T == 4) {
+        // at most 32 output channels: one 32 x 32 block per workgroup, the consumer waves split the tile's rows (wgrad_ws_kernel<1, 1>)
+        if (A.Cout <= 32 && !s.pool && !(A.debug & (8 | 16))) {           // (16: tests - the 32 x 128 form)
+            const bool plain = !s.scale && !s.relu && !s.f16 && !res;
+            const bool fast = s.scale && s.relu && s.f16;
+            if (plain) return launch_wgrad_ws<1, 1, TAPS, false, XF_PLAIN>(A, st);
+            if (fast) return res ? launch_wgrad_ws<1, 1, TAPS, true, XF_FAST>(A, st) : launch_wgrad_ws<1, 1, TAPS, false, XF_FAST>(A, st);
+            if (!res) return launch_wgrad_ws<1, 1, TAPS, false, XF_GEN>(A, st);
+        }
+    }
     if (CI_T != 4 && !s.pool && !(A.debug & 8)) {
         const bool plain = !s.scale && !s.relu && !s.f16 && !res;
         const bool fast = s.scale && s.relu && s.f16;

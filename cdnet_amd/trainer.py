@@ -35,6 +35,7 @@ class BnBwdArgs(C.Structure):
 # workgroups of one weight-gradient launch while it runs beside the input-gradient chain (bf16 mode; see _weight_backward):
 # layers of up to 128 x 128 pixels / larger ones
 _WGRAD_WGS_DEEP, _WGRAD_WGS_SHALLOW = 128, 160
+_WGRAD_WGS_KQ = 128                        # wgrad_ws_kernel<1, 1> on 512 x 512 layers (HRNet's branch 1)
 _WGRAD_WGS_F32 = 160                      # (128 / 160 / 256: 989 / 994 / 987 tiles/s, three runs each on one box)
 _RU_1X1_SIDE = True      # residual units' 1x1 backward-data beside the chain (tests flip it: same gradients either way)
 WGRAD_STREAM = True       # weight gradients on a second stream beside the input-gradient chain
@@ -105,6 +106,9 @@ class FlatState:
 
 
 def _choose_ci_tiles(C_src, Cout):
+    if Cout <= 32 and runtime.PRECISION != 'fp32':
+        return 1            # 16-bit path: 32-input-channel blocks; with at most 32 output channels the library runs ONE 32 x 32 block per
+                            # workgroup and splits the tile's rows over the consumer waves (wgrad_ws_kernel<1, 1>)
     best, best_cost = 2, None
     for ci_t in (2, 1, 4):
         CI, CO = ci_t * 32, (4 // ci_t) * 32
@@ -586,6 +590,8 @@ class Trainer:
                 cap = _WGRAD_WGS_F32
             else:
                 cap = _WGRAD_WGS_DEEP if H * W <= _WGRAD_DEEP_HW or H * W > 65536 else _WGRAD_WGS_SHALLOW    # (512 x 512 layers of HRNet: 128 again)
+                if Cout <= 32 and H * W > 65536:
+                    cap = _WGRAD_WGS_KQ
             ksplit = max(1, min(ntiles, cap // other if other < cap else 1))      # one 8-wave workgroup per CU
             nslab = lib.cdnet_conv_wgrad_slab_floats(s.C, Cout, taps, npar, ci_t, ksplit)
             defer = self._rd_mb > 0

@@ -68,7 +68,7 @@ def _reduce_batch(deferred):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 24, 40), (1, 32, 128, 16, 16), (2, 128, 32, 9, 21), (1, 16, 64, 32, 32),
-                                  (2, 64, 16, 16, 48), (1, 256, 64, 8, 8)])
+                                  (2, 64, 16, 16, 48), (1, 256, 64, 8, 8), (2, 32, 32, 24, 40), (3, 48, 24, 17, 33), (1, 16, 16, 64, 64)])
 def test_wgrad_conv3x3_plain(case):
     import torch
     from cdnet_amd import engine
