@@ -625,9 +625,9 @@ __global__ __launch_bounds__(NT) void wgrad_ws_kernel(WgradArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            const int ky0 = KQ ? 2 * quad : 0, ky1 = KQ ? 2 * quad + 2 : TH;
 #pragma unroll 2
-            for (int ky = ky0; ky < ky1; ++ky) {          // one k-step = one tile row of 16 pixels
+            for (int k = 0; k < (KQ ? 2 : TH); ++k) {     // one k-step = one tile row of 16 pixels
+                const int ky = (KQ ? 2 * quad : 0) + k;
                 const bf16x8 gf = frag(g_lane + ky * TW * PG, PG);
                 const int abase = a_lane + ky * HALO_W * PA;
 #pragma unroll
@@ -709,20 +709,26 @@ __device__ __forceinline__ void wg_split8(const float *v, u32x4 &hi, u32x4 &lo) 
 
 constexpr int NT32 = 256;      // 4 waves, one per SIMD (512 registers each): one dW quadrant x all k-steps of a tile per wave
 
-template <int CI_T, int CO_T, int TAPS>
+// QM (64 x 64 blocks, the transposed convolutions of the decoder's 32- and 16-channel blocks): as wgrad_ws32_kernel's - 1: at most 32
+// channels on both sides, one quadrant, every wave two of the tile's eight rows; 2: at most 32 output channels, the two input-channel
+// quadrants, a wave pair each, four rows per wave.  The zero half of the staged vectors is neither requested nor split.
+template <int CI_T, int CO_T, int TAPS, int QM = 0>
 __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int PA = pstride(CI), PG = pstride(CO);
     constexpr int A_BYTES = NPIX_A * PA, G_BYTES = NPIX_G * PG;
-    constexpr int VA = CI / 8, VG = CO / 8;
+    static_assert(QM == 0 || (CI_T == 2 && CO_T == 2 && TAPS != 9 && (QM == 1 || QM == 2)), "quadrant modes: 64 x 64 blocks, the plain k loop");
+    constexpr int VA = QM == 1 ? 4 : CI / 8, VG = QM != 0 ? 4 : CO / 8;
     constexpr int NA = (NPIX_A * VA + NT32 - 1) / NT32, NG = NPIX_G * VG / NT32;
     static_assert(CI_T * CO_T == 4 && NPIX_G * VG % NT32 == 0, "one 32x32 quadrant per wave");
+    constexpr int KROWS = QM == 0 ? TH : (QM == 1 ? TH / 4 : TH / 2);        // tile rows (k-steps) per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [A_hi][A_lo][G_hi][G_lo]
     typedef s16x4 __attribute__((address_space(3))) * lptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int quad = wave;
-    const int wci = quad / CO_T, wco = quad % CO_T;
+    const int wci = QM == 0 ? quad / CO_T : (QM == 2 ? (quad & 1) : 0), wco = QM == 0 ? quad % CO_T : 0;
+    const int row0 = QM == 0 ? 0 : (QM == 1 ? quad : (quad >> 1)) * KROWS;    // this wave's first tile row
     const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int co_blocks = (A.Cout + CO - 1) / CO;
     const int ci_blocks = (A.src.C + CI - 1) / CI;
@@ -920,7 +926,8 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
             }
         } else {
 #pragma unroll 2
-            for (int ky = 0; ky < TH; ++ky) {
+            for (int k = 0; k < KROWS; ++k) {
+                const int ky = row0 + k;
                 const int gaddr = g_lane + ky * TW * PG;
                 const bf16x8 gh = frag2(gaddr, PG), gl = frag2(gaddr + G_BYTES, PG);
                 const int abase = a_lane + ky * HALO_W * PA;
@@ -932,6 +939,29 @@ __global__ __launch_bounds__(NT32) void wgrad_f32_kernel(WgradArgs A) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh, acc[t], 0, 0, 0);
                 }
             }
+        }
+    }
+    if (QM != 0) {
+        // the waves that share a quadrant, in a fixed order through the (dead) staging buffer: QM 1 ((w0 + w1) + w2) + w3, QM 2 w0 + w2, w1 + w3
+        static_assert(QM == 0 || 2 * A_BYTES + 2 * G_BYTES >= 3 * TAPS * 16 * 64 * 4, "the parked accumulators fit the staging buffer");
+        float *s_acc = reinterpret_cast<float *>(smem);
+        __syncthreads();                                  // the last tile's fragment reads are done
+        if (QM == 1 ? quad != 0 : quad >= 2) {
+            float *d = s_acc + (QM == 1 ? quad - 1 : (quad & 1)) * TAPS * 16 * 64;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[(t * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (QM == 1 ? quad != 0 : quad >= 2) return;
+#pragma unroll 1
+        for (int w = 0; w < (QM == 1 ? 3 : 1); ++w) {
+            const float *d = s_acc + (QM == 1 ? w : (quad & 1)) * TAPS * 16 * 64;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += d[(t * 16 + r) * 64 + lane];
         }
     }
     float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
@@ -963,13 +993,24 @@ constexpr int TH32 = 4, NPIX_A32 = (TH32 + 2) * HALO_W, NPIX_G32 = TH32 * TW;
 // XF: source transform: 0 plain fp32, 1 x * scale + shift -> ReLU, 2 run-time flags (scale / shift, residual, ReLU).  TAPS: 9 (3x3), or 1
 // (the residual units' 1x1 convolutions: the same pipeline on the tile's inner 4 x 16 pixels - the halo vectors are never requested;
 // wgrad_f32_kernel took 250-470 us per launch for this HBM-bound product, one 4-wave workgroup per CU waiting out every load)
-template <int XF, int TAPS = 9>
+// QM (layers with at most 32 input or output channels - the decoder's 32- and 16-channel blocks, the 16-channel input of the first
+// residual unit): quadrants of the 64 x 64 block that hold nothing but zero padding are not multiplied; the consumer waves they free split
+// the tile's four rows (the k dimension) instead.  0: four quadrants, one per wave (the 64-channel layers); 1: one quadrant (at most 32
+// channels on both sides), every wave one tile row; 2: the two input-channel quadrants (Cout <= 32), 3: the two output-channel quadrants
+// (C <= 32) - a wave pair per quadrant, two tile rows each.  The partial blocks of the waves that share a quadrant are folded through the
+// LDS in a fixed order when the run ends.  (A 16 -> 16 layer at 256 x 256 x 16 took the 64 -> 64 layer's 233 us on quadrants of zeros.)
+template <int XF, int TAPS = 9, int QM = 0>
 __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
     constexpr int CI = 64, CO = 64, CO_T = 2;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
+    constexpr int NQ = QM == 0 ? 4 : (QM == 1 ? 1 : 2);          // quadrants multiplied
+    constexpr int KROWS = TH32 * NQ / 4;                         // tile rows (k-steps) per consumer wave
+    constexpr int FOLD_BARRIERS = QM == 0 ? 0 : (QM == 1 ? 6 : 2);
     constexpr int PA = pstride(CI), PG = pstride(CO);
     constexpr int A_PLANE = NPIX_A32 * PA, G_PLANE = NPIX_G32 * PG, STAGE = 2 * A_PLANE + 2 * G_PLANE;      // [A_hi][A_lo][G_hi][G_lo]
-    constexpr int VA = CI / 8, VG = CO / 8;
+    // (QM 1 / 3: nobody reads input channels 32..63 of the staged tile, QM 1 / 2: nor gradient channels 32..63 - the movers stage four
+    //  8-channel vectors per pixel instead of eight; the LDS rows keep their 64-channel pitch)
+    constexpr int VA = (QM == 1 || QM == 3) ? 4 : CI / 8, VG = (QM == 1 || QM == 2) ? 4 : CO / 8;
     constexpr int NA = (NPIX_A32 * VA + 255) / 256, NG = NPIX_G32 * VG / 256;
     static_assert(NPIX_G32 * VG % 256 == 0, "whole gradient vectors per mover thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -997,9 +1038,13 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 #endif
     if (wave >= 4) {
         // ------------------------------- movers -------------------------------
-        if (ntl == 0) return;                                    // (a slice without tiles: the consumers store a slab of zeros)
+        if (ntl == 0) {                                          // (a slice without tiles: the consumers store a slab of zeros)
+            for (int i = 0; i < FOLD_BARRIERS; ++i) __syncthreads();
+            return;
+        }
         if (A.debug & 2) {                                       // ablation: consumers alone (whatever the LDS holds)
             for (int j = -1; j < ntl2; ++j) __syncthreads();
+            for (int i = 0; i < FOLD_BARRIERS; ++i) __syncthreads();
             return;
         }
         const int ptid = tid - 256;
@@ -1188,14 +1233,17 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 #ifdef CDNET_WS_STAMPS
         if (stamp_on) g_wg_stamps[sbase + sn] = 0;
 #endif
+        for (int i = 0; i < FOLD_BARRIERS; ++i) __syncthreads();       // (the consumers' fold: every wave meets every barrier)
         return;
     }
     // ------------------------------- consumers -------------------------------
     const int quad = wave;
-    const int wci = quad / CO_T, wco = quad % CO_T;
+    const int qi = QM <= 1 ? 0 : (quad & 1), kgrp = QM == 0 ? 0 : (QM == 1 ? quad : (quad >> 1));
+    const int wci = QM == 0 ? quad / CO_T : (QM == 2 ? qi : 0), wco = QM == 0 ? quad % CO_T : (QM == 3 ? qi : 0);
     const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2;
-    const int g_lane = 2 * A_PLANE + (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2;
+    const int row0 = kgrp * KROWS;                               // this wave's first tile row
+    const int a_lane = (8 * (grp >> 1) + q) * PA + (wci * 32 + 16 * (grp & 1) + 4 * p) * 2 + row0 * HALO_W * PA;
+    const int g_lane = 2 * A_PLANE + (8 * (grp >> 1) + q) * PG + (wco * 32 + 16 * (grp & 1) + 4 * p) * 2 + row0 * TW * PG;
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -1219,7 +1267,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
             return TAPS == 1 ? a_lane + ((tau + 1) * HALO_W + 1) * PA                      // 1x1: the pixel itself
                              : a_lane + ((tau / TAPS + (tau % TAPS) / 3) * HALO_W + (tau % TAPS) % 3) * PA;
         };
-        constexpr int NTAU = TH32 * TAPS;
+        constexpr int NTAU = KROWS * TAPS;
         constexpr int PFD = 3, RING = PFD + 1;                   // fragment pairs requested PFD taps (3 PFD MFMAs) ahead of their use
         bf16x8 ah[RING], al[RING], gh[2], gl[2];
         if (!(A.debug & 1)) {
@@ -1239,8 +1287,8 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
                 if (tau + PFD < NTAU) al[(tau + PFD) % RING] = frag(a_off(tau + PFD) + A_PLANE, PA);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tau % RING], gh[ky & 1], acc[t], 0, 0, 0);
-                if (ky + 1 < TH32 && t == (TAPS == 1 ? 0 : 2)) gh[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG, PG);
-                if (ky + 1 < TH32 && t == (TAPS == 1 ? 0 : 5)) gl[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG + G_PLANE, PG);
+                if (ky + 1 < KROWS && t == (TAPS == 1 ? 0 : 2)) gh[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG, PG);
+                if (ky + 1 < KROWS && t == (TAPS == 1 ? 0 : 5)) gl[(ky + 1) & 1] = frag(g_lane + (ky + 1) * TW * PG + G_PLANE, PG);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1251,6 +1299,30 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
 #ifdef CDNET_WS_STAMPS
     if (stamp_on) g_wg_stamps[sbase + sn] = 0;
 #endif
+    if (QM != 0) {
+        // the waves that share a quadrant: QM 1 ((w0 + w1) + w2) + w3, QM 2 / 3 w0 + w2 and w1 + w3 - through the (dead) staging buffers
+        static_assert(QM == 0 || 2 * STAGE >= 2 * TAPS * 16 * 64 * 4, "two parked accumulator sets fit the staging buffers");
+        float *s_acc = reinterpret_cast<float *>(smem) + (QM == 1 ? 0 : (quad & 1) * TAPS * 16 * 64);
+#pragma unroll 1
+        for (int rd = 1; rd <= FOLD_BARRIERS / 2; ++rd) {
+            const bool park = QM == 1 ? quad == rd : quad >= 2, take = QM == 1 ? quad == 0 : quad < 2;
+            if (park) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_acc[(t * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (take) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += s_acc[(t * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (QM == 1 ? quad != 0 : quad >= 2) return;
+    }
     float *slab = A.slab + ((((size_t)ks * A.npar + par) * ci_blocks + ib) * co_blocks + cb) * (size_t)(TAPS * CI * CO);
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -1402,9 +1474,9 @@ int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
     constexpr int smem = 2 * (2 * NPIX_A32 * pstride(64) + 2 * NPIX_G32 * pstride(64));
     const ConvSrc &s = A.src;
     const bool plain = !s.scale && !s.relu && !s.res, fast = s.scale && s.shift && s.relu == 1 && !s.res;
-    auto go = [&](auto xf_c) -> int {
-        constexpr int XF = decltype(xf_c)::value;
-        auto kern = wgrad_ws32_kernel<XF, TAPS>;
+    auto go2 = [&](auto xf_c, auto qm_c) -> int {
+        constexpr int XF = decltype(xf_c)::value, QM = decltype(qm_c)::value;
+        auto kern = wgrad_ws32_kernel<XF, TAPS, QM>;
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1414,6 +1486,14 @@ int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
         dim3 grid(cdiv(A.src.C, 64) * cdiv(A.Cout, 64), A.npar, A.ksplit);
         kern<<<grid, 512, smem, st>>>(A);
         return check_launch("wgrad_ws32_kernel");
+    };
+    // quadrants of zero padding are not multiplied (QM): at most 32 channels on the input side, the output side, or both
+    const bool csmall = s.C <= 32 && !(A.debug & 16), gsmall = A.Cout <= 32 && !(A.debug & 16);       // (16: tests / A-B - all four quadrants)
+    auto go = [&](auto xf_c) -> int {
+        if (csmall && gsmall) return go2(xf_c, std::integral_constant<int, 1>{});
+        if (gsmall) return go2(xf_c, std::integral_constant<int, 2>{});
+        if (csmall) return go2(xf_c, std::integral_constant<int, 3>{});
+        return go2(xf_c, std::integral_constant<int, 0>{});
     };
     if (plain) return go(std::integral_constant<int, 0>{});
     if (fast) return go(std::integral_constant<int, 1>{});
@@ -1429,16 +1509,24 @@ int launch_wgrad_f32(const WgradArgs &A, hipStream_t st) {
         return launch_wgrad_ws32<(TAPS == 1 ? 1 : 9)>(A, st);
     constexpr int CI = CI_T * 32, CO = CO_T * 32;
     constexpr int smem = 2 * (NPIX_A * pstride(CI) + NPIX_G * pstride(CO));
-    auto kern = wgrad_f32_kernel<CI_T, CO_T, TAPS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(wgrad_f32)");
-        attr_done = true;
+    auto go = [&](auto qm_c) -> int {
+        constexpr int QM = decltype(qm_c)::value;
+        auto kern = wgrad_f32_kernel<CI_T, CO_T, TAPS, QM>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(wgrad_f32)");
+            attr_done = true;
+        }
+        dim3 grid(cdiv(A.src.C, CI) * cdiv(A.Cout, CO), A.npar, A.ksplit);
+        kern<<<grid, NT32, smem, st>>>(A);
+        return check_launch("wgrad_f32_kernel");
+    };
+    if constexpr (CI_T == 2 && CO_T == 2 && TAPS != 9) {
+        // quadrants of zero padding are not multiplied (the transposed convolutions into the decoder's 32- and 16-channel blocks)
+        if (A.Cout <= 32 && !A.src.pool && !(A.debug & 16)) return A.src.C <= 32 ? go(std::integral_constant<int, 1>{}) : go(std::integral_constant<int, 2>{});
     }
-    dim3 grid(cdiv(A.src.C, CI) * cdiv(A.Cout, CO), A.npar, A.ksplit);
-    kern<<<grid, NT32, smem, st>>>(A);
-    return check_launch("wgrad_f32_kernel");
+    return go(std::integral_constant<int, 0>{});
 }
 
 // kernel choice: un-pooled sources with CI <= 64 take the specialised-wave kernel with a compile-time transform

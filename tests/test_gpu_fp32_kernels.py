@@ -45,7 +45,7 @@ def _wgrad(srcs, g, weight_shape, kind, H, W, cin_real=None, ksplit=7):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 24, 40), (1, 32, 128, 16, 16), (2, 128, 32, 9, 21), (1, 16, 64, 32, 32),
-                                  (2, 64, 16, 16, 48), (1, 256, 64, 8, 8)])
+                                  (2, 64, 16, 16, 48), (1, 256, 64, 8, 8), (2, 16, 16, 24, 40), (1, 32, 32, 17, 33), (3, 32, 16, 8, 64)])
 def test_wgrad_fp32_conv3x3(case):
     import torch
     from cdnet_amd import engine
@@ -58,7 +58,8 @@ def test_wgrad_fp32_conv3x3(case):
     assert _rel(got, want) < 5e-5, _rel(got, want)
 
 
-@pytest.mark.parametrize('case', [(2, 64, 64, 24, 16, False), (3, 64, 64, 10, 20, True), (1, 128, 64, 7, 33, True), (2, 64, 128, 16, 48, False)])
+@pytest.mark.parametrize('case', [(2, 64, 64, 24, 16, False), (3, 64, 64, 10, 20, True), (1, 128, 64, 7, 33, True), (2, 64, 128, 16, 48, False),
+                                  (2, 16, 16, 24, 16, False), (3, 32, 64, 10, 20, True), (2, 64, 32, 9, 21, True)])
 def test_wgrad_fp32_conv1x1_ws32(case):
     """1x1 weight gradient on wgrad_ws32_kernel<XF, 1> (64 x 64 channel blocks): plain and BatchNorm + ReLU sources, ragged sizes (tiles
     of 4 x 16 pixels cut by the image), several channel blocks, more slices than tiles"""

@@ -5,7 +5,10 @@ import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cdnet_amd
 from cdnet_amd import _lib, engine, trainer
+
+cdnet_amd.set_precision('fp32')          # (the block shape the trainer picks depends on the precision mode)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -72,3 +75,9 @@ run('64->64@256 BN+ReLU source', 64, 64, 256, fused=True)
 run('128->128@128 BN+ReLU source', 128, 128, 128, fused=True)
 run('256->256@64 BN+ReLU source', 256, 256, 64, fused=True)
 run('512->512@32 BN+ReLU source', 512, 512, 32, fused=True)
+# layers with at most 32 channels on one side (the decoder's 32- / 16-channel blocks, the first residual unit's 16-channel input): quadrants of zero
+# padding are not multiplied (wgrad_ws32_kernel<XF, TAPS, QM>); CDNET_WGRAD_DEBUG=16 multiplies all four again
+run('16->16@256 BN+ReLU source', 16, 16, 256, fused=True, cap=160)
+run('64->16@256 plain', 64, 16, 256, cap=160)
+run('16->64@256 plain', 16, 64, 256, cap=160)
+run('32->32@128 BN+ReLU source', 32, 32, 128, fused=True, cap=160)
