@@ -16,22 +16,22 @@ lib = _lib.load()
 dev = 'cuda'
 
 
-def run(name, Cin, Cout, H, fused=False, cap=256):
+def run(name, Cin, Cout, H, fused=False, cap=256, taps=9):
     N = B
     x = torch.randn(N, H, H, Cin, device=dev)
     g = torch.randn(N, H, H, Cout, device=dev)
     kw = dict(scale=torch.rand(Cin, device=dev) + 0.5, shift=torch.rand(Cin, device=dev) - 0.5, relu=True) if fused else {}
     s = engine.Src(x, **kw)
-    dw = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    dw = torch.zeros((Cout, Cin, 3, 3) if taps == 9 else (Cout, Cin, 1, 1), dtype=torch.float32, device=dev)
     ci_t = trainer._choose_ci_tiles(Cin, Cout)
     CI, CO = ci_t * 32, (4 // ci_t) * 32
     other = -(-Cin // CI) * -(-Cout // CO)
     ntiles = N * (-(-H // 8)) * (-(-H // 16))
     ks = max(1, min(ntiles, cap // other if other < cap else 1))
-    slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(Cin, Cout, 9, 1, ci_t, ks),), dtype=torch.float32, device=dev)
+    slab = torch.empty((lib.cdnet_conv_wgrad_slab_floats(Cin, Cout, taps, 1, ci_t, ks),), dtype=torch.float32, device=dev)
     cs = engine.ConvSrc()
     s.fill(cs)
-    call = lambda: _lib.call('cdnet_conv_backward_weight', C.byref(cs), 0, Cin, Cin, _lib.ptr(g), Cout, N, H, H, 9, 1, 1, ci_t, ks,
+    call = lambda: _lib.call('cdnet_conv_backward_weight', C.byref(cs), 0, Cin, Cin, _lib.ptr(g), Cout, N, H, H, taps, 1, 1, ci_t, ks,
                              _lib.ptr(slab), _lib.ptr(dw), 0, _lib.stream_ptr())
     for _ in range(20):
         call()
@@ -42,8 +42,9 @@ def run(name, Cin, Cout, H, fused=False, cap=256):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / REPS
-    fl = 3 * 2.0 * N * H * H * Cin * Cout * 9
-    print(f'{name:34s} ksplit={ks:4d} {ms*1e3:8.1f} us   {fl / ms / 1e9:7.1f} TFLOP/s of bf16 MFMA work')
+    fl = 3 * 2.0 * N * H * H * Cin * Cout * taps
+    gbs = 4.0 * N * H * H * (Cin + Cout) / ms / 1e6
+    print(f'{name:34s} ksplit={ks:4d} {ms*1e3:8.1f} us   {fl / ms / 1e9:7.1f} TFLOP/s of bf16 MFMA work, {gbs:6.0f} GB/s of operand bytes')
 
 
 run('64->64@256 plain', 64, 64, 256)
@@ -81,3 +82,7 @@ run('16->16@256 BN+ReLU source', 16, 16, 256, fused=True, cap=160)
 run('64->16@256 plain', 64, 16, 256, cap=160)
 run('16->64@256 plain', 16, 64, 256, cap=160)
 run('32->32@128 BN+ReLU source', 32, 32, 128, fused=True, cap=160)
+# the residual units' 1x1 convolutions (TAPS = 1: HBM-bound - 537 MB of operands per launch at 16 tiles)
+run('1x1 64->64@256 plain', 64, 64, 256, cap=160, taps=1)
+run('1x1 64->64@256 plain, 256 workgroups', 64, 64, 256, cap=256, taps=1)
+run('1x1 16->64@256 plain', 16, 64, 256, cap=160, taps=1)
