@@ -1,14 +1,15 @@
-# every kernel call of ONE training step in launch order (name, stream, duration, grid): bash tools/prof_step_calls.sh [fp32|bf16]  (through gpurun)
+# every kernel call of ONE step in launch order (name, stream, duration, grid): bash tools/prof_step_calls.sh [fp32|bf16] [train|infer]  (through gpurun)
 DT=${1:-fp32}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/step_calls -o t -- python3 $R/bench.py --mode train --dtype $DT --no-extras --no-cpu-baseline --steps 6 --warmup 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/step_calls -o t -- python3 $R/bench.py --mode ${2:-train} --dtype $DT --no-extras --no-cpu-baseline --steps 6 --warmup 3 > /dev/null 2>&1
 python3 - <<'PY'
 import csv, os, re
 rows = list(csv.DictReader(open(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/step_calls/t_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-seg = rows[adam[-3] + 1:adam[-2] + 1]
+mark = 'adam_kernel' if any('adam_kernel' in r['Kernel_Name'] for r in rows) else 'input_pack'      # (a step ends with Adam / an inference batch starts with the input pack)
+adam = [i for i, r in enumerate(rows) if mark in r['Kernel_Name']]
+seg = rows[adam[-3] + 1:adam[-2] + 1] if mark == 'adam_kernel' else rows[adam[-3]:adam[-2]]
 t0 = int(seg[0]['Start_Timestamp'])
 out = open(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/step_calls.txt', 'w')
 for r in seg:
