@@ -1394,7 +1394,8 @@ int try_launch_conv_ws(const ConvArgs &A, hipStream_t st, bool dry_run = false) 
     const int Gmax = n_cu / ctiles > 0 ? n_cu / ctiles : 1;
     // (few tiles but long channel loops - the 16x16-pixel bottleneck layers - still take it: the workgroups that exist keep the memory
     //  pipeline full, which the one-tile-per-workgroup kernel does not)
-    if (!(A.debug & 64) && ((long long)T * A.nchunk < 16LL * Gmax || (T < Gmax && A.nchunk < 16))) return -1;
+    // (12, not 16: the decoder's first block - 768 -> 256 channels on 16 tiles of 16 x 16 pixels, 64 workgroups either way - 120 us on the one-tile kernel)
+    if (!(A.debug & 64) && ((long long)T * A.nchunk < 12LL * Gmax || (T < Gmax && A.nchunk < 16))) return -1;
     bool all_plain = true, all_fast = true;
     for (int i = 0; i < A.nsrc; ++i) {
         const ConvSrc &s = A.src[i];
