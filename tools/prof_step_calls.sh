@@ -1,8 +1,12 @@
-# every kernel call of ONE step in launch order (name, stream, duration, grid): bash tools/prof_step_calls.sh [fp32|bf16] [train|infer]  (through gpurun)
+# every kernel call of ONE step in launch order (name, stream, duration, grid): bash tools/prof_step_calls.sh [fp32|bf16] [train|infer] [serial]  (through gpurun)
 DT=${1:-fp32}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/step_calls -o t -- python3 $R/bench.py --mode ${2:-train} --dtype $DT --no-extras --no-cpu-baseline --steps 6 --warmup 3 > /dev/null 2>&1
+if [ "$3" = serial ]; then    # the training step on ONE stream: every duration is the kernel's own
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/step_calls -o t -- python3 $R/tools/step_serial.py $DT 6 > /dev/null 2>&1
+else
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/step_calls -o t -- python3 $R/bench.py --mode ${2:-train} --dtype $DT --no-extras --no-cpu-baseline --steps 6 --warmup 3 > /dev/null 2>&1
+fi
 python3 - <<'PY'
 import csv, os, re
 rows = list(csv.DictReader(open(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/step_calls/t_kernel_trace.csv')))
