@@ -1004,15 +1004,18 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
     constexpr int CI = 64, CO = 64, CO_T = 2;
     static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     constexpr int NQ = QM == 0 ? 4 : (QM == 1 ? 1 : 2);          // quadrants multiplied
-    constexpr int KROWS = TH32 * NQ / 4;                         // tile rows (k-steps) per consumer wave
+    // (QM 1 - 32 channels on both sides, 8 KB of operands per 4-row tile - takes 8-row tiles: its rate was the barrier period, 94 us for
+    //  a 16 -> 16 layer at 256 x 256 x 16 against ~35 us of traffic; the LDS rows shrink to the 32-channel pitch)
+    constexpr int TH_ = QM == 1 ? 8 : TH32, NPA = (TH_ + 2) * HALO_W, NPG = TH_ * TW;
+    constexpr int KROWS = TH_ * NQ / 4;                          // tile rows (k-steps) per consumer wave
     constexpr int FOLD_BARRIERS = QM == 0 ? 0 : (QM == 1 ? 6 : 2);
-    constexpr int PA = pstride(CI), PG = pstride(CO);
-    constexpr int A_PLANE = NPIX_A32 * PA, G_PLANE = NPIX_G32 * PG, STAGE = 2 * A_PLANE + 2 * G_PLANE;      // [A_hi][A_lo][G_hi][G_lo]
+    constexpr int PA = QM == 1 ? pstride(32) : pstride(CI), PG = QM == 1 ? pstride(32) : pstride(CO);
+    constexpr int A_PLANE = NPA * PA, G_PLANE = NPG * PG, STAGE = 2 * A_PLANE + 2 * G_PLANE;      // [A_hi][A_lo][G_hi][G_lo]
     // (QM 1 / 3: nobody reads input channels 32..63 of the staged tile, QM 1 / 2: nor gradient channels 32..63 - the movers stage four
     //  8-channel vectors per pixel instead of eight; the LDS rows keep their 64-channel pitch)
     constexpr int VA = (QM == 1 || QM == 3) ? 4 : CI / 8, VG = (QM == 1 || QM == 2) ? 4 : CO / 8;
-    constexpr int NA = (NPIX_A32 * VA + 255) / 256, NG = NPIX_G32 * VG / 256;
-    static_assert(NPIX_G32 * VG % 256 == 0, "whole gradient vectors per mover thread");
+    constexpr int NA = (NPA * VA + 255) / 256, NG = NPG * VG / 256;
+    static_assert(NPG * VG % 256 == 0, "whole gradient vectors per mover thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef s16x4 __attribute__((address_space(3))) * lptr;
 
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
     const int cb = blockIdx.x % co_blocks, ib = blockIdx.x / co_blocks;
     const int par = blockIdx.y;
     const int ks = blockIdx.z;
-    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH32 - 1) / TH32;
+    const int tiles_x = (A.W + TW - 1) / TW, tiles_y = (A.H + TH_ - 1) / TH_;
     const int tiles_img = tiles_y * tiles_x;
     const int ntiles = A.N * tiles_img;
     const int ntl = ks < ntiles ? (ntiles - ks + A.ksplit - 1) / A.ksplit : 0;      // tiles of this workgroup
@@ -1081,7 +1084,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
         for (int i = 0; i < NA; ++i) {
             const int v = ptid + i * 256, pix = v / VA;
             const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-            const bool exists = v < NPIX_A32 * VA && cok_a && (TAPS == 9 || (hy >= 1 && hy <= TH32 && hx >= 1 && hx <= TW));
+            const bool exists = v < NPA * VA && cok_a && (TAPS == 9 || (hy >= 1 && hy <= TH_ && hx >= 1 && hx <= TW));
             ahy[i] = exists ? hy : 31;
             ahx[i] = exists ? hx : 31;
             aoffb[i] = (unsigned)(hy * rs + hx * s.C + slot_a * 8) * 4u;
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
         unsigned av[2][NA];                  // byte offsets of the input vectors (read again for a residual operand), ~0 = zero fill
         auto issue = [&](auto rc) {
             constexpr int R = decltype(rc)::value;
-            const int y0 = c_ty * TH32, x0 = c_tx * TW;
+            const int y0 = c_ty * TH_, x0 = c_tx * TW;
             // halo row r <-> y = y0 - 1 + r, halo column c <-> x = x0 - 1 + c
             const unsigned rowbad = bad_mask(ylo - (y0 - 1), yhi - (y0 - 1)), colbad = bad_mask(xlo - (x0 - 1), xhi - (x0 - 1));
             const unsigned abase_b = (unsigned)((c_n * s.Hs + (y0 - 1 - s.off_y)) * rs + (x0 - 1 - s.off_x) * s.C + ib * CI) * 4u;
@@ -1186,7 +1189,7 @@ __global__ __launch_bounds__(512) void wgrad_ws32_kernel(WgradArgs A) {
                         lo &= keep;
                     }
                 }
-                if (i < NA - 1 || ptid + i * 256 < NPIX_A32 * VA) {
+                if (i < NA - 1 || ptid + i * 256 < NPA * VA) {
                     *reinterpret_cast<u32x4 *>(nb + adst[i]) = hi;
                     *reinterpret_cast<u32x4 *>(nb + A_PLANE + adst[i]) = lo;
                 }
@@ -1471,11 +1474,12 @@ int launch_wgrad_gen(const WgradArgs &A, hipStream_t st) {
 // the wave-specialised fp32 kernel: 3x3 layers on 64 x 64 channel blocks (ostride 1), tensors below 4 GB (32-bit byte offsets)
 template <int TAPS>
 int launch_wgrad_ws32(const WgradArgs &A, hipStream_t st) {
-    constexpr int smem = 2 * (2 * NPIX_A32 * pstride(64) + 2 * NPIX_G32 * pstride(64));
     const ConvSrc &s = A.src;
     const bool plain = !s.scale && !s.relu && !s.res, fast = s.scale && s.shift && s.relu == 1 && !s.res;
     auto go2 = [&](auto xf_c, auto qm_c) -> int {
         constexpr int XF = decltype(xf_c)::value, QM = decltype(qm_c)::value;
+        constexpr int smem = QM == 1 ? 2 * (2 * (8 + 2) * HALO_W * pstride(32) + 2 * 8 * TW * pstride(32))
+                                     : 2 * (2 * NPIX_A32 * pstride(64) + 2 * NPIX_G32 * pstride(64));
         auto kern = wgrad_ws32_kernel<XF, TAPS, QM>;
         static bool attr_done = false;
         if (!attr_done) {
