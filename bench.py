@@ -221,6 +221,63 @@ def child_json(args, timeout_s):
     return json.loads(lines[-1])
 
 
+def box_calibration(torch, dev, copy_bytes=1 << 30):
+    """What THIS box grants, measured before anything else (boxes of the pool differ by 10-25 %): a float4 copy over 1 GiB
+    (read + write bytes / time) and a v_mfma_f32_32x32x16_bf16 loop on random LDS-fed operands, one 8-wave workgroup per CU, settled for
+    ~1.5 s, with the clock the chip holds inside that loop (s_memtime / s_memrealtime stamps, median over workgroups) - cdnet_box_copy /
+    cdnet_box_mfma (csrc/box.hip)."""
+    import numpy as np
+    from cdnet_amd import _lib
+    n = copy_bytes // 4
+    src = torch.empty((n,), dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    st = _lib.stream_ptr
+
+    def copy():
+        _lib.call('cdnet_box_copy', _lib.ptr(src), _lib.ptr(dst), copy_bytes, st())
+    for _ in range(5):
+        copy()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        copy()
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2.0 * copy_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    rs = np.random.RandomState(1)
+    bf = lambda k: ((rs.randint(0, 2, k) << 15) | ((120 + rs.randint(0, 7, k)) << 7) | rs.randint(0, 128, k)).astype(np.uint32)    # random bf16 in [-1, 1)
+    seed = torch.from_numpy((bf(16384) | (bf(16384) << 16)).view(np.int32).copy()).to(dev)
+    sink = torch.zeros((4,), dtype=torch.float32, device=dev)
+    WG, WAVES, ITERS = 256, 8, 20000
+    stamps = torch.zeros((2 * WG,), dtype=torch.int64, device=dev)
+
+    def mfma(stamp):
+        _lib.call('cdnet_box_mfma', _lib.ptr(seed), _lib.ptr(sink), _lib.ptr(stamps) if stamp else None, WG, WAVES, ITERS, st())
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.5:                 # settle: the clock under matrix load is reached after about a second
+        mfma(False)
+        torch.cuda.synchronize()
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        mfma(False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tflops = WG * WAVES * ITERS * 4 * 32768.0 / (ms * 1e-3) / 1e12
+    mfma(True)
+    torch.cuda.synchronize()
+    sc = stamps.cpu().numpy().reshape(WG, 2).astype(np.float64)
+    clk = np.median(sc[:, 0] / np.maximum(sc[:, 1], 1.0)) * 100.0           # MHz: shader cycles per tick of the constant 100 MHz counter
+    return dict(copy_GBs=copy_gbs, copy_bytes=copy_bytes, mfma_TFLOPs=tflops, mfma_clock_mhz=float(clk), mfma_ms_per_launch=ms,
+                mfma_loop='v_mfma_f32_32x32x16_bf16, operands re-read from LDS (ds_read_b128), random bf16, %d workgroups x %d waves x %d iterations '
+                          '(4 MFMAs each), settled 1.5 s' % (WG, WAVES, ITERS),
+                note='measured in this run before any other leg; `value_per_box_mfma` / `inference_per_box_copy` divide the rates by these')
+
+
 def dominant_roofline(ms, B, precision, traffic=None, traffic_src=None, mfma_busy=None, clock=None, kernel=None):
     """The `roofline` object of the dominant layer (3x3 conv 64->64 @256x256 x B tiles) from its measured launch duration `ms` (pure
     arithmetic - tests/test_bench_contract.py calls it on the CPU).  `frac` is the ALGORITHMIC fraction of SURVEY 8d:
@@ -349,7 +406,7 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5, live_
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    name = engine.dominant_kernel_name(precision)
+    name = engine.dominant_kernel_name(precision, B)
     # HBM traffic of this kernel: measured in this run by PMC child passes when asked and possible, else quoted from the committed
     # summary; matrix-pipe busy fraction and clock always from the committed summary (six more passes: tools/prof_roofline_pmc.sh)
     traffic, traffic_src, mfma_busy, clock = committed_pmc(precision, B)
@@ -529,7 +586,7 @@ def main():
                 lab, dirn, point = targets()
                 tr.train_step(x, lab, dirn, point, weight)
         else:
-            side = streams.side_stream(dev)
+            side = streams.side_stream(dev, 1)       # (a stream of the loader's own: not the trainer's weight-gradient stream, not its queue)
             state = {}
 
             def produce():
@@ -552,7 +609,7 @@ def main():
         dt = timed(step, steps, warmup)
         return dict(value=world * B * steps / dt, unit='tiles/s', ms_per_step=dt / steps * 1e3, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup,
                     dtype=precision, workload='label_encoding_batch (CDM generation of one batch on the device) + train_step per iteration; ' +
-                    ('targets of batch i + 1 generated on a second stream beside step i (prefetching loader)' if prefetch else 'same stream, one after the other'))
+                    ('targets of batch i + 1 generated on a third stream (the loader\'s own: neither the compute nor the weight-gradient stream) beside step i (prefetching loader)' if prefetch else 'same stream, one after the other'))
 
     def run_unet_cfg1(precision, B, steps, warmup):
         """BASELINE config 1 at its own size: plain UNet (models/unet.py:53-106) train step, 4 x 256x256x3 tiles"""
@@ -597,7 +654,7 @@ def main():
             batch = trainer.synthetic_batch(B, dev, seed=2022 + rank)
             dt = timed(lambda: tr.train_step(*batch), steps, warmup)
             st = tr.ar_stats or {}
-            probe = streams.PROBES[-1] if streams.PROBES else None
+            probe = next((p_ for p_ in reversed(streams.PROBES) if p_.get('k', 0) == 0), None)
             return dict(ms_per_step=dt / steps * 1e3, value=B * steps / dt, unit='tiles/s', steps=steps, warmup=warmup, dtype=precision,
                         buckets=st.get('buckets'), buckets_released_during_backward=st.get('released_during_backward'),
                         bucket_mb=tr.bucket * 4 / (1 << 20), process_group='%s, %d rank(s)' % (dist.get_backend(), dist.get_world_size()),
@@ -616,6 +673,7 @@ def main():
         return
     other = 'fp32' if a.dtype == 'bf16' else 'bf16'
     extras = not a.no_extras
+    box = box_calibration(torch, dev)               # before anything else is timed: what this box grants (copy GB/s, MFMA TFLOP/s, clock)
     if mode == 'train':
         B = a.batch or 16
         head = run_train(a.dtype, B, a.steps, a.warmup)
@@ -638,6 +696,10 @@ def main():
                                  'split operands (hi*hi + hi*lo + lo*hi), <= 2^-16 relative error per product ("bf16x3"; not IEEE-fp32 '
                                  'multiplication: gfx950 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 rate)')},
     }
+    line['box'] = box
+    # rates beside what the box itself grants: the fp32 / bf16 training steps are matrix-bound (per TFLOP/s of the box's MFMA loop), the
+    # inference steps lean on the memory side (per GB/s of the box's copy) - the columns of DESIGN section 0's per-round table
+    line['value_per_box_mfma'] = head['value'] / box['mfma_TFLOPs']
     line['config']['process_group'] = ('%s, %d rank(s)' % (dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else None
     rp = {}
     if mode != 'image':
@@ -647,6 +709,7 @@ def main():
         line['inference'] = {'metric': inf['metric'], 'value': inf['value'], 'unit': 'tiles/s', 'ms_per_step': inf['ms_per_step'],
                              'tiles_per_gpu_per_step': 64, 'steps': inf['steps'], 'dtype': a.dtype, 'workload': inf['workload']}
         rp['infer_' + a.dtype] = path_roofline('infer', a.dtype, 64, inf['ms_per_step'])
+        line['inference_per_box_copy'] = inf['value'] / box['copy_GBs']
     if extras and mode == 'train' and world == 1:
         # the same two rates in the other arithmetic, and BASELINE config 3, same protocol with fewer steps
         ksteps = max(5, a.steps // 2)
@@ -655,6 +718,8 @@ def main():
         line[other] = {'value': t2['value'], 'unit': 'tiles/s', 'ms_per_step': t2['ms_per_step'], 'steps': ksteps, 'warmup': 2,
                        'tiles_per_gpu_per_step': B, 'dtype': other,
                        'inference': {'value': i2['value'], 'unit': 'tiles/s', 'ms_per_step': i2['ms_per_step'], 'tiles_per_gpu_per_step': 64, 'steps': i2['steps']}}
+        line[other]['value_per_box_mfma'] = t2['value'] / box['mfma_TFLOPs']
+        line[other]['inference_per_box_copy'] = i2['value'] / box['copy_GBs']
         rp['train_' + other] = path_roofline('train', other, B, t2['ms_per_step'])
         rp['infer_' + other] = path_roofline('infer', other, 64, i2['ms_per_step'])
         IMG_STEPS, IMG_WARMUP = 8, 2
@@ -675,7 +740,7 @@ def main():
         line['unet_cfg1'] = run_unet_cfg1(a.dtype, 4, 10, 2)
     if rp:
         line['roofline_path'] = rp
-    line['config']['side_stream_probe'] = streams.PROBES[-1] if streams.PROBES else None       # (the trainer's / pipeline's second stream)
+    line['config']['side_stream_probe'] = next((p_ for p_ in reversed(streams.PROBES) if p_.get('k', 0) == 0), None)       # (the trainer's / pipeline's second stream)
     if rank == 0:
         cdnet_amd.set_precision(a.dtype)
         line['roofline'] = time_dominant_conv(torch, 16, precision=a.dtype, live_pmc=(world == 1 and extras and not a.no_live_pmc))

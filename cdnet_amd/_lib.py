@@ -23,6 +23,8 @@ SIGNATURES = {
     'cdnet_last_error': (C.c_char_p, []),
     'cdnet_build_info': (C.c_char_p, []),
     'cdnet_spin': (_i, [_i, _vp]),
+    'cdnet_box_copy': (_i, [_vp, _vp, _sz, _vp]),
+    'cdnet_box_mfma': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'cdnet_ddm_codes': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     'cdnet_ddm_normalize': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'cdnet_probmaps': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -44,6 +46,8 @@ SIGNATURES = {
     'cdnet_watershed_workspace_bytes': (_sz, [_i, _i, _i]),
     'cdnet_watershed_process': (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     'cdnet_fill_label_process': (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    'cdnet_tile_postproc_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'cdnet_tile_postproc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _sz] + [_vp] * 10),
     'cdnet_cc_workspace_bytes': (_sz, [_i, _i, _i]),
     'cdnet_cc_chain': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cdnet_conv_packed_weight_elems': (_sz, [_i] * 6),
@@ -114,8 +118,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.cdnet_abi_version() != 4:
-        raise CdnetHipError('ABI version mismatch (libcdnet_hip.so is version %d, this binding 4): rebuild with python -m cdnet_amd.csrc.build' % lib.cdnet_abi_version())
+    if lib.cdnet_abi_version() != 5:
+        raise CdnetHipError('ABI version mismatch (libcdnet_hip.so is version %d, this binding 5): rebuild with python -m cdnet_amd.csrc.build' % lib.cdnet_abi_version())
     _lib = lib
     return lib
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libcdnet_hip.so')
 OBJ_DIR = os.path.join(HERE, 'build')
-SOURCES = ['abi.hip', 'postproc.hip', 'conv.hip', 'conv32.hip', 'conv32ws.hip', 'conv16ws.hip', 'wgrad.hip', 'model.hip', 'train.hip', 'cdm.hip', 'metrics.hip']
+SOURCES = ['abi.hip', 'box.hip', 'postproc.hip', 'postproc_tile.hip', 'conv.hip', 'conv32.hip', 'conv32ws.hip', 'conv16ws.hip', 'wgrad.hip', 'model.hip', 'train.hip', 'cdm.hip', 'metrics.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result']
 

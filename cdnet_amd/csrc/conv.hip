@@ -1640,6 +1640,9 @@ extern "C" int cdnet_conv_forward(const cdnet_conv_args *args, void *stream) {
         CDNET_REQUIRE(A.taps1 == 0 || A.taps1 == A.taps, "cdnet_conv_forward: a one-tap second source runs on conv_ws16_kernel only (ask cdnet_conv_ws_eligible)");
         CDNET_REQUIRE(!A.pool_out, "cdnet_conv_forward: the fused max-pool output needs conv_ws16_kernel's out-image form (ask cdnet_conv_ws_eligible)");
         CDNET_REQUIRE(!A.dot_out, "cdnet_conv_forward: the fused 1x1 classifier (dot_out) needs conv_ws16_kernel's out-image form with resident weights (ask cdnet_conv_ws_eligible)");
+        // (only conv_ws16_kernel / conv_ws_kernel read through bounded buffer descriptors: the one-tile kernels would index the scale / shift
+        //  table and the tensor past the second source's channels)
+        CDNET_REQUIRE(!padded, "cdnet_conv_forward: a padding chunk (nchunk = real + 1) runs on conv_ws16_kernel only (ask cdnet_conv_ws_eligible)");
     }
     static const int dbg = getenv("CDNET_CONV_DEBUG") ? atoi(getenv("CDNET_CONV_DEBUG")) : 0;
     if (!(A.debug & 32) && A.taps == 9 && A.npar == 1 && A.ostride == 1 && A.tile == 16 && A.CK == 16 && (A.BN == 64 || A.BN == 32)) {

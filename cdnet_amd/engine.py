@@ -133,12 +133,15 @@ def choose_cfg(src_channels, Cout, H, W, override=None, taps=9, transposed=False
     return (16, ck, bn)
 
 
-def dominant_kernel_name(precision):
+def dominant_kernel_name(precision, tiles=16):
     """the kernel cdnet_conv_forward runs the dominant layer (3x3 64 -> 64 on full 16x16 tiles) on - what bench.py's `roofline` object and
-    the profile filters name"""
+    the profile filters name.  The 16-bit kernel's instantiation depends on the launch's size: chunk-PAIR requests while the tensors fit the
+    256 MB Infinity Cache, QUAD requests beyond it (csrc/conv16ws.hip: launch_ws16's `quad` test) - the 16- and 64-tile figures of
+    `roofline_bf16*` come from two different instantiations"""
     if precision == 'fp32':
         return 'conv_ws32_kernel<64,0,false>'
-    return 'conv_ws16_kernel<64,0,false,false,0,4,4,true>'
+    quad = tiles * 256 * 256 * (64 + 64) * 2 >= (512 << 20)         # io_bytes of launch_ws16
+    return 'conv_ws16_kernel<64,0,false,false,0,4,4,true,false,true,%s>' % ('true' if quad else 'false')
 
 
 def packed_elems(Cout, nchunk, taps, CK, BN, npar):
@@ -215,7 +218,7 @@ CONV_DEBUG = 0        # cdnet_conv_args.debug of every launch (tests: 32 = conv_
 
 def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, oscale=None, oshift=None,
                  orelu=False, out=None, stats=None, H=None, W=None, out_dtype=torch.bfloat16, eres=None, query_ws=False, bns=None, taps1=0, pool_out=None, dot=None,
-                 pad_chunks=0):
+                 pad_chunks=0, debug_or=0):
     """Launch one convolution.  srcs: list of Src (1 or 2).  Returns (out, stats).  fp32 sources select the fp32-precision
     kernels (`wpacked` must then be the split pack and the output is fp32)."""
     tile, CK, BN = cfg[:3]
@@ -263,7 +266,7 @@ def conv_forward(srcs, wpacked, Cout, cfg, taps=9, transposed=False, bias=None, 
     a.ws = 0
     a.taps1 = taps1
     a.pool_out = _dp(pool_out)           # nn.MaxPool2d(2, 2) of the activated output beside it (conv_ws16_kernel's out-image form; ask query_ws first)
-    a.debug = CONV_DEBUG
+    a.debug = CONV_DEBUG | debug_or      # (debug_or: a caller's kernel-selection bits for THIS launch - no global is touched)
     a.f32 = int(f32)
     assert out is None or (out.dtype == torch.float32) == f32
     if eres is not None:                 # fused residual epilogue: eres = Src(other branch[, scale, shift], relu=...)

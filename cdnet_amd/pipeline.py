@@ -14,8 +14,10 @@ from . import postproc
 
 
 @torch.no_grad()
-def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, post_stream=None):
-    """x: float32 NCHW [B,3,H,W] on the GPU.  Returns dict(final int32 [B,H,W], counts, pred, ...).
+def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, post_stream=None, check=False, want_prob=False, fused=True):
+    """x: float32 NCHW [B,3,H,W] on the GPU.  Returns dict(final int32 [B,H,W], counts, pred, dcm, minmax, ...; `prob` with want_prob / want_stages).
+    `fused=False` takes the per-step chain (probmaps -> ddm_codes -> tta_boost_argmax -> cc_chain: ~17 launches) whatever the shape - the
+    form every shape falls back to that the two-launch chain does not serve (W not a multiple of 64, more than 65536 pixels per tile).
 
     `post_stream` (a torch.cuda.Stream; cdnet_amd.streams.side_stream() picks one that does not share the compute stream's hardware
     queue): the post-processing chain is queued on that stream, ordered after this batch's forward, and
@@ -23,10 +25,11 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
     convolutions of batch i + 1 queued on the caller's stream.  The returned tensors belong to `post_stream`: wait for `r['done']`
     (an event) - or synchronize - before reading them on another stream.
 
-    The reference asserts on a tile whose direction-difference map is constant (0/0 -> NaN, test_dam.py:535).  Serial form: the same
-    AssertionError here, as postproc.postprocess_views raises it.  Pipelined form (`post_stream`): a host-side assert would drain the
-    pipeline, so the test is left to `check_tiles(r)`: it reads the (min, max) codes the DDM kernel already leaves in `r['minmax']` (int32
-    [B, 2]; no extra launch in the chain) once the caller has waited for `r['done']`, and raises the reference's assertion."""
+    The reference asserts PER IMAGE on a constant direction-difference map (0/0 -> NaN, test_dam.py:535) - `infer_image` keeps that assertion.
+    A batch of independent tiles may legitimately hold a background-only tile, and a host-side assert costs a device-to-host
+    synchronisation: here the test is opt-in.  `check=True` (serial form only) raises the reference's AssertionError for the batch;
+    otherwise call `check_tiles(r)` when wanted - it reads the (min, max) codes the DDM kernel already leaves in `r['minmax']` (int32 [B, 2];
+    no extra launch in the chain), after waiting for `r['done']` in the pipelined form."""
     assert not model.training
     mask, point, direction = model(x)
     B, _, H, W = mask.shape
@@ -37,18 +40,24 @@ def infer_tiles(model, x, classes=9, min_area=20, radius=2, want_stages=False, p
             t.record_stream(post_stream)                  # (allocated on the caller's stream, last read on the other one)
         ctx = torch.cuda.stream(post_stream)
     with ctx:
-        prob, dcm = postproc.probmaps(mask, direction)                        # test_dam.py:984, 1011-1013
-        code, minmax = postproc.ddm_codes(dcm, classes)                       # generate_dd_map per tile
-        r = postproc.tta_boost_argmax(prob.reshape(B, 1, 3 * H * W), point.reshape(B, 1, H * W),
-                                      code.reshape(B, 1, H * W), minmax.reshape(B, 1, 2), [0], H, W,
-                                      want_stages=want_stages)
-        cc = postproc.cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
-        r.update(cc)
-        r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
+        if fused and postproc.tile_postproc_eligible(B, direction.shape[1], H, W):
+            # two launches: probabilities / direction classes / DDM codes, then everything else of a tile in one workgroup (csrc/postproc_tile.hip);
+            # the probability planes are written only when asked for (want_prob / want_stages)
+            r = postproc.tile_postproc(mask, direction, point, min_area, radius, want_stages=want_stages, want_prob=want_prob)
+        else:
+            prob, dcm = postproc.probmaps(mask, direction)                        # test_dam.py:984, 1011-1013
+            code, minmax = postproc.ddm_codes(dcm, classes)                       # generate_dd_map per tile
+            r = postproc.tta_boost_argmax(prob.reshape(B, 1, 3 * H * W), point.reshape(B, 1, H * W),
+                                          code.reshape(B, 1, H * W), minmax.reshape(B, 1, 2), [0], H, W,
+                                          want_stages=want_stages)
+            cc = postproc.cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
+            r.update(cc)
+            r.update(prob=prob, dcm=dcm, minmax=minmax, point=point)
         if post_stream is not None:
             r['done'] = torch.cuda.Event()
             r['done'].record(post_stream)
-    if post_stream is None and not torch.cuda.is_current_stream_capturing():      # (inside a HIP-graph capture nothing may synchronise: the flag stays for the caller)
+    if check:
+        assert post_stream is None and not torch.cuda.is_current_stream_capturing(), 'check=True synchronises: serial form, outside a graph capture'
         check_tiles(r)
     return r
 

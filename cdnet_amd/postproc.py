@@ -100,8 +100,8 @@ def tta_boost_argmax(probs, points, codes, minmax, xforms, H, W, want_stages=Tru
 _WS = {}
 
 
-def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, kind='cc'):
+    key = (device.index, torch.cuda.current_stream().cuda_stream, kind)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
@@ -128,6 +128,49 @@ def cc_chain(pred, fg_value=1, min_area=20, radius=2, want_stages=False):
               ws.numel(), _lib.ptr(fill), _lib.ptr(small), _lib.ptr(label), _lib.ptr(final), _lib.ptr(counts),
               _lib.stream_ptr())
     out = dict(final=final, counts=counts)
+    if want_stages:
+        out.update(fill=fill, small=small, label=label)
+    return out
+
+
+def tile_postproc_eligible(B, classes, H, W):
+    """the fused two-launch chain takes this batch of tiles (cdnet_tile_postproc: W a multiple of 64, at most 65536 pixels per tile)"""
+    return _lib.load().cdnet_tile_postproc_workspace_bytes(int(B), int(classes), int(H), int(W)) > 0
+
+
+def tile_postproc(mask_logits, dir_logits, point, min_area=20, radius=2, want_stages=False, want_prob=False):
+    """The whole post-processing chain of a batch of independent tiles (one view each) in TWO launches (cdnet_tile_postproc): get_probmaps
+    epilogue + direction-difference codes, then boost / arg-max / fill holes / remove small / label / dilate of a tile inside one workgroup.
+    mask_logits f32 [B,3,H,W], dir_logits f32 [B,C,H,W], point f32 [B,1,H,W] or [B,H,W] - what Unet.forward returns.
+    Returns dict(final i32 [B,H,W], counts i32 [B], pred u8, dcm u8, minmax i32 [B,2] [, prob] [, fill, small, label]) - bit-identical to
+    probmaps -> ddm_codes -> tta_boost_argmax -> cc_chain."""
+    assert mask_logits.dtype == torch.float32 and dir_logits.dtype == torch.float32 and point.dtype == torch.float32
+    B, _, H, W = mask_logits.shape
+    Cd = dir_logits.shape[1]
+    dev = mask_logits.device
+    mask_logits, dir_logits, point = mask_logits.contiguous(), dir_logits.contiguous(), point.contiguous()
+    assert point.numel() == B * H * W
+    nbytes = _lib.load().cdnet_tile_postproc_workspace_bytes(B, Cd, H, W)
+    assert nbytes > 0, 'shape not served by the fused tile chain: ask tile_postproc_eligible first'
+    ws = _workspace(nbytes, dev, 'tile')
+    u8 = lambda: torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    i32 = lambda: torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    prob = torch.empty_like(mask_logits) if (want_prob or want_stages) else None
+    dcm, pred, final = u8(), u8(), i32()
+    minmax = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    fill = small = label = None
+    if want_stages:
+        fill, small, label = u8(), u8(), i32()
+    lut = ddm_lut(Cd)
+    nbr, extra = _nbr_extra(Cd)
+    _lib.call('cdnet_tile_postproc', _lib.ptr(mask_logits), _lib.ptr(dir_logits), _lib.ptr(point), B, Cd, H, W,
+              lut.ctypes.data_as(C.c_void_p), nbr, extra, int(min_area), int(radius), _lib.ptr(ws), ws.numel(), _lib.ptr(prob), _lib.ptr(dcm),
+              _lib.ptr(minmax), _lib.ptr(pred), _lib.ptr(fill), _lib.ptr(small), _lib.ptr(label), _lib.ptr(final), _lib.ptr(counts),
+              _lib.stream_ptr())
+    out = dict(final=final, counts=counts, pred=pred, dcm=dcm, minmax=minmax, point=point)
+    if prob is not None:
+        out['prob'] = prob
     if want_stages:
         out.update(fill=fill, small=small, label=label)
     return out

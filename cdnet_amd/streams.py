@@ -22,45 +22,49 @@ def _spin(us, stream):
     _lib.call('cdnet_spin', int(us), stream.cuda_stream)
 
 
-def side_stream(device=None):
+def side_stream(device=None, k=0):
     """One stream per device (and per process-group state), chosen once.  HIP places streams on a few hardware queues in creation order; a
     side stream that shares the compute stream's queue serialises with it, and the cross-stream events then cost more than one stream would
     (training: 1 456 vs 1 622 vs 1 780 tiles/s; inference with the post-processing stream: 9 490 vs 10 300 vs 10 700 tiles/s - the stream a
-    process gets from torch.cuda.Stream() depends on how many it created before).  Candidates are timed with two spin kernels of the
+    process gets from torch.cuda.Stream() depends on how many it created before).  Candidates are timed with spin kernels of the
     library's own (`cdnet_spin`: one wave waiting on the constant 100 MHz counter, no memory traffic): together they take as long as one
     when the queues differ, twice as long when they do not.  No candidate passing is not an error: the first one is used and the record in
-    `PROBES` says so."""
+    `PROBES` says so.
+
+    `k` > 0: ANOTHER stream, that shares its queue neither with the compute stream nor with the streams of 0 .. k - 1 (the input pipeline's
+    prefetch stream beside the trainer's weight-gradient stream): the candidate spins beside all of them."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (idx, _group_state())
+    key = (idx, _group_state(), k)
     hit = _SIDE.get(key)
     if hit is not None:
         return hit
+    taken = [side_stream(dev, j) for j in range(k)]
     cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
     pick = cands[0]
-    rec = dict(device=idx, group=key[1], alone_ms=None, together_ms=None, picked=0, probed=False)
+    rec = dict(device=idx, group=key[1], k=k, alone_ms=None, together_ms=None, picked=0, probed=False)
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream()
         SPIN_US = 300
 
-        def timed(other):
+        def timed(others):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main)
-            if other is not None:
-                other.wait_stream(main)                 # (starts with the compute stream's spin, not before the first event)
-                _spin(SPIN_US, other)
+            for o in others:
+                o.wait_stream(main)                     # (starts with the compute stream's spin, not before the first event)
+                _spin(SPIN_US, o)
             _spin(SPIN_US, main)
-            if other is not None:
-                main.wait_stream(other)
+            for o in others:
+                main.wait_stream(o)
             e1.record(main)
             torch.cuda.synchronize()
             return e0.elapsed_time(e1)
-        timed(None)
-        alone = min(timed(None), timed(None))
+        timed([])
+        alone = min(timed([]), timed([]))
         rec.update(alone_ms=alone, probed=True)
         for i, c in enumerate(cands):
-            t = min(timed(c), timed(c))
+            t = min(timed(taken + [c]), timed(taken + [c]))
             if t < 1.5 * alone:
                 pick = c
                 rec.update(picked=i, together_ms=t)

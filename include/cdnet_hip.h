@@ -29,9 +29,10 @@ extern "C" {
 #define CDNET_E_WORKSPACE   2   /* workspace too small */
 #define CDNET_E_LAUNCH      3   /* HIP launch error */
 
-#define CDNET_ABI_VERSION   4   /* 2, 3 (round 4): cdnet_conv_args grew (taps1, pool_out; dot_w, dot_b, dot_out) - a caller built against an older
+#define CDNET_ABI_VERSION   5   /* 2, 3 (round 4): cdnet_conv_args grew (taps1, pool_out; dot_w, dot_b, dot_out) - a caller built against an older
                                  version must not pass its struct.  4 (round 5): cdnet_spin added; cdnet_tta_boost_argmax accepts point_mean == NULL
-                                 for one view in its own frame (no struct changed) */
+                                 for one view in its own frame (no struct changed).  5 (round 6): cdnet_box_copy / cdnet_box_mfma (box calibration),
+                                 cdnet_tile_postproc (the fused tile post-processing chain); no struct changed */
 
 int         cdnet_abi_version(void);
 /* sizeof() of an argument struct of this header by name ("cdnet_conv_args", ...), 0 for an unknown name: a binding that mirrors the structs
@@ -44,6 +45,34 @@ const char *cdnet_build_info(void);
  * side's stream probe times two of them on two streams (cdnet_amd/streams.py): streams that share a hardware queue run them one after the
  * other.  Replaces nothing of the reference (nn.DataParallel has no streams of its own, train.py:185); a diagnostic of the runtime. */
 int         cdnet_spin(int microseconds, void *stream);
+/* Box calibration (bench.py's `box` object: boxes of one pool differ by 10-25 % on memory-bound kernels and in the clock they hold under
+ * matrix load; rates are reported beside what the box itself grants).  Diagnostics of the runtime; nothing of the reference.
+ * cdnet_box_copy: dst[i] = src[i] over `bytes` (multiple of 16, both 16-byte aligned) with float4 accesses, 4096 workgroups grid-stride.
+ * cdnet_box_mfma: `workgroups` x `waves_per_wg` waves each run `iters` iterations of four v_mfma_f32_32x32x16_bf16 whose operands are
+ * re-read from LDS (64 KB of patterns copied from `seed`, u32 [16384] = bf16 pairs); 4 x 32768 flop per wave and iteration.  `stamps`
+ * (NULL or u64 [2 * workgroups]): per workgroup the loop's duration in shader cycles (s_memtime) and in ticks of the constant 100 MHz counter
+ * (s_memrealtime) - clock = cycles / ticks x 100 MHz. */
+int         cdnet_box_copy(const void *src, void *dst, size_t bytes, void *stream);
+int         cdnet_box_mfma(const uint32_t *seed, float *sink, unsigned long long *stamps, int workgroups, int waves_per_wg, int iters, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * The whole post-processing chain of a batch of independent tiles (one view each, in its own frame) in two launches (round 6).
+ * Replaces, per tile, test_dam.py:982-1015 (get_probmaps epilogue), getDirectionDiffMap.py:44-108 (generate_dd_map), test_dam.py:529-539
+ * (point-guided boost + arg-max) and test_dam.py:546-563 (fill holes, remove small objects, label, dilate) - the same steps as
+ * cdnet_probmaps + cdnet_ddm_codes + cdnet_tta_boost_argmax (V = 1) + cdnet_cc_chain, with bit-identical results: launch 1 leaves the
+ * direction-difference codes (its direction-class window lives in LDS, the halo recomputed from the logits), launch 2 runs everything else of
+ * a tile inside ONE workgroup with the tile in LDS (16-bit union-find).
+ *   mask_logits f32 [B,3,H,W], dir_logits f32 [B,C,H,W] (C = 5 / 9 / 17), point f32 [B,H,W]      (device, NCHW as Unet.forward returns them)
+ *   lut_host: int8 [C*C] HOST memory as for cdnet_ddm_codes; nbr / extra_zero as there
+ *   prob f32 [B,3,H,W] or NULL, dcm u8 [B,H,W] or NULL (stage outputs); minmax i32 [B,2] (min, max DDM code per tile: equal = the reference's
+ *   assertion test_dam.py:535 would fail); pred u8 [B,H,W]; fill / small u8 [B,H,W] or NULL; label i32 [B,H,W] or NULL; final i32 [B,H,W];
+ *   counts i32 [B] or NULL
+ * Shapes: W a multiple of 64 and H * W <= 65536 (cdnet_tile_postproc_workspace_bytes returns 0 otherwise: use the per-step entries). */
+size_t cdnet_tile_postproc_workspace_bytes(int B, int C, int H, int W);
+int cdnet_tile_postproc(const float *mask_logits, const float *dir_logits, const float *point, int B, int C, int H, int W,
+                        const int8_t *lut_host, int nbr, int extra_zero, int min_area, int radius, void *workspace, size_t workspace_bytes,
+                        float *prob, uint8_t *dcm, int32_t *minmax, uint8_t *pred, uint8_t *fill, uint8_t *small, int32_t *label,
+                        int32_t *final_, int32_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Direction-difference map.   Replaces data_prepare/getDirectionDiffMap.py:44-108 `generate_dd_map`
@@ -170,7 +199,8 @@ typedef struct cdnet_conv_args {
     int npar;               /* 1, or 4 sub-pixel parities (ConvTranspose2d stride 2) */
     int ostride;            /* 1, or 2 for the transposed convolutions */
     int nchunk;             /* total Cin chunks over both sources (two-source 3x3 launches of the 16-bit path: one more is allowed - a padding chunk
-                               behind the second source whose packed weights are zeros, making the count even for conv_ws16_kernel's out-image form) */
+                               behind the second source whose packed weights are zeros, making the count even for conv_ws16_kernel's out-image form.  Valid on conv_ws16_kernel ONLY
+                               (bounded buffer descriptors): ask cdnet_conv_ws_eligible == 2 first, any other kernel returns CDNET_E_ARG) */
     int tile, CK, BN;       /* kernel configuration: spatial tile (16 or 8), Cin chunk, Cout tile */
     int out_f16;            /* 1: store the output as fp16 instead of bf16 */
     int debug;              /* 0 in production.  Kernel-selection switches for the tests: 32 = never take the wave-specialised

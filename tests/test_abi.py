@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'missing export ' + n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.cdnet_abi_version() == 4
+    assert lib.cdnet_abi_version() == 5
     assert b'gfx950' in lib.cdnet_build_info()
 
 

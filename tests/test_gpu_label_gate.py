@@ -140,7 +140,7 @@ def test_tiles_label_parity(trained):
     m, ref, prec = trained
     x, lab, dirn, point, weight, inst = synth.nuclei_batch(3, 256, 256, 777, n=60)
     with torch.no_grad():
-        r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda())
+        r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda(), want_prob=True)
     got_mask, got_dir = r['prob'].argmax(1).cpu().numpy(), r['dcm'].cpu().numpy().reshape(3, 256, 256)
     report, gt_scores = [], []
     for b in range(3):
@@ -205,7 +205,7 @@ def test_dense_touching_nuclei_boost(trained):
     m, ref, prec = trained
     x, lab, dirn, point, weight, inst = synth.nuclei_batch(1, 256, 256, 4321, n=400)
     with torch.no_grad():
-        r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda())
+        r = pipeline.infer_tiles(m, torch.from_numpy(x).cuda(), want_prob=True)
     w = _oracle('dense', lambda: oinf.infer_image(ref, x[0], tta=False, all_img_test=1))
     got_pred = r['pred'][0].cpu().numpy()
     flips_got = int((r['prob'][0].argmax(0).cpu().numpy() != got_pred).sum())

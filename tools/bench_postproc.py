@@ -3,6 +3,7 @@ boost / arg-max -> CC chain, on logits synthesised from the centripetal-directio
 classes and the union-find load look like a network's output).
     python3 tools/bench_postproc.py [tiles] [steps]             ms per batch, GB/s against the chain's algorithmic bytes
     rocprofv3 --kernel-trace --stats ... -- python3 tools/bench_postproc.py      per-kernel durations without convolutions beside them
+POSTPROC_FUSED=0: the per-step chain of rounds 1-5 (~17 launches) instead of the two-launch chain.
 (`bench.py`'s inference legs run this chain on a second stream beside the next batch's forward: its kernels show 2-3 x these durations there)"""
 import os
 import sys
@@ -33,6 +34,8 @@ def logits(B, dev, seed=7):
 
 def chain(mask, point, direction, classes=9, min_area=20, radius=2):
     B, _, H, W = mask.shape
+    if os.environ.get('POSTPROC_FUSED', '1') == '1' and postproc.tile_postproc_eligible(B, classes, H, W):
+        return postproc.tile_postproc(mask, direction, point, min_area, radius)        # two launches (csrc/postproc_tile.hip)
     prob, dcm = postproc.probmaps(mask, direction)
     code, minmax = postproc.ddm_codes(dcm, classes)
     r = postproc.tta_boost_argmax(prob.reshape(B, 1, 3 * H * W), point.reshape(B, 1, H * W), code.reshape(B, 1, H * W), minmax.reshape(B, 1, 2),
