@@ -37,6 +37,14 @@ TRAIN_MB_PER_TILE = {'bf16': 770.0, 'fp32': 1540.0}         # ~3x forward (fwd w
 WEIGHT_MB = {'bf16': 41.0, 'fp32': 81.9}                    # read once per batch (inference)
 OPT_MB_PER_STEP = 4 * 81.9                                  # parameter / gradient / Adam-moment traffic per step (fp32 masters in both modes)
 POSTPROC_MB_PER_TILE = 1.835                                # 28 B/pixel
+# plain UNet (cfg 1) 96.35 / 289.1 GFLOP per tile (inference / train), 328.2 MB fp32 forward activations, 124.2 MB of weights;
+# HRNet18_rev1 (cfg 5) per 512x512 tile: 455.8 GFLOP and 6.68 GB fp32 / 3.34 GB bf16 forward; training = 3 x forward (as for the DAM-Unet)
+UNET_TRAIN_GFLOP_PER_TILE = 289.1
+UNET_FWD_MB_PER_TILE = {'bf16': 164.1, 'fp32': 328.2}
+UNET_WEIGHT_MB = 124.2
+HRNET_TRAIN_GFLOP_PER_TILE = 3 * 455.8
+HRNET_FWD_MB_PER_TILE = {'bf16': 3340.0, 'fp32': 6680.0}
+HRNET_WEIGHT_MB = 38.5                                      # 9.64 M parameters in fp32
 
 
 def parse():
@@ -309,7 +317,7 @@ def committed_pmc(precision, B=16):
     """(traffic bytes per launch, source note, matrix-pipe busy fraction, clock MHz) of the dominant kernel at B tiles per launch from the newest
     committed PMC summary (tools/prof_roofline_pmc.sh -> profiles/<round>/dominant_conv_<dtype>[_<B>tiles]_pmc.json)"""
     name = 'dominant_conv_%s%s_pmc.json' % (precision, '' if B == 16 else '_%dtiles' % B)
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         tj = os.path.join(ROOT, 'profiles', rnd, name)
         if os.path.exists(tj):
             with open(tj) as f:
@@ -345,9 +353,9 @@ def live_pmc_traffic(precision, kernel_names, timeout_s=60):
     vals = {}
     out = tempfile.mkdtemp(prefix='cdnet_pmc_', dir='/tmp')
     try:
-        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-            d = os.path.join(out, ctr)
-            cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 't', '--',
+        for ctrs in (('FETCH_SIZE',), ('WRITE_SIZE',), ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')):
+            d = os.path.join(out, ctrs[0])
+            cmd = [exe, '--kernel-trace', '--pmc'] + list(ctrs) + ['--output-format', 'csv', '-d', d, '-o', 't', '--',
                    sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'roofline', '--dtype', precision, '--steps', '20']
             # the profiler and the program it starts form their own process group: on a timeout the WHOLE group is killed and reaped
             # before anything else is timed (killing only the launcher would leave `bench.py --mode roofline` running on this GPU)
@@ -360,25 +368,53 @@ def live_pmc_traffic(precision, kernel_names, timeout_s=60):
                 except ProcessLookupError:
                     pass
                 proc.wait()
-                return None, 'rocprofv3 --pmc %s pass exceeded %d s (its process group was killed and reaped)' % (ctr, timeout_s)
+                if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+                    break                                   # (the traffic is there: the matrix-pipe pass is optional)
+                return None, 'rocprofv3 --pmc %s pass exceeded %d s (its process group was killed and reaped)' % (ctrs[0], timeout_s)
             if rc != 0:
-                return None, 'rocprofv3 --pmc %s failed (rc %d)' % (ctr, rc)
-            per = {}
-            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if row.get('Counter_Name') == ctr and any(w in row.get('Kernel_Name', '') for w in kernel_names):
-                            per[row['Dispatch_Id']] = per.get(row['Dispatch_Id'], 0.0) + float(row['Counter_Value'])
-            if len(per) < 10:
-                return None, 'no %s rows for the dominant kernel' % ctr
-            vals[ctr] = sum(per.values()) / len(per)
+                if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+                    break
+                return None, 'rocprofv3 --pmc %s failed (rc %d)' % (ctrs[0], rc)
+            for ctr in ctrs:
+                per = {}
+                for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if row.get('Counter_Name') == ctr and any(w in row.get('Kernel_Name', '') for w in kernel_names):
+                                per[row['Dispatch_Id']] = per.get(row['Dispatch_Id'], 0.0) + float(row['Counter_Value'])
+                if len(per) < 10:
+                    if ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+                        return None, 'no %s rows for the dominant kernel' % ctr
+                    continue
+                vals[ctr] = sum(per.values()) / len(per)
+            if ctrs[0] == 'SQ_VALU_MFMA_BUSY_CYCLES':
+                durs = []
+                for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if any(w in row.get('Kernel_Name', '') for w in kernel_names):
+                                durs.append(float(row['End_Timestamp']) - float(row['Start_Timestamp']))
+                if len(durs) >= 10:
+                    vals['duration_ns_under_pmc'] = sum(durs) / len(durs)
         traffic = vals['FETCH_SIZE'] * 1024 * 2 + vals['WRITE_SIZE'] * 1024
+        extra = {}
+        if 'GRBM_GUI_ACTIVE' in vals and 'duration_ns_under_pmc' in vals:
+            # (tools/make_roofline_pmc.py's formulas: GRBM_GUI_ACTIVE sums the 8 XCDs; busy cycles sum the chip's 1024 SIMDs)
+            extra['clock_mhz'] = vals['GRBM_GUI_ACTIVE'] / 8.0 / vals['duration_ns_under_pmc'] * 1e3
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in vals:
+                extra['mfma_busy_frac'] = vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * vals['GRBM_GUI_ACTIVE'] / 8.0)
+        LIVE_EXTRA.clear()
+        LIVE_EXTRA.update(extra)
         return traffic, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of `bench.py --mode roofline '
-                         '--dtype %s`), per-launch mean, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB units' % precision)
+                         '--dtype %s`), per-launch mean, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB units%s' %
+                         (precision, '; mfma_busy_frac / clock_mhz from a third live pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE)' if extra else ''))
     except Exception as e:                               # (timeouts, parse errors: the committed summary is the fallback)
         return None, 'live PMC pass failed: %r' % (e,)
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+LIVE_EXTRA = {}          # mfma_busy_frac / clock_mhz of the last successful live_pmc_traffic call (its third pass)
 
 
 def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5, live_pmc=False):
@@ -416,6 +452,7 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5, live_
         live, note = live_pmc_traffic(precision, (name.split('<')[0],))
         if live is not None:
             traffic, traffic_src = live, note
+            mfma_busy, clock = LIVE_EXTRA.get('mfma_busy_frac', mfma_busy), LIVE_EXTRA.get('clock_mhz', clock)
         elif traffic_src is not None:
             traffic_src += '; live pass: ' + note
     return dominant_roofline(ms, B, precision, traffic, traffic_src, mfma_busy, clock,
@@ -444,6 +481,35 @@ def path_roofline(kind, precision, tiles_per_step, ms_per_step):
     if precision == 'fp32':
         out['vs_fp32_mfma_peak'] = gflop / ms_per_step / FP32_MATRIX_PEAK_TFLOPS
     return out
+
+
+def step_roofline(gflop, mb, ms_per_step, precision):
+    """whole-step fraction of roofline from algorithmic GFLOP and MB per step (SURVEY 8d's units), against the dense bf16 MFMA peak and 8 TB/s"""
+    t_flop, t_hbm = gflop / DENSE_BF16_PEAK_TFLOPS, mb / HBM_PEAK_GBS
+    t_roof = max(t_flop, t_hbm)
+    return dict(frac=t_roof / ms_per_step, bound='mfma' if t_flop > t_hbm else 'hbm', roofline_ms=t_roof, hbm_ms=t_hbm, mfma_ms=t_flop,
+                hbm_frac=t_hbm / ms_per_step, mfma_frac=t_flop / ms_per_step, achieved_GBs=mb / ms_per_step, achieved_TFLOPs=gflop / ms_per_step,
+                algorithmic_MB_per_step=mb, algorithmic_GFLOP_per_step=gflop, peak_GBs=HBM_PEAK_GBS, peak_TFLOPs=DENSE_BF16_PEAK_TFLOPS,
+                mfma_work_per_product=3 if precision == 'fp32' else 1)
+
+
+def cpu_baseline_hrnet(n_tiles=1):
+    """BASELINE config 5's network as the reference runs it: HRNet18_rev1 (models/dam/seg_hrnet_rev1.py:289-548) train iteration on one
+    512x512 tile, PyTorch fp32 CPU (oracle/hrnet.py + oracle/train.py train_iteration, pinned by tests/golden/hrnet_train.npz)"""
+    import torch
+    from cdnet_amd.trainer import synthetic_batch
+    from oracle import hrnet as oh
+    from oracle import train as ot
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = oh.HighResolutionNet(3)
+    opt = ot.make_adam(net)
+    x, lab, dirn, point, weight = [t.cpu() for t in synthetic_batch(n_tiles, torch.device('cpu'), H=512, W=512)]
+    med, reps = _median_time(lambda: ot.train_iteration(net, opt, x, lab, dirn, point, weight), 1, 3, 30.0)
+    return dict(value=n_tiles / med, unit='tiles/s', cores=cores, kind='port', cpu=cpu_model(), seconds_per_iteration=med,
+                sample='%d synthetic 512x512 tile per iteration (the GPU leg runs 4): oracle fp32 PyTorch-CPU HRNet18_rev1 train iteration '
+                       '(forward, 5 losses, autograd backward, Adam; %d threads), median of %d repetitions after 1 warm-up' % (n_tiles, cores, reps))
 
 
 def main():
@@ -623,6 +689,27 @@ def main():
                     ms_per_step=dt / steps * 1e3, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup, dtype=precision,
                     workload='BASELINE config 1: UNet 3-class (31.04 M parameters), %d x 256x256x3 synthetic tiles, forward, CE x weight + dice, backward, Adam' % B)
 
+    def run_hrnet_cfg5(precision, B, steps, warmup):
+        """BASELINE config 5's per-rank shape: HRNet18_rev1 + DAM head (models/dam/seg_hrnet_rev1.py:289-548), B x 512x512x3 tiles, train step"""
+        from cdnet_amd.models.dam.seg_hrnet_rev1 import HighResolutionNet
+
+        class _Cfg:
+            model = {'out_c': 3}
+        cdnet_amd.set_precision(precision)
+        torch.manual_seed(2022)
+        tr = trainer.Trainer(HighResolutionNet(_Cfg()).to(dev), world_size=world)
+        batch = trainer.synthetic_batch(B, dev, seed=2022 + rank, H=512, W=512)
+        dt = timed(lambda: tr.train_step(*batch), steps, warmup, settle_s=0.5)
+        ms = dt / steps * 1e3
+        out = dict(metric='tiles/sec (train fwd+bwd+Adam), HRNet18_rev1 + DAM head, 512x512', value=world * B * steps / dt, unit='tiles/s',
+                   ms_per_step=ms, tiles_per_gpu_per_step=B, steps=steps, warmup=warmup, dtype=precision,
+                   workload='BASELINE config 5 (per-rank shape): HRNet18_rev1 (9.64 M parameters) + DAM head, %d x 512x512x3 synthetic tiles, forward, '
+                            '5-term loss, backward, fused Adam' % B,
+                   roofline_path=step_roofline(HRNET_TRAIN_GFLOP_PER_TILE * B, 3 * HRNET_FWD_MB_PER_TILE[precision] * B + 4 * HRNET_WEIGHT_MB, ms, precision))
+        del tr, batch
+        torch.cuda.empty_cache()
+        return out
+
     def run_image_postproc(steps, warmup):
         """BASELINE.md section 4 (d) on the device: everything after get_probmaps for one 1000x1000 image with 8 views (per-view
         direction-difference maps, mean, boost, arg-max, CC chain)"""
@@ -738,6 +825,13 @@ def main():
         line['train_e2e'] = e2e
         # BASELINE config 1 at its own size
         line['unet_cfg1'] = run_unet_cfg1(a.dtype, 4, 10, 2)
+        line['unet_cfg1']['roofline_path'] = step_roofline(UNET_TRAIN_GFLOP_PER_TILE * 4, 3 * UNET_FWD_MB_PER_TILE[a.dtype] * 4 + 4 * UNET_WEIGHT_MB,
+                                                           line['unet_cfg1']['ms_per_step'], a.dtype)
+        # BASELINE config 5 at its per-rank size (VERDICT r05 missing #3): the 16-bit step (the one profiles/<round>/hrnet_train_b4_512_* describe)
+        # and the headline arithmetic's
+        line['hrnet_cfg5'] = run_hrnet_cfg5('bf16', 4, 8, 2)
+        if a.dtype != 'bf16':
+            line['hrnet_cfg5'][a.dtype] = run_hrnet_cfg5(a.dtype, 4, 5, 2)
     if rp:
         line['roofline_path'] = rp
     line['config']['side_stream_probe'] = next((p_ for p_ in reversed(streams.PROBES) if p_.get('k', 0) == 0), None)       # (the trainer's / pipeline's second stream)
@@ -769,6 +863,7 @@ def main():
                 line['cpu_baseline_cdm'] = cpu_baseline_cdm()
                 line['cpu_baseline_image_postproc'] = cpu_baseline_image_postproc()
                 line['cpu_baseline_unet_cfg1'] = cpu_baseline_unet()
+                line['cpu_baseline_hrnet'] = cpu_baseline_hrnet()
         sys.stdout.flush()
         os.dup2(fd_out, 1)
         print(json.dumps(line), flush=True)

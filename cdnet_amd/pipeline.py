@@ -78,12 +78,14 @@ def check_tiles(r):
 
 @torch.no_grad()
 def infer_image(model, image, opt=None, tta=True, all_img_test=1, patch_size=256, overlap=40, classes=9, min_area=20,
-                radius=2, want_stages=False):
+                radius=2, want_stages=False, defer=False):
     """The reference's per-image inference (test_dam.py:297-563) for one image tensor [3,H,W] float32 on the GPU
     (already ToTensor'd / normalised): the eight dihedral views (TTA) through the network - whole image
     (all_img_test == 1, options.py:35) or 256/40 sliding windows (utils.split_forward_dam) - softmax / gated direction
     argmax per view (get_probmaps), per-view direction-difference maps, their mean, the point-guided boundary boost, argmax,
-    fill holes, remove small objects, label, dilate.  Returns dict(final int32 [H,W], count, pred, ...)."""
+    fill holes, remove small objects, label, dilate.  Returns dict(final int32 [H,W], count, pred, ...).
+    `defer=True`: nothing is read back - no host synchronisation; instead of `count` the device tensor `counts` stays in the result and the
+    reference's constant-DDM assertion is left to the caller (postproc.check_views on `minmax`) - the form test_dam.main pipelines images with."""
     from . import utils
     if opt is not None:
         tta, all_img_test = opt.test['tta'], opt.all_img_test
@@ -109,7 +111,8 @@ def infer_image(model, image, opt=None, tta=True, all_img_test=1, patch_size=256
         points[0, v] = point.reshape(-1)
         dcms[0, v] = dcm.reshape(-1)
     r = postproc.postprocess_views(probs, points, dcms, xforms=xforms, H=H, W=W, classes=classes, min_area=min_area,
-                                   radius=radius, want_stages=want_stages)
+                                   radius=radius, want_stages=want_stages, check=not defer)
     out = {k: (v[0] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v) for k, v in r.items()}
-    out['count'] = int(r['counts'][0])
+    if not defer:
+        out['count'] = int(r['counts'][0])
     return out

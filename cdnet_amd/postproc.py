@@ -177,10 +177,12 @@ def tile_postproc(mask_logits, dir_logits, point, min_area=20, radius=2, want_st
 
 
 def postprocess_views(probs, points, dcms, xforms=None, H=None, W=None, classes=9, min_area=20, radius=2,
-                      want_stages=False):
+                      want_stages=False, check=True):
     """Everything after get_probmaps for I images with V views each (test_dam.py:445-563).
     probs f32 [I,V,3,H,W], points f32 [I,V,H,W] (or [I,V,1,H,W]), dcms u8 [I,V,H,W] (or [I,V,1,H,W]); views in
-    their own frame.  Raises AssertionError (like test_dam.py:535) if a view's DDM is constant (0/0 = NaN)."""
+    their own frame.  Raises AssertionError (like test_dam.py:535) if a view's DDM is constant (0/0 = NaN) - `check=False` leaves that test
+    to the caller (`check_views(r)` on the returned dict): the assertion reads the codes' (min, max) back, a device-to-host synchronisation a
+    pipelined caller (test_dam.main: image i + 1 in flight while image i is copied out) postpones."""
     I, V = probs.shape[0], probs.shape[1]
     if H is None:
         H, W = probs.shape[-2:]
@@ -206,7 +208,13 @@ def postprocess_views(probs, points, dcms, xforms=None, H=None, W=None, classes=
     cc = cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
     r.update(cc)
     r['codes'], r['minmax'] = codes, minmax
-    mm = minmax.cpu()
+    if check:
+        check_views(r)
+    return r
+
+
+def check_views(r, minmax_host=None):
+    """the reference's assertion test_dam.py:535 for a result of postprocess_views (or its (min, max) codes already copied to the host)"""
+    mm = r['minmax'].cpu() if minmax_host is None else minmax_host
     assert bool((mm[..., 0] != mm[..., 1]).all()), \
         'a view has a constant direction-difference map: 0/0 -> NaN; the reference asserts here (test_dam.py:535)'
-    return r

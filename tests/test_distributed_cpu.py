@@ -230,3 +230,59 @@ def test_parameter_broadcast_and_scalar_mean_two_ranks():
     assert torch.equal(P0, P1) and torch.equal(M0, M1) and step0 == step1 == 7
     np.testing.assert_allclose(mean0, np.arange(11) * 1.5)
     np.testing.assert_allclose(mean1, mean0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inference entry point sharded by image (cdnet_amd/test_dam.py main): the host logic at world size 2
+# ---------------------------------------------------------------------------------------------------------
+def _fake_rows(names):
+    """deterministic per-image metric rows (what evaluate_labels + nuclei_accuracy_object_level leave per image)"""
+    rows = {}
+    for n in names:
+        h = sum(ord(c) * (i + 1) for i, c in enumerate(n))
+        rows[n[:-4]] = {'pixel_iou': (h % 97) / 97.0, 'AJI': (h % 89) / 89.0, 'Dice': (h % 83) / 83.0, 'obj_F1': (h % 79) / 79.0}
+    return rows
+
+
+def _shard_worker(rank, world, port, names, save_dir, out):
+    import torch.distributed as dist
+    from cdnet_amd import test_dam
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = test_dam.shard_names(names, rank, world)
+    merged = test_dam.gather_results(_fake_rows(mine), rank, world)
+    if rank == 0:
+        out.put((mine, test_dam.write_results(merged, save_dir), sorted(merged)))
+    else:
+        assert merged is None
+        out.put((mine, None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inference_entry_shards_by_image_and_gathers_on_rank0(tmp_path):
+    """names[rank::world] partitions the images, the per-image rows of both ranks arrive on rank 0, and test_results.txt (averages + sorted
+    rows) is byte for byte the single-process file"""
+    from cdnet_amd import test_dam
+    names = ['im%02d.png' % i for i in range(7)]
+    assert test_dam.shard_names(names, 0, 1) == names
+    assert sorted(test_dam.shard_names(names, 0, 2) + test_dam.shard_names(names, 1, 2)) == names
+    assert not set(test_dam.shard_names(names, 0, 2)) & set(test_dam.shard_names(names, 1, 2))
+    one, two = tmp_path / 'one', tmp_path / 'two'
+    one.mkdir(); two.mkdir()
+    want = test_dam.write_results(test_dam.gather_results(_fake_rows(names), 0, 1), str(one))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, names, str(two), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    avg = [g[1] for g in got if g[1] is not None]
+    assert len(avg) == 1 and avg[0] == want
+    assert sorted(n for g in got for n in g[0]) == names
+    assert (one / 'test_results.txt').read_bytes() == (two / 'test_results.txt').read_bytes()

@@ -44,8 +44,8 @@ def test_graphed_inference_pipeline_is_bit_identical_to_eager():
     torch.manual_seed(3)
     m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda().eval()
     x = torch.from_numpy(synth.tiles_u8(4, 128, 128, seed=1).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().cuda()
-    want = pipeline.infer_tiles(m, x)
-    g = GraphedCallable(lambda t: pipeline.infer_tiles(m, t), x.clone())
+    want = pipeline.infer_tiles(m, x, want_prob=True)
+    g = GraphedCallable(lambda t: pipeline.infer_tiles(m, t, want_prob=True), x.clone())
     got = g(x)
     torch.cuda.synchronize()
     for k in ('final', 'pred', 'prob', 'dcm', 'point'):

@@ -139,6 +139,61 @@ def test_test_dam_entry_point_with_ground_truth(tmp_path):
     assert none['AJI'] == 0.0 and none['pixel_recall'] == 0.0
 
 
+def test_entry_point_sharded_over_two_ranks(tmp_path):
+    """SURVEY 8e / test_dam.py:158-760: `cdnet_amd.test_dam.main` as TWO ranks (the one GPU of the box, gloo for the gather) against the
+    one-process run on the same five images: every label map bit-identical, one test_results.txt on rank 0 with the same averages, the other
+    rank returns None"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_data_folder import make_dataset
+    from cdnet_amd import checkpoint, test_dam, trainer
+    from cdnet_amd.models.dam.model_unet_rev1 import Unet
+    make_dataset(tmp_path, n=5, size=(96, 112), seed=7, sub='test1')
+    torch.manual_seed(0)
+    m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).cuda()
+    tr = trainer.Trainer(m)
+    batch = trainer.synthetic_batch(2, torch.device('cuda:0'), seed=1, H=64, W=64)
+    for _ in range(3):
+        tr.train_step(*batch)
+    ck = checkpoint.save_checkpoint(checkpoint.make_state(m, tr, 0), 0, True, str(tmp_path), 'Main', 0)
+    args = ['--img-dir', str(tmp_path / 'images' / 'test1'), '--label-dir', str(tmp_path / 'labels' / 'test1'), '--model-path', ck]
+    one = str(tmp_path / 'one')
+    want = test_dam.main(args + ['--save-dir', one])
+    assert want is not None
+    two = str(tmp_path / 'two')
+    os.makedirs(two)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_test_dam_world2_worker.py')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker, two] + args + ['--save-dir', two], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, o[-2000:] + '\n' + e[-4000:]
+    got0, got1 = [json.load(open(os.path.join(two, 'rank%d.json' % r))) for r in range(2)]
+    assert got1 is None and got0 is not None
+    assert set(got0) == set(want)
+    for k in want:
+        assert abs(got0[k] - want[k]) < 1e-12, (k, got0[k], want[k])
+    for i in range(5):
+        a, b = np.asarray(Image.open(os.path.join(one, 'im%d_seg.tiff' % i))), np.asarray(Image.open(os.path.join(two, 'im%d_seg.tiff' % i)))
+        assert np.array_equal(a, b), i
+    assert open(os.path.join(one, 'test_results.txt')).read() == open(os.path.join(two, 'test_results.txt')).read()
+
+
 def test_full_size_image_properties():
     """BASELINE config 3 (one 1000x1000 image, 8 TTA views x 25 windows of 256/40, DDM, boost, CC chain): too large for the CPU
     oracle in a test, so size-independent properties - bit-identical repeat runs, instance ids exactly 1..count, no instance
@@ -185,11 +240,11 @@ def test_post_stream_pipelining_is_bit_identical():
             m = Unet(backbone_name='vgg16_bn', pretrained=False, classes=3).to(dev).eval()
             xs = [torch.from_numpy(synth.tiles_u8(8, seed=40 + k).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous().to(dev)
                   for k in range(3)]
-            serial = [pipeline.infer_tiles(m, x) for x in xs]
+            serial = [pipeline.infer_tiles(m, x, want_prob=True) for x in xs]
             torch.cuda.synchronize()
             post = torch.cuda.Stream()
             for rep in range(3):
-                piped = [pipeline.infer_tiles(m, x, post_stream=post) for x in xs]         # no synchronisation in between
+                piped = [pipeline.infer_tiles(m, x, post_stream=post, want_prob=True) for x in xs]         # no synchronisation in between
                 for r in piped:
                     r['done'].synchronize()
                 for a, b in zip(serial, piped):
