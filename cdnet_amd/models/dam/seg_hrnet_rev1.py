@@ -233,7 +233,11 @@ class HighResolutionNet(nn.Module):
             p0 += _pad16(c)
         self._cat_layout = [(p, _pad16(c)) for (_, c, p) in segs]
         mf = self.mask_feature
-        ctot = p0
+        # 18 + 36 + 72 + 144 carried as 32 + 48 + 80 + 144 = 304 channels = 19 chunks of 16: one more chunk of zeros (zero weights on the other
+        # side) makes the concatenation 320 channels wide - 640-byte pixels, whole 128-byte lines per 64-channel block, and an even chunk count,
+        # which the persistent convolution kernels' chunk-pair requests need (mask_feature.conv1's training forward ran on the one-tile kernel)
+        ctot = (p0 + 31) // 32 * 32
+        self._cat_width = ctot
         shim = types.SimpleNamespace(conv1=types.SimpleNamespace(weight=self._compute_param(mf.conv1.weight, (64, ctot, 3, 3), segs)),
                                      bn1=mf.bn1, conv2=mf.conv2, bn2=mf.bn2,
                                      conv_1x1=types.SimpleNamespace(weight=self._compute_param(mf.conv_1x1.weight, (64, ctot, 1, 1), segs),
@@ -402,8 +406,15 @@ class HighResolutionNet(nn.Module):
             ys = xs
         # F.upsample + torch.cat (:528-533): every branch written (up-sampled) into its slice of one padded buffer
         N, H, W, _ = ys[0].x.shape
-        ctot = sum(w for _, w in self._cat_layout)
-        cat = torch.empty((N, H, W, ctot), dtype=runtime.act_dtype(), device=x.device)
+        ctot, used = self._cat_width, sum(w for _, w in self._cat_layout)
+        key = (N, H, W, runtime.act_dtype(), x.device)
+        if getattr(self, '_cat_key', None) != key:
+            # one buffer per shape, kept: its padding channels are zeroed once (every forward rewrites the branch slices only)
+            self._cat_buf = torch.empty((N, H, W, ctot), dtype=runtime.act_dtype(), device=x.device)
+            if ctot > used:
+                self._cat_buf[..., used:].zero_()
+            self._cat_key = key
+        cat = self._cat_buf
         for k, (y, (p0, _)) in enumerate(zip(ys, self._cat_layout)):
             self._node(('cat', k)).forward([y], False, out=cat, out_coff=p0, training=training)
         f1 = rt['ru'][0].forward(Src(cat), training, store=True)
