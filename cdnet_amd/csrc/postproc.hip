@@ -25,8 +25,11 @@ __device__ __forceinline__ int view_offset(int xf, int y, int x, int H, int W) {
     return yv * wv + xv;
 }
 
-struct DdmLut { int8_t v[17 * 17]; };
 struct ViewXf { int v[16]; };
+
+__device__ __forceinline__ int ld_relaxed(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -47,19 +50,39 @@ __device__ __forceinline__ float wave_maxf(float v) {
 // ------------------------------------------------------------------------------------------------------
 // DDM
 // ------------------------------------------------------------------------------------------------------
+// A direction-difference code is one of 0 .. 3 (1 - min of rounded cosines in {-1 .. 2}): the (min, max) of a map are gathered as four
+// PRESENCE BYTES in the map's first minmax word - plain idempotent byte stores, no read-modify-write.  (Round 5 used atomicMin / atomicMax per
+// workgroup: 16 000 atomics on 16 addresses per 8-view image serialise at the L2 - 186 us of a kernel that moves 16 MB; "only when it still
+// moves the value" left the first wave of 2 048 resident workgroups, 69 us.)
 __global__ void init_minmax_kernel(int32_t *minmax, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { minmax[2 * i] = 0x7fffffff; minmax[2 * i + 1] = -0x7fffffff; }
+    if (i < n) { minmax[2 * i] = 0; minmax[2 * i + 1] = 0; }
 }
 
-// block (64,4): 256 px x 4 rows, 4 consecutive pixels per thread
+__global__ void finish_minmax_kernel(int32_t *minmax, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned f = (unsigned)minmax[2 * i];
+    int mn = 0x7fffffff, mx = -0x7fffffff;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        if ((f >> (8 * v)) & 0xffu) { mn = v < mn ? v : mn; mx = v; }
+    minmax[2 * i] = mn; minmax[2 * i + 1] = mx;
+}
+
+// block (64,4): 256 px x 4 rows, 4 consecutive pixels per thread.
+// Round 6: the cosine table as PACKED ROWS - two bits per entry (round(cos) + 1 in {0, 1, 2}), one 64-bit word per centre class, ONE LDS read per
+// pixel instead of eight byte reads with bank conflicts - and, for row pitches that are multiples of four, the 3 x 6 neighbourhood from three
+// aligned 32-bit loads plus the neighbouring lanes' words (8 views of a 1000 x 1000 image: 97 -> ~15 us per four views).
+struct DdmRows { unsigned long long r[17]; };
+
 __global__ __launch_bounds__(256) void ddm_codes_kernel(const uint8_t *__restrict__ dcm, int H, int W, int classes,
-                                                        DdmLut lut, int nbr, int extra_zero,
+                                                        DdmRows rows, int nbr, int extra_zero,
                                                         uint8_t *__restrict__ code, int32_t *minmax) {
-    __shared__ int8_t s_lut[17 * 17];
+    __shared__ unsigned long long s_rows[17];
     __shared__ int s_red[8];
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < classes * classes; i += 256) s_lut[i] = lut.v[i];
+    if (tid < 17) s_rows[tid] = rows.r[tid];
     __syncthreads();
 
     const int n = blockIdx.z;
@@ -67,17 +90,39 @@ __global__ __launch_bounds__(256) void ddm_codes_kernel(const uint8_t *__restric
     const uint8_t *src = dcm + n * plane;
     const int y = blockIdx.y * 4 + threadIdx.y;
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    int lmin = 0x7fffffff, lmax = -0x7fffffff;
-    if (y < H && x0 < W) {
-        uint8_t t[3][6];
+    unsigned pmask = 0;                                       // codes among this thread's pixels
+    const bool vec = (W & 3) == 0 && (((size_t)src) & 3) == 0;
+    uint8_t t[3][6];
+    if (vec) {
+        // three aligned words (zero outside the image); the byte left / right of them comes from the neighbouring lanes' words
+        unsigned wv[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            int yy = y + r - 1;
-            bool rowok = yy >= 0 && yy < H;
+            const int yy = y + r - 1;
+            wv[r] = (yy >= 0 && yy < H && x0 < W) ? *reinterpret_cast<const unsigned *>(src + (size_t)yy * W + x0) : 0u;
+        }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                int xx = x0 + c - 1;
-                t[r][c] = (rowok && xx >= 0 && xx < W) ? src[(size_t)yy * W + xx] : (uint8_t)0;
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            unsigned lw = __shfl_up(wv[r], 1), rw = __shfl_down(wv[r], 1);
+            if (threadIdx.x == 0) lw = (yy >= 0 && yy < H && x0 >= 4 && x0 - 4 < W) ? *reinterpret_cast<const unsigned *>(src + (size_t)yy * W + x0 - 4) : 0u;
+            if (threadIdx.x == 63) rw = (yy >= 0 && yy < H && x0 + 4 < W) ? *reinterpret_cast<const unsigned *>(src + (size_t)yy * W + x0 + 4) : 0u;
+            t[r][0] = (uint8_t)(lw >> 24);
+            t[r][1] = (uint8_t)wv[r]; t[r][2] = (uint8_t)(wv[r] >> 8); t[r][3] = (uint8_t)(wv[r] >> 16); t[r][4] = (uint8_t)(wv[r] >> 24);
+            t[r][5] = (uint8_t)rw;
+        }
+    }
+    if (y < H && x0 < W) {
+        if (!vec) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                int yy = y + r - 1;
+                bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    int xx = x0 + c - 1;
+                    t[r][c] = (rowok && xx >= 0 && xx < W) ? src[(size_t)yy * W + xx] : (uint8_t)0;
+                }
             }
         }
         uint8_t out[4];
@@ -87,27 +132,28 @@ __global__ __launch_bounds__(256) void ddm_codes_kernel(const uint8_t *__restric
             int v = 0;
             if (c != 0) {
                 int m = extra_zero ? 0 : 2;
-                const int8_t *row = s_lut + c * classes;
+                const unsigned long long row = s_rows[c];
+                auto q_of = [&](int nb) { return (int)((row >> (2 * nb)) & 3ull) - 1; };
                 if (nbr == 8) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int d = 0; d < 3; ++d) {
                             if (r == 1 && d == 1) continue;
-                            int q = row[t[r][j + d]];
+                            int q = q_of(t[r][j + d]);
                             m = q < m ? q : m;
                         }
                 } else {
                     int q;
-                    q = row[t[0][j + 1]]; m = q < m ? q : m;
-                    q = row[t[2][j + 1]]; m = q < m ? q : m;
-                    q = row[t[1][j]];     m = q < m ? q : m;
-                    q = row[t[1][j + 2]]; m = q < m ? q : m;
+                    q = q_of(t[0][j + 1]); m = q < m ? q : m;
+                    q = q_of(t[2][j + 1]); m = q < m ? q : m;
+                    q = q_of(t[1][j]);     m = q < m ? q : m;
+                    q = q_of(t[1][j + 2]); m = q < m ? q : m;
                 }
                 v = 1 - m;
             }
             out[j] = (uint8_t)v;
-            if (x0 + j < W) { lmin = v < lmin ? v : lmin; lmax = v > lmax ? v : lmax; }
+            if (x0 + j < W) pmask |= 1u << v;
         }
         uint8_t *dst = code + n * plane + (size_t)y * W + x0;
         if ((W & 3) == 0) {
@@ -118,14 +164,20 @@ __global__ __launch_bounds__(256) void ddm_codes_kernel(const uint8_t *__restric
                 if (x0 + j < W) dst[j] = out[j];
         }
     }
-    lmin = wave_min(lmin);
-    lmax = wave_max(lmax);
-    if (threadIdx.x == 0) { s_red[threadIdx.y] = lmin; s_red[4 + threadIdx.y] = lmax; }
+    // which of the four codes occur in this workgroup's pixels -> their presence bytes (skipped when already set)
+    unsigned present = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        if (__ballot((pmask >> v) & 1u)) present |= 1u << v;
+    if (threadIdx.x == 0) s_red[threadIdx.y] = (int)present;
     __syncthreads();
     if (tid == 0) {
-        int a = s_red[0], b = s_red[4];
-        for (int i = 1; i < 4; ++i) { a = s_red[i] < a ? s_red[i] : a; b = s_red[4 + i] > b ? s_red[4 + i] : b; }
-        if (a != 0x7fffffff) { atomicMin(&minmax[2 * n], a); atomicMax(&minmax[2 * n + 1], b); }
+        present = (unsigned)(s_red[0] | s_red[1] | s_red[2] | s_red[3]);
+        uint8_t *flags = reinterpret_cast<uint8_t *>(&minmax[2 * n]);
+        const unsigned have = (unsigned)ld_relaxed(&minmax[2 * n]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (((present >> v) & 1u) && !((have >> (8 * v)) & 0xffu)) flags[v] = 1;
     }
 }
 
@@ -185,44 +237,6 @@ __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// block (64,4); one pixel per thread
-__global__ __launch_bounds__(256) void tta_mean_kernel(const float *__restrict__ probs, const float *__restrict__ points,
-                                                       int V, ViewXf xf, int H, int W, float *__restrict__ prob_mean,
-                                                       float *__restrict__ point_mean, unsigned *pmax_key) {
-    __shared__ float s_red[4];
-    const int img = blockIdx.z;
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    const int plane = H * W;
-    float pm = -INFINITY;
-    if (x < W && y < H) {
-        const float *pr = probs + (size_t)img * V * 3 * plane;
-        const float *pt = points + (size_t)img * V * plane;
-        int o = view_offset(xf.v[0], y, x, H, W);
-        float s0 = pr[o], s1 = pr[plane + o], s2 = pr[2 * plane + o], sp = pt[o];
-        for (int v = 1; v < V; ++v) {
-            o = view_offset(xf.v[v], y, x, H, W);
-            const float *q = pr + (size_t)v * 3 * plane;
-            s0 = s0 + q[o]; s1 = s1 + q[plane + o]; s2 = s2 + q[2 * plane + o];
-            sp = sp + pt[(size_t)v * plane + o];
-        }
-        const float fv = (float)V;
-        const int p = y * W + x;
-        if (prob_mean) {
-            float *dst = prob_mean + (size_t)img * 3 * plane;
-            dst[p] = s0 / fv; dst[plane + p] = s1 / fv; dst[2 * plane + p] = s2 / fv;
-        }
-        pm = sp / fv;
-        point_mean[(size_t)img * plane + p] = pm;
-    }
-    pm = wave_maxf(pm);
-    if (threadIdx.x == 0) s_red[threadIdx.y] = pm;
-    __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        if (m != -INFINITY) atomicMax(&pmax_key[img], f2key(m));
-    }
-}
-
 // one view in its own frame (the tile pipeline): the "mean" over views IS the view - nothing to average or to store; what is left of
 // tta_mean_kernel is the maximum of the point map (test_dam.py:530), four pixels per thread
 __global__ __launch_bounds__(256) void point_max_kernel(const float *__restrict__ points, int plane, unsigned *pmax_key) {
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256) void point_max_kernel(const float *__restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        if (m != -INFINITY) atomicMax(&pmax_key[img], f2key(m));
+        if (m != -INFINITY && f2key(m) > (unsigned)ld_relaxed(reinterpret_cast<const int *>(&pmax_key[img]))) atomicMax(&pmax_key[img], f2key(m));
     }
 }
 
@@ -304,13 +318,152 @@ __global__ __launch_bounds__(256) void boost_argmax_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The same two steps for V views in their own frames (round 6): a 32 x 32-pixel image tile per workgroup, four pixels per thread.  A view
+// that is rotated against the image (bit 2) lies transposed in memory - a lane per image column would touch a cache line per lane (the r05
+// kernels: 79 + 63 us per 1000 x 1000 image, 1.6 TB/s of mostly wasted lines) - so its tile is read along ITS rows (lanes along the image's
+// y) into an LDS tile and taken out transposed (pitch 33: conflict-free).  Arithmetic and summation order are tta_mean_kernel's /
+// boost_argmax_kernel's: bit-identical results.
+//   views_point_kernel: mean of the point maps + its maximum (test_dam.py:445-450, 530)
+//   views_boost_kernel: mean of the probabilities, mean of the normalised direction-difference maps, boost, arg-max (test_dam.py:479-539)
+// ------------------------------------------------------------------------------------------------------
+constexpr int VT = 32;                 // tile edge
+
+// value of pixel (y0 + ty + 8k, x0 + tx), k = 0..3, of one plane of view `xf`; `tile`: [VT][VT + 1] floats of LDS (rotated views only).
+// Every thread of the workgroup calls it (barriers inside for a rotated view).
+template <typename T>
+__device__ __forceinline__ void view_tile_load(const T *__restrict__ plane, int xf, int H, int W, int y0, int x0, int tx, int ty, float *tile,
+                                               float out[4]) {
+    if (!(xf & 4)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = y0 + ty + 8 * k, x = x0 + tx;
+            out[k] = (y < H && x < W) ? (float)plane[view_offset(xf, y, x, H, W)] : 0.f;
+        }
+        return;
+    }
+    __syncthreads();                                          // (the previous plane's readers are done with the tile)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + tx, x = x0 + ty + 8 * k;          // lanes along y: consecutive elements of the rotated view's row
+        tile[(ty + 8 * k) * (VT + 1) + tx] = (y < H && x < W) ? (float)plane[view_offset(xf, y, x, H, W)] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = tile[tx * (VT + 1) + ty + 8 * k];      // pixel (y0 + ty + 8k, x0 + tx) sits at [x - x0][y - y0]
+}
+
+__global__ __launch_bounds__(256) void views_point_kernel(const float *__restrict__ points, int V, ViewXf xf, int H, int W,
+                                                          float *__restrict__ point_mean, unsigned *pmax_key) {
+    __shared__ float s_tile[VT * (VT + 1)];
+    __shared__ float s_red[4];
+    const int img = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * VT, y0 = blockIdx.y * VT;
+    const int plane = H * W;
+    const float *pt = points + (size_t)img * V * plane;
+    float sp[4], v[4];
+    view_tile_load(pt, xf.v[0], H, W, y0, x0, tx, ty, s_tile, sp);
+    for (int k = 1; k < V; ++k) {
+        view_tile_load(pt + (size_t)k * plane, xf.v[k], H, W, y0, x0, tx, ty, s_tile, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sp[j] = sp[j] + v[j];
+    }
+    const float fv = (float)V;
+    float pm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + ty + 8 * j, x = x0 + tx;
+        if (y < H && x < W) {
+            const float m = sp[j] / fv;
+            point_mean[(size_t)img * plane + (size_t)y * W + x] = m;
+            pm = fmaxf(pm, m);
+        }
+    }
+    pm = wave_maxf(pm);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = pm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        if (m != -INFINITY && f2key(m) > (unsigned)ld_relaxed(reinterpret_cast<const int *>(&pmax_key[img]))) atomicMax(&pmax_key[img], f2key(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void views_boost_kernel(const float *__restrict__ probs, const float *__restrict__ point_mean,
+                                                          const uint8_t *__restrict__ codes, const int32_t *__restrict__ minmax, int V,
+                                                          ViewXf xf, int H, int W, const unsigned *__restrict__ pmax_key,
+                                                          float *__restrict__ prob_mean, uint8_t *__restrict__ ddm16, uint8_t *__restrict__ pred) {
+    __shared__ float s_tile[VT * (VT + 1)];
+    const int img = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * VT, y0 = blockIdx.y * VT;
+    const int plane = H * W;
+    const float *pr = probs + (size_t)img * V * 3 * plane;
+    const uint8_t *cd = codes + (size_t)img * V * plane;
+    const int32_t *mm = minmax + (size_t)img * V * 2;
+    float s0[4], s1[4], s2[4], v[4];
+    double sd[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < V; ++k) {
+        const float *q = pr + (size_t)k * 3 * plane;
+        const int x_ = xf.v[k];
+        if (k == 0) {
+            view_tile_load(q, x_, H, W, y0, x0, tx, ty, s_tile, s0);
+            view_tile_load(q + plane, x_, H, W, y0, x0, tx, ty, s_tile, s1);
+            view_tile_load(q + 2 * plane, x_, H, W, y0, x0, tx, ty, s_tile, s2);
+        } else {
+            view_tile_load(q, x_, H, W, y0, x0, tx, ty, s_tile, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0[j] = s0[j] + v[j];
+            view_tile_load(q + plane, x_, H, W, y0, x0, tx, ty, s_tile, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1[j] = s1[j] + v[j];
+            view_tile_load(q + 2 * plane, x_, H, W, y0, x0, tx, ty, s_tile, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s2[j] = s2[j] + v[j];
+        }
+        view_tile_load(cd + (size_t)k * plane, x_, H, W, y0, x0, tx, ty, s_tile, v);       // (a code is an integer 0 .. 3: exact as a float)
+        const float mn = (float)mm[2 * k], den = (float)(mm[2 * k + 1] - mm[2 * k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sd[j] += (double)((v[j] - mn) / den);
+    }
+    const float pmax = key2f(pmax_key[img]);
+    const float *pt = point_mean + (size_t)img * plane;
+    const float fv = (float)V;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + ty + 8 * j, x = x0 + tx;
+        if (y >= H || x >= W) continue;
+        const int p = y * W + x;
+        bool in3 = pt[p] / pmax > 0.2f;
+        if (y > 0) in3 |= pt[p - W] / pmax > 0.2f;
+        if (y < H - 1) in3 |= pt[p + W] / pmax > 0.2f;
+        if (x > 0) in3 |= pt[p - 1] / pmax > 0.2f;
+        if (x < W - 1) in3 |= pt[p + 1] / pmax > 0.2f;
+        const double ddm = sd[j] / (double)V;
+        if (ddm16) {
+            double t = ddm * 16.0;
+            ddm16[(size_t)img * plane + p] = (t >= 0.0 && t <= 254.0 && t == (double)(int)t) ? (uint8_t)(int)t : (uint8_t)255;
+        }
+        const double eb = 2.0 * (ddm - ddm * (double)(in3 ? 1 : 0));
+        const float p0 = s0[j] / fv, p1 = s1[j] / fv;
+        float p2 = s2[j] / fv;
+        if (prob_mean) {
+            float *dst = prob_mean + (size_t)img * 3 * plane;
+            dst[p] = p0; dst[plane + p] = p1; dst[2 * plane + p] = p2;
+        }
+        p2 = (float)(((double)p2 + 0.5 * eb) * (1.0 + eb));
+        int a = 0;
+        float m = p0;
+        if (p1 > m || (p1 != p1 && m == m)) { a = 1; m = p1; }
+        if (p2 > m || (p2 != p2 && m == m)) { a = 2; m = p2; }
+        pred[(size_t)img * plane + p] = (uint8_t)a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Connected components: union-find over pixel indices, roots = smallest (raster-first) index of a component.
 // One wave = 64 consecutive pixels of one row: the row runs come from a ballot, so only run heads talk to
 // the forest.  Block (64,4); grid (ceil(W/64), ceil(H/4), N).  L: int32 per pixel, -1 = not in the mask.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ld_relaxed(const int *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ int uf_find(const int *L, int a) {
     int p = ld_relaxed(L + a);
@@ -648,11 +801,19 @@ extern "C" int cdnet_ddm_codes(const uint8_t *dcm, int N, int H, int W, int clas
     CDNET_REQUIRE(classes >= 2 && classes <= 17, "cdnet_ddm_codes: classes=%d not in [2,17]", classes);
     CDNET_REQUIRE(nbr == 4 || nbr == 8, "cdnet_ddm_codes: nbr must be 4 or 8");
     hipStream_t st = (hipStream_t)stream;
-    DdmLut lut;
-    for (int i = 0; i < 17 * 17; ++i) lut.v[i] = i < classes * classes ? lut_host[i] : 0;
+    DdmRows rows;
+    for (int c = 0; c < 17; ++c) {
+        rows.r[c] = 0ull;
+        for (int k = 0; k < 17; ++k) {
+            const int v = (c < classes && k < classes) ? lut_host[c * classes + k] : 0;
+            CDNET_REQUIRE(v >= -1 && v <= 1, "cdnet_ddm_codes: table entry %d outside {-1, 0, 1} (rounded cosines)", v);
+            rows.r[c] |= (unsigned long long)(v + 1) << (2 * k);
+        }
+    }
     init_minmax_kernel<<<cdiv(N, 256), 256, 0, st>>>(minmax, N);
     dim3 grid(cdiv(W, 256), cdiv(H, 4), N);
-    ddm_codes_kernel<<<grid, dim3(64, 4), 0, st>>>(dcm, H, W, classes, lut, nbr, extra_zero, code, minmax);
+    ddm_codes_kernel<<<grid, dim3(64, 4), 0, st>>>(dcm, H, W, classes, rows, nbr, extra_zero, code, minmax);
+    finish_minmax_kernel<<<cdiv(N, 256), 256, 0, st>>>(minmax, N);
     return check_launch("cdnet_ddm_codes");
 }
 
@@ -699,13 +860,15 @@ extern "C" int cdnet_tta_boost_argmax(const float *probs, const float *points, c
         int g = cdiv(H * W / 4, 256); if (g > 64) g = 64;
         point_max_kernel<<<dim3(g, I), 256, 0, st>>>(points, H * W, reinterpret_cast<unsigned *>(pmax_ws));
         point_mean = const_cast<float *>(points);
+        boost_argmax_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, prob_mean, point_mean, codes, minmax, V, xf, H, W,
+                                                          reinterpret_cast<const unsigned *>(pmax_ws), ddm16, pred);
     } else {
         CDNET_REQUIRE(point_mean, "cdnet_tta_boost_argmax: point_mean is required for this shape (pixel count not a multiple of 4 or unaligned points)");
-        tta_mean_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, points, V, xf, H, W, prob_mean, point_mean,
-                                                      reinterpret_cast<unsigned *>(pmax_ws));
+        const dim3 gt(cdiv(W, VT), cdiv(H, VT), I);
+        views_point_kernel<<<gt, 256, 0, st>>>(points, V, xf, H, W, point_mean, reinterpret_cast<unsigned *>(pmax_ws));
+        views_boost_kernel<<<gt, 256, 0, st>>>(probs, point_mean, codes, minmax, V, xf, H, W, reinterpret_cast<const unsigned *>(pmax_ws), prob_mean,
+                                               ddm16, pred);
     }
-    boost_argmax_kernel<<<grid, dim3(64, 4), 0, st>>>(probs, prob_mean, point_mean, codes, minmax, V, xf, H, W,
-                                                      reinterpret_cast<const unsigned *>(pmax_ws), ddm16, pred);
     return check_launch("cdnet_tta_boost_argmax");
 }
 

@@ -41,13 +41,15 @@ def _nbr_extra(classes):
     raise ValueError('direction_classes must be 5, 9 or 17 (getDirectionDiffMap.py:58,69)')
 
 
-def ddm_codes(dcm, classes):
-    """dcm uint8 [N,H,W] (cuda) -> (code uint8 [N,H,W], minmax int32 [N,2])."""
+def ddm_codes(dcm, classes, out=None, minmax_out=None):
+    """dcm uint8 [N,H,W] (cuda) -> (code uint8 [N,H,W], minmax int32 [N,2]); `out` / `minmax_out`: contiguous tensors of those element
+    counts to write into (slices of a larger buffer)"""
     assert dcm.dtype == torch.uint8 and dcm.dim() == 3
     N, H, W = dcm.shape
     dcm = dcm.contiguous()
-    code = torch.empty_like(dcm)
-    minmax = torch.empty((N, 2), dtype=torch.int32, device=dcm.device)
+    code = torch.empty_like(dcm) if out is None else out
+    minmax = torch.empty((N, 2), dtype=torch.int32, device=dcm.device) if minmax_out is None else minmax_out
+    assert code.is_contiguous() and code.numel() == dcm.numel() and minmax.is_contiguous() and minmax.numel() == 2 * N
     lut = ddm_lut(classes)
     nbr, extra = _nbr_extra(classes)
     _lib.call('cdnet_ddm_codes', _lib.ptr(dcm), N, H, W, classes, lut.ctypes.data_as(C.c_void_p), nbr, extra,
@@ -196,13 +198,24 @@ def postprocess_views(probs, points, dcms, xforms=None, H=None, W=None, classes=
     groups = {}
     for v, xf in enumerate(xforms):
         groups.setdefault(bool(xf & 4), []).append(v)
-    for rot, vs in groups.items():
+    dflat = dcms.reshape(I, V, plane)
+    if H == W or len(groups) == 1:
+        # one launch over every view: a rotated view of a square image has the image's own shape
+        rot = next(iter(groups)) if len(groups) == 1 else False
         hv, wv = (W, H) if rot else (H, W)
-        idx = torch.tensor(vs, device=probs.device)
-        sub = dcms.reshape(I, V, plane)[:, idx].reshape(I * len(vs), hv, wv)
-        c, mm = ddm_codes(sub, classes)
-        codes[:, idx] = c.reshape(I, len(vs), plane)
-        minmax[:, idx] = mm.reshape(I, len(vs), 2)
+        ddm_codes(dflat.reshape(I * V, hv, wv), classes, out=codes, minmax_out=minmax)
+    else:
+        for rot, vs in groups.items():
+            hv, wv = (W, H) if rot else (H, W)
+            if I == 1 and vs == list(range(vs[0], vs[0] + len(vs))):
+                # the views of the group lie next to each other (the reference's order: four plain, four rotated): written in place
+                ddm_codes(dflat[0, vs[0]:vs[0] + len(vs)].reshape(len(vs), hv, wv), classes, out=codes[0, vs[0]:vs[0] + len(vs)],
+                          minmax_out=minmax[0, vs[0]:vs[0] + len(vs)])
+                continue
+            idx = torch.tensor(vs, device=probs.device)
+            c, mm = ddm_codes(dflat[:, idx].reshape(I * len(vs), hv, wv), classes)
+            codes[:, idx] = c.reshape(I, len(vs), plane)
+            minmax[:, idx] = mm.reshape(I, len(vs), 2)
     r = tta_boost_argmax(probs.reshape(I, V, 3 * plane), points.reshape(I, V, plane), codes, minmax, xforms, H, W,
                          want_stages=want_stages)
     cc = cc_chain(r['pred'], 1, min_area, radius, want_stages=want_stages)
