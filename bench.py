@@ -328,7 +328,7 @@ def committed_pmc(precision, B=16):
     return None, None, None, None
 
 
-def live_pmc_traffic(precision, kernel_names, timeout_s=60):
+def live_pmc_traffic(precision, kernel_names, timeout_s=60, batch=16):
     """HBM bytes per launch of the dominant kernel measured IN THIS RUN when rocprofv3 is on the box: two child processes
     `rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 bench.py --mode roofline` (separate passes, the program right
     after `--`, from /tmp: MI355X_MICROARCH.md's HBM / rocprofv3 section), FETCH_SIZE x 2 on gfx950 (a 16-B/lane read stream counts
@@ -356,7 +356,7 @@ def live_pmc_traffic(precision, kernel_names, timeout_s=60):
         for ctrs in (('FETCH_SIZE',), ('WRITE_SIZE',), ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')):
             d = os.path.join(out, ctrs[0])
             cmd = [exe, '--kernel-trace', '--pmc'] + list(ctrs) + ['--output-format', 'csv', '-d', d, '-o', 't', '--',
-                   sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'roofline', '--dtype', precision, '--steps', '20']
+                   sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'roofline', '--dtype', precision, '--steps', '20', '--batch', str(batch)]
             # the profiler and the program it starts form their own process group: on a timeout the WHOLE group is killed and reaped
             # before anything else is timed (killing only the launcher would leave `bench.py --mode roofline` running on this GPU)
             proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -406,8 +406,8 @@ def live_pmc_traffic(precision, kernel_names, timeout_s=60):
         LIVE_EXTRA.clear()
         LIVE_EXTRA.update(extra)
         return traffic, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of `bench.py --mode roofline '
-                         '--dtype %s`), per-launch mean, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB units%s' %
-                         (precision, '; mfma_busy_frac / clock_mhz from a third live pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE)' if extra else ''))
+                         '--dtype %s --batch %d`), per-launch mean, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB units%s' %
+                         (precision, batch, '; mfma_busy_frac / clock_mhz from a third live pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE)' if extra else ''))
     except Exception as e:                               # (timeouts, parse errors: the committed summary is the fallback)
         return None, 'live PMC pass failed: %r' % (e,)
     finally:
@@ -446,10 +446,10 @@ def time_dominant_conv(torch, B, steps=20, precision='bf16', settle_s=0.5, live_
     # HBM traffic of this kernel: measured in this run by PMC child passes when asked and possible, else quoted from the committed
     # summary; matrix-pipe busy fraction and clock always from the committed summary (six more passes: tools/prof_roofline_pmc.sh)
     traffic, traffic_src, mfma_busy, clock = committed_pmc(precision, B)
-    if live_pmc and B == 16:
+    if live_pmc:
         del x, out
         torch.cuda.synchronize()
-        live, note = live_pmc_traffic(precision, (name.split('<')[0],))
+        live, note = live_pmc_traffic(precision, (name.split('<')[0],), batch=B)
         if live is not None:
             traffic, traffic_src = live, note
             mfma_busy, clock = LIVE_EXTRA.get('mfma_busy_frac', mfma_busy), LIVE_EXTRA.get('clock_mhz', clock)
@@ -842,7 +842,7 @@ def main():
             # the 16-bit path's dominant layer at the INFERENCE batch (64 tiles: 1.07 GB of tensors, beyond the 256 MB Infinity Cache - at 16 tiles
             # the 268 MB working set is re-used across launches out of that cache and the figure flatters the kernel); 16 tiles beside it
             if other == 'bf16':
-                line['roofline_bf16'] = time_dominant_conv(torch, 64, precision='bf16')
+                line['roofline_bf16'] = time_dominant_conv(torch, 64, precision='bf16', live_pmc=not a.no_live_pmc)
                 line['roofline_bf16_16tiles'] = time_dominant_conv(torch, 16, precision='bf16')
             else:
                 line['roofline_' + other] = time_dominant_conv(torch, 16, precision=other)

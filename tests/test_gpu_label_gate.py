@@ -234,12 +234,13 @@ def test_second_draw(gate_net, gate_net2):
     from oracle import infer as oinf
     before = cdnet_amd.get_precision()
     rows = []
-    S = 600
+    S = int(os.environ.get('CDNET_GATE_DRAW_SIZE', '600'))      # (1000: BASELINE config 3's size - 1.5-2 minutes of CPU oracle per draw; profiles/<round>/label_gate_1000x1000_draws.log)
+    NI = 250 if S <= 600 else 700
     try:
         for ni, (m, ref, crc) in enumerate((gate_net, gate_net2)):
             for seed in (4242, 9191):
                 rs = np.random.RandomState(seed)
-                inst = synth.ellipse_instances(S, S, 250, rs, 5, 14, 10)
+                inst = synth.ellipse_instances(S, S, NI, rs, 5, 14, 10)
                 img = synth.render_nuclei(inst, rs)
                 w = _oracle(('draw', ni, seed), lambda: oinf.infer_image(ref, img, tta=True, all_img_test=0, patch_size=256, overlap=40))
                 for prec in ('fp32', 'bf16'):
