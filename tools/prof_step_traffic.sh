@@ -1,11 +1,11 @@
 # HBM bytes of one whole training step from the PMC counters (two separate passes, FETCH_SIZE x 2 on gfx950 - MI355X_MICROARCH.md):
 #   bash tools/prof_step_traffic.sh [fp32|bf16] [train|infer]     (through gpurun)
 # train: one step = the launches after the second-to-last adam_kernel up to the last one (16 tiles); infer: one batch of 64 tiles = the
-# launches after the second-to-last probmaps_kernel up to the last one (dispatch ids follow the enqueue order: batch i's post-processing is
+# launches after the second-to-last tile_maps_kernel (the first launch of a batch's post-processing chain; rounds 1-5: probmaps_kernel) up to the last one (dispatch ids follow the enqueue order: batch i's post-processing is
 # queued between the forwards of batches i and i + 1; under the counters the launches run one at a time).
 DT=${1:-fp32}
 MODE=${2:-train}
-export CDNET_TRAFFIC_MARK=$([ "$MODE" = infer ] && echo probmaps_kernel || echo adam_kernel)
+export CDNET_TRAFFIC_MARK=$([ "$MODE" = infer ] && echo tile_maps_kernel || echo adam_kernel)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/step_pmc_$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --mode $MODE --dtype $DT --steps 4 --warmup 2 --no-extras --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/step_pmc_$c.log 2>&1
