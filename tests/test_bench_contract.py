@@ -144,3 +144,44 @@ def test_committed_round5_line_carries_every_leg_and_its_cpu_baseline():
         p = json.load(f)
     assert p['tiles_per_launch'] == 64 and p['algorithmic_bytes_per_launch'] == b['algorithmic_bytes']
     assert 1.0 < p['hbm_bytes_per_launch'] / p['algorithmic_bytes_per_launch'] < 1.2          # quad requests: 1.15 x (1.32 x with pairs)
+
+
+def test_committed_round6_line_is_comparable_across_boxes_and_carries_config_5():
+    """profiles/r06/bench_default_line.json: what the round-5 verdict asked of the line - the box record measured in the run and the rates per unit
+    of it, the dominant kernel's traffic AND matrix-pipe occupancy / clock measured live in both arithmetics, BASELINE config 5 (HRNet18_rev1 at
+    its per-rank size) with its roofline and CPU baseline, config 1's roofline, the kernel instantiation that really runs at each batch size"""
+    with open(os.path.join(ROOT, 'profiles', 'r06', 'bench_default_line.json')) as f:
+        d = json.loads([ln for ln in f.read().splitlines() if ln.startswith('{')][-1])
+    assert d['dtype'] == 'fp32' and d['n_gpus'] == 1 and d['vs_baseline'] is None and d['scaling'] == 'weak'
+    box = d['box']
+    assert 3000 < box['copy_GBs'] < 8000 and 800 < box['mfma_TFLOPs'] < 2500 and 1000 < box['mfma_clock_mhz'] < 2600
+    assert abs(d['value_per_box_mfma'] - d['value'] / box['mfma_TFLOPs']) < 1e-9
+    assert abs(d['inference_per_box_copy'] - d['inference']['value'] / box['copy_GBs']) < 1e-9
+    assert abs(d['bf16']['inference_per_box_copy'] - d['bf16']['inference']['value'] / box['copy_GBs']) < 1e-9
+    r = d['roofline']
+    assert r['traffic_source'].startswith('measured in this run') and 'third live pass' in r['traffic_source']
+    assert 0.98 < r['traffic'] / r['algorithmic_bytes'] < 1.05 and 0.4 < r['mfma_busy_frac'] < 0.9 and 1500 < r['clock_mhz'] < 2600
+    b = d['roofline_bf16']
+    assert b['traffic_source'].startswith('measured in this run') and '--batch 64' in b['traffic_source'] and 1.0 < b['traffic'] / b['algorithmic_bytes'] < 1.25
+    assert b['kernel'].startswith('conv_ws16_kernel<64,0,false,false,0,4,4,true,false,true,true>')          # the QUAD-request instantiation at 64 tiles
+    assert d['roofline_bf16_16tiles']['kernel'].startswith('conv_ws16_kernel<64,0,false,false,0,4,4,true,false,true,false>')
+    h = d['hrnet_cfg5']
+    assert h['tiles_per_gpu_per_step'] == 4 and h['dtype'] == 'bf16' and 20 < h['ms_per_step'] < 60 and 'fp32' in h
+    rp = h['roofline_path']
+    assert rp['bound'] == 'hbm' and abs(rp['algorithmic_MB_per_step'] - (3 * 3340.0 * 4 + 4 * 38.5)) < 1e-6 and abs(rp['frac'] - rp['roofline_ms'] / h['ms_per_step']) < 1e-9
+    c = d['cpu_baseline_hrnet']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and '512x512' in c['sample']
+    u = d['unet_cfg1']['roofline_path']
+    assert abs(u['algorithmic_GFLOP_per_step'] - 4 * 289.1) < 1e-6 and 0.05 < u['frac'] < 0.3
+    assert d['image_postproc']['ms_per_image'] < 0.35                     # (round 5: 0.50 ms)
+    assert d['config']['side_stream_probe'].get('k', 0) == 0
+
+
+def test_box_and_step_roofline_helpers():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.step_roofline(1000.0, 8000.0, 2.0, 'bf16')
+    assert r['bound'] == 'hbm' and abs(r['roofline_ms'] - 1.0) < 1e-12 and abs(r['frac'] - 0.5) < 1e-12 and r['mfma_work_per_product'] == 1
+    r = bench.step_roofline(5000.0, 800.0, 4.0, 'fp32')
+    assert r['bound'] == 'mfma' and abs(r['frac'] - 0.5) < 1e-12 and r['mfma_work_per_product'] == 3
