@@ -150,8 +150,8 @@ def test_hrnet_parameters_live_in_padded_flat_storage():
     m._ensure_runtime()
     named = m.trainer_named_parameters()
     pp = named['mask_feature.conv1.weight']
-    assert tuple(pp.shape) == (64, 304, 3, 3)
-    assert torch.equal(pp[:, 32:68], ref2.mask_feature.conv1.weight[:, 18:54]) and float(pp[:, 18:32].abs().max()) == 0
+    assert tuple(pp.shape) == (64, 320, 3, 3)          # 32 + 48 + 80 + 144 = 304 carried channels + one chunk of zeros (round 6: 640-byte pixels, an even chunk count)
+    assert torch.equal(pp[:, 32:68], ref2.mask_feature.conv1.weight[:, 18:54]) and float(pp[:, 18:32].abs().max()) == 0 and float(pp[:, 304:].abs().max()) == 0
     g = named['stage3.0.branches.2.0.bn1.weight']
     assert tuple(g.shape) == (80,) and torch.equal(g[:72], ref2.stage3[0].branches[2][0].bn1.weight) and float(g[72:].abs().max()) == 0
     # values written into the padded storage (what the fused Adam does) show up in the module's state_dict
