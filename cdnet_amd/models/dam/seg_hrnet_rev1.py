@@ -407,14 +407,17 @@ class HighResolutionNet(nn.Module):
         # F.upsample + torch.cat (:528-533): every branch written (up-sampled) into its slice of one padded buffer
         N, H, W, _ = ys[0].x.shape
         ctot, used = self._cat_width, sum(w for _, w in self._cat_layout)
-        key = (N, H, W, runtime.act_dtype(), x.device)
-        if getattr(self, '_cat_key', None) != key:
-            # one buffer per shape, kept: its padding channels are zeroed once (every forward rewrites the branch slices only)
-            self._cat_buf = torch.empty((N, H, W, ctot), dtype=runtime.act_dtype(), device=x.device)
+        # one buffer per (shape, mode), kept: its padding channels are zeroed once, every forward rewrites the branch slices only.  (A training
+        # forward's buffer is what the tape holds until its backward has run: an eval forward in between takes the other one.)
+        key = (N, H, W, runtime.act_dtype(), x.device, bool(training))
+        bufs = self.__dict__.setdefault('_cat_bufs', {})
+        cat = bufs.get(key)
+        if cat is None:
+            if len(bufs) >= 4:
+                bufs.clear()
+            cat = bufs[key] = torch.empty((N, H, W, ctot), dtype=runtime.act_dtype(), device=x.device)
             if ctot > used:
-                self._cat_buf[..., used:].zero_()
-            self._cat_key = key
-        cat = self._cat_buf
+                cat[..., used:].zero_()
         for k, (y, (p0, _)) in enumerate(zip(ys, self._cat_layout)):
             self._node(('cat', k)).forward([y], False, out=cat, out_coff=p0, training=training)
         f1 = rt['ru'][0].forward(Src(cat), training, store=True)

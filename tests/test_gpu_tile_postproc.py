@@ -31,6 +31,8 @@ def _nuclei_logits(B, H, W, classes, dev, seed):
     import torch
     from cdnet_amd import synth
     from cdnet_amd.my_transforms_direction import label_encoding_batch
+    if min(H, W) < 16:                                         # (no room for an ellipse: noise with a foreground bias)
+        return _noise_logits(B, H, W, classes, dev, seed, 0.7)
     rs = np.random.RandomState(seed)
     n = max(2, 60 * H * W // 65536)
     lab = np.stack([(synth.ellipse_instances(H, W, n, rs, 5, 12, 4) > 0).astype(np.uint8) * 255 for _ in range(B)])
@@ -65,7 +67,7 @@ def _assert_same(f, s, what):
 
 
 @pytest.mark.parametrize('B,H,W,classes', [(3, 256, 256, 9), (5, 64, 64, 9), (2, 128, 256, 9), (2, 256, 128, 9), (2, 512, 128, 9), (1, 16, 64, 9),
-                                           (2, 128, 128, 5), (2, 128, 128, 17), (1, 1024, 64, 9)])
+                                           (2, 128, 128, 5), (2, 128, 128, 17), (1, 1024, 64, 9), (3, 1, 64, 9), (2, 3, 192, 9), (2, 80, 320, 9)])
 def test_fused_equals_per_step_chain(dev, B, H, W, classes):
     import torch
     from cdnet_amd import postproc
