@@ -35,5 +35,7 @@ constexpr int WAVE = 64;
 // postproc.hip: 8-connected labelling with raster-order ids (shared with the CDM generator)
 int label8_raster(const uint8_t *mask, int N, int H, int W, int *L, int *aux, int *chunk, int32_t *labels, int32_t *counts,
                   hipStream_t st);
+// postproc_tile.hip: the same labelling of tiles (W % 64 == 0, at most 65 536 pixels) in one launch; false: shape not served, nothing queued
+bool label8_tile(const uint8_t *mask, int N, int H, int W, int32_t *labels, int32_t *counts, hipStream_t st, int *rc);
 
 }  // namespace cdnet

@@ -777,6 +777,10 @@ inline int grid_lin(int plane) { int g = cdiv(plane, 256); return g > 2048 ? 204
 namespace cdnet {
 int label8_raster(const uint8_t *mask, int N, int H, int W, int *L, int *aux, int *chunk, int32_t *labels, int32_t *counts,
                   hipStream_t st) {
+    {
+        int rc = 0;                                          // tiles: one launch with the tile in LDS (postproc_tile.hip)
+        if (label8_tile(mask, N, H, W, labels, counts, st, &rc)) return rc;
+    }
     const int plane = H * W, nchunk = cdiv(plane, CHUNK);
     const dim3 gr = grid_rows(N, H, W), br(64, 4);
     const dim3 gl(grid_lin(plane), N);

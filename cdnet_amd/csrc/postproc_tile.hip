@@ -632,6 +632,105 @@ __global__ __launch_bounds__(1024) void tile_chain_kernel(const u64 *__restrict_
     TSTAMP(16);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 8-connected labelling of a binary tile in raster order (skimage.measure.label) in ONE launch: tile_chain_kernel's machinery without the
+// hole filling and the area test - what the target generation (cdm.hip: label_instance = measure.label(new_label == 1),
+// my_transforms_direction.py:785-790) needs per label image; replaces the seven launches of label8_raster for tiles.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tile_label8_kernel(const uint8_t *__restrict__ mask, int H, int W, int32_t *__restrict__ labels,
+                                                           int32_t *__restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int P = H * W;
+    u16 *L = reinterpret_cast<u16 *>(smem);
+    u64 *AM = reinterpret_cast<u64 *>(smem + 131072);
+    int *S = reinterpret_cast<int *>(AM + 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x;
+    const size_t base = (size_t)n * P;
+    const int nseg = P >> 6, spr = W >> 6;
+    const int t = tid;
+    // the mask's bit plane: sixteen pixels per lane and load (four loads per lane for a 256 x 256 tile instead of 64 dependent byte loads), four
+    // neighbouring lanes OR their 16 bits into a segment's word
+    for (int q = tid; q < (P >> 4); q += 1024) {
+        const uint4 v = reinterpret_cast<const uint4 *>(mask + base)[q];
+        const unsigned xs4[4] = {v.x, v.y, v.z, v.w};
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned x = xs4[i];
+            const unsigned nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;       // bit 7 of every non-zero byte
+            bits |= (((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u)) << (4 * i);
+        }
+        u64 w = (u64)bits << (16 * (q & 3));
+        w |= __shfl_xor(w, 1);
+        w |= __shfl_xor(w, 2);
+        if ((q & 3) == 0) AM[q >> 2] = w;
+    }
+    __syncthreads();
+    const u64 am = t < nseg ? AM[t] : 0ull;
+    t_init(AM, L, t, nseg);
+    __syncthreads();
+    t_merge4(AM, L, t, nseg, spr, W);
+    __syncthreads();
+    if (t >= spr && t < nseg && am) {                        // the diagonal contacts (cc_merge_kernel<1, 8>: NW / NE only where N, W / E do not connect already)
+        const int xs = t % spr;
+        const u64 up = AM[t - spr];
+        const u64 awest = (am << 1) | ((xs > 0 && (AM[t - 1] >> 63)) ? 1ull : 0ull);
+        const u64 aeast = (am >> 1) | ((xs < spr - 1 && (AM[t + 1] & 1ull)) ? (1ull << 63) : 0ull);
+        const u64 unw = (up << 1) | ((xs > 0 && (AM[t - spr - 1] >> 63)) ? 1ull : 0ull);
+        const u64 une = (up >> 1) | ((xs < spr - 1 && (AM[t - spr + 1] & 1ull)) ? (1ull << 63) : 0ull);
+        u64 c = am & ~up & ~awest & unw;
+        while (c) { const int l = __ffsll((long long)c) - 1; c &= c - 1; tf_union(AM, L, t * 64 + l, t * 64 + l - W - 1); }
+        c = am & ~up & ~aeast & une;
+        while (c) { const int l = __ffsll((long long)c) - 1; c &= c - 1; tf_union(AM, L, t * 64 + l, t * 64 + l - W + 1); }
+    }
+    __syncthreads();
+    const u64 hds = am & ~(am << 1);
+    if (t < nseg) {
+        u64 heads = hds;
+        while (heads) { const int l = __ffsll((long long)heads) - 1; heads &= heads - 1; L[t * 64 + l] = (u16)tf_root_ro(L, t * 64 + l); }
+    }
+    __syncthreads();
+    u64 roots = 0ull;
+    {
+        u64 heads = hds;
+        while (heads) { const int l = __ffsll((long long)heads) - 1; heads &= heads - 1; if (ldl(L, t * 64 + l) == t * 64 + l) roots |= 1ull << l; }
+        const int c = __popcll(roots);
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (lane == 63) S[wave] = inc;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { if (i < wave) woff += S[i]; tot += S[i]; }
+        if (tid == 0 && counts) counts[n] = tot;
+        int rk = woff + inc - c;
+        u64 r = roots;
+        while (r) { const int l = __ffsll((long long)r) - 1; r &= r - 1; L[t * 64 + l] = (u16)(++rk); }
+    }
+    __syncthreads();
+    if (t < nseg) {
+        u64 heads = hds & ~roots;
+        while (heads) { const int l = __ffsll((long long)heads) - 1; heads &= heads - 1; L[t * 64 + l] = ldl(L, ldl(L, t * 64 + l)); }
+    }
+    __syncthreads();
+    for (int p = tid * 4; p < P; p += 4096) {
+        const int sg = p >> 6, lb = p & 63;
+        const u64 a = AM[sg];
+        const u64 hw = a & ~(a << 1);
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = lb + j;
+            const u64 x = hw & (~0ull >> (63 - l));
+            const int hpos = 63 - __clzll((long long)(x | 1ull));
+            v[j] = ((a >> l) & 1ull) ? (int)L[sg * 64 + hpos] : 0;
+        }
+        *reinterpret_cast<int4 *>(labels + base + p) = make_int4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 }  // namespace
 
 #ifdef CDNET_TILE_STAMPS
@@ -639,6 +738,25 @@ extern "C" int cdnet_debug_tile_stamps(unsigned long long *host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 64 * 32) == hipSuccess ? 0 : 3;
 }
 #endif
+
+namespace cdnet {
+// internal (cdm.hip through label8_raster): true when the shape is the tile kernel's (W a multiple of 64, at most 65 536 pixels) and the launch was queued
+bool label8_tile(const uint8_t *mask, int N, int H, int W, int32_t *labels, int32_t *counts, hipStream_t st, int *rc) {
+    if (N <= 0 || W % 64 != 0 || (long long)H * W > 65536 || (((size_t)labels) & 15) != 0 || (((size_t)mask) & 15) != 0) return false;
+    constexpr int SMEM = 131072 + 8192 + 64 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_label8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+            *rc = check_launch("hipFuncSetAttribute(tile_label8)");
+            return true;
+        }
+        attr = true;
+    }
+    tile_label8_kernel<<<N, 1024, SMEM, st>>>(mask, H, W, labels, counts);
+    *rc = check_launch("tile_label8_kernel");
+    return true;
+}
+}  // namespace cdnet
 
 // workspace: code u8 [B*P] | area i32 [B*P] | fg bit plane u64 [B*P/64] | part_mm i32 [B*nb*2] | part_pmax f32 [B*nb]
 static size_t tile_ws_layout(int B, int H, int W, size_t *oCode, size_t *oArea, size_t *oBits, size_t *oMM, size_t *oPM, int *nb_out) {
