@@ -94,22 +94,23 @@ def infer_image(model, image, opt=None, tta=True, all_img_test=1, patch_size=256
     assert not model.training and image.dim() == 3
     _, H, W = image.shape
     xforms = list(postproc.TTA_XFORMS) if tta else [0]
-    if all_img_test == 1:
-        # whole-image forward: one window as large as the view
-        size = max(H, W)
-        views = utils.split_forward_views(model, image, size, 0, xforms, classes)
-    else:
-        views = utils.split_forward_views(model, image, patch_size, overlap, xforms, classes)
     V = len(xforms)
     plane = H * W
-    probs = torch.empty((1, V, 3 * plane), dtype=torch.float32, device=image.device)
-    points = torch.empty((1, V, plane), dtype=torch.float32, device=image.device)
-    dcms = torch.empty((1, V, plane), dtype=torch.uint8, device=image.device)
-    for v, (mask, point, direction) in enumerate(views):
-        prob, dcm = postproc.probmaps(mask[None], direction[None])
-        probs[0, v] = prob.reshape(-1)
-        points[0, v] = point.reshape(-1)
-        dcms[0, v] = dcm.reshape(-1)
+    dev = image.device
+    # every view's logits are stitched straight into one buffer per output (a rotated view as [K][W][H]: the same element count), get_probmaps'
+    # epilogue is ONE launch over all views and writes the post-processing's inputs in place (round 5: eight launches and 24 device copies)
+    mask_all = torch.empty((V, 3, plane), dtype=torch.float32, device=dev)
+    dir_all = torch.empty((V, classes, plane), dtype=torch.float32, device=dev)
+    probs = torch.empty((1, V, 3 * plane), dtype=torch.float32, device=dev)
+    points = torch.empty((1, V, plane), dtype=torch.float32, device=dev)
+    dcms = torch.empty((1, V, plane), dtype=torch.uint8, device=dev)
+    bufs = (mask_all, points[0].view(V, 1, plane), dir_all)
+    if all_img_test == 1:
+        # whole-image forward: one window as large as the view
+        utils.split_forward_views(model, image, max(H, W), 0, xforms, classes, out=bufs)
+    else:
+        utils.split_forward_views(model, image, patch_size, overlap, xforms, classes, out=bufs)
+    postproc.probmaps(mask_all.view(V, 3, 1, plane), dir_all.view(V, classes, 1, plane), prob_out=probs, dcm_out=dcms)
     r = postproc.postprocess_views(probs, points, dcms, xforms=xforms, H=H, W=W, classes=classes, min_area=min_area,
                                    radius=radius, want_stages=want_stages, check=not defer)
     out = {k: (v[0] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 1 else v) for k, v in r.items()}

@@ -64,14 +64,17 @@ def ddm_normalize(code, minmax):
     return out
 
 
-def probmaps(mask_logits, dir_logits):
-    """float32 [N,3,H,W], [N,C,H,W] -> prob float32 [N,3,H,W], dcm uint8 [N,H,W]."""
+def probmaps(mask_logits, dir_logits, prob_out=None, dcm_out=None):
+    """float32 [N,3,H,W], [N,C,H,W] -> prob float32 [N,3,H,W], dcm uint8 [N,H,W] (`prob_out` / `dcm_out`: contiguous tensors of those element
+    counts to write into)."""
     assert mask_logits.dtype == torch.float32 and dir_logits.dtype == torch.float32
     N, _, H, W = mask_logits.shape
     Cd = dir_logits.shape[1]
     mask_logits, dir_logits = mask_logits.contiguous(), dir_logits.contiguous()
-    prob = torch.empty_like(mask_logits)
-    dcm = torch.empty((N, H, W), dtype=torch.uint8, device=mask_logits.device)
+    prob = torch.empty_like(mask_logits) if prob_out is None else prob_out
+    dcm = torch.empty((N, H, W), dtype=torch.uint8, device=mask_logits.device) if dcm_out is None else dcm_out
+    assert prob.is_contiguous() and prob.numel() == mask_logits.numel() and prob.dtype == torch.float32
+    assert dcm.is_contiguous() and dcm.numel() == N * H * W and dcm.dtype == torch.uint8
     _lib.call('cdnet_probmaps', _lib.ptr(mask_logits), _lib.ptr(dir_logits), N, Cd, H, W, _lib.ptr(prob),
               _lib.ptr(dcm), _lib.stream_ptr())
     return prob, dcm

@@ -41,9 +41,11 @@ def window_grid(h0, w0, size, overlap):
     return stride, min(size, h), min(size, w), ny, nx
 
 
-def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=128):
+def split_forward_views(model, image, size, overlap, xforms=(0,), direction_classes=9, max_batch=128, out=None):
     """Sliding-window forward of one image [3,H,W] (cuda float32) for several TTA views at once.
-    Returns a list (one entry per view) of stitched logits (mask [3,hv,wv], point [1,hv,wv], direction [9,hv,wv])."""
+    Returns a list (one entry per view) of stitched logits (mask [3,hv,wv], point [1,hv,wv], direction [9,hv,wv]).
+    `out` = (mask f32 [V,3,H*W], point f32 [V,1,H*W], direction f32 [V,K,H*W]): the views are stitched straight into these buffers (a rotated
+    view as [K][W][H]: the same element count) - pipeline.infer_image's one get_probmaps launch over all views reads them in place."""
     assert image.dim() == 3 and image.is_cuda and image.dtype == torch.float32
     Cc, H0, W0 = image.shape
     image = image.contiguous()
@@ -64,9 +66,9 @@ def split_forward_views(model, image, size, overlap, xforms=(0,), direction_clas
         hv, wv, stride, th, tw, ny, nx = geo[i]
         n = ny * nx
         st = []
-        for t_ in logits:
+        for j_, t_ in enumerate(logits):
             K = t_.shape[1]
-            o = torch.empty((K, hv, wv), dtype=torch.float32, device=image.device)
+            o = torch.empty((K, hv, wv), dtype=torch.float32, device=image.device) if out is None else out[j_][i].view(K, hv, wv)
             src = t_[off:off + n]                          # (a batch slice of a contiguous tensor is contiguous)
             _lib.call('cdnet_window_stitch', _lib.ptr(src), K, th, tw, stride, overlap, ny, nx, hv, wv, _lib.ptr(o), _lib.stream_ptr())
             st.append(o)
